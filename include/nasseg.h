@@ -1,0 +1,146 @@
+/* nasseg.h - C ABI of libnasseg_hip.so: the MI355X (gfx950) kernels behind the
+ * NAS inner loop of DrSleep/nas-segm-pytorch.
+ *
+ * The reference has no FFI for this path: its boundary is the Python op
+ * registry OPS / AGG_OPS (src/nn/layer_factory.py:27-91), the decoder classes
+ * (src/nn/micro_decoders.py:142,257) and one Cython module
+ * (src/helpers/miou_utils.pyx).  Underneath, every op is an ATen call; the
+ * entry points below are the from-scratch gfx950 replacements of exactly those
+ * ATen calls, one group per reference call site.  The host side
+ * (nas-segm-pytorch_amd/) binds them with ctypes and re-creates the reference's
+ * registry / decoder / engine API on top.
+ *
+ * Conventions
+ *  - plain C types only; every pointer except `const int64_t* cm` in
+ *    nasseg_compute_ius_accs is a DEVICE pointer owned by the caller (PyTorch's
+ *    caching allocator); the library allocates nothing and keeps no state apart
+ *    from a per-thread error string;
+ *  - activations are fp32 NHWC ("channels_last"): element (b,y,x,c) of a tensor
+ *    with pixel stride ld is at ((b*H + y)*W + x)*ld + c; weights arrive in the
+ *    PyTorch layouts ((C,1,k,k) depthwise, (N,K,kh,kw) dense) and are re-packed
+ *    by the pack entry points;
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream); calls are
+ *    asynchronous on that stream, re-entrant and thread-safe;
+ *  - return value 0 = ok, negative = error; nasseg_last_error() then returns a
+ *    message valid until the same thread's next failing call.  The Python
+ *    binding raises RuntimeError, which the reference's try_except decorator
+ *    (src/helpers/utils.py:172-187) turns into reward 0 for that candidate;
+ *  - act codes: 0 none, 1 ReLU, 2 ReLU6.
+ */
+#ifndef NASSEG_H
+#define NASSEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* nasseg_last_error(void);
+int nasseg_abi_version(void);
+int nasseg_device_count(void);
+
+/* ---- depthwise convolution ------------------------------------------------
+ * replaces nn.Conv2d(C, C, k, stride, padding, dilation, groups=C, bias=False)
+ * in SepConv / DilConv (layer_factory.py:198-265) and InvertedResidual
+ * (layer_factory.py:125-158). */
+int nasseg_dw_pack_weight(const float* w, float* wt, int C, int K, int flip, void* stream);
+int nasseg_dwconv(const float* x, const float* wt, float* y, const float* scale,
+                  const float* shift, int B, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                  int pad, int dil, int transposed, int relu_in, int act, void* stream);
+int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K);
+int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int H, int W,
+                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, int relu_in,
+                        void* stream);
+
+/* ---- dense convolution on the fp32 matrix cores ----------------------------
+ * replaces conv1x1 / conv3x3 / conv_bn / conv_bn_relu (layer_factory.py:7-24,
+ * 94-122), every pointwise stage (:125-382) and the classifier heads
+ * (micro_decoders.py:210-227,360-363); fused input affine+act prologue and
+ * output affine/bias+act(+residual) epilogue. */
+int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int kw, int mode,
+                            void* stream);
+int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
+                    const float* in_scale, const float* in_shift, int in_act,
+                    const float* out_scale, const float* out_shift, int out_act, const float* res,
+                    int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
+                    int stride, int pad, int dil, int transposed, void* stream);
+int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw);
+int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                      const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
+                      int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                      int dil, void* stream);
+
+/* ---- per-channel reductions / BatchNorm ------------------------------------
+ * replaces nn.BatchNorm2d (layer_factory.py:56-75,94-158,369-382), x.mean(2).mean(3)
+ * in GAPConv1x1 (:181-195), bias / ParamSum coefficient gradients (:353-366). */
+int64_t nasseg_colred_workspace(int S, int64_t R, int C);
+int nasseg_colred(int mode, const float* a, int64_t lda, const float* b, int64_t ldb,
+                  const float* c, int64_t ldc, float* out, float* ws, int S, int64_t R, int C,
+                  float mul, void* stream);
+int nasseg_bn_stats(const float* x, int64_t ldx, int64_t M, int C, float eps, float momentum,
+                    const float* gamma, const float* beta, float* mean, float* invstd,
+                    float* scale, float* shift, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, float* ws, void* stream);
+int nasseg_bn_eval_params(int C, float eps, const float* gamma, const float* beta,
+                          const float* running_mean, const float* running_var, float* mean,
+                          float* invstd, float* scale, float* shift, void* stream);
+int nasseg_bn_bwd_reduce(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t M,
+                         int C, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int act, float* sums, float* ws, void* stream);
+int nasseg_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* sums, int64_t M,
+                        int C, int train, int act, float* dx, void* stream);
+
+/* ---- elementwise / copies ----------------------------------------------------
+ * BN apply + ReLU/ReLU6 + residual (layer_factory.py:94-158), cell sums
+ * (micro_decoders.py:48-51,110-121), ParamSum (:353-366), Skip / Zero (:268-297),
+ * torch.cat (+F.relu) (micro_decoders.py:11-25,251; layer_factory.py:369-382). */
+int nasseg_affine_act(const float* x, const float* scale, const float* shift, const float* res,
+                      float* y, int64_t n, int C, int act, void* stream);
+int nasseg_axpby(const float* a, const float* b, const float* alpha, const float* beta, float* y,
+                 int64_t n, int C, int act, void* stream);
+int nasseg_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int act, void* stream);
+int nasseg_fill(float* y, int64_t n, float v, void* stream);
+int nasseg_chan_copy(const float* x, int64_t ldx, int xoff, float* y, int64_t ldy, int yoff,
+                     const float* mref, int64_t ldm, int moff, int64_t P, int C, int act, int mact,
+                     void* stream);
+int nasseg_chan_fold(const float* dy, float* dx, int64_t P, int C, int rep, void* stream);
+
+/* ---- pooling: Pool (layer_factory.py:161-178); mode 0 max, 1 avg ------------- */
+int nasseg_pool_fwd(int mode, const float* x, float* y, uint8_t* idx, int B, int H, int W, int C,
+                    int Ho, int Wo, int K, int stride, int pad, void* stream);
+int nasseg_pool_bwd(int mode, const float* dy, const uint8_t* idx, float* dx, int B, int H, int W,
+                    int C, int Ho, int Wo, int K, int stride, int pad, void* stream);
+
+/* ---- resize: nn.Upsample / F.interpolate bilinear, align_corners=False
+ * (layer_factory.py:190-194,338-350; micro_decoders.py:11-25,46-51; trainer.py:141-143,
+ * 236-238,245-247; inference.py:58-60) and nearest label resize (trainer.py:43-49,236-238). */
+int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
+                        int C, int Ho, int Wo, int act, void* stream);
+int nasseg_bilinear_bwd(const float* dy, int64_t lddy, int dyoff, float* dx, int B, int Hi, int Wi,
+                        int C, int Ho, int Wo, void* stream);
+int nasseg_nearest_label(const void* x, int elem_size, int64_t* y, int B, int Hi, int Wi, int Ho,
+                         int Wo, void* stream);
+
+/* ---- loss: nn.LogSoftmax() + nn.NLLLoss2d(ignore_index=255)
+ * (main_search.py:435; trainer.py:144-146,239-241) -------------------------------- */
+int64_t nasseg_ce_workspace(void);
+int nasseg_ce_fwd(const float* logits, const void* target, int elem_size, int64_t P, int C,
+                  int ignore, float* out, float* ws, void* stream);
+int nasseg_ce_bwd(const float* logits, const void* target, int elem_size, const float* stats,
+                  const float* gscale, int64_t P, int C, int ignore, float* dlogits, void* stream);
+
+/* ---- mean-IoU reward: helpers/miou_utils.pyx fast_cm :7-30, compute_iu :32-57,
+ * compute_ius_accs :59-90; argmax + up-sampling of engine/inference.py:58-66 ------ */
+int nasseg_fast_cm(const uint8_t* preds, const uint8_t* gt, int64_t P, int n, int64_t* cm,
+                   void* stream);
+int nasseg_argmax_cm(const float* logits, const uint8_t* gt, uint8_t* preds, int B, int h, int w,
+                     int C, int H, int W, int n, int64_t* cm, void* stream);
+/* host-side (cm, iu, n_pixels, accs are HOST pointers) */
+int nasseg_compute_ius_accs(const int64_t* cm, int n, double* iu, int64_t* n_pixels, double* accs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NASSEG_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of libnasseg_hip.so (the C ABI declared in include/nasseg.h).
+
+Prototypes are parsed from the header so the header stays the single source of
+truth.  Every call that returns a negative status raises RuntimeError - the
+error class the reference's ``try_except`` wrapper (src/helpers/utils.py:172-187)
+converts into reward 0.  There is no CPU fallback: if the shared library is
+missing, loading fails loudly.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnasseg_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nasseg.h")
+
+_CTYPE = {
+    "int": ctypes.c_int,
+    "int64_t": ctypes.c_int64,
+    "float": ctypes.c_float,
+    "double": ctypes.c_double,
+}
+_PROTO = re.compile(r"^\s*(const char\*|int64_t|int)\s+(nasseg_\w+)\s*\(([^)]*)\)\s*;", re.M | re.S)
+
+
+def parse_header(path=HEADER_PATH):
+    """Return {symbol: (restype, [argtypes])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for ret, name, args in _PROTO.findall(text):
+        args = " ".join(args.split())
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    base = a.replace("const ", "").split()[0]
+                    argtypes.append(_CTYPE[base])
+        restype = {"const char*": ctypes.c_char_p, "int64_t": ctypes.c_int64, "int": ctypes.c_int}[ret]
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class NassegError(RuntimeError):
+    """A nasseg C-ABI call failed (bad arguments, HIP launch failure, ...)."""
+
+
+class _Library(object):
+    def __init__(self):
+        self._dll = None
+        self._fn = {}
+
+    def load(self):
+        if self._dll is not None:
+            return self
+        if not os.path.exists(LIB_PATH):
+            raise NassegError(
+                "{} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.".format(LIB_PATH)
+            )
+        dll = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(dll, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
+            self._fn[name] = fn
+        self._dll = dll
+        return self
+
+    def symbols(self):
+        self.load()
+        return sorted(self._fn)
+
+    def last_error(self):
+        self.load()
+        msg = self._fn["nasseg_last_error"]()
+        return msg.decode("utf-8", "replace") if msg else ""
+
+    def call(self, name, *args):
+        """Call a status-returning entry point; raise RuntimeError on failure."""
+        fn = self._fn.get(name)
+        if fn is None:
+            self.load()
+            fn = self._fn[name]
+        rc = fn(*args)
+        if rc < 0:
+            raise NassegError("{}: {}".format(name, self.last_error()))
+        return rc
+
+    def query(self, name, *args):
+        """Call a value-returning entry point (workspace sizes, versions)."""
+        fn = self._fn.get(name)
+        if fn is None:
+            self.load()
+            fn = self._fn[name]
+        return fn(*args)
+
+
+lib = _Library()
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors):
+    """The product path never computes on the host: fail loudly instead."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NassegError(
+                "nasseg kernels need tensors on a HIP device (got {}); there is no CPU "
+                "fallback - use oracle/ for CPU reference results".format(t.device)
+            )

@@ -1,0 +1,65 @@
+"""Build recipe for libnasseg_hip.so (hipcc, gfx950 only, in-tree).
+
+`python nas-segm-pytorch_amd/build.py` or `build_library()` compiles every
+csrc/*.hip / *.cpp to an object under csrc/build/ and links them into
+nas-segm-pytorch_amd/libnasseg_hip.so.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(CSRC, "build")
+LIB_PATH = os.path.join(HERE, "libnasseg_hip.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp")
+    )
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
+    if _stale(obj, deps):
+        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for {}:\n{}\n{}".format(src, r.stdout, r.stderr))
+    return obj
+
+
+def build_library(force=False, verbose=False):
+    """Compile and link; returns the path of the shared library."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    srcs = sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if force or _stale(LIB_PATH, objs):
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n{}\n{}".format(r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,70 @@
+// Shared device/host helpers for the nasseg gfx950 kernels.
+// All activations are fp32 NHWC ("channels_last"): element (b, y, x, c) of a
+// tensor with pixel stride ld lives at ((b*H + y)*W + x)*ld + c.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NASSEG_OK 0
+#define NASSEG_ERR_ARG (-1)
+#define NASSEG_ERR_LAUNCH (-2)
+#define NASSEG_ERR_UNSUPPORTED (-3)
+
+// activation codes shared by every fused prologue / epilogue
+#define NASSEG_ACT_NONE 0
+#define NASSEG_ACT_RELU 1
+#define NASSEG_ACT_RELU6 2
+
+int nasseg_fail(int code, const char* fmt, ...);
+
+#define NASSEG_REQUIRE(cond, ...)                                  \
+  do {                                                             \
+    if (!(cond)) return nasseg_fail(NASSEG_ERR_ARG, __VA_ARGS__);  \
+  } while (0)
+
+#define NASSEG_LAUNCH_CHECK(name)                                                  \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess)                                                          \
+      return nasseg_fail(NASSEG_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == NASSEG_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == NASSEG_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+__device__ __forceinline__ float4 act_apply4(float4 v, int act) {
+  v.x = act_apply(v.x, act);
+  v.y = act_apply(v.y, act);
+  v.z = act_apply(v.z, act);
+  v.w = act_apply(v.w, act);
+  return v;
+}
+// derivative mask of the activation evaluated at pre-activation value z
+__device__ __forceinline__ float act_mask(float z, int act) {
+  if (act == NASSEG_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == NASSEG_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+  return 1.f;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+  c.x = fmaf(a.x, b.x, c.x);
+  c.y = fmaf(a.y, b.y, c.y);
+  c.z = fmaf(a.z, b.z, c.z);
+  c.w = fmaf(a.w, b.w, c.w);
+  return c;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}

@@ -1,0 +1,244 @@
+// Bilinear resize (align_corners=False, no antialias; up- and down-sampling)
+// and nearest label resize, fp32 NHWC, gfx950.
+//
+// Reference call sites: resize() / Adapt (src/nn/layer_factory.py:316-350),
+// GAPConv1x1 broadcast (:190-194), collect_all and AggregateCell
+// (src/nn/micro_decoders.py:11-25,46-51), loss / validation up-sampling
+// (src/engine/trainer.py:141-143,153-155,236-238,245-247; inference.py:58-60).
+//
+// Index math follows torch's area_pixel_compute_source_index:
+//   scale = in/out (fp32); src = max(scale*(dst+0.5)-0.5, 0); i0 = floor(src);
+//   i1 = i0 + (i0 < in-1); l1 = src - i0; l0 = 1 - l1.
+// Forward can write into a channel slice of a wider slab (ldy / yoff) and apply
+// a ReLU, which is how collect_all's cat+relu is produced without an extra pass.
+// Backward is a gather over the destination footprint of each source pixel
+// (deterministic; no atomics).
+#include "common.h"
+
+namespace {
+
+struct Lin {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lin lin_coeff(int dst, float scale, int in_size, int out_size) {
+  Lin r;
+  if (in_size == out_size) {
+    r.i0 = r.i1 = dst;
+    r.l0 = 1.f;
+    r.l1 = 0.f;
+    return r;
+  }
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  r.i0 = (int)src;
+  if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+  r.i1 = r.i0 + ((r.i0 < in_size - 1) ? 1 : 0);
+  float l1 = src - (float)r.i0;
+  l1 = fminf(fmaxf(l1, 0.f), 1.f);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+
+inline int rs_grid(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x,
+                                                           float* __restrict__ y, int64_t ldy,
+                                                           int yoff, int B, int Hi, int Wi, int C4,
+                                                           int Ho, int Wo, float sh, float sw,
+                                                           int act) {
+  const int C = C4 * 4;
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int ox = (int)(p % Wo);
+    const int64_t prow = p / Wo;
+    const int oy = (int)(prow % Ho);
+    const int b = (int)(prow / Ho);
+    const Lin ly = lin_coeff(oy, sh, Hi, Ho);
+    const Lin lx = lin_coeff(ox, sw, Wi, Wo);
+    const float* xb = x + (int64_t)b * Hi * Wi * C + c4 * 4;
+    const float4 v00 = ld4(xb + ((int64_t)ly.i0 * Wi + lx.i0) * C);
+    const float4 v01 = ld4(xb + ((int64_t)ly.i0 * Wi + lx.i1) * C);
+    const float4 v10 = ld4(xb + ((int64_t)ly.i1 * Wi + lx.i0) * C);
+    const float4 v11 = ld4(xb + ((int64_t)ly.i1 * Wi + lx.i1) * C);
+    float4 o;
+    o.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+    o.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+    o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+    o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+    st4(y + p * ldy + yoff + c4 * 4, act_apply4(o, act));
+  }
+}
+
+// scalar-channel variant (C not a multiple of 4: class logits)
+__global__ __launch_bounds__(256) void bilinear_fwd_scalar_kernel(const float* __restrict__ x,
+                                                                  float* __restrict__ y, int B,
+                                                                  int Hi, int Wi, int C, int Ho,
+                                                                  int Wo, float sh, float sw) {
+  const int64_t total = (int64_t)B * Ho * Wo * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int ox = (int)(p % Wo);
+    const int64_t prow = p / Wo;
+    const int oy = (int)(prow % Ho);
+    const int b = (int)(prow / Ho);
+    const Lin ly = lin_coeff(oy, sh, Hi, Ho);
+    const Lin lx = lin_coeff(ox, sw, Wi, Wo);
+    const float* xb = x + (int64_t)b * Hi * Wi * C + c;
+    const float v00 = xb[((int64_t)ly.i0 * Wi + lx.i0) * C];
+    const float v01 = xb[((int64_t)ly.i0 * Wi + lx.i1) * C];
+    const float v10 = xb[((int64_t)ly.i1 * Wi + lx.i0) * C];
+    const float v11 = xb[((int64_t)ly.i1 * Wi + lx.i1) * C];
+    y[i] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+  }
+}
+
+// conservative destination range [lo, hi] whose source footprint can touch index i
+__device__ __forceinline__ void dst_range(int i, float scale, int out_size, int& lo, int& hi) {
+  // src(o) in [i-1, i+1)  <=>  o in [(i-0.5)/scale - 0.5, (i+1.5)/scale - 0.5)
+  const float inv = 1.0f / scale;
+  lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+__device__ __forceinline__ float lin_weight(int o, int i, float scale, int in_size, int out_size) {
+  const Lin l = lin_coeff(o, scale, in_size, out_size);
+  float w = 0.f;
+  if (l.i0 == i) w += l.l0;
+  if (l.i1 == i) w += l.l1;
+  return w;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy,
+                                                           int64_t lddy, int dyoff,
+                                                           float* __restrict__ dx, int B, int Hi,
+                                                           int Wi, int CV, int Ho, int Wo, float sh,
+                                                           float sw) {
+  const int64_t total = (int64_t)B * Hi * Wi * CV;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int ix = (int)(p % Wi);
+    p /= Wi;
+    const int iy = (int)(p % Hi);
+    const int b = (int)(p / Hi);
+    int ylo, yhi, xlo, xhi;
+    if (Hi == Ho) { ylo = yhi = iy; } else dst_range(iy, sh, Ho, ylo, yhi);
+    if (Wi == Wo) { xlo = xhi = ix; } else dst_range(ix, sw, Wo, xlo, xhi);
+    float4 g = f4zero();
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = lin_weight(oy, iy, sh, Hi, Ho);
+      if (wy == 0.f) continue;
+      const float* drow = dy + (((int64_t)b * Ho + oy) * Wo) * lddy + dyoff + cv * VEC;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = lin_weight(ox, ix, sw, Wi, Wo);
+        if (wx == 0.f) continue;
+        const float w = wy * wx;
+        if (VEC == 4) {
+          const float4 d = ld4(drow + (int64_t)ox * lddy);
+          g.x = fmaf(w, d.x, g.x);
+          g.y = fmaf(w, d.y, g.y);
+          g.z = fmaf(w, d.z, g.z);
+          g.w = fmaf(w, d.w, g.w);
+        } else {
+          g.x = fmaf(w, drow[(int64_t)ox * lddy], g.x);
+        }
+      }
+    }
+    if (VEC == 4)
+      st4(dx + i * 4, g);
+    else
+      dx[i] = g.x;
+  }
+}
+
+// nearest resize of integer label maps (torch 'nearest': src = min(floor(dst*in/out), in-1))
+template <typename TI>
+__global__ __launch_bounds__(256) void nearest_label_kernel(const TI* __restrict__ x,
+                                                            int64_t* __restrict__ y, int B, int Hi,
+                                                            int Wi, int Ho, int Wo, float sh,
+                                                            float sw) {
+  const int64_t total = (int64_t)B * Ho * Wo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ox = (int)(i % Wo);
+    const int64_t t = i / Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    int iy = (int)floorf((float)oy * sh);
+    int ix = (int)floorf((float)ox * sw);
+    if (iy > Hi - 1) iy = Hi - 1;
+    if (ix > Wi - 1) ix = Wi - 1;
+    y[i] = (int64_t)x[((int64_t)b * Hi + iy) * Wi + ix];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// y[b,oy,ox, yoff:yoff+C] = act(bilinear(x)[b,oy,ox,:]); x dense [B][Hi][Wi][C]
+int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
+                        int C, int Ho, int Wo, int act, void* stream) {
+  NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_fwd: bad shape");
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0) {
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(rs_grid((int64_t)B * Ho * Wo * (C / 4))),
+                       dim3(256), 0, s, x, y, ldy, yoff, B, Hi, Wi, C / 4, Ho, Wo, sh, sw, act);
+  } else {
+    NASSEG_REQUIRE(ldy == C && yoff == 0 && act == 0,
+                   "bilinear_fwd: slab output / activation need C %% 4 == 0");
+    hipLaunchKernelGGL(bilinear_fwd_scalar_kernel, dim3(rs_grid((int64_t)B * Ho * Wo * C)),
+                       dim3(256), 0, s, x, y, B, Hi, Wi, C, Ho, Wo, sh, sw);
+  }
+  NASSEG_LAUNCH_CHECK("bilinear_fwd");
+  return NASSEG_OK;
+}
+
+// dx [B][Hi][Wi][C] = transpose of the forward map applied to dy[..., dyoff:dyoff+C]
+int nasseg_bilinear_bwd(const float* dy, int64_t lddy, int dyoff, float* dx, int B, int Hi, int Wi,
+                        int C, int Ho, int Wo, void* stream) {
+  NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad shape");
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0)
+    hipLaunchKernelGGL((bilinear_bwd_kernel<4>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
+                       dim3(256), 0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+  else
+    hipLaunchKernelGGL((bilinear_bwd_kernel<1>), dim3(rs_grid((int64_t)B * Hi * Wi * C)), dim3(256),
+                       0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C, Ho, Wo, sh, sw);
+  NASSEG_LAUNCH_CHECK("bilinear_bwd");
+  return NASSEG_OK;
+}
+
+// labels: elem_size 1 (uint8) or 8 (int64) -> int64 [B][Ho][Wo]
+int nasseg_nearest_label(const void* x, int elem_size, int64_t* y, int B, int Hi, int Wi, int Ho,
+                         int Wo, void* stream) {
+  NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "nearest_label: bad shape");
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = rs_grid((int64_t)B * Ho * Wo);
+  if (elem_size == 1)
+    hipLaunchKernelGGL((nearest_label_kernel<uint8_t>), dim3(grid), dim3(256), 0, s,
+                       (const uint8_t*)x, y, B, Hi, Wi, Ho, Wo, sh, sw);
+  else if (elem_size == 8)
+    hipLaunchKernelGGL((nearest_label_kernel<int64_t>), dim3(grid), dim3(256), 0, s,
+                       (const int64_t*)x, y, B, Hi, Wi, Ho, Wo, sh, sw);
+  else
+    return nasseg_fail(NASSEG_ERR_ARG, "nearest_label: elem_size %d not supported", elem_size);
+  NASSEG_LAUNCH_CHECK("nearest_label");
+  return NASSEG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+"""Candidate training: end-to-end step (task1), decoder-only step on cached
+encoder features (task0) and the feature cache itself.
+
+Step semantics follow src/engine/trainer.py (populate_task0 :17-74, train_task0
+:78-175, train_segmenter :179-283): LogSoftmax(dim 1) + NLL(ignore 255, mean over
+valid pixels), auxiliary heads weighted by ``aux_weight``, per-sub-module
+gradient-norm clipping, separate encoder / decoder optimisers, optional Polyak
+averaging, one host sync per step for the loss value.  Differences are confined
+to where the work runs: forward, backward and loss are nasseg HIP kernels;
+gradients of data-parallel replicas are all-reduced over RCCL before clipping.
+"""
+import logging
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import functional as F
+from ..helpers.utils import AverageMeter, try_except
+
+logger = logging.getLogger(__name__)
+
+
+def _inner(segmenter):
+    return segmenter.module if hasattr(segmenter, "module") else segmenter
+
+
+def _set_stage(loader, stage):
+    ds = getattr(loader, "dataset", None)
+    if ds is None:
+        return
+    try:
+        ds.set_stage(stage)
+    except AttributeError:
+        sub = getattr(ds, "dataset", None)
+        if sub is not None and hasattr(sub, "set_stage"):
+            sub.set_stage(stage)
+
+
+def _freeze_bn(module):
+    for m in module.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+
+
+def _ignore_index(segm_crit):
+    return int(getattr(segm_crit, "ignore_index", 255))
+
+
+def _to_device_image(image, device):
+    return image.to(device=device, dtype=torch.float32, non_blocking=True).contiguous(
+        memory_format=torch.channels_last)
+
+
+def _model_device(module):
+    return next(module.parameters()).device
+
+
+def _labels(mask, device):
+    if mask.dtype not in (torch.uint8, torch.int64):
+        mask = mask.to(torch.int64)
+    return mask.to(device, non_blocking=True)
+
+
+def _polyak_update(params, avg_param, decay):
+    with torch.no_grad():
+        for p, avg_p in zip(params, avg_param):
+            avg_p.mul_(decay).add_(p.data, alpha=1.0 - decay)
+
+
+def _clip_and_step(groups):
+    """groups: [(parameters, max_norm, optimiser)]"""
+    for params, max_norm, _ in groups:
+        if max_norm > 0:
+            nn.utils.clip_grad_norm_(params, max_norm)
+    for _, _, optim in groups:
+        if optim is not None:
+            optim.step()
+
+
+def _zero_grads(segmenter, optimisers):
+    if hasattr(segmenter, "attach_flat_grads") and getattr(segmenter, "world_size", 1) > 1:
+        segmenter.attach_flat_grads()
+    else:
+        for o in optimisers:
+            if o is not None:
+                o.zero_grad()
+
+
+@try_except
+def populate_task0(segmenter, train_loader, kd_net, n_train, do_kd=False):
+    """Run the encoder (eval, no grad, one image at a time) over ``n_train``
+    samples and keep its feature maps, the nearest-resized labels and optionally
+    the teacher's logits on the device.  Returns the cache dict
+    {0..S-1: (N,C,h,w), 'y': (N,h,w) int64, ['kd_y'], 'out_size': (h,w)}."""
+    cache = defaultdict(list)
+    segmenter.eval()
+    _set_stage(train_loader, "train")
+    if hasattr(train_loader, "batch_sampler") and train_loader.batch_sampler is not None:
+        train_loader.batch_sampler.batch_size = 1
+    model = _inner(segmenter)
+    device = _model_device(model)
+    with torch.no_grad():
+        seen = 0
+        for sample in train_loader:
+            image = _to_device_image(sample["image"], device)
+            feats = model.encoder(image)
+            for i, f in enumerate(feats):
+                cache[i].extend(f.unbind(0))
+            size = feats[0].size()[2:]
+            cache["y"].extend(F.nearest_label_resize(_labels(sample["mask"], device), size).unbind(0))
+            if do_kd:
+                cache["kd_y"].extend(F.bilinear_resize(kd_net(image), size).unbind(0))
+            seen += image.size(0)
+            if seen >= n_train:
+                cache["out_size"] = size
+                logger.info(" Populated Xy_train, N = {}".format(seen))
+                break
+        for k, v in cache.items():
+            if k != "out_size":
+                cache[k] = torch.stack(v)
+    return cache
+
+
+@try_except
+def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch_size, freeze_bn,
+                do_kd, kd_coeff, dec_grad_clip, do_polyak, avg_param=None, polyak_decay=0.9,
+                aux_weight=0):
+    """Decoder-only epoch over the cached encoder features (trainer.py:78-175)."""
+    decoder = _inner(segmenter).decoder
+    n_examples = Xy_train[0].size(0)
+    batch_size = min(batch_size, n_examples)
+    n_passes = n_examples // batch_size
+    indices = np.arange(n_examples)
+    batch_time, losses = AverageMeter(), AverageMeter()
+    decoder.train()
+    if freeze_bn:
+        _freeze_bn(decoder)
+    ignore = _ignore_index(segm_crit)
+    np.random.shuffle(indices)
+    feat_keys = [k for k in Xy_train.keys() if k not in ("y", "kd_y", "out_size")]
+    out_size = tuple(Xy_train["out_size"])
+    for i in range(n_passes):
+        start = time.time()
+        idx = torch.as_tensor(indices[i * batch_size:(i + 1) * batch_size],
+                              device=Xy_train["y"].device)
+        feats = [Xy_train[k][idx] for k in feat_keys]
+        target = Xy_train["y"][idx]
+        output = decoder(feats)
+        aux_outs = []
+        if isinstance(output, tuple):
+            output, aux_outs = output
+        output = F.bilinear_resize(output, out_size)
+        loss = F.log_softmax_nll(output, target, ignore)
+        if do_kd:
+            loss = loss + kd_coeff * kd_crit(output, Xy_train["kd_y"][idx])
+        if aux_weight > 0:
+            for aux_out in aux_outs:
+                aux_out = F.bilinear_resize(aux_out, out_size)
+                loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
+        optim_dec.zero_grad()
+        loss.backward()
+        _clip_and_step([(list(decoder.parameters()), dec_grad_clip, optim_dec)])
+        losses.update(loss.item())
+        batch_time.update(time.time() - start)
+        if do_polyak:
+            _polyak_update(decoder.parameters(), avg_param, polyak_decay)
+    logger.info(" Train epoch: {}\tAvg. Loss: {:.3f}\tAvg. Time: {:.3f}".format(
+        epoch, losses.avg, batch_time.avg))
+
+
+def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=255,
+                   enc_grad_clip=0.0, dec_grad_clip=0.0, aux_weight=-1):
+    """One end-to-end training step on device tensors; returns the (device) loss.
+
+    forward -> nearest-resize labels to the logits' size -> fused log-softmax/NLL
+    (+ weighted aux heads) -> backward -> gradient all-reduce (if data parallel)
+    -> per-sub-module norm clipping -> optimiser steps.
+    """
+    model = _inner(segmenter)
+    output = segmenter(image)
+    aux_outs = []
+    if isinstance(output, tuple):
+        output, aux_outs = output
+    target = F.nearest_label_resize(target, output.size()[2:])
+    loss = F.log_softmax_nll(output, target, ignore_index)
+    if aux_weight > 0:
+        for aux_out in aux_outs:
+            aux_out = F.bilinear_resize(aux_out, target.size()[1:])
+            loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
+    _zero_grads(segmenter, (optim_enc, optim_dec))
+    loss.backward()
+    if hasattr(segmenter, "sync_gradients"):
+        segmenter.sync_gradients()
+    _clip_and_step([
+        (list(model.encoder.parameters()), enc_grad_clip, optim_enc),
+        (list(model.decoder.parameters()), dec_grad_clip, optim_dec),
+    ])
+    return loss
+
+
+@try_except
+def train_segmenter(segmenter, train_loader, optim_enc, optim_dec, epoch, segm_crit, freeze_bn,
+                    enc_grad_clip, dec_grad_clip, do_polyak, print_every=10, aux_weight=-1,
+                    avg_param=None, polyak_decay=0.99):
+    """End-to-end epoch (trainer.py:179-283)."""
+    _set_stage(train_loader, "train")
+    segmenter.train()
+    if freeze_bn:
+        _freeze_bn(segmenter)
+    batch_time, losses = AverageMeter(), AverageMeter()
+    ignore = _ignore_index(segm_crit)
+    device = _model_device(_inner(segmenter))
+    for i, sample in enumerate(train_loader):
+        start = time.time()
+        image = _to_device_image(sample["image"], device)
+        target = _labels(sample["mask"], device)
+        loss = segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore,
+                              enc_grad_clip, dec_grad_clip, aux_weight)
+        if do_polyak:
+            _polyak_update(segmenter.parameters(), avg_param, polyak_decay)
+        losses.update(loss.item())
+        batch_time.update(time.time() - start)
+        if i % print_every == 0:
+            logger.info(" Train epoch: {} [{}/{}]\tAvg. Loss: {:.3f}\tAvg. Time: {:.3f}".format(
+                epoch, i, len(train_loader), losses.avg, batch_time.avg))

@@ -1,0 +1,643 @@
+"""Differentiable host-side wrappers of the nasseg HIP kernels.
+
+Each function here is one ``torch.autograd.Function`` whose forward and backward
+are calls into libnasseg_hip.so (see include/nasseg.h).  PyTorch supplies device
+memory (caching allocator), the current HIP stream and the autograd tape only;
+no ATen compute op runs on the hot path.  Tensors keep the reference's NCHW
+*shape* but live in ``torch.channels_last`` memory, which is the NHWC layout the
+kernels address directly.
+"""
+import torch
+
+from ._lib import NassegError, current_stream, lib, ptr, require_device
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+RED_SUM, RED_SUMSQ, RED_DOT2, RED_DOT1 = 0, 1, 3, 4
+
+
+# ---------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------
+def _cl(x):
+    """fp32 NHWC-contiguous view/copy of a 4-D NCHW-shaped tensor."""
+    require_device(x)
+    if x.dtype != torch.float32:
+        raise NassegError("nasseg kernels are fp32 (got {})".format(x.dtype))
+    if x.dim() != 4:
+        raise NassegError("expected a 4-D activation, got shape {}".format(tuple(x.shape)))
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _new(like, B, C, H, W):
+    return torch.empty((B, C, H, W), device=like.device, dtype=torch.float32,
+                       memory_format=torch.channels_last)
+
+
+def _ws(like, n):
+    return torch.empty((max(int(n), 1),), device=like.device, dtype=torch.float32)
+
+
+def _vec(like, n):
+    return torch.empty((int(n),), device=like.device, dtype=torch.float32)
+
+
+def conv_out_size(size, k, stride, pad, dil):
+    return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def _colred(mode, a, lda, b, ldb, c, ldc, S, R, C, mul=1.0):
+    """[S][nacc][C] sums; nacc = 2 for SUMSQ / DOT2."""
+    nacc = 2 if mode in (RED_SUMSQ, RED_DOT2) else 1
+    out = _vec(a, S * nacc * C)
+    ws = _ws(a, lib.query("nasseg_colred_workspace", S, R, C))
+    lib.call("nasseg_colred", mode, ptr(a), lda, ptr(b), ldb, ptr(c), ldc, ptr(out), ptr(ws),
+             S, R, C, float(mul), current_stream())
+    return out
+
+
+def _affine_act(x, scale, shift, res, act):
+    B, C, H, W = x.shape
+    y = _new(x, B, C, H, W)
+    lib.call("nasseg_affine_act", ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(y), x.numel(), C,
+             act, current_stream())
+    return y
+
+
+def _axpby(a, b, alpha, beta, act=ACT_NONE):
+    B, C, H, W = a.shape
+    y = _new(a, B, C, H, W)
+    lib.call("nasseg_axpby", ptr(a), ptr(b), ptr(alpha), ptr(beta), ptr(y), a.numel(), C, act,
+             current_stream())
+    return y
+
+
+def _act_bwd(dy, ref, act):
+    dx = torch.empty_like(dy)
+    lib.call("nasseg_act_bwd", ptr(dy), ptr(ref), ptr(dx), dy.numel(), act, current_stream())
+    return dx
+
+
+# ---------------------------------------------------------------------------
+# depthwise convolution
+# ---------------------------------------------------------------------------
+class _DepthwiseConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad, dil, relu_in):
+        x = _cl(x)
+        w = weight.contiguous()
+        B, C, H, W = x.shape
+        K = w.shape[-1]
+        if w.shape[0] != C or w.shape[1] != 1 or w.shape[2] != K:
+            raise NassegError("depthwise weight {} does not match C={}".format(tuple(w.shape), C))
+        Ho, Wo = conv_out_size(H, K, stride, pad, dil), conv_out_size(W, K, stride, pad, dil)
+        if Ho <= 0 or Wo <= 0:
+            raise NassegError("depthwise conv output would be empty")
+        s = current_stream()
+        wt = _vec(x, K * K * C)
+        lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
+        y = _new(x, B, C, Ho, Wo)
+        lib.call("nasseg_dwconv", ptr(x), ptr(wt), ptr(y), None, None, B, H, W, C, Ho, Wo, K,
+                 stride, pad, dil, 0, int(relu_in), ACT_NONE, s)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, dil, bool(relu_in))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, relu_in = ctx.cfg
+        dy = _cl(dy)
+        B, C, H, W = x.shape
+        K = w.shape[-1]
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        s = current_stream()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = _vec(x, K * K * C)
+            dx = _new(x, B, C, H, W)
+            padb = dil * (K - 1) - pad
+            if stride == 1 and padb >= 0:
+                # correlation with the 180-degree rotated kernel
+                lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 1, s)
+                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, B, Ho, Wo, C, H, W,
+                         K, 1, padb, dil, 0, 0, ACT_NONE, s)
+            else:
+                lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
+                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, B, Ho, Wo, C, H, W,
+                         K, stride, pad, dil, 1, 0, ACT_NONE, s)
+            if relu_in:
+                dx = _act_bwd(dx, x, ACT_RELU)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws = _ws(x, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, K))
+            lib.call("nasseg_dwconv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, Ho, Wo,
+                     K, stride, pad, dil, int(relu_in), s)
+        return dx, dw, None, None, None, None
+
+
+def depthwise_conv2d(x, weight, stride=1, padding=0, dilation=1, relu_in=False):
+    """groups == channels convolution; ``relu_in`` fuses a preceding ReLU (DilConv)."""
+    return _DepthwiseConv.apply(x, weight, int(stride), int(padding), int(dilation), bool(relu_in))
+
+
+# ---------------------------------------------------------------------------
+# dense convolution (1x1 and k x k) on the fp32 matrix cores
+# ---------------------------------------------------------------------------
+def _pack_dense(w, mode):
+    N, K, kh, kw = w.shape
+    if kh == 1 and kw == 1 and mode == 0:
+        return w  # (N,K,1,1) contiguous already is [tap=0][N][K]
+    wp = _vec(w, w.numel())
+    lib.call("nasseg_conv_pack_weight", ptr(w), ptr(wp), N, K, kh, kw, mode, current_stream())
+    return wp
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        x = _cl(x)
+        w = weight.contiguous()
+        B, K, H, W = x.shape
+        N, Kw, kh, kw = w.shape
+        if Kw != K:
+            raise NassegError("conv weight {} does not match C_in={}".format(tuple(w.shape), K))
+        Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+        if Ho <= 0 or Wo <= 0:
+            raise NassegError("conv output would be empty")
+        y = _new(x, B, N, Ho, Wo)
+        wp = _pack_dense(w, 0)
+        lib.call("nasseg_conv_fwd", ptr(x), K, ptr(wp), ptr(y), N, None, None, 0, None, ptr(bias),
+                 ACT_NONE, None, 0, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0,
+                 current_stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, dil, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, dil, has_bias = ctx.cfg
+        dy = _cl(dy)
+        B, K, H, W = x.shape
+        N, _, kh, kw = w.shape
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        s = current_stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(x, B, K, H, W)
+            wp = _pack_dense(w, 1)
+            lib.call("nasseg_conv_fwd", ptr(dy), N, ptr(wp), ptr(dx), K, None, None, 0, None, None,
+                     ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, s)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
+            lib.call("nasseg_conv_wgrad", ptr(x), K, ptr(dy), N, ptr(dw), ptr(ws), None, None, 0, B,
+                     H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colred(RED_SUM, dy, N, None, 0, None, 0, 1, B * Ho * Wo, N)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
+    """Dense convolution, groups == 1 (nn.Conv2d semantics, square stride/pad/dilation)."""
+    return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation))
+
+
+# ---------------------------------------------------------------------------
+# BatchNorm (+ activation, + residual)
+# ---------------------------------------------------------------------------
+class _BatchNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, nbt, training, momentum, eps, act,
+                residual):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        M = B * H * W
+        s = current_stream()
+        stats = _vec(x, 4 * C)  # mean | invstd | scale | shift
+        mean, invstd, scale, shift = stats[0:C], stats[C:2 * C], stats[2 * C:3 * C], stats[3 * C:]
+        if training:
+            if M <= 1:
+                # same condition and exception class as torch.nn.functional.batch_norm
+                raise ValueError(
+                    "Expected more than 1 value per channel when training, got input size {}".format(
+                        tuple(x.shape)))
+            ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
+            lib.call("nasseg_bn_stats", ptr(x), C, M, C, float(eps), float(momentum), ptr(gamma),
+                     ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(running_mean),
+                     ptr(running_var), ptr(nbt), ptr(ws), s)
+        else:
+            lib.call("nasseg_bn_eval_params", C, float(eps), ptr(gamma), ptr(beta),
+                     ptr(running_mean), ptr(running_var), ptr(mean), ptr(invstd), ptr(scale),
+                     ptr(shift), s)
+        res = _cl(residual) if residual is not None else None
+        y = _affine_act(x, scale, shift, res, act)
+        ctx.save_for_backward(x, stats)
+        ctx.cfg = (bool(training), act, residual is not None, gamma is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, stats = ctx.saved_tensors
+        training, act, has_res, affine = ctx.cfg
+        dy = _cl(dy)
+        B, C, H, W = x.shape
+        M = B * H * W
+        mean, invstd, scale, shift = stats[0:C], stats[C:2 * C], stats[2 * C:3 * C], stats[3 * C:]
+        s = current_stream()
+        sums = _vec(x, 2 * C)
+        ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
+        lib.call("nasseg_bn_bwd_reduce", ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift),
+                 ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            lib.call("nasseg_bn_bwd_apply", ptr(dy), ptr(x), ptr(scale), ptr(shift), ptr(mean),
+                     ptr(invstd), ptr(sums), M, C, int(training), act, ptr(dx), s)
+        dgamma = sums[C:2 * C] if (affine and ctx.needs_input_grad[1]) else None
+        dbeta = sums[0:C] if (affine and ctx.needs_input_grad[2]) else None
+        dres = dy if (has_res and ctx.needs_input_grad[10]) else None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, dres
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, num_batches_tracked, training,
+                   momentum=0.1, eps=1e-5, act=ACT_NONE, residual=None):
+    """y = act(BN(x)) (+ residual).  Training mode updates the running buffers in place."""
+    return _BatchNormAct.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked,
+                               bool(training), momentum, eps, int(act), residual)
+
+
+# ---------------------------------------------------------------------------
+# pooling
+# ---------------------------------------------------------------------------
+class _Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode, k, stride, pad):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        Ho, Wo = conv_out_size(H, k, stride, pad, 1), conv_out_size(W, k, stride, pad, 1)
+        y = _new(x, B, C, Ho, Wo)
+        idx = None
+        if mode == 0:
+            idx = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.uint8)
+        lib.call("nasseg_pool_fwd", mode, ptr(x), ptr(y), ptr(idx), B, H, W, C, Ho, Wo, k, stride,
+                 pad, current_stream())
+        ctx.cfg = (mode, k, stride, pad, (B, C, H, W))
+        ctx.idx = idx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mode, k, stride, pad, (B, C, H, W) = ctx.cfg
+        dy = _cl(dy)
+        dx = _new(dy, B, C, H, W)
+        lib.call("nasseg_pool_bwd", mode, ptr(dy), ptr(ctx.idx), ptr(dx), B, H, W, C, dy.shape[2],
+                 dy.shape[3], k, stride, pad, current_stream())
+        return dx, None, None, None, None
+
+
+def max_pool2d(x, kernel_size=3, stride=1, padding=1):
+    return _Pool.apply(x, 0, int(kernel_size), int(stride), int(padding))
+
+
+def avg_pool2d(x, kernel_size=3, stride=1, padding=1):
+    """count_include_pad=False semantics."""
+    return _Pool.apply(x, 1, int(kernel_size), int(stride), int(padding))
+
+
+# ---------------------------------------------------------------------------
+# bilinear resize, concat
+# ---------------------------------------------------------------------------
+class _Bilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        y = _new(x, B, C, Ho, Wo)
+        lib.call("nasseg_bilinear_fwd", ptr(x), ptr(y), C, 0, B, H, W, C, Ho, Wo, ACT_NONE,
+                 current_stream())
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = _cl(dy)
+        dx = _new(dy, B, C, H, W)
+        lib.call("nasseg_bilinear_bwd", ptr(dy), C, 0, ptr(dx), B, H, W, C, dy.shape[2],
+                 dy.shape[3], current_stream())
+        return dx, None, None
+
+
+def bilinear_resize(x, size):
+    """nn.Upsample(size, mode='bilinear') / F.interpolate(..., align_corners=False)."""
+    Ho, Wo = int(size[0]), int(size[1])
+    if tuple(x.shape[2:]) == (Ho, Wo):
+        return x
+    return _Bilinear.apply(x, Ho, Wo)
+
+
+class _ConcatResize(torch.autograd.Function):
+    """cat(dim=1) of tensors, each bilinearly resized to (Ho, Wo) when needed,
+    written straight into the output slab, with an optional fused ReLU."""
+
+    @staticmethod
+    def forward(ctx, Ho, Wo, act, *xs):
+        xs = [_cl(x) for x in xs]
+        B = xs[0].shape[0]
+        Ct = sum(x.shape[1] for x in xs)
+        y = _new(xs[0], B, Ct, Ho, Wo)
+        s = current_stream()
+        off = 0
+        shapes = []
+        for x in xs:
+            _, C, H, W = x.shape
+            if x.shape[0] != B:
+                raise NassegError("concat: batch sizes differ")
+            if (H, W) == (Ho, Wo):
+                lib.call("nasseg_chan_copy", ptr(x), C, 0, ptr(y), Ct, off, None, 0, 0, B * Ho * Wo,
+                         C, act, ACT_NONE, s)
+            else:
+                lib.call("nasseg_bilinear_fwd", ptr(x), ptr(y), Ct, off, B, H, W, C, Ho, Wo, act, s)
+            shapes.append((C, H, W))
+            off += C
+        ctx.shapes = shapes
+        ctx.act = act
+        if act != ACT_NONE:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _cl(dy)
+        B, Ct, Ho, Wo = dy.shape
+        s = current_stream()
+        if ctx.act != ACT_NONE:
+            (y,) = ctx.saved_tensors
+            dy = _act_bwd(dy, y, ctx.act)
+        grads = []
+        off = 0
+        for i, (C, H, W) in enumerate(ctx.shapes):
+            if not ctx.needs_input_grad[3 + i]:
+                grads.append(None)
+                off += C
+                continue
+            dx = _new(dy, B, C, H, W)
+            if (H, W) == (Ho, Wo):
+                lib.call("nasseg_chan_copy", ptr(dy), Ct, off, ptr(dx), C, 0, None, 0, 0,
+                         B * Ho * Wo, C, ACT_NONE, ACT_NONE, s)
+            else:
+                lib.call("nasseg_bilinear_bwd", ptr(dy), Ct, off, ptr(dx), B, H, W, C, Ho, Wo, s)
+            grads.append(dx)
+            off += C
+        return (None, None, None) + tuple(grads)
+
+
+def concat_resize(tensors, size, relu=False):
+    return _ConcatResize.apply(int(size[0]), int(size[1]), ACT_RELU if relu else ACT_NONE, *tensors)
+
+
+# ---------------------------------------------------------------------------
+# elementwise
+# ---------------------------------------------------------------------------
+class _Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _cl(a), _cl(b)
+        if a.shape != b.shape:
+            raise NassegError("add: shapes {} and {} differ".format(tuple(a.shape), tuple(b.shape)))
+        return _axpby(a, b, None, None)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return _Add.apply(a, b)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        y = _axpby(x, None, None, None, ACT_RELU)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return _act_bwd(_cl(dy), y, ACT_RELU)
+
+
+def relu(x):
+    return _ReLU.apply(x)
+
+
+class _ParamSum(torch.autograd.Function):
+    """a[c]*x + b[c]*y  (ParamSum, src/nn/layer_factory.py:353-366)."""
+
+    @staticmethod
+    def forward(ctx, x, y, a, b):
+        x, y = _cl(x), _cl(y)
+        if x.shape != y.shape:
+            raise NassegError("psum: shapes {} and {} differ".format(tuple(x.shape), tuple(y.shape)))
+        a, b = a.contiguous(), b.contiguous()
+        out = _axpby(x, y, a, b)
+        ctx.save_for_backward(x, y, a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, a, b = ctx.saved_tensors
+        dy = _cl(dy)
+        B, C, H, W = x.shape
+        dx = _axpby(dy, None, a, None) if ctx.needs_input_grad[0] else None
+        dyy = _axpby(dy, None, b, None) if ctx.needs_input_grad[1] else None
+        da = db = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            sums = _colred(RED_DOT2, dy, C, x, C, y, C, 1, B * H * W, C)
+            da, db = sums[0:C], sums[C:2 * C]
+        return dx, dyy, da, db
+
+
+def param_sum(x, y, a, b):
+    return _ParamSum.apply(x, y, a, b)
+
+
+class _ChannelRepeat(torch.autograd.Function):
+    """x.repeat(1, rep, 1, 1)  (Skip / Zero, src/nn/layer_factory.py:268-297)."""
+
+    @staticmethod
+    def forward(ctx, x, rep):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        y = _new(x, B, C * rep, H, W)
+        s = current_stream()
+        for r in range(rep):
+            lib.call("nasseg_chan_copy", ptr(x), C, 0, ptr(y), C * rep, r * C, None, 0, 0, B * H * W,
+                     C, ACT_NONE, ACT_NONE, s)
+        ctx.cfg = (rep, (B, C, H, W))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rep, (B, C, H, W) = ctx.cfg
+        dy = _cl(dy)
+        dx = _new(dy, B, C, H, W)
+        lib.call("nasseg_chan_fold", ptr(dy), ptr(dx), B * H * W, C, rep, current_stream())
+        return dx, None
+
+
+def channel_repeat(x, rep):
+    if rep == 1:
+        # torch's repeat always copies; values are what matter downstream
+        return _ChannelRepeat.apply(x, 1)
+    return _ChannelRepeat.apply(x, int(rep))
+
+
+def zeros(like, B, C, H, W):
+    """A zero activation that is not connected to the autograd graph (Zero op)."""
+    require_device(like)
+    y = _new(like, B, C, H, W)
+    lib.call("nasseg_fill", ptr(y), y.numel(), 0.0, current_stream())
+    return y
+
+
+# ---------------------------------------------------------------------------
+# global average pooling and its broadcast
+# ---------------------------------------------------------------------------
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        out = _colred(RED_SUM, x, C, None, 0, None, 0, B, H * W, C, 1.0 / (H * W))
+        ctx.shape = (B, C, H, W)
+        return out.view(B, C, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = dy.contiguous().view(B, C, 1, 1)
+        # every pixel receives dy / (H*W): a broadcast with a scale
+        scale = _vec(dy, C)
+        lib.call("nasseg_fill", ptr(scale), C, 1.0 / (H * W), current_stream())
+        dx = _new(dy, B, C, H, W)
+        lib.call("nasseg_bilinear_fwd", ptr(dy), ptr(dx), C, 0, B, 1, 1, C, H, W, ACT_NONE,
+                 current_stream())
+        return _axpby(dx, None, scale, None)
+
+
+def global_avg_pool(x):
+    """x.mean(2, keepdim=True).mean(3, keepdim=True) -> (B, C, 1, 1)."""
+    return _GlobalAvgPool.apply(x)
+
+
+class _Broadcast(torch.autograd.Function):
+    """Bilinear interpolation from a 1x1 map = broadcast over (H, W)."""
+
+    @staticmethod
+    def forward(ctx, v, H, W):
+        require_device(v)
+        B, C = v.shape[0], v.shape[1]
+        v = v.contiguous().view(B, C, 1, 1)
+        y = _new(v, B, C, H, W)
+        lib.call("nasseg_bilinear_fwd", ptr(v), ptr(y), C, 0, B, 1, 1, C, H, W, ACT_NONE,
+                 current_stream())
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        dy = _cl(dy)
+        dv = _colred(RED_SUM, dy, C, None, 0, None, 0, B, H * W, C)
+        return dv.view(B, C, 1, 1), None, None
+
+
+def broadcast_to(v, size):
+    return _Broadcast.apply(v, int(size[0]), int(size[1]))
+
+
+# ---------------------------------------------------------------------------
+# loss and reward
+# ---------------------------------------------------------------------------
+def _label_tensor(target):
+    require_device(target)
+    if target.dtype == torch.int64:
+        return target.contiguous(), 8
+    if target.dtype == torch.uint8:
+        return target.contiguous(), 1
+    raise NassegError("labels must be int64 or uint8 (got {})".format(target.dtype))
+
+
+class _LogSoftmaxNLL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits = _cl(logits)
+        B, C, H, W = logits.shape
+        target, esz = _label_tensor(target)
+        if tuple(target.shape) != (B, H, W):
+            raise NassegError("loss: target {} does not match logits {}".format(
+                tuple(target.shape), tuple(logits.shape)))
+        out = _vec(logits, 2)
+        ws = _ws(logits, lib.query("nasseg_ce_workspace"))
+        lib.call("nasseg_ce_fwd", ptr(logits), ptr(target), esz, B * H * W, C, int(ignore_index),
+                 ptr(out), ptr(ws), current_stream())
+        ctx.save_for_backward(logits, target, out)
+        ctx.cfg = (esz, int(ignore_index))
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, out = ctx.saved_tensors
+        esz, ignore = ctx.cfg
+        B, C, H, W = logits.shape
+        g = g.to(torch.float32).contiguous().view(1)
+        d = torch.empty_like(logits)
+        lib.call("nasseg_ce_bwd", ptr(logits), ptr(target), esz, ptr(out), ptr(g), B * H * W, C,
+                 ignore, ptr(d), current_stream())
+        return d, None, None
+
+
+def log_softmax_nll(logits, target, ignore_index=255):
+    """nn.NLLLoss2d(ignore_index)(nn.LogSoftmax()(logits), target) -> 0-dim tensor."""
+    return _LogSoftmaxNLL.apply(logits, target, ignore_index)
+
+
+def nearest_label_resize(target, size):
+    """F.interpolate(target[:, None].float(), size, mode='nearest').long()[:, 0]."""
+    target, esz = _label_tensor(target)
+    B, H, W = target.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = torch.empty((B, Ho, Wo), device=target.device, dtype=torch.int64)
+    lib.call("nasseg_nearest_label", ptr(target), esz, ptr(y), B, H, W, Ho, Wo, current_stream())
+    return y
+
+
+def argmax_confusion(logits, gt, n_classes, cm=None, out_size=None, return_preds=False):
+    """Fused bilinear up-sampling -> argmax -> uint8 -> confusion-matrix update.
+
+    logits (B,C,h,w) fp32 on device, gt (B,H,W) uint8 on device; ``cm`` is an
+    int64 (n,n) device tensor that is accumulated into (created when None).
+    """
+    logits = _cl(logits.detach())
+    B, C, h, w = logits.shape
+    preds = None
+    if gt is not None:
+        require_device(gt)
+        if gt.dtype != torch.uint8:
+            raise NassegError("gt must be uint8")
+        gt = gt.contiguous()
+        H, W = gt.shape[1], gt.shape[2]
+        if cm is None:
+            cm = torch.zeros((n_classes, n_classes), device=logits.device, dtype=torch.int64)
+    else:
+        H, W = (int(out_size[0]), int(out_size[1])) if out_size is not None else (h, w)
+    if return_preds:
+        preds = torch.empty((B, H, W), device=logits.device, dtype=torch.uint8)
+    lib.call("nasseg_argmax_cm", ptr(logits), ptr(gt), ptr(preds), B, h, w, C, H, W,
+             int(n_classes), ptr(cm) if gt is not None else None, current_stream())
+    return (cm, preds) if return_preds else cm

@@ -1,0 +1,326 @@
+"""Op registry of the search space, backed by the nasseg HIP kernels.
+
+Plugin boundary of the reference (src/nn/layer_factory.py:27-91):
+
+    OPS[name](C_in, C_out, stride, affine, repeats=1)               -> nn.Module
+    AGG_OPS[name](C_in0, C_in1, C_out, affine, repeats=1, larger=True) -> nn.Module
+
+with ``forward(x)`` / ``forward(x, y)`` over NCHW-shaped fp32 tensors.  Keys,
+signatures, module tree (hence ``state_dict`` names and parameter shapes),
+default initialisation order and the documented quirks of the reference
+(Skip ignores ``stride``; a strided SepConv strides in *every* repeat; Pool is
+1x1 conv + BN *then* pooling; resize() compares sizes lexicographically) are
+kept.  Every leaf runs on gfx950 through ``functional``; nothing falls back to
+ATen.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from .modules import AvgPool2d, BatchNorm2d, Conv2d, FusedSequential, MaxPool2d, ReLU, ReLU6
+
+
+# ---------------------------------------------------------------------------
+# small builders (reference: layer_factory.py:7-24,94-122)
+# ---------------------------------------------------------------------------
+def conv3x3(in_planes, out_planes, stride=1, bias=False, dilation=1):
+    """3x3 convolution, 'same' padding for the given dilation."""
+    return Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=dilation,
+                  dilation=dilation, bias=bias)
+
+
+def conv1x1(in_planes, out_planes, stride=1, bias=False):
+    return Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, padding=0, bias=bias)
+
+
+def conv_bn(C_in, C_out, kernel_size, stride, padding, affine=True):
+    return FusedSequential(
+        Conv2d(C_in, C_out, kernel_size, stride=stride, padding=padding, bias=False),
+        BatchNorm2d(C_out, affine=affine),
+    )
+
+
+def conv_bn_relu(C_in, C_out, kernel_size, stride, padding, affine=True):
+    return FusedSequential(
+        Conv2d(C_in, C_out, kernel_size, stride=stride, padding=padding, bias=False),
+        BatchNorm2d(C_out, affine=affine),
+        ReLU(inplace=False),
+    )
+
+
+def conv_bn_relu6(inp, oup, stride):
+    return FusedSequential(Conv2d(inp, oup, 3, stride, 1, bias=False), BatchNorm2d(oup),
+                           ReLU6(inplace=True))
+
+
+def conv_1x1_bn_relu6(inp, oup):
+    return FusedSequential(Conv2d(inp, oup, 1, 1, 0, bias=False), BatchNorm2d(oup),
+                           ReLU6(inplace=True))
+
+
+def _dense_bn_relu(C_in, C_out, ksize, stride, affine, dilation=1):
+    conv = conv1x1(C_in, C_out, stride=stride) if ksize == 1 else conv3x3(
+        C_in, C_out, stride=stride, dilation=dilation)
+    return FusedSequential(conv, BatchNorm2d(C_out, affine=affine), ReLU(inplace=False))
+
+
+# ---------------------------------------------------------------------------
+# encoder block (reference: layer_factory.py:125-158)
+# ---------------------------------------------------------------------------
+class InvertedResidual(nn.Module):
+    """MobileNetV2 block: 1x1 expand (also when t == 1) -> 3x3 depthwise -> 1x1 linear."""
+
+    def __init__(self, inp, oup, stride, expand_ratio):
+        super(InvertedResidual, self).__init__()
+        assert stride in [1, 2]
+        self.stride = stride
+        self.use_res_connect = stride == 1 and inp == oup
+        hidden = inp * expand_ratio
+        self.conv = FusedSequential(
+            Conv2d(inp, hidden, 1, 1, 0, bias=False),
+            BatchNorm2d(hidden),
+            ReLU6(inplace=True),
+            Conv2d(hidden, hidden, 3, stride, 1, groups=hidden, bias=False),
+            BatchNorm2d(hidden),
+            ReLU6(inplace=True),
+            Conv2d(hidden, oup, 1, 1, 0, bias=False),
+            BatchNorm2d(oup),
+        )
+
+    def forward(self, x):
+        # the skip connection is fused into the last BatchNorm's epilogue
+        return self.conv(x, residual=x if self.use_res_connect else None)
+
+
+# ---------------------------------------------------------------------------
+# cell primitives
+# ---------------------------------------------------------------------------
+class Pool(nn.Module):
+    """1x1 conv + BN (no activation) followed by 3x3 pooling (layer_factory.py:161-178)."""
+
+    def __init__(self, C_in, C_out, stride, repeats, ksize, mode):
+        super(Pool, self).__init__()
+        self.conv1x1 = conv_bn(C_in, C_out, 1, 1, 0)
+        if mode == "avg":
+            self.pool = AvgPool2d(ksize, stride=stride, padding=(ksize // 2),
+                                  count_include_pad=False)
+        elif mode == "max":
+            self.pool = MaxPool2d(ksize, stride=stride, padding=(ksize // 2))
+        else:
+            raise ValueError("Unknown pooling method {}".format(mode))
+
+    def forward(self, x):
+        return self.pool(self.conv1x1(x))
+
+
+class GAPConv1x1(nn.Module):
+    """Global average pool -> 1x1 conv + BN + ReLU on (B,C,1,1) -> broadcast back
+    (layer_factory.py:181-195; bilinear interpolation from 1x1 is a broadcast)."""
+
+    def __init__(self, C_in, C_out):
+        super(GAPConv1x1, self).__init__()
+        self.conv1x1 = conv_bn_relu(C_in, C_out, 1, stride=1, padding=0)
+
+    def forward(self, x):
+        size = x.size()[2:]
+        pooled = F.global_avg_pool(x)
+        return F.broadcast_to(self.conv1x1(pooled), size)
+
+
+class DilConv(nn.Module):
+    """ReLU -> dilated depthwise -> 1x1 -> BN (layer_factory.py:198-222)."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, dilation, affine=True):
+        super(DilConv, self).__init__()
+        self.op = FusedSequential(
+            ReLU(inplace=False),
+            Conv2d(C_in, C_in, kernel_size=kernel_size, stride=stride, padding=padding,
+                   dilation=dilation, groups=C_in, bias=False),
+            Conv2d(C_in, C_out, kernel_size=1, padding=0, bias=False),
+            BatchNorm2d(C_out, affine=affine),
+        )
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class SepConv(nn.Module):
+    """``repeats`` x [depthwise k x k -> 1x1 -> BN -> ReLU]; the stride applies to
+    every repeat (layer_factory.py:225-265)."""
+
+    def __init__(self, C_in, C_out, kernel_size, stride, padding, dilation=1, affine=True,
+                 repeats=1):
+        super(SepConv, self).__init__()
+        self.op = FusedSequential()
+        width = C_in
+        for idx in range(repeats):
+            stage = FusedSequential(
+                Conv2d(width, width, kernel_size=kernel_size, stride=stride, padding=padding,
+                       dilation=dilation, groups=width, bias=False),
+                Conv2d(width, C_out, kernel_size=1, padding=0, bias=False),
+                BatchNorm2d(C_out, affine=affine),
+                ReLU(inplace=False),
+            )
+            self.op.add_module("sep_{}".format(idx), stage)
+            width = C_out
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class Skip(nn.Module):
+    """Channel repeat; ``stride`` is accepted and ignored (layer_factory.py:268-275)."""
+
+    def __init__(self, C_in, C_out, stride):
+        super(Skip, self).__init__()
+        assert (C_out % C_in) == 0, "C_out must be divisible by C_in"
+        self.repeats = (1, C_out // C_in, 1, 1)
+
+    def forward(self, x):
+        return F.channel_repeat(x, self.repeats[1])
+
+
+class Identity(nn.Module):
+    def __init__(self):
+        super(Identity, self).__init__()
+
+    def forward(self, x):
+        return x
+
+
+class Zero(nn.Module):
+    """Zeros of the (channel-repeated, spatially strided) input shape (layer_factory.py:286-297)."""
+
+    def __init__(self, C_in, C_out, stride):
+        super(Zero, self).__init__()
+        self.stride = stride
+        assert (C_out % C_in) == 0, "C_out must be divisible by C_in"
+        self.repeats = (1, C_out // C_in, 1, 1)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        s = self.stride
+        return F.zeros(x, B, C * self.repeats[1], (H + s - 1) // s, (W + s - 1) // s)
+
+
+def resize(x1, x2, largest=True):
+    """Bilinearly bring the two maps to a common size: the larger one if
+    ``largest`` else the smaller.  Sizes are compared as (H, W) tuples, i.e.
+    lexicographically, exactly like torch.Size (layer_factory.py:338-350)."""
+    s1, s2 = tuple(x1.size()[2:]), tuple(x2.size()[2:])
+    if s1 == s2:
+        return x1, x2
+    first_is_target = (s1 > s2) if largest else (s1 < s2)
+    if first_is_target:
+        return x1, F.bilinear_resize(x2, s1)
+    return F.bilinear_resize(x1, s2), x2
+
+
+class Adapt(nn.Module):
+    """Optional 1x1 conv+BN+ReLU per input to ``C_out`` channels, then resize()
+    (layer_factory.py:316-335)."""
+
+    def __init__(self, C_in0, C_in1, C_out, larger):
+        super(Adapt, self).__init__()
+        self.C_in0, self.C_in1, self.C_out = C_in0, C_in1, C_out
+        if C_in0 != C_out:
+            self.conv0 = conv_bn_relu(C_in0, C_out, 1, 1, 0)
+        if C_in1 != C_out:
+            self.conv1 = conv_bn_relu(C_in1, C_out, 1, 1, 0)
+        self.larger = larger
+
+    def forward(self, x1, x2):
+        if self.C_in0 != self.C_out:
+            x1 = self.conv0(x1)
+        if self.C_in1 != self.C_out:
+            x2 = self.conv1(x2)
+        return resize(x1, x2, self.larger)
+
+
+class ParamSum(nn.Module):
+    """a[c]*x + b[c]*y with learnable per-channel a, b (layer_factory.py:353-366)."""
+
+    def __init__(self, C_in0, C_in1, C_out, larger):
+        super(ParamSum, self).__init__()
+        self.adapt = Adapt(C_in0, C_in1, C_out, larger)
+        self.a = nn.Parameter(torch.ones(C_out))
+        self.b = nn.Parameter(torch.ones(C_out))
+
+    def forward(self, x, y):
+        x, y = self.adapt(x, y)
+        return F.param_sum(x, y, self.a, self.b)
+
+
+class ConcatReduce(nn.Module):
+    """cat -> BN(2C) -> ReLU -> 1x1 (2C -> C) (layer_factory.py:369-382)."""
+
+    def __init__(self, C_in0, C_in1, C_out, affine=True, repeats=1, larger=True):
+        super(ConcatReduce, self).__init__()
+        self.adapt = Adapt(C_in0, C_in1, C_out, larger)
+        self.conv1x1 = FusedSequential(
+            BatchNorm2d(2 * C_out, affine=affine),
+            ReLU(inplace=False),
+            Conv2d(2 * C_out, C_out, 1, stride=1, padding=0, bias=False),
+        )
+
+    def forward(self, x, y):
+        x, y = self.adapt(x, y)
+        if tuple(x.shape[2:]) != tuple(y.shape[2:]):
+            # torch.cat would refuse; same exception class so try_except scores the candidate 0
+            raise RuntimeError("Sizes of tensors must match except in dimension 1")
+        z = F.concat_resize([x, y], x.shape[2:])
+        return self.conv1x1(z)
+
+
+# ---------------------------------------------------------------------------
+# registries
+# ---------------------------------------------------------------------------
+# separable convs: name -> (kernel, padding, dilation)
+_SEP_GEOMETRY = {
+    "sep_conv_3x3": (3, 1, 1),
+    "sep_conv_5x5": (5, 2, 1),
+    "sep_conv_7x7": (7, 3, 1),
+    "sep_conv_3x3_dil3": (3, 3, 3),
+    "sep_conv_5x5_dil6": (5, 12, 6),
+}
+# DARTS-style dilated convs: name -> (kernel, padding, dilation)
+_DIL_GEOMETRY = {"dil_conv_3x3": (3, 2, 2), "dil_conv_5x5": (5, 4, 2)}
+# dense conv + BN + ReLU: name -> (kernel, dilation)
+_DENSE_GEOMETRY = {"conv1x1": (1, 1), "conv3x3": (3, 1), "conv3x3_dil3": (3, 3),
+                   "conv3x3_dil12": (3, 12)}
+
+
+def _sep_factory(k, p, d):
+    return lambda C_in, C_out, stride, affine, repeats=1: SepConv(
+        C_in, C_out, k, stride, p, dilation=d, affine=affine, repeats=repeats)
+
+
+def _dil_factory(k, p, d):
+    return lambda C_in, C_out, stride, affine, repeats=1: DilConv(
+        C_in, C_out, k, stride, p, d, affine=affine)
+
+
+def _dense_factory(k, d):
+    return lambda C_in, C_out, stride, affine, repeats=1: _dense_bn_relu(
+        C_in, C_out, k, stride, affine, dilation=d)
+
+
+OPS = {
+    "none": lambda C_in, C_out, stride, affine, repeats=1: Zero(C_in, C_out, stride),
+    "avg_pool_3x3": lambda C_in, C_out, stride, affine, repeats=1: Pool(
+        C_in, C_out, stride, repeats, ksize=3, mode="avg"),
+    "max_pool_3x3": lambda C_in, C_out, stride, affine, repeats=1: Pool(
+        C_in, C_out, stride, repeats, ksize=3, mode="max"),
+    "global_average_pool": lambda C_in, C_out, stride, affine, repeats=1: GAPConv1x1(C_in, C_out),
+    "skip_connect": lambda C_in, C_out, stride, affine, repeats=1: Skip(C_in, C_out, stride),
+}
+OPS.update({name: _sep_factory(*geo) for name, geo in _SEP_GEOMETRY.items()})
+OPS.update({name: _dil_factory(*geo) for name, geo in _DIL_GEOMETRY.items()})
+OPS.update({name: _dense_factory(*geo) for name, geo in _DENSE_GEOMETRY.items()})
+
+AGG_OPS = {
+    "psum": lambda C_in0, C_in1, C_out, affine, repeats=1, larger=True: ParamSum(
+        C_in0, C_in1, C_out, larger),
+    "cat": lambda C_in0, C_in1, C_out, affine, repeats=1, larger=True: ConcatReduce(
+        C_in0, C_in1, C_out, affine=affine, repeats=repeats, larger=larger),
+}
