@@ -1,0 +1,513 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; the GPU box never has
+it).  The reference is imported unmodified from /root/reference/src; its engine
+functions hard-code ``.cuda()``, so ``Tensor.cuda`` / ``Module.cuda`` are made
+identity for the duration of this script.  The Cython module
+src/helpers/miou_utils.pyx does not compile under Cython 3 + NumPy 2 as is
+(removed ``np.int_t`` / ``np.float_t`` aliases); a copy under /tmp gets a
+type-alias-only edit (np.int_t -> np.int64_t, np.float_t -> np.float64_t,
+np.int_ -> np.int64) and is built there - nothing of the reference is written
+into the repository, only inputs and outputs (data) are.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, *.json
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+np.int = int  # src/helpers/storage.py:20 uses the removed alias
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+TMP = "/tmp/nasseg_golden"
+
+sys.path[:0] = [os.path.join(REF, "src"), REF]
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def build_cython():
+    hdir = os.path.join(TMP, "helpers")
+    os.makedirs(hdir, exist_ok=True)
+    src = open(os.path.join(REF, "src/helpers/miou_utils.pyx")).read()
+    src = src.replace("np.int_t", "np.int64_t").replace("np.float_t", "np.float64_t")
+    src = src.replace("dtype=np.int_)", "dtype=np.int64)")
+    open(os.path.join(hdir, "miou_utils.pyx"), "w").write(src)
+    setup = (
+        "from setuptools import setup, Extension\nfrom Cython.Build import cythonize\nimport numpy\n"
+        "setup(ext_modules=cythonize([Extension('helpers.miou_utils', ['helpers/miou_utils.pyx'],"
+        " include_dirs=[numpy.get_include()])], language_level=2))\n"
+    )
+    open(os.path.join(TMP, "setup.py"), "w").write(setup)
+    subprocess.check_call([sys.executable, "setup.py", "-q", "build_ext", "--inplace"], cwd=TMP)
+    sys.path.insert(0, TMP)
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+class Store(object):
+    def __init__(self):
+        self.d = {}
+
+    def put(self, key, value):
+        if isinstance(value, torch.Tensor):
+            value = t2n(value)
+        self.d[key] = np.array(value, copy=True)  # never alias live module buffers
+
+    def put_sd(self, prefix, sd):
+        for k, v in sd.items():
+            self.put(prefix + "/" + k, v)
+
+    def save(self, name):
+        path = os.path.join(OUT, name)
+        np.savez_compressed(path, **self.d)
+        print("wrote", path, "{:.1f} KB".format(os.path.getsize(path) / 1024.0), len(self.d), "arrays")
+
+
+def randomize_bn(module, gen):
+    for m in module.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+
+
+def checksums(sd):
+    """per-key (sum, abs-sum) in float64 - pins seeded initialisation without storing weights"""
+    return {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------------------
+# A. op registry
+# ---------------------------------------------------------------------------
+def gen_ops():
+    from nn.layer_factory import AGG_OPS, OPS
+
+    st = Store()
+    cases = []
+    gen = torch.Generator().manual_seed(1234)
+    for name in sorted(OPS.keys()):
+        for stride in (1, 2):
+            C_in, C_out = 8, (8 if stride == 1 else 16)
+            case = "{}__s{}".format(name, stride)
+            torch.manual_seed(100 + len(cases))
+            mod = OPS[name](C_in, C_out, stride, True, 2)
+            randomize_bn(mod, gen)
+            x = torch.randn(2, C_in, 13, 17, generator=gen)
+            st.put(case + "/x", x)
+            st.put_sd(case + "/sd", mod.state_dict())
+            mod.eval()
+            with torch.no_grad():
+                st.put(case + "/y_eval", mod(x))
+            mod.train()
+            xg = x.clone().requires_grad_(True)
+            y = mod(xg)
+            g = torch.randn(y.shape, generator=gen)
+            st.put(case + "/y_train", y)
+            st.put(case + "/g", g)
+            params = [(k, p) for k, p in mod.named_parameters()]
+            if y.requires_grad:
+                grads = torch.autograd.grad(y, [xg] + [p for _, p in params], g, allow_unused=True)
+                st.put(case + "/dx", grads[0] if grads[0] is not None else torch.zeros_like(x))
+                for (k, _), gr in zip(params, grads[1:]):
+                    st.put(case + "/grad/" + k, gr)
+            st.put_sd(case + "/sd_after", {k: v for k, v in mod.state_dict().items()
+                                           if "running" in k or "num_batches" in k})
+            cases.append({"case": case, "name": name, "stride": stride, "C_in": C_in,
+                          "C_out": C_out, "repeats": 2, "kind": "op"})
+    # aggregation ops: (shape of x, shape of y) exercising the tuple comparison of resize()
+    shapes = [((13, 17), (7, 9)), ((7, 9), (13, 17)), ((13, 17), (13, 17)), ((10, 5), (9, 20))]
+    for name in sorted(AGG_OPS.keys()):
+        for larger in (True, False):
+            for si, (s0, s1) in enumerate(shapes):
+                C0, C1, Co = 8, 16, 16
+                case = "agg_{}__l{}__{}".format(name, int(larger), si)
+                torch.manual_seed(500 + len(cases))
+                mod = AGG_OPS[name](C0, C1, Co, True, 2, larger)
+                randomize_bn(mod, gen)
+                with torch.no_grad():
+                    for k, p in mod.named_parameters():
+                        if k in ("a", "b"):
+                            p.copy_(torch.rand(p.shape, generator=gen) + 0.5)
+                x = torch.randn(2, C0, *s0, generator=gen)
+                y = torch.randn(2, C1, *s1, generator=gen)
+                st.put(case + "/x", x)
+                st.put(case + "/y", y)
+                st.put_sd(case + "/sd", mod.state_dict())
+                mod.eval()
+                with torch.no_grad():
+                    st.put(case + "/out_eval", mod(x, y))
+                mod.train()
+                xg, yg = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+                out = mod(xg, yg)
+                g = torch.randn(out.shape, generator=gen)
+                params = [(k, p) for k, p in mod.named_parameters()]
+                grads = torch.autograd.grad(out, [xg, yg] + [p for _, p in params], g)
+                st.put(case + "/out_train", out)
+                st.put(case + "/g", g)
+                st.put(case + "/dx", grads[0])
+                st.put(case + "/dy", grads[1])
+                for (k, _), gr in zip(params, grads[2:]):
+                    st.put(case + "/grad/" + k, gr)
+                st.put_sd(case + "/sd_after", {k: v for k, v in mod.state_dict().items()
+                                               if "running" in k or "num_batches" in k})
+                cases.append({"case": case, "name": name, "larger": larger, "C_in0": C0,
+                              "C_in1": C1, "C_out": Co, "kind": "agg"})
+    st.save("ops.npz")
+    json.dump(cases, open(os.path.join(OUT, "ops_cases.json"), "w"), indent=1)
+
+
+# ---------------------------------------------------------------------------
+# B. whole networks
+# ---------------------------------------------------------------------------
+GENOTYPES = {
+    # tests/test_inference.py:19-111 (published architectures)
+    "cvpr_arch0": [[8, [0, 0, 5, 2], [0, 2, 8, 8], [0, 5, 1, 4]], [[3, 3], [3, 2], [3, 0]]],
+    "cvpr_arch1": [[2, [1, 0, 3, 6], [0, 1, 2, 8], [2, 0, 6, 1]], [[2, 3], [3, 1], [4, 4]]],
+    "cvpr_arch2": [[5, [0, 0, 4, 1], [3, 2, 0, 1], [5, 6, 5, 0]], [[1, 3], [4, 3], [2, 2]]],
+    "wacv_arch0": [[[3, 0, 1], [4, 1, 1], [3, 1, 1]],
+                   [[0, 1, 0, 0, 1], [2, 1, 2, 1, 0], [3, 1, 1, 1, 0], [1, 1, 2, 0, 0],
+                    [3, 0, 2, 0, 0], [5, 3, 2, 1, 0], [0, 5, 0, 1, 0]]],
+    "wacv_arch1": [[[1, 1, 0], [1, 3, 0], [3, 4, 0]],
+                   [[1, 1, 0, 0, 0], [0, 1, 1, 1, 1], [3, 1, 2, 3, 0], [3, 0, 2, 2, 0],
+                    [0, 1, 2, 0, 0], [2, 1, 1, 3, 0], [4, 0, 2, 2, 0]]],
+}
+
+NETS = [
+    # name, kind, genotype, classes, decoder kwargs, input shape, seed, store full state_dict
+    ("wacv_arch0", "template", "wacv_arch0", 19, dict(agg_size=64, repeats=2), (2, 3, 65, 97), 0, True),
+    ("wacv_arch1", "template", "wacv_arch1", 19, dict(agg_size=64, repeats=2), (2, 3, 65, 97), 1, False),
+    ("cvpr_arch0", "micro", "cvpr_arch0", 21, dict(agg_size=64, repeats=2), (2, 3, 97, 129), 2, False),
+    ("cvpr_arch1_search", "micro", "cvpr_arch1", 21, dict(agg_size=48, repeats=1, aux_cell=True),
+     (2, 3, 97, 129), 3, False),
+    ("cvpr_arch2_depth", "micro", "cvpr_arch2", 1, dict(agg_size=64, repeats=2), (2, 3, 97, 129), 4, False),
+]
+
+
+def build_ref_net(kind, genotype, classes, dec_kwargs, seed):
+    from functools import partial
+
+    from nn.encoders import mbv2
+    from nn.micro_decoders import MicroDecoder, TemplateDecoder
+
+    torch.manual_seed(seed)
+    if kind == "template":
+        enc = mbv2(pretrained=False, return_layers=[1, 2])
+        dec = TemplateDecoder(inp_sizes=enc.out_sizes, num_classes=classes, config=GENOTYPES[genotype],
+                              **dec_kwargs)
+    else:
+        enc = mbv2(pretrained=False)
+        dec = MicroDecoder(inp_sizes=list(enc.out_sizes), num_classes=classes,
+                           config=GENOTYPES[genotype], **dec_kwargs)
+
+    class EncoderDecoder(nn.Module):
+        def __init__(self, encoder, decoder):
+            super(EncoderDecoder, self).__init__()
+            self.encoder = encoder
+            self.decoder = decoder
+
+        def forward(self, x):
+            return self.decoder(self.encoder(x))
+
+    return EncoderDecoder(enc, dec)
+
+
+def make_labels(gen, B, H, W, classes):
+    t = torch.randint(0, max(classes, 2), (B, H, W), generator=gen)
+    t[:, H // 3: H // 3 + 5, :] = 255
+    return t
+
+
+def gen_nets():
+    st = Store()
+    meta = {}
+    for name, kind, geno, classes, kw, shape, seed, full in NETS:
+        net = build_ref_net(kind, geno, classes, kw, seed)
+        gen = torch.Generator().manual_seed(9000 + seed)
+        x = torch.randn(*shape, generator=gen)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        st.put(name + "/x", x)
+        if full:
+            st.put_sd(name + "/sd", sd0)
+        net.eval()
+        with torch.no_grad():
+            out = net(x)
+        aux = []
+        if isinstance(out, tuple):
+            out, aux = out
+        st.put(name + "/logits_eval", out)
+        for i, a in enumerate(aux):
+            st.put(name + "/aux_eval/{}".format(i), a)
+        rec = {"kind": kind, "genotype": GENOTYPES[geno], "classes": classes, "dec_kwargs": kw,
+               "shape": list(shape), "seed": seed, "full_sd": full, "checksums": checksums(sd0),
+               "n_params": sum(p.numel() for p in net.parameters()), "n_aux": len(aux)}
+        if classes > 1:
+            # training-mode forward/backward with the loss of train_segmenter (trainer.py:233-255)
+            net.train()
+            target = make_labels(gen, shape[0], shape[2], shape[3], classes)
+            st.put(name + "/target", target.to(torch.uint8))
+            aux_weight = 0.15 if aux else -1
+            output = net(x)
+            aux_outs = []
+            if isinstance(output, tuple):
+                output, aux_outs = output
+            tv = nn.functional.interpolate(target[:, None].float(), size=output.size()[2:],
+                                           mode="nearest").long()[:, 0]
+            crit = nn.NLLLoss(ignore_index=255)
+            loss = crit(nn.LogSoftmax(dim=1)(output), tv)
+            if aux_weight > 0:
+                for a in aux_outs:
+                    a = nn.Upsample(size=tv.size()[1:], mode="bilinear", align_corners=False)(a)
+                    loss = loss + crit(nn.LogSoftmax(dim=1)(a), tv) * aux_weight
+            net.zero_grad()
+            loss.backward()
+            st.put(name + "/logits_train", output)
+            st.put(name + "/loss", loss)
+            grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+            rec["grad_checksums"] = checksums(grads)
+            rec["aux_weight"] = aux_weight
+            keys = sorted(grads.keys())
+            pick = [keys[i] for i in np.linspace(0, len(keys) - 1, 14).astype(int)]
+            for k in pick:
+                st.put(name + "/grad/" + k, grads[k])
+            bn_after = {k: v for k, v in net.state_dict().items() if "running_mean" in k}
+            rec["bn_after_checksums"] = checksums(bn_after)
+        meta[name] = rec
+    st.save("nets.npz")
+    json.dump(meta, open(os.path.join(OUT, "nets_meta.json"), "w"))
+
+
+# ---------------------------------------------------------------------------
+# C. mean-IoU / reward
+# ---------------------------------------------------------------------------
+class FakeDataset(object):
+    def set_stage(self, stage):
+        self.stage = stage
+
+
+class FakeLoader(object):
+    def __init__(self, batches):
+        self.batches = batches
+        self.dataset = FakeDataset()
+        self.batch_sampler = type("BS", (), {"batch_size": 1})()
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+class FixedLogits(nn.Module):
+    """a 'segmenter' whose output for batch i is a stored logits tensor"""
+
+    def __init__(self, logits):
+        super(FixedLogits, self).__init__()
+        self.logits = logits
+        self.i = 0
+        self.dummy = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        out = self.logits[self.i]
+        self.i += 1
+        return out
+
+
+def gen_miou():
+    from helpers.miou_utils import compute_iu, compute_ius_accs, fast_cm
+
+    import engine.inference as ref_inf
+
+    st = Store()
+    rng = np.random.RandomState(7)
+    cases = []
+    for ci, (n_cls, n_px) in enumerate([(21, 50000), (19, 20011), (5, 1), (11, 4096), (3, 0)]):
+        gt = rng.randint(0, n_cls, size=n_px).astype(np.uint8)
+        pr = rng.randint(0, n_cls, size=n_px).astype(np.uint8)
+        if n_px > 100:
+            # make two classes absent from gt and one absent from both
+            gt[gt == 2] = 1
+            pr[pr == 4] = 3
+            gt[gt == 4] = 3
+        cm = fast_cm(pr, gt, n_cls)
+        iu = compute_iu(cm)
+        iu2, npx, acc = compute_ius_accs(cm)
+        assert np.array_equal(iu, iu2)
+        case = "cm{}".format(ci)
+        st.put(case + "/preds", pr)
+        st.put(case + "/gt", gt)
+        st.put(case + "/cm", cm)
+        st.put(case + "/iu", iu)
+        st.put(case + "/n_pixels", npx)
+        st.put(case + "/accs", acc)
+        cases.append({"case": case, "n_classes": n_cls})
+    # validate(): logits at 1/4 resolution, labels at full resolution with 255 / out-of-range ids
+    gen = torch.Generator().manual_seed(77)
+    for vi, (n_cls, omit) in enumerate([(21, [0]), (19, [])]):
+        logits = [torch.randn(2, n_cls, 17, 23, generator=gen) * 3 for _ in range(3)]
+        masks = []
+        for _ in range(3):
+            m = torch.randint(0, n_cls - 2, (2, 65, 89), generator=gen)  # top classes absent
+            m[:, 10:14, :] = 255
+            m[:, :, 40] = n_cls + 3
+            masks.append(m)
+        loader = FakeLoader([{"image": torch.zeros(2, 3, 65, 89), "mask": mk} for mk in masks])
+        reward = ref_inf.validate(FixedLogits(logits), loader, 0, 0, num_classes=n_cls,
+                                  print_every=100, omit_classes=omit)
+        case = "val{}".format(vi)
+        for i in range(3):
+            st.put("{}/logits/{}".format(case, i), logits[i])
+            st.put("{}/mask/{}".format(case, i), masks[i].to(torch.uint8))
+        st.put(case + "/reward", np.float64(reward))
+        cases.append({"case": case, "n_classes": n_cls, "omit": omit, "n_batches": 3})
+    st.save("miou.npz")
+    json.dump(cases, open(os.path.join(OUT, "miou_cases.json"), "w"), indent=1)
+
+
+# ---------------------------------------------------------------------------
+# D. engine: reference train_segmenter / populate_task0 / train_task0 / validate
+# ---------------------------------------------------------------------------
+def gen_engine():
+    import engine.inference as ref_inf
+    import engine.trainer as ref_tr
+    from utils.solvers import create_optimisers
+
+    st = Store()
+    meta = {}
+    for name, kind, geno, classes, kw, aux_weight in [
+        ("wacv_arch0", "template", "wacv_arch0", 19, dict(agg_size=64, repeats=2), -1),
+        ("cvpr_arch1_search", "micro", "cvpr_arch1", 21, dict(agg_size=48, repeats=1, aux_cell=True), 0.15),
+    ]:
+        net = build_ref_net(kind, geno, classes, kw, seed=11)
+
+        class Seg(nn.Module):  # src/main_search.py:411-420
+            def __init__(self, encoder, decoder):
+                super(Seg, self).__init__()
+                self.encoder, self.decoder = encoder, decoder
+
+            def forward(self, x):
+                return self.decoder(self.encoder(x))
+
+        segmenter = nn.DataParallel(Seg(net.encoder, net.decoder))
+        gen = torch.Generator().manual_seed(4242)
+        H, W = (65, 97) if kind == "template" else (97, 129)
+        batches = []
+        for _ in range(2):
+            img = torch.randn(2, 3, H, W, generator=gen)
+            batches.append({"image": img, "mask": make_labels(gen, 2, H, W, classes).to(torch.uint8)})
+        for i, b in enumerate(batches):
+            st.put("{}/train/image/{}".format(name, i), b["image"])
+            st.put("{}/train/mask/{}".format(name, i), b["mask"])
+        meta[name] = {"kind": kind, "genotype": GENOTYPES[geno], "classes": classes, "dec_kwargs": kw,
+                      "seed": 11, "aux_weight": aux_weight,
+                      "init_checksums": checksums(segmenter.module.state_dict())}
+        # --- task1: end-to-end, SGD encoder / Adam decoder (default_args.py:57-66) ---
+        optim_enc, optim_dec = create_optimisers(
+            "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
+            segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
+        losses = []
+        crit = nn.NLLLoss(ignore_index=255)
+
+        def rec_crit(inp, tgt, _c=crit, _l=losses):
+            v = _c(inp, tgt)
+            _l.append(float(v))
+            return v
+
+        avg_param = [p.data.clone() for p in segmenter.parameters()]
+        ret = ref_tr.train_segmenter(segmenter, FakeLoader(batches), optim_enc, optim_dec, 0, rec_crit,
+                                     False, 3.0, 3.0, True, print_every=100, aux_weight=aux_weight,
+                                     avg_param=avg_param, polyak_decay=0.99)
+        assert ret is None, "reference train_segmenter failed"
+        sd1 = segmenter.module.state_dict()
+        meta[name]["task1_crit_values"] = losses[:]
+        meta[name]["task1_checksums"] = checksums(sd1)
+        meta[name]["task1_polyak_checksums"] = checksums({str(i): a for i, a in enumerate(avg_param)})
+        st.put(name + "/task1/conv_clf.weight", sd1["decoder.conv_clf.weight"])
+        st.put(name + "/task1/layer1.0.weight", sd1["encoder.layer1.0.weight"])
+        # --- validation reward of the trained candidate ---
+        vbatches = []
+        for _ in range(2):
+            img = torch.randn(2, 3, H, W, generator=gen)
+            vbatches.append({"image": img, "mask": make_labels(gen, 2, H, W, classes - 3).to(torch.uint8)})
+        for i, b in enumerate(vbatches):
+            st.put("{}/val/image/{}".format(name, i), b["image"])
+            st.put("{}/val/mask/{}".format(name, i), b["mask"])
+        reward = ref_inf.validate(segmenter, FakeLoader(vbatches), 0, 0, num_classes=classes,
+                                  print_every=100, omit_classes=[0])
+        meta[name]["val_reward"] = float(reward)
+        # --- task0: cache encoder features, decoder-only epoch ---
+        loader1 = FakeLoader([{"image": b["image"][i:i + 1], "mask": b["mask"][i:i + 1]}
+                              for b in batches for i in range(2)])
+        Xy = ref_tr.populate_task0(segmenter, loader1, None, 4, do_kd=False)
+        assert not isinstance(Xy, int), "reference populate_task0 failed"
+        meta[name]["task0_cache_checksums"] = checksums(
+            {str(k): v for k, v in Xy.items() if k != "out_size"})
+        meta[name]["task0_out_size"] = [int(s) for s in Xy["out_size"]]
+        _, optim_dec0 = create_optimisers(
+            "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
+            segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
+        np.random.seed(123)
+        losses0 = []
+
+        def rec_crit0(inp, tgt, _c=crit, _l=losses0):
+            v = _c(inp, tgt)
+            _l.append(float(v))
+            return v
+
+        ret = ref_tr.train_task0(Xy, segmenter, optim_dec0, 0, rec_crit0, None, 2, False, False, 0.0,
+                                 3.0, False, aux_weight=max(aux_weight, 0))
+        assert ret is None, "reference train_task0 failed"
+        meta[name]["task0_crit_values"] = losses0[:]
+        meta[name]["task0_checksums"] = checksums(segmenter.module.decoder.state_dict())
+    st.save("engine.npz")
+    json.dump(meta, open(os.path.join(OUT, "engine_meta.json"), "w"))
+
+
+# ---------------------------------------------------------------------------
+# E. controller -> decoder contract
+# ---------------------------------------------------------------------------
+def gen_controller():
+    from rl.agent import create_agent
+
+    out = {}
+    for version, kw in [("cvpr", dict(num_ops=11, cell_num_layers=4)),
+                        ("wacv", dict(num_ops=6, cell_num_layers=7))]:
+        torch.manual_seed(9314)
+        agent = create_agent(enc_num_layers=4 if version == "cvpr" else 2, num_agg_ops=2,
+                             lstm_hidden_size=100, lstm_num_layers=2, dec_num_cells=3,
+                             cell_max_repeat=4, cell_max_stride=2, ctrl_lr=1e-4,
+                             ctrl_baseline_decay=0.95, ctrl_agent="ppo", ctrl_version=version, **kw)
+        samples = []
+        for _ in range(6):
+            config, entropy, log_prob = agent.controller.sample()
+            action = agent.controller.config2action(config)
+            samples.append({"config": config, "action": [int(a) for a in action],
+                            "entropy": float(entropy), "log_prob": float(log_prob)})
+        out[version] = {"action_size": int(agent.controller.action_size()), "samples": samples}
+    json.dump(out, open(os.path.join(OUT, "controller.json"), "w"), indent=1)
+    print("wrote controller.json")
+
+
+if __name__ == "__main__":
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    shutil.rmtree(TMP, ignore_errors=True)
+    build_cython()
+    which = sys.argv[1:] or ["ops", "nets", "miou", "engine", "controller"]
+    for w in which:
+        globals()["gen_" + w]()
