@@ -1,0 +1,287 @@
+"""Headline benchmark: images/sec of the NAS inner-loop training step
+(forward + backward + gradient all-reduce + clip + optimiser step) of the WACV
+arch0 segmenter (MobileNetV2[1,2] encoder + TemplateDecoder, 19 classes) on
+synthetic 2048x1024 images, 4 images per GPU, fp32 - BASELINE.json `metric`.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events on
+the launch stream (LaunchProfiler) in extra, untimed steps after the timed
+region; `cpu_baseline` times the CPU oracle (oracle/, the restatement of the
+reference's torch graph) on the host cores of the same box, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WACV_ARCH0 = [[[3, 0, 1], [4, 1, 1], [3, 1, 1]],
+              [[0, 1, 0, 0, 1], [2, 1, 2, 1, 0], [3, 1, 1, 1, 0], [1, 1, 2, 0, 0],
+               [3, 0, 2, 0, 0], [5, 3, 2, 1, 0], [0, 5, 0, 1, 0]]]
+NUM_CLASSES = 19
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(name, a):
+    """ALGORITHMIC bytes of one launch of a C-ABI entry point (fp32; inputs read
+    once + outputs written once, SURVEY.md section 8(d) per-primitive formulas).
+    `a` is the positional argument tuple of the call (include/nasseg.h order)."""
+    if name == "nasseg_dwconv":
+        B, H, W, C, Ho, Wo, K = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
+        return 4 * (B * C * H * W + B * C * Ho * Wo + C * K * K)
+    if name == "nasseg_dwconv_wgrad":
+        B, H, W, C, Ho, Wo, K = a[4], a[5], a[6], a[7], a[8], a[9], a[10]
+        return 4 * (B * C * H * W + B * C * Ho * Wo + C * K * K)
+    if name == "nasseg_conv_fwd":
+        B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[13], a[14], a[15], a[16], a[17], a[18], a[19], a[20], a[21]
+        res = B * Ho * Wo * N if a[11] else 0
+        return 4 * (B * Hs * Ws * K + B * Ho * Wo * N + N * K * kh * kw + res)
+    if name == "nasseg_conv_wgrad":
+        B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17]
+        return 4 * (B * Hs * Ws * K + B * Ho * Wo * N + N * K * kh * kw)
+    if name == "nasseg_bn_stats":
+        return 4 * a[2] * a[3]
+    if name == "nasseg_bn_bwd_reduce":
+        return 4 * 2 * a[4] * a[5]
+    if name == "nasseg_bn_bwd_apply":
+        return 4 * 3 * a[7] * a[8]
+    if name == "nasseg_affine_act":
+        return 4 * a[5] * (3 if a[3] else 2)
+    if name == "nasseg_axpby":
+        return 4 * a[5] * (3 if a[1] else 2)
+    if name == "nasseg_act_bwd":
+        return 4 * 3 * a[3]
+    if name == "nasseg_chan_copy":
+        return 4 * a[9] * a[10] * (3 if a[6] else 2)
+    if name in ("nasseg_pool_fwd", "nasseg_pool_bwd"):
+        B, H, W, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
+        return 4 * B * C * (H * W + Ho * Wo) + B * C * Ho * Wo  # + uint8 winner index
+    if name == "nasseg_bilinear_fwd":
+        B, Hi, Wi, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
+        return 4 * B * C * (Hi * Wi + Ho * Wo)
+    if name == "nasseg_bilinear_bwd":
+        B, Hi, Wi, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
+        return 4 * B * C * (Hi * Wi + Ho * Wo)
+    if name == "nasseg_colred":
+        n = a[9] * a[10] * a[11]
+        return 4 * n * (1 + (1 if a[3] else 0) + (1 if a[5] else 0))
+    if name in ("nasseg_ce_fwd", "nasseg_ce_bwd"):
+        P, C = (a[3], a[4]) if name == "nasseg_ce_fwd" else (a[5], a[6])
+        return P * (4 * C * (2 if name == "nasseg_ce_bwd" else 1) + 8)
+    return 0
+
+
+def build_model(device):
+    from nas_segm_amd.engine import RankParallel, Segmenter
+    from nas_segm_amd.nn.encoders import mbv2
+    from nas_segm_amd.nn.micro_decoders import TemplateDecoder
+
+    torch.manual_seed(0)  # random-init weights of the published architecture (no checkpoints offline)
+    enc = mbv2(pretrained=False, return_layers=[1, 2])
+    dec = TemplateDecoder(enc.out_sizes, NUM_CLASSES, WACV_ARCH0, agg_size=64, repeats=2)
+    net = Segmenter(enc, dec).to(device)
+    return RankParallel(net), net
+
+
+def synthetic_batch(batch, height, width, rank, device):
+    g = torch.Generator().manual_seed(rank)
+    image = torch.randn(batch, 3, height, width, generator=g)
+    mask = torch.randint(0, NUM_CLASSES, (batch, height, width), generator=g)
+    mask[:, height // 2: height // 2 + 5, :] = 255
+    image = image.to(device).contiguous(memory_format=torch.channels_last)
+    return image, mask.to(device)
+
+
+def cpu_baseline(height, width):
+    """The oracle (CPU restatement of the reference graph) on the host cores:
+    1 warm-up + 3 timed train-mode forward+backward passes of WACV arch0 at
+    1x3xHxW (the metric's unit), plus the eval forward of BASELINE.md section 4."""
+    from oracle import engine as oeng
+    from oracle import nets as onets
+
+    from nas_segm_amd.engine import Segmenter
+    from nas_segm_amd.nn.encoders import mbv2
+    from nas_segm_amd.nn.micro_decoders import TemplateDecoder
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    enc = mbv2(pretrained=False, return_layers=[1, 2])
+    dec = TemplateDecoder(enc.out_sizes, NUM_CLASSES, WACV_ARCH0, agg_size=64, repeats=2)
+    net = Segmenter(enc, dec)
+    params = {k for k, _ in net.named_parameters()}
+    sd = {k: (v.clone().requires_grad_(True) if k in params else v.clone())
+          for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 3, height, width, generator=g)
+    t = torch.randint(0, NUM_CLASSES, (1, height, width), generator=g)
+
+    def fwd_bwd():
+        for v in sd.values():
+            v.grad = None
+        out = onets.segmenter(sd, x, "template", WACV_ARCH0, [24, 32], (1, 2), True, repeats=2)
+        oeng.train_loss(out, t).backward()
+
+    def fwd_eval():
+        with torch.no_grad():
+            onets.segmenter(sd, x, "template", WACV_ARCH0, [24, 32], (1, 2), False, repeats=2)
+
+    fwd_bwd()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fwd_bwd()
+        times.append(time.perf_counter() - t0)
+    fwd_eval()
+    ftimes = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fwd_eval()
+        ftimes.append(time.perf_counter() - t0)
+    med = sorted(times)[1]
+    fmed = sorted(ftimes)[1]
+    cpu_name = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": 1.0 / med, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "3 train-mode fwd+bwd passes (median) of WACV arch0 at 1x3x{}x{} fp32 after 1 warm-up, "
+                      "torch CPU threads = cores".format(height, width),
+            "fwd_only_images_per_sec": 1.0 / fmed, "cpu_model": cpu_name}
+
+
+def roofline_from_profile(summary):
+    """Per entry point: launches, total ms, algorithmic GB/s; dominant = most time."""
+    rows = []
+    for name, (n, ms, recs) in summary.items():
+        nbytes = sum(algorithmic_bytes(name, args) for _, args in recs)
+        rows.append({"kernel": name, "launches": n, "ms": ms, "bytes": nbytes,
+                     "gbs": (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0})
+    rows.sort(key=lambda r: -r["ms"])
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    import nas_segm_amd  # noqa: F401
+    from nas_segm_amd._lib import LaunchProfiler, lib
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    segmenter, net = build_model(device)
+    segmenter.train()
+    # default_args.py:57-66: SGD(lr 1e-3, mom 0.9, wd 1e-5) encoder, Adam(lr 3e-3, wd 1e-5) decoder
+    optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+    image, mask = synthetic_batch(args.batch, args.height, args.width, rank, device)
+
+    def step():
+        return segmenter_step(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_value = float(loss.item())
+
+    roof = None
+    rows = []
+    if not args.no_roofline and rank == 0:
+        lib.profiler = LaunchProfiler()
+        step()
+        step()
+        rows = roofline_from_profile(lib.profiler.summary())
+        lib.profiler = None
+        if rows:
+            top = rows[0]
+            total_ms = sum(r["ms"] for r in rows)
+            dw = [r for r in rows if r["kernel"] == "nasseg_dwconv"]
+            roof = {"bound": "hbm", "kernel": top["kernel"],
+                    "achieved": top["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": top["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": top["ms"] / top["launches"], "launches_per_step": top["launches"] / 2,
+                    "share_of_kernel_time": top["ms"] / total_ms,
+                    "depthwise_gbs": dw[0]["gbs"] if dw else None,
+                    "depthwise_frac": dw[0]["gbs"] / HBM_PEAK_GBS if dw else None}
+        if args.breakdown:
+            for r in rows:
+                sys.stderr.write("{kernel:28s} n={launches:5d} {ms:9.3f} ms {gbs:9.1f} GB/s\n".format(**r))
+    if world > 1:
+        fence()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.height, args.width)
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        out = {
+            "metric": "images/sec (fwd+bwd+optimizer step) WACV arch0 {}x{} bs={}/GPU".format(
+                args.width, args.height, args.batch),
+            "value": imgs / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (randn images, randint labels with a 255 band; random-init weights)",
+            "config": {"workload": "headline: WACV arch0 (MobileNetV2[1,2] + TemplateDecoder, 19 classes, "
+                                   "agg 64, sep repeats 2), {}x3x{}x{} per GPU, train_segmenter step".format(
+                                       args.batch, args.height, args.width),
+                       "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
+                       "loss": loss_value},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = out["value"] / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

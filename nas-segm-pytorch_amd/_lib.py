@@ -48,10 +48,53 @@ class NassegError(RuntimeError):
     """A nasseg C-ABI call failed (bad arguments, HIP launch failure, ...)."""
 
 
+class LaunchProfiler(object):
+    """Optional per-entry-point timing with HIP events on the launch stream.
+
+    While installed (``lib.profiler = LaunchProfiler()``) every status-returning
+    call is bracketed by a pair of events recorded on torch's current stream -
+    the stream the kernels are launched on.  ``summary()`` synchronises and
+    returns {entry point: (launches, total ms, [per-launch (ms, args)])}.
+    Used by bench.py for the roofline figures; off by default (zero overhead).
+    """
+
+    def __init__(self, names=None):
+        self.names = set(names) if names else None
+        self.records = []
+
+    def wants(self, name):
+        return self.names is None or name in self.names
+
+    def bracket(self, name, args, fn):
+        import torch
+
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        self.records.append((name, args, e0, e1))
+        return rc
+
+    def summary(self):
+        import torch
+
+        torch.cuda.synchronize()
+        out = {}
+        for name, args, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            ent = out.setdefault(name, [0, 0.0, []])
+            ent[0] += 1
+            ent[1] += ms
+            ent[2].append((ms, args))
+        return out
+
+
 class _Library(object):
     def __init__(self):
         self._dll = None
         self._fn = {}
+        self.profiler = None
 
     def load(self):
         if self._dll is not None:
@@ -85,7 +128,11 @@ class _Library(object):
         if fn is None:
             self.load()
             fn = self._fn[name]
-        rc = fn(*args)
+        prof = self.profiler
+        if prof is not None and prof.wants(name):
+            rc = prof.bracket(name, args, fn)
+        else:
+            rc = fn(*args)
         if rc < 0:
             raise NassegError("{}: {}".format(name, self.last_error()))
         return rc

@@ -1,0 +1,196 @@
+"""Engine parity on the GPU: train_segmenter / populate_task0 / train_task0 /
+validate against what the reference's own engine produced on the same inputs
+(tests/golden/engine*.{npz,json}), plus full-size property checks."""
+import numpy as np
+import pytest
+import torch
+
+from _util import assert_checksums_close, build_product_net, checksums, load_json, load_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+ENG_NPZ = load_npz("engine.npz")
+ENG_META = load_json("engine_meta.json")
+
+
+class _DS(object):
+    def set_stage(self, stage):
+        self.stage = stage
+
+
+class Loader(object):
+    def __init__(self, batches):
+        self.batches = batches
+        self.dataset = _DS()
+        self.batch_sampler = type("BS", (), {"batch_size": 1})()
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+class _Crit(object):
+    ignore_index = 255
+
+
+def _cpu_sd(module):
+    return {k: v.detach().cpu() for k, v in module.state_dict().items()}
+
+
+def _record_losses(monkeypatch):
+    from nas_segm_amd.engine import trainer
+
+    values = []
+    orig = trainer.F.log_softmax_nll
+
+    def rec(logits, target, ignore_index=255):
+        v = orig(logits, target, ignore_index)
+        values.append(float(v.detach()))
+        return v
+
+    monkeypatch.setattr(trainer.F, "log_softmax_nll", rec)
+    return values
+
+
+@pytest.mark.parametrize("name", sorted(ENG_META))
+def test_engine_matches_reference_run(name, monkeypatch):
+    from nas_segm_amd.engine import RankParallel
+    from nas_segm_amd.engine.inference import validate
+    from nas_segm_amd.engine.trainer import populate_task0, train_segmenter, train_task0
+
+    rec = ENG_META[name]
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], rec["seed"])
+    assert_checksums_close(checksums(net.state_dict()), rec["init_checksums"], what="init")
+    segmenter = RankParallel(net.to(DEV))
+    batches = [{"image": torch.from_numpy(ENG_NPZ["{}/train/image/{}".format(name, i)]),
+                "mask": torch.from_numpy(ENG_NPZ["{}/train/mask/{}".format(name, i)])} for i in range(2)]
+    # default_args.py:57-66 - SGD(1e-3, 0.9, wd 1e-5) encoder, Adam(3e-3, wd 1e-5) decoder
+    optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+    avg_param = [p.data.clone() for p in segmenter.parameters()]
+    values = _record_losses(monkeypatch)
+    ret = train_segmenter.__wrapped__(segmenter, Loader(batches), optim_enc, optim_dec, 0, _Crit(), False,
+                                      3.0, 3.0, True, print_every=100, aux_weight=rec["aux_weight"],
+                                      avg_param=avg_param, polyak_decay=0.99)
+    assert ret is None
+    want = rec["task1_crit_values"]
+    assert len(values) == len(want)
+    # the first batch sees identical weights; the second one weights after one optimiser step
+    n_first = len(want) // 2
+    assert np.allclose(values[:n_first], want[:n_first], atol=1e-4), (values, want)
+    assert np.allclose(values, want, atol=5e-3), (values, want)
+    got = checksums(_cpu_sd(net))
+    for k, (s, sa) in rec["task1_checksums"].items():
+        if "num_batches_tracked" in k:
+            assert got[k][0] == s, k
+        else:
+            # Adam normalises tiny gradients to +-lr: compare the mass of every tensor, loosely
+            assert abs(got[k][1] - sa) <= 2e-2 * sa + 2e-3, "{}: {} vs {}".format(k, got[k][1], sa)
+    pol = checksums({str(i): a.cpu() for i, a in enumerate(avg_param)})
+    for k, (s, sa) in rec["task1_polyak_checksums"].items():
+        assert abs(pol[k][1] - sa) <= 1e-3 * sa + 1e-4, k
+
+    # validation reward of the (slightly different) trained candidate
+    vb = [{"image": torch.from_numpy(ENG_NPZ["{}/val/image/{}".format(name, i)]),
+           "mask": torch.from_numpy(ENG_NPZ["{}/val/mask/{}".format(name, i)])} for i in range(2)]
+    reward = validate.__wrapped__(segmenter, Loader(vb), 0, 0, num_classes=rec["classes"], print_every=100,
+                                  omit_classes=[0])
+    assert np.isfinite(reward) and abs(reward - rec["val_reward"]) < 0.05 * max(rec["val_reward"], 1e-3) + 5e-3
+
+    # task0: feature cache + decoder-only epoch
+    loader1 = Loader([{"image": b["image"][i:i + 1], "mask": b["mask"][i:i + 1]} for b in batches for i in range(2)])
+    Xy = populate_task0.__wrapped__(segmenter, loader1, None, 4, do_kd=False)
+    assert list(Xy["out_size"]) == rec["task0_out_size"]
+    assert Xy["y"].dtype == torch.int64 and Xy[0].shape[0] == 4
+    cache = checksums({str(k): v.cpu() for k, v in Xy.items() if k != "out_size"})
+    for k, (s, sa) in rec["task0_cache_checksums"].items():
+        assert abs(cache[k][1] - sa) <= 3e-2 * sa + 1e-3, "cache {}: {} vs {}".format(k, cache[k][1], sa)
+    assert cache["y"] == rec["task0_cache_checksums"]["y"]  # labels are integers: exact
+    optim_dec0 = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+    np.random.seed(123)
+    del values[:]
+    ret = train_task0.__wrapped__(Xy, segmenter, optim_dec0, 0, _Crit(), None, 2, False, False, 0.0, 3.0,
+                                  False, aux_weight=max(rec["aux_weight"], 0))
+    assert ret is None
+    assert len(values) == len(rec["task0_crit_values"])
+    assert np.allclose(values, rec["task0_crit_values"], atol=3e-2), (values, rec["task0_crit_values"])
+
+
+def test_step_is_deterministic_run_to_run():
+    """no atomics on float data anywhere: two identical steps give bit-identical gradients"""
+    from nas_segm_amd import functional as F
+
+    rec = load_json("nets_meta.json")["wacv_arch0"]
+    grads = []
+    for _ in range(2):
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(2, 3, 129, 161, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+        t = torch.randint(0, 19, (2, 129, 161), generator=g).to(DEV)
+        out = net(x)
+        loss = F.log_softmax_nll(out, F.nearest_label_resize(t, out.shape[2:]), 255)
+        loss.backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu())
+    assert torch.equal(grads[0], grads[1])
+
+
+def test_full_size_headline_shape_properties():
+    """BASELINE headline shape (WACV arch0, 1024x2048): output geometry, finite
+    loss / gradients, reward-path conservation laws (size-independent properties)."""
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.helpers.miou_utils import fast_cm
+
+    rec = load_json("nets_meta.json")["wacv_arch0"]
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+    B, H, W = 2, 1024, 2048
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 3, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    t = torch.randint(0, 19, (B, H, W), generator=g)
+    t[:, 100:105] = 255
+    t = t.to(DEV)
+    out = net(x)
+    assert tuple(out.shape) == (B, 19, 256, 512)
+    tv = F.nearest_label_resize(t, out.shape[2:])
+    loss = F.log_softmax_nll(out, tv, 255)
+    loss.backward()
+    assert torch.isfinite(loss)
+    # an untrained net on random labels sits near log(19)
+    assert abs(float(loss) - np.log(19.0)) < 1.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    # softmax-CE gradient sums to zero over classes for every valid pixel and is zero on ignored ones
+    lg = out.detach().clone().requires_grad_(True)
+    F.log_softmax_nll(lg, tv, 255).backward()
+    per_pixel = lg.grad.sum(1)
+    assert float(per_pixel.abs().max()) < 1e-6
+    ign = lg.grad.permute(0, 2, 3, 1)[tv == 255]
+    assert ign.numel() > 0 and float(ign.abs().max()) == 0.0
+    # confusion matrix at full label resolution: total == number of valid pixels, rows == gt histogram
+    gt8 = t.to(torch.uint8)
+    cm = F.argmax_confusion(out.detach(), gt8, 19)
+    valid = int((gt8 < 19).sum())
+    assert int(cm.sum()) == valid
+    hist = torch.bincount(gt8[gt8 < 19].reshape(-1).long(), minlength=19)
+    assert torch.equal(cm.sum(1), hist)
+    # fast_cm on identical uint8 inputs: diagonal only
+    same = fast_cm(gt8.reshape(-1), gt8.reshape(-1), 19)
+    assert int(same.diagonal().sum()) == valid and int(same.sum()) == valid
+
+
+def test_linearity_of_dense_and_depthwise_conv_at_size():
+    """conv(a*x + y) == a*conv(x) + conv(y) at a BASELINE-sized activation"""
+    from nas_segm_amd import functional as F
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 32, 256, 512, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    y = torch.randn(2, 32, 256, 512, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    wd = (torch.randn(32, 1, 5, 5, generator=g) * 0.2).to(DEV)
+    wp = (torch.randn(64, 32, 1, 1, generator=g) * 0.2).to(DEV)
+    z = F.add(F.param_sum(x, y, torch.full((32,), 0.5, device=DEV), torch.ones(32, device=DEV)), y * 0)
+    for f in (lambda t: F.depthwise_conv2d(t, wd, 1, 12, 6), lambda t: F.conv2d(t, wp)):
+        lhs = f(z)
+        rhs = 0.5 * f(x) + f(y)
+        assert float((lhs - rhs).abs().max()) < 2e-4

@@ -1,0 +1,187 @@
+"""HIP path against the committed golden vectors (produced by the reference
+itself): every registry op / aggregation op (module level, forward + backward +
+BN buffers), the published networks end to end, and the reward path."""
+import numpy as np
+import pytest
+import torch
+
+from _util import (assert_checksums_close, assert_close, build_product_net, checksums, load_json,
+                   load_npz, sub_dict)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+OPS_NPZ = load_npz("ops.npz")
+OPS_CASES = load_json("ops_cases.json")
+NETS_NPZ = load_npz("nets.npz")
+NETS_META = load_json("nets_meta.json")
+MIOU_NPZ = load_npz("miou.npz")
+MIOU_CASES = load_json("miou_cases.json")
+
+
+def cl(a):
+    t = torch.from_numpy(np.array(a)) if not isinstance(a, torch.Tensor) else a
+    t = t.to(DEV)
+    return t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t
+
+
+def _grad_tol(ref):
+    return 2e-3 * (float(torch.as_tensor(ref).abs().max()) + 1e-12)
+
+
+@pytest.mark.parametrize("case", [c for c in OPS_CASES if c["kind"] == "op"], ids=lambda c: c["case"])
+def test_registry_op(case):
+    from nas_segm_amd.nn.layer_factory import OPS
+
+    name = case["case"]
+    mod = OPS[case["name"]](case["C_in"], case["C_out"], case["stride"], True, case["repeats"])
+    sd = sub_dict(OPS_NPZ, name + "/sd")
+    assert set(mod.state_dict().keys()) == set(sd.keys())
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV)
+    x = cl(OPS_NPZ[name + "/x"])
+    mod.eval()
+    with torch.no_grad():
+        assert_close(mod(x), OPS_NPZ[name + "/y_eval"], 3e-5, 3e-5, "eval")
+    mod.train()
+    xg = x.clone().requires_grad_(True)
+    y = mod(xg)
+    assert_close(y, OPS_NPZ[name + "/y_train"], 5e-5, 5e-5, "train")
+    if (name + "/dx") in OPS_NPZ.files and y.requires_grad:
+        y.backward(cl(OPS_NPZ[name + "/g"]))
+        ref_dx = OPS_NPZ[name + "/dx"]
+        dx = xg.grad if xg.grad is not None else torch.zeros_like(xg)
+        assert_close(dx, ref_dx, _grad_tol(ref_dx), 2e-3, "dx")
+        params = dict(mod.named_parameters())
+        for k, g in sub_dict(OPS_NPZ, name + "/grad").items():
+            assert params[k].grad is not None, k
+            assert_close(params[k].grad, g, _grad_tol(g), 2e-3, "grad " + k)
+    after = mod.state_dict()
+    for k, v in sub_dict(OPS_NPZ, name + "/sd_after").items():
+        assert_close(after[k], v, 1e-5, 1e-5, "buffer " + k)
+
+
+@pytest.mark.parametrize("case", [c for c in OPS_CASES if c["kind"] == "agg"], ids=lambda c: c["case"])
+def test_registry_agg(case):
+    from nas_segm_amd.nn.layer_factory import AGG_OPS
+
+    name = case["case"]
+    mod = AGG_OPS[case["name"]](case["C_in0"], case["C_in1"], case["C_out"], True, 2, case["larger"])
+    sd = sub_dict(OPS_NPZ, name + "/sd")
+    assert set(mod.state_dict().keys()) == set(sd.keys())
+    mod.load_state_dict(sd)
+    mod = mod.to(DEV)
+    x, y = cl(OPS_NPZ[name + "/x"]), cl(OPS_NPZ[name + "/y"])
+    mod.eval()
+    with torch.no_grad():
+        assert_close(mod(x, y), OPS_NPZ[name + "/out_eval"], 3e-5, 3e-5, "eval")
+    mod.train()
+    xg, yg = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    out = mod(xg, yg)
+    assert_close(out, OPS_NPZ[name + "/out_train"], 5e-5, 5e-5, "train")
+    out.backward(cl(OPS_NPZ[name + "/g"]))
+    for got, key in ((xg.grad, "/dx"), (yg.grad, "/dy")):
+        ref = OPS_NPZ[name + key]
+        assert_close(got, ref, _grad_tol(ref), 2e-3, key)
+    params = dict(mod.named_parameters())
+    for k, g in sub_dict(OPS_NPZ, name + "/grad").items():
+        assert_close(params[k].grad, g, _grad_tol(g), 2e-3, "grad " + k)
+    after = mod.state_dict()
+    for k, v in sub_dict(OPS_NPZ, name + "/sd_after").items():
+        assert_close(after[k], v, 1e-5, 1e-5, "buffer " + k)
+
+
+@pytest.mark.parametrize("name", sorted(NETS_META))
+def test_network(name):
+    """logits within 1e-4 of the reference (BASELINE tolerance), loss, gradients, BN buffers"""
+    from nas_segm_amd import functional as F
+
+    rec = NETS_META[name]
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], rec["seed"])
+    assert_checksums_close(checksums(net.state_dict()), rec["checksums"], what="init")
+    assert sum(p.numel() for p in net.parameters()) == rec["n_params"]
+    net = net.to(DEV)
+    x = cl(NETS_NPZ[name + "/x"])
+    net.eval()
+    with torch.no_grad():
+        out = net(x)
+    aux = []
+    if isinstance(out, tuple):
+        out, aux = out
+    assert_close(out, NETS_NPZ[name + "/logits_eval"], 1e-4, 1e-4, "eval logits")
+    for i, a in enumerate(aux):
+        assert_close(a, NETS_NPZ["{}/aux_eval/{}".format(name, i)], 1e-4, 1e-4, "aux {}".format(i))
+    if rec["classes"] <= 1:
+        return
+    net.train()
+    target = torch.from_numpy(NETS_NPZ[name + "/target"]).to(DEV)
+    output = net(x)
+    aux_outs = []
+    if isinstance(output, tuple):
+        output, aux_outs = output
+    assert_close(output, NETS_NPZ[name + "/logits_train"], 1e-4, 1e-4, "train logits")
+    tv = F.nearest_label_resize(target, output.shape[2:])
+    loss = F.log_softmax_nll(output, tv, 255)
+    if rec["aux_weight"] > 0:
+        for a in aux_outs:
+            a = F.bilinear_resize(a, tv.shape[1:])
+            loss = loss + F.log_softmax_nll(a, tv, 255) * rec["aux_weight"]
+    assert abs(float(loss) - float(NETS_NPZ[name + "/loss"])) < 1e-4
+    loss.backward()
+    params = dict(net.named_parameters())
+    for k, g in sub_dict(NETS_NPZ, name + "/grad").items():
+        assert_close(params[k].grad, g, _grad_tol(g), 5e-3, "grad " + k)
+    grads = {k: p.grad for k, p in params.items() if p.grad is not None}
+    assert set(grads) == set(rec["grad_checksums"])
+    got = checksums({k: v.cpu() for k, v in grads.items()})
+    for k, (s, sa) in rec["grad_checksums"].items():
+        assert abs(got[k][1] - sa) <= 5e-3 * sa + 1e-7, "grad abs-sum {}: {} vs {}".format(k, got[k][1], sa)
+    after = {k: v.cpu() for k, v in net.state_dict().items() if "running_mean" in k}
+    assert_checksums_close(checksums(after), rec["bn_after_checksums"], rtol=1e-4, atol=1e-5,
+                           what="running_mean")
+
+
+@pytest.mark.parametrize("case", [c for c in MIOU_CASES if c["case"].startswith("cm")],
+                         ids=lambda c: c["case"])
+def test_fast_cm_and_iou_bit_exact(case):
+    from nas_segm_amd.helpers.miou_utils import compute_iu, compute_ius_accs, fast_cm
+
+    n, name = case["n_classes"], case["case"]
+    pr, gt = MIOU_NPZ[name + "/preds"], MIOU_NPZ[name + "/gt"]
+    cm = fast_cm(pr, gt, n)
+    assert cm.dtype == np.int64 and np.array_equal(cm, MIOU_NPZ[name + "/cm"])
+    # device tensors in -> device tensor out
+    cm_dev = fast_cm(torch.from_numpy(pr).to(DEV), torch.from_numpy(gt).to(DEV), n)
+    assert cm_dev.is_cuda and np.array_equal(cm_dev.cpu().numpy(), MIOU_NPZ[name + "/cm"])
+    iu, npx, acc = compute_ius_accs(cm)
+    assert np.array_equal(iu, MIOU_NPZ[name + "/iu"])
+    assert np.array_equal(npx, MIOU_NPZ[name + "/n_pixels"])
+    assert np.array_equal(acc, MIOU_NPZ[name + "/accs"])
+    assert np.array_equal(compute_iu(cm), MIOU_NPZ[name + "/iu"])
+
+
+class _FixedLogits(torch.nn.Module):
+    def __init__(self, logits):
+        super(_FixedLogits, self).__init__()
+        self.logits, self.i = logits, 0
+        self.dummy = torch.nn.Parameter(torch.zeros(1, device=DEV))
+
+    def forward(self, x):
+        out = self.logits[self.i]
+        self.i += 1
+        return out
+
+
+@pytest.mark.parametrize("case", [c for c in MIOU_CASES if c["case"].startswith("val")],
+                         ids=lambda c: c["case"])
+def test_validate_reward(case):
+    from nas_segm_amd.engine.inference import validate
+
+    n, name = case["n_classes"], case["case"]
+    logits = [cl(MIOU_NPZ["{}/logits/{}".format(name, i)]) for i in range(case["n_batches"])]
+    loader = [{"image": torch.zeros(2, 3, 4, 4), "mask": torch.from_numpy(MIOU_NPZ["{}/mask/{}".format(name, i)])}
+              for i in range(case["n_batches"])]
+    reward = validate.__wrapped__(_FixedLogits(logits), loader, 0, 0, num_classes=n, print_every=100,
+                                  omit_classes=case["omit"])
+    # random logits have no exact ties; a handful of interpolation near-ties may flip
+    assert abs(reward - float(MIOU_NPZ[name + "/reward"])) < 2e-5

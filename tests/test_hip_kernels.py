@@ -1,0 +1,327 @@
+"""Kernel-level parity: every HIP primitive (through the C ABI) against the plain
+PyTorch-CPU fp32 op the reference would have dispatched, forward and backward,
+over the geometries that occur on the path plus ragged / edge shapes."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def F():
+    from nas_segm_amd import functional
+
+    return functional
+
+
+def dev(t):
+    t = t.to(DEV)
+    return t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t
+
+
+def run_pair(fn_hip, fn_ref, inputs, fwd_tol=2e-5, grad_rtol=1e-3, seed=0, names=None):
+    """run fn on device tensors and fn_ref on CPU leaf copies; compare outputs and input grads"""
+    cpu = [t.clone().requires_grad_(t.is_floating_point()) for t in inputs]
+    gpu = [dev(t.clone()).requires_grad_(t.is_floating_point()) for t in inputs]
+    y_ref = fn_ref(*cpu)
+    y = fn_hip(*gpu)
+    assert_close(y, y_ref, fwd_tol, fwd_tol, "forward")
+    g = torch.Generator().manual_seed(seed + 99)
+    cot = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(cot)
+    y.backward(dev(cot) if cot.dim() == 4 else cot.to(DEV))
+    for i, (a, b) in enumerate(zip(gpu, cpu)):
+        if b.grad is None:
+            continue
+        scale = float(b.grad.abs().max()) + 1e-12
+        assert_close(a.grad, b.grad, grad_rtol * scale, grad_rtol,
+                     "grad of input {}".format(names[i] if names else i))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------
+DW_CASES = [
+    # B, C, H, W, K, stride, pad, dil
+    (2, 24, 13, 17, 3, 1, 1, 1),
+    (2, 32, 16, 20, 5, 1, 2, 1),
+    (1, 8, 9, 11, 7, 1, 3, 1),
+    (2, 16, 21, 19, 3, 1, 3, 3),
+    (2, 32, 30, 33, 5, 1, 12, 6),
+    (2, 24, 17, 23, 3, 2, 1, 1),
+    (2, 16, 18, 22, 5, 2, 2, 1),
+    (1, 32, 29, 31, 5, 2, 12, 6),
+    (1, 16, 20, 20, 3, 2, 3, 3),
+    (1, 8, 12, 14, 3, 1, 2, 2),
+    (1, 8, 14, 12, 5, 1, 4, 2),
+    (3, 96, 10, 12, 3, 2, 1, 1),
+    (1, 144, 8, 8, 3, 1, 1, 1),
+    (1, 4, 3, 3, 5, 1, 12, 6),
+]
+
+
+@pytest.mark.parametrize("case", DW_CASES, ids=lambda c: "B{}C{}_{}x{}_k{}s{}p{}d{}".format(*c))
+@pytest.mark.parametrize("relu_in", [False, True])
+def test_depthwise_conv(case, relu_in):
+    B, C, H, W, K, s, p, d = case
+    if relu_in and K == 7:
+        pytest.skip("relu_in only occurs with DilConv (k 3/5)")
+    x = rnd(B, C, H, W, seed=1)
+    w = rnd(C, 1, K, K, seed=2, scale=0.3)
+
+    def ref(x, w):
+        xi = TF.relu(x) if relu_in else x
+        return TF.conv2d(xi, w, None, s, p, d, groups=C)
+
+    run_pair(lambda x, w: F().depthwise_conv2d(x, w, s, p, d, relu_in=relu_in), ref, [x, w],
+             names=["x", "weight"])
+
+
+CONV_CASES = [
+    # B, K(Cin), H, W, N(Cout), k, stride, pad, dil, bias
+    (2, 32, 9, 11, 32, 1, 1, 0, 1, False),
+    (2, 16, 10, 10, 96, 1, 1, 0, 1, False),
+    (2, 96, 7, 9, 24, 1, 1, 0, 1, False),
+    (1, 24, 8, 12, 144, 1, 1, 0, 1, False),
+    (1, 144, 6, 6, 32, 1, 1, 0, 1, False),
+    (2, 224, 5, 7, 64, 1, 1, 0, 1, False),
+    (1, 128, 9, 9, 64, 1, 1, 0, 1, False),
+    (1, 48, 9, 9, 48, 1, 1, 0, 1, False),
+    (1, 320, 4, 5, 64, 1, 1, 0, 1, False),
+    (1, 160, 4, 5, 960, 1, 1, 0, 1, False),
+    (2, 64, 13, 17, 19, 3, 1, 1, 1, True),
+    (2, 64, 11, 11, 21, 3, 1, 1, 1, True),
+    (1, 64, 12, 10, 1, 3, 1, 1, 1, True),
+    (2, 64, 14, 15, 64, 3, 1, 3, 3, False),
+    (1, 64, 27, 29, 64, 3, 1, 12, 12, False),
+    (2, 3, 33, 37, 32, 3, 2, 1, 1, False),
+    (2, 8, 13, 17, 16, 3, 2, 1, 1, False),
+    (2, 8, 13, 17, 16, 1, 2, 0, 1, False),
+    (2, 8, 13, 17, 16, 3, 2, 12, 12, False),
+    (3, 64, 1, 1, 64, 1, 1, 0, 1, False),
+    (1, 20, 5, 5, 12, 1, 1, 0, 1, False),
+]
+
+
+@pytest.mark.parametrize(
+    "case", CONV_CASES, ids=lambda c: "B{}K{}_{}x{}_N{}_k{}s{}p{}d{}b{}".format(*[int(v) for v in c]))
+def test_dense_conv(case):
+    B, K, H, W, N, k, s, p, d, bias = case
+    x = rnd(B, K, H, W, seed=3)
+    w = rnd(N, K, k, k, seed=4, scale=1.0 / np.sqrt(K * k * k))
+    ins = [x, w] + ([rnd(N, seed=5)] if bias else [])
+
+    def ref(x, w, b=None):
+        return TF.conv2d(x, w, b, s, p, d)
+
+    def hip(x, w, b=None):
+        return F().conv2d(x, w, b, s, p, d)
+
+    run_pair(hip, ref, ins, fwd_tol=3e-5, names=["x", "weight", "bias"])
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 13, 17), (4, 32, 8, 8), (2, 8, 1, 1), (3, 144, 5, 7),
+                                   (1, 960, 3, 4), (2, 64, 33, 31)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("residual", [False, True])
+def test_batch_norm_act(shape, act, training, residual):
+    B, C, H, W = shape
+    x = rnd(B, C, H, W, seed=6, scale=2.0) + 0.5
+    gamma = torch.rand(C, generator=torch.Generator().manual_seed(7)) + 0.5
+    beta = rnd(C, seed=8, scale=0.2)
+    rm0 = rnd(C, seed=9, scale=0.1)
+    rv0 = torch.rand(C, generator=torch.Generator().manual_seed(10)) + 0.5
+    res = rnd(B, C, H, W, seed=11) if residual else None
+    rm_c, rv_c = rm0.clone(), rv0.clone()
+    rm_g, rv_g = rm0.clone().to(DEV), rv0.clone().to(DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+
+    def ref(x, g, b, r=None):
+        y = TF.batch_norm(x, rm_c, rv_c, g, b, training, 0.1, 1e-5)
+        y = TF.relu(y) if act == 1 else (TF.hardtanh(y, 0.0, 6.0) if act == 2 else y)
+        return y + r if r is not None else y
+
+    def hip(x, g, b, r=None):
+        return F().batch_norm_act(x, g, b, rm_g, rv_g, nbt if training else None, training, 0.1,
+                                  1e-5, act, r)
+
+    ins = [x, gamma, beta] + ([res] if residual else [])
+    run_pair(hip, ref, ins, fwd_tol=3e-5, grad_rtol=2e-3, names=["x", "gamma", "beta", "res"])
+    assert_close(rm_g, rm_c, 1e-6, 1e-5, "running_mean")
+    assert_close(rv_g, rv_c, 1e-6, 1e-5, "running_var")
+    assert int(nbt) == (1 if training else 0)
+
+
+def test_batch_norm_single_value_raises_value_error():
+    x = dev(rnd(1, 8, 1, 1))
+    with pytest.raises(ValueError):
+        F().batch_norm_act(x, None, None, torch.zeros(8, device=DEV), torch.ones(8, device=DEV), None,
+                           True, 0.1, 1e-5, 0, None)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 13, 17), (1, 48, 16, 16), (2, 16, 7, 9), (1, 4, 1, 1), (1, 4, 2, 3)])
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("mode", ["max", "avg"])
+def test_pool(shape, stride, mode):
+    x = rnd(*shape, seed=12)
+    if mode == "max":
+        run_pair(lambda x: F().max_pool2d(x, 3, stride, 1), lambda x: TF.max_pool2d(x, 3, stride, 1), [x])
+    else:
+        run_pair(lambda x: F().avg_pool2d(x, 3, stride, 1),
+                 lambda x: TF.avg_pool2d(x, 3, stride, 1, count_include_pad=False), [x])
+
+
+RESIZE_CASES = [((7, 9), (13, 17)), ((13, 17), (7, 9)), ((4, 5), (32, 40)), ((32, 64), (8, 16)),
+                ((10, 5), (9, 20)), ((1, 1), (6, 7)), ((5, 5), (5, 9)), ((3, 4), (81, 81)),
+                ((16, 16), (61, 3))]
+
+
+@pytest.mark.parametrize("sizes", RESIZE_CASES, ids=lambda s: "{}x{}_to_{}x{}".format(*s[0], *s[1]))
+@pytest.mark.parametrize("C", [8, 19, 1])
+def test_bilinear_resize(sizes, C):
+    (hi, wi), (ho, wo) = sizes
+    x = rnd(2, C, hi, wi, seed=13)
+    run_pair(lambda x: F().bilinear_resize(x, (ho, wo)),
+             lambda x: TF.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False), [x],
+             fwd_tol=1e-5)
+
+
+def test_concat_resize_with_relu():
+    a, b, c = rnd(2, 8, 13, 17, seed=14), rnd(2, 16, 7, 9, seed=15), rnd(2, 4, 13, 17, seed=16)
+
+    def ref(a, b, c):
+        bu = TF.interpolate(b, size=(13, 17), mode="bilinear", align_corners=False)
+        return TF.relu(torch.cat([a, bu, c], 1))
+
+    run_pair(lambda a, b, c: F().concat_resize([a, b, c], (13, 17), relu=True), ref, [a, b, c])
+    run_pair(lambda a, b, c: F().concat_resize([a, b, c], (13, 17), relu=False),
+             lambda a, b, c: torch.cat([a, TF.interpolate(b, size=(13, 17), mode="bilinear",
+                                                          align_corners=False), c], 1), [a, b, c])
+
+
+def test_add_relu_paramsum_repeat():
+    x, y = rnd(2, 16, 9, 11, seed=17), rnd(2, 16, 9, 11, seed=18)
+    a = torch.rand(16, generator=torch.Generator().manual_seed(19)) + 0.5
+    b = torch.rand(16, generator=torch.Generator().manual_seed(20)) + 0.5
+    run_pair(lambda x, y: F().add(x, y), lambda x, y: x + y, [x, y])
+    run_pair(lambda x: F().relu(x), lambda x: TF.relu(x), [x])
+    run_pair(lambda x, y, a, b: F().param_sum(x, y, a, b),
+             lambda x, y, a, b: a[None, :, None, None] * x + b[None, :, None, None] * y, [x, y, a, b],
+             grad_rtol=2e-3)
+    run_pair(lambda x: F().channel_repeat(x, 3), lambda x: x.repeat(1, 3, 1, 1), [x])
+    z = F().zeros(dev(x), 2, 32, 5, 6)
+    assert tuple(z.shape) == (2, 32, 5, 6) and float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 11, 11), (3, 8, 1, 1), (2, 32, 81, 81), (1, 24, 128, 256)])
+def test_global_avg_pool_and_broadcast(shape):
+    x = rnd(*shape, seed=21)
+    run_pair(lambda x: F().global_avg_pool(x),
+             lambda x: x.mean(2, keepdim=True).mean(3, keepdim=True), [x], fwd_tol=1e-5)
+    v = rnd(shape[0], shape[1], 1, 1, seed=22)
+    size = (shape[2], shape[3])
+    run_pair(lambda v: F().broadcast_to(v, size),
+             lambda v: TF.interpolate(v, size=size, mode="bilinear", align_corners=False), [v],
+             fwd_tol=1e-6, grad_rtol=2e-3)
+
+
+@pytest.mark.parametrize("C", [19, 21, 2, 1])
+@pytest.mark.parametrize("all_ignored", [False, True])
+def test_log_softmax_nll(C, all_ignored):
+    B, H, W = 2, 17, 23
+    logits = rnd(B, C, H, W, seed=23, scale=3.0)
+    g = torch.Generator().manual_seed(24)
+    target = torch.randint(0, C, (B, H, W), generator=g)
+    target[:, 3:6] = 255
+    if all_ignored:
+        target[:] = 255
+    lc = logits.clone().requires_grad_(True)
+    ref = TF.nll_loss(TF.log_softmax(lc, dim=1), target, ignore_index=255)
+    lg = dev(logits.clone()).requires_grad_(True)
+    out = F().log_softmax_nll(lg, target.to(DEV), 255)
+    if all_ignored:
+        assert torch.isnan(out) and torch.isnan(ref)
+        return
+    assert abs(float(out) - float(ref)) < 1e-5
+    (ref * 0.7).backward()
+    (out * 0.7).backward()
+    assert_close(lg.grad, lc.grad, 1e-8, 1e-4, "dlogits")
+    out8 = F().log_softmax_nll(dev(logits), target.to(torch.uint8).to(DEV), 255)
+    assert abs(float(out8) - float(ref)) < 1e-5
+
+
+def test_nearest_label_resize():
+    g = torch.Generator().manual_seed(25)
+    for (hi, wi), (ho, wo) in [((65, 97), (17, 25)), ((1024, 2048), (256, 512)), ((17, 25), (65, 97)), ((7, 7), (7, 7))]:
+        t = torch.randint(0, 256, (2, hi, wi), generator=g)
+        ref = TF.interpolate(t[:, None].float(), size=(ho, wo), mode="nearest").long()[:, 0]
+        for tt in (t, t.to(torch.uint8)):
+            got = F().nearest_label_resize(tt.to(DEV), (ho, wo))
+            assert got.dtype == torch.int64 and torch.equal(got.cpu(), ref)
+
+
+def test_fast_cm_bit_exact_and_edge_cases():
+    from nas_segm_amd.helpers.miou_utils import compute_ius_accs, fast_cm
+    from oracle import miou as omiou
+
+    rng = np.random.RandomState(3)
+    for n, npx in [(21, 100003), (19, 1), (255, 70000), (3, 0), (70, 5000)]:
+        gt = rng.randint(0, n, size=npx).astype(np.uint8)
+        pr = rng.randint(0, n, size=npx).astype(np.uint8)
+        cm = fast_cm(pr, gt, n)
+        ref = omiou.fast_cm(pr, gt, n)
+        assert cm.dtype == np.int64 and cm.shape == (n, n) and np.array_equal(cm, ref)
+        if npx:
+            a, b = compute_ius_accs(cm), omiou.compute_ius_accs(ref)
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v)
+    # all pixels in one bin: worst-case LDS atomic contention, still exact
+    z = np.zeros(1 << 20, dtype=np.uint8)
+    assert fast_cm(z, z, 21)[0, 0] == 1 << 20
+    with pytest.raises(ValueError):
+        fast_cm(np.zeros(4, dtype=np.int64), np.zeros(4, dtype=np.uint8), 3)
+
+
+@pytest.mark.parametrize("C,lowres,full", [(19, (17, 23), (65, 89)), (21, (16, 16), (16, 16)), (5, (9, 7), (70, 55))])
+def test_argmax_confusion_fused_upsample(C, lowres, full):
+    from oracle import engine as oeng
+
+    logits = rnd(2, C, *lowres, seed=26, scale=3.0)
+    g = torch.Generator().manual_seed(27)
+    gt = torch.randint(0, C, (2,) + full, generator=g)
+    gt[:, 5:8] = 255
+    gt = gt.to(torch.uint8)
+    cm, preds = F().argmax_confusion(dev(logits), gt.to(DEV), C, return_preds=True)
+    up = TF.interpolate(logits, size=full, mode="bilinear", align_corners=False)
+    ref_pred = up.numpy().argmax(axis=1).astype(np.uint8)
+    diff = preds.cpu().numpy() != ref_pred
+    if diff.any():
+        # only genuine near-ties may differ (rounding of the interpolation weights)
+        top2 = np.sort(up.numpy(), axis=1)[:, -2:]
+        gap = (top2[:, 1] - top2[:, 0])[diff]
+        assert diff.mean() < 1e-4 and gap.max() < 1e-5
+    # the histogram itself is exact for the predictions the kernel made
+    from oracle import miou as omiou
+
+    keep = gt.numpy() < C
+    assert np.array_equal(cm.cpu().numpy(), omiou.fast_cm(preds.cpu().numpy()[keep], gt.numpy()[keep], C))
+    ref_cm = oeng.confusion(logits, gt.numpy(), C)
+    assert np.abs(cm.cpu().numpy() - ref_cm).sum() <= 2 * int(diff.sum())
+
+
+def test_cpu_tensors_fail_loudly():
+    from nas_segm_amd import NassegError
+
+    with pytest.raises(NassegError):
+        F().relu(rnd(1, 4, 2, 2))
+    with pytest.raises(RuntimeError):
+        F().conv2d(rnd(1, 4, 2, 2), rnd(4, 4, 1, 1))

@@ -1,0 +1,36 @@
+#!/bin/bash
+# Run on the MI355X box through gpurun: GPU test-suite (one pytest process per
+# file so that a faulting kernel cannot take the other files down), smoke(),
+# a short bench and a rocprofv3 kernel-trace summary.  Logs -> gpurun_out/.
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=gpurun_out
+mkdir -p $OUT
+WHAT="${1:-all}"
+python -c "import torch; print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))" > $OUT/env.log 2>&1
+nproc >> $OUT/env.log; grep -m1 "model name" /proc/cpuinfo >> $OUT/env.log
+if [[ "$WHAT" == "all" || "$WHAT" == "tests" ]]; then
+  for f in tests/test_hip_kernels.py tests/test_hip_golden.py tests/test_hip_engine.py; do
+    n=$(basename $f .py)
+    timeout 900 python -m pytest $f -m gpu -q --tb=short --timeout 300 -p no:cacheprovider > $OUT/$n.log 2>&1
+    echo "$n exit $?" >> $OUT/summary.log
+    tail -3 $OUT/$n.log >> $OUT/summary.log
+  done
+fi
+if [[ "$WHAT" == "all" || "$WHAT" == "smoke" ]]; then
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+  echo "smoke exit $?" >> $OUT/summary.log
+fi
+if [[ "$WHAT" == "all" || "$WHAT" == "bench" ]]; then
+  timeout 600 python bench.py --steps 5 --warmup 2 --breakdown > $OUT/bench.json 2> $OUT/bench.err
+  echo "bench exit $?" >> $OUT/summary.log
+  cat $OUT/bench.json >> $OUT/summary.log
+fi
+if [[ "$WHAT" == "all" || "$WHAT" == "prof" ]]; then
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o run -- \
+     python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > "$OLDPWD/$OUT/prof.log" 2>&1)
+  echo "prof exit $?" >> $OUT/summary.log
+  find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/summary.log
+fi
+cat $OUT/summary.log
