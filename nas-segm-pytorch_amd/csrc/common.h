@@ -68,3 +68,43 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) {
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) {
   return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 }
+
+// ---------------------------------------------------------------------------
+// Second stage of every deterministic two-stage reduction: sum partial[b][e]
+// over b = 0..nblk-1 for 16 consecutive elements per workgroup.  256 threads =
+// 16 elements x 16 slices of the partial index; each thread adds its slice in a
+// fixed order (fp64), the 16 slices are then combined in a fixed order through
+// LDS.  Returns the total in the threads with slice == 0 (valid == e < per).
+// ---------------------------------------------------------------------------
+#define NASSEG_RP_ELEMS 16
+#define NASSEG_RP_SLICES 16
+__device__ __forceinline__ double reduce_partials16(const float* __restrict__ partial, int nblk,
+                                                    int64_t per, int64_t e, bool valid,
+                                                    double (*red)[NASSEG_RP_ELEMS + 1]) {
+  const int slice = threadIdx.x >> 4;
+  const int el = threadIdx.x & 15;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (valid) {
+    int b = slice;
+    for (; b + 3 * NASSEG_RP_SLICES < nblk; b += 4 * NASSEG_RP_SLICES) {
+      const float v0 = partial[(int64_t)b * per + e];
+      const float v1 = partial[(int64_t)(b + NASSEG_RP_SLICES) * per + e];
+      const float v2 = partial[(int64_t)(b + 2 * NASSEG_RP_SLICES) * per + e];
+      const float v3 = partial[(int64_t)(b + 3 * NASSEG_RP_SLICES) * per + e];
+      s0 += (double)v0;
+      s1 += (double)v1;
+      s2 += (double)v2;
+      s3 += (double)v3;
+    }
+    for (; b < nblk; b += NASSEG_RP_SLICES) s0 += (double)partial[(int64_t)b * per + e];
+  }
+  red[slice][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  double tot = 0.0;
+  if (slice == 0) {
+#pragma unroll
+    for (int i = 0; i < NASSEG_RP_SLICES; ++i) tot += red[i][el];
+  }
+  __syncthreads();
+  return tot;
+}

@@ -331,18 +331,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 }
 
 // dw (N,K,kh,kw) = sum over slabs of partial[slab][tap][N][K]
-__global__ void conv_wgrad_finalize(const float* __restrict__ partial, float* __restrict__ dw,
-                                    int nslab, int ntaps, int N, int K) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over tap*N*K
+__global__ __launch_bounds__(256) void conv_wgrad_finalize(const float* __restrict__ partial,
+                                                           float* __restrict__ dw, int nslab,
+                                                           int ntaps, int N, int K) {
+  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
   const int64_t per = (int64_t)ntaps * N * K;
-  if (i >= per) return;
-  double s = 0.0;
-  for (int sl = 0; sl < nslab; ++sl) s += (double)partial[(int64_t)sl * per + i];
-  const int k = (int)(i % K);
-  int64_t t = i / K;
-  const int n = (int)(t % N);
-  const int tap = (int)(t / N);
-  dw[((int64_t)n * K + k) * ntaps + tap] = (float)s;
+  const int64_t i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + (threadIdx.x & 15);  // (tap*N + n)*K + k
+  const bool valid = i < per;
+  const double s = reduce_partials16(partial, nslab, per, i, valid, red);
+  if (valid && (threadIdx.x >> 4) == 0) {
+    const int k = (int)(i % K);
+    const int64_t t = i / K;
+    const int n = (int)(t % N);
+    const int tap = (int)(t / N);
+    dw[((int64_t)n * K + k) * ntaps + tap] = (float)s;
+  }
 }
 
 // OIHW (N,K,kh,kw) -> [tap][N][K]  (mode 0)  or  [tap][K][N] (mode 1)
@@ -480,8 +483,8 @@ int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float*
     hipLaunchKernelGGL((conv_wgrad_kernel<false, false>), grid, dim3(256), 0, s, a);
   NASSEG_LAUNCH_CHECK("conv_wgrad_kernel");
   const int64_t per = (int64_t)kh * kw * N * K;
-  hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64(per, 256)), dim3(256), 0, s, ws, dw,
-                     nslab, kh * kw, N, K);
+  hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64(per, NASSEG_RP_ELEMS)), dim3(256), 0,
+                     s, ws, dw, nslab, kh * kw, N, K);
   NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
   return NASSEG_OK;
 }

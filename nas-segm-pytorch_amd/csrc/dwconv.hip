@@ -294,14 +294,18 @@ __global__ __launch_bounds__(256) void dw_wgrad_generic(
 }
 
 // sum partial[blk][tap][C] over blk -> dw[(c*KK + tap)]  ((C,1,K,K) layout)
-__global__ void dw_wgrad_finalize(const float* __restrict__ partial, float* __restrict__ dw,
-                                  int nblk, int KK, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over tap*C + c
-  if (i >= KK * C) return;
-  const int t = i / C, c = i - t * C;
-  double s = 0.0;
-  for (int bk = 0; bk < nblk; ++bk) s += (double)partial[(size_t)bk * KK * C + i];
-  dw[c * KK + t] = (float)s;
+__global__ __launch_bounds__(256) void dw_wgrad_finalize(const float* __restrict__ partial,
+                                                         float* __restrict__ dw, int nblk, int KK,
+                                                         int C) {
+  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  const int64_t per = (int64_t)KK * C;
+  const int64_t i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + (threadIdx.x & 15);  // tap*C + c
+  const bool valid = i < per;
+  const double s = reduce_partials16(partial, nblk, per, i, valid, red);
+  if (valid && (threadIdx.x >> 4) == 0) {
+    const int t = (int)(i / C), c = (int)(i - (int64_t)t * C);
+    dw[c * KK + t] = (float)s;
+  }
 }
 
 struct StripCfg {
@@ -415,8 +419,8 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, i
                        Ho, Wo, K, stride, pad, dil, relu_in);
     NASSEG_LAUNCH_CHECK("dw_wgrad_generic");
   }
-  hipLaunchKernelGGL(dw_wgrad_finalize, dim3(cdiv(K * K * C, 256)), dim3(256), 0, s, ws, dw,
-                     gx * gy, K * K, C);
+  hipLaunchKernelGGL(dw_wgrad_finalize, dim3(cdiv(K * K * C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws,
+                     dw, gx * gy, K * K, C);
   NASSEG_LAUNCH_CHECK("dw_wgrad_finalize");
   return NASSEG_OK;
 }

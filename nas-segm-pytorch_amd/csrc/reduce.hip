@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void colred_kernel(RedArgs q) {
     const float* pa = q.a + (int64_t)seg * q.R * q.lda + cv * VEC;
     const float* pb = q.b ? q.b + (int64_t)seg * q.R * q.ldb + cv * VEC : nullptr;
     const float* pc = q.c ? q.c + (int64_t)seg * q.R * q.ldc + cv * VEC : nullptr;
+#pragma unroll 4
     for (int64_t r = r0 + rr; r < r1; r += rpi) {
       T va = V::ld(pa + r * q.lda);
       if (MODE == RED_SUM) {
@@ -140,35 +141,35 @@ __global__ __launch_bounds__(256) void colred_kernel(RedArgs q) {
 }
 
 // out[seg][acc][c] = mul * sum_blk partial[seg][blk][acc][c]
-__global__ void colred_finalize(const float* __restrict__ partial, float* __restrict__ out, int S,
-                                int nblk, int nacc, int C, float mul) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over S*nacc*C
-  if (i >= S * nacc * C) return;
-  const int c = i % C;
-  const int t = i / C;
-  const int acc = t % nacc;
-  const int seg = t / nacc;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(((int64_t)seg * nblk + b) * 2 + acc) * C + c];
-  out[i] = (float)(s * (double)mul);
+// grid: (ceil(2*C/16), S); 256 threads (see reduce_partials16)
+__global__ __launch_bounds__(256) void colred_finalize(const float* __restrict__ partial,
+                                                       float* __restrict__ out, int nblk, int nacc,
+                                                       int C, float mul) {
+  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  const int seg = blockIdx.y;
+  const int64_t per = 2 * (int64_t)C;  // [2][C] per block, only the first nacc rows are used
+  const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + (threadIdx.x & 15);
+  const bool valid = e < (int64_t)nacc * C;
+  const double s = reduce_partials16(partial + (int64_t)seg * nblk * per, nblk, per, e, valid, red);
+  if (valid && (threadIdx.x >> 4) == 0) out[(int64_t)seg * nacc * C + e] = (float)(s * (double)mul);
 }
 
 // BatchNorm statistics finalisation (training mode).  Normalisation uses the
 // biased variance, running_var the unbiased one (torch semantics).
-__global__ void bn_stats_finalize(const float* __restrict__ partial, int nblk, int C, double M,
-                                  float eps, float momentum, const float* __restrict__ gamma,
-                                  const float* __restrict__ beta, float* __restrict__ mean,
-                                  float* __restrict__ invstd, float* __restrict__ scale,
-                                  float* __restrict__ shift, float* __restrict__ running_mean,
-                                  float* __restrict__ running_var, int64_t* nbt) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += 1;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    s0 += (double)partial[((int64_t)b * 2) * C + c];
-    s1 += (double)partial[((int64_t)b * 2 + 1) * C + c];
-  }
+// grid: ceil(C/16) workgroups of 256 threads.
+__global__ __launch_bounds__(256) void bn_stats_finalize(
+    const float* __restrict__ partial, int nblk, int C, double M, float eps, float momentum,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+    float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* nbt) {
+  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  const int c = blockIdx.x * NASSEG_RP_ELEMS + (threadIdx.x & 15);
+  const bool valid = c < C;
+  const int64_t per = 2 * (int64_t)C;
+  const double s0 = reduce_partials16(partial, nblk, per, c, valid, red);
+  const double s1 = reduce_partials16(partial, nblk, per, (int64_t)C + c, valid, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+  if (!valid || (threadIdx.x >> 4) != 0) return;
   const double mu = s0 / M;
   double var = s1 / M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -273,9 +274,8 @@ int nasseg_colred(int mode, const float* a, int64_t lda, const float* b, int64_t
     default: return nasseg_fail(NASSEG_ERR_ARG, "colred: bad mode %d", mode);
   }
   if (rc) return rc;
-  const int n = S * nacc * C;
-  hipLaunchKernelGGL(colred_finalize, dim3(cdiv(n, 256)), dim3(256), 0, s, ws, out, S, q.nblk,
-                     nacc, C, mul);
+  hipLaunchKernelGGL(colred_finalize, dim3(cdiv(nacc * C, NASSEG_RP_ELEMS), S), dim3(256), 0, s, ws,
+                     out, q.nblk, nacc, C, mul);
   NASSEG_LAUNCH_CHECK("colred_finalize");
   return NASSEG_OK;
 }
@@ -293,7 +293,7 @@ int nasseg_bn_stats(const float* x, int64_t ldx, int64_t M, int C, float eps, fl
   q.a = x; q.lda = ldx; q.S = 1; q.R = M; q.C = C; q.partial = ws;
   int rc = launch_colred<RED_SUMSQ>(q, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, ws, q.nblk, C,
+  hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws, q.nblk, C,
                      (double)M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
                      running_mean, running_var, num_batches_tracked);
   NASSEG_LAUNCH_CHECK("bn_stats_finalize");
@@ -323,8 +323,8 @@ int nasseg_bn_bwd_reduce(const float* dy, int64_t lddy, const float* x, int64_t 
   q.S = 1; q.R = M; q.C = C; q.partial = ws;
   int rc = launch_colred<RED_BN_BWD>(q, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(colred_finalize, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, ws, sums, 1, q.nblk,
-                     2, C, 1.0f);
+  hipLaunchKernelGGL(colred_finalize, dim3(cdiv(2 * C, NASSEG_RP_ELEMS), 1), dim3(256), 0, s, ws,
+                     sums, q.nblk, 2, C, 1.0f);
   NASSEG_LAUNCH_CHECK("colred_finalize");
   return NASSEG_OK;
 }

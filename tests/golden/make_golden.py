@@ -275,7 +275,7 @@ def gen_nets():
             loss.backward()
             st.put(name + "/logits_train", output)
             st.put(name + "/loss", loss)
-            grads = {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+            grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
             rec["grad_checksums"] = checksums(grads)
             rec["aux_weight"] = aux_weight
             keys = sorted(grads.keys())
@@ -284,6 +284,32 @@ def gen_nets():
                 st.put(name + "/grad/" + k, grads[k])
             bn_after = {k: v for k, v in net.state_dict().items() if "running_mean" in k}
             rec["bn_after_checksums"] = checksums(bn_after)
+            # Conditioning of the whole-network gradients: tiny batches through ~100
+            # train-mode BatchNorms and ReLUs make some of them change by percents when
+            # the input moves by 1e-6 (fp32 rounding level).  Record, with the reference
+            # itself, how far every stored gradient moves under two such perturbations;
+            # parity tests use it as the tolerance floor.
+            sens = {k: 0.0 for k in pick}
+            for ps in (1, 2):
+                net.load_state_dict(sd0)
+                net.train()
+                pg = torch.Generator().manual_seed(ps)
+                xp = x + 1e-6 * torch.randn(x.shape, generator=pg)
+                outp = net(xp)
+                auxp = []
+                if isinstance(outp, tuple):
+                    outp, auxp = outp
+                lp = crit(nn.LogSoftmax(dim=1)(outp), tv)
+                if aux_weight > 0:
+                    for a in auxp:
+                        a = nn.Upsample(size=tv.size()[1:], mode="bilinear", align_corners=False)(a)
+                        lp = lp + crit(nn.LogSoftmax(dim=1)(a), tv) * aux_weight
+                net.zero_grad()
+                lp.backward()
+                named = dict(net.named_parameters())
+                for k in pick:
+                    sens[k] = max(sens[k], float((named[k].grad - grads[k]).abs().max()))
+            rec["grad_sensitivity"] = sens
         meta[name] = rec
     st.save("nets.npz")
     json.dump(meta, open(os.path.join(OUT, "nets_meta.json"), "w"))

@@ -86,9 +86,16 @@ def test_engine_matches_reference_run(name, monkeypatch):
     for k, (s, sa) in rec["task1_checksums"].items():
         if "num_batches_tracked" in k:
             assert got[k][0] == s, k
+        elif "running_" in k:
+            assert abs(got[k][1] - sa) <= 1e-3 * sa + 1e-4, "{}: {} vs {}".format(k, got[k][1], sa)
         else:
-            # Adam normalises tiny gradients to +-lr: compare the mass of every tensor, loosely
-            assert abs(got[k][1] - sa) <= 2e-2 * sa + 2e-3, "{}: {} vs {}".format(k, got[k][1], sa)
+            # Adam moves every element by ~lr per step whatever the gradient's size, so a
+            # gradient that is numerically zero (e.g. a bias in front of a BatchNorm) takes
+            # a rounding-dependent direction: allow a quarter of that worst-case drift
+            # (numel * lr * steps) on top of 2 % of the tensor's mass
+            numel = net.state_dict()[k].numel()
+            slack = 0.25 * numel * 3e-3 * 2
+            assert abs(got[k][1] - sa) <= 2e-2 * sa + slack, "{}: {} vs {}".format(k, got[k][1], sa)
     pol = checksums({str(i): a.cpu() for i, a in enumerate(avg_param)})
     for k, (s, sa) in rec["task1_polyak_checksums"].items():
         assert abs(pol[k][1] - sa) <= 1e-3 * sa + 1e-4, k

@@ -28,7 +28,7 @@ if [[ "$WHAT" == "all" || "$WHAT" == "bench" ]]; then
   cat $OUT/bench.json >> $OUT/summary.log
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == "prof" ]]; then
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o run -- \
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o run -- \
      python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > "$OLDPWD/$OUT/prof.log" 2>&1)
   echo "prof exit $?" >> $OUT/summary.log
   find $OUT/prof -name "*kernel_stats*" | head -3 >> $OUT/summary.log
