@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
+    ap.add_argument("--shapes", type=int, default=0,
+                    help="with --breakdown: also print the N most expensive (entry point, shape) rows")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -244,7 +246,8 @@ def main():
         lib.profiler = LaunchProfiler()
         step()
         step()
-        rows = roofline_from_profile(lib.profiler.summary())
+        summary = lib.profiler.summary()
+        rows = roofline_from_profile(summary)
         lib.profiler = None
         if rows:
             top = rows[0]
@@ -260,6 +263,19 @@ def main():
         if args.breakdown:
             for r in rows:
                 sys.stderr.write("{kernel:28s} n={launches:5d} {ms:9.3f} ms {gbs:9.1f} GB/s\n".format(**r))
+            if args.shapes:
+                by_shape = {}
+                for name, (n, ms, recs) in summary.items():
+                    for t, a in recs:
+                        key = (name,) + tuple(v for v in a if isinstance(v, (int, float)) and abs(v) < (1 << 31))
+                        ent = by_shape.setdefault(key, [0, 0.0, 0])
+                        ent[0] += 1
+                        ent[1] += t
+                        ent[2] += algorithmic_bytes(name, a)
+                top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[: args.shapes]
+                for key, (n, ms, nb) in top:
+                    sys.stderr.write("{:9.3f} ms n={:3d} {:8.1f} GB/s  {} {}\n".format(
+                        ms, n, nb / 1e6 / ms if ms > 0 else 0.0, key[0], list(key[1:])))
     if world > 1:
         fence()
 
