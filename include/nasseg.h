@@ -60,6 +60,7 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, i
  * output affine/bias+act(+residual) epilogue. */
 int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int kw, int mode,
                             void* stream);
+int nasseg_conv_fwd_pack_mode(int K, int kh, int kw);
 int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     const float* in_scale, const float* in_shift, int in_act,
                     const float* out_scale, const float* out_shift, int out_act, const float* res,

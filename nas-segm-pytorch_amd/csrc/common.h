@@ -71,34 +71,36 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) {
 
 // ---------------------------------------------------------------------------
 // Second stage of every deterministic two-stage reduction: sum partial[b][e]
-// over b = 0..nblk-1 for 16 consecutive elements per workgroup.  256 threads =
-// 16 elements x 16 slices of the partial index; each thread adds its slice in a
-// fixed order (fp64), the 16 slices are then combined in a fixed order through
-// LDS.  Returns the total in the threads with slice == 0 (valid == e < per).
+// over b = 0..nblk-1 for NASSEG_RP_ELEMS consecutive elements per workgroup.
+// 256 threads = 8 elements x 32 slices of the partial index; each thread adds
+// its slice in a fixed order (fp64, 8 loads in flight), the 32 slices are then
+// combined in a fixed order through LDS.  The total is returned in the threads
+// with slice == 0 (rp_slice() == 0); `valid` == (e < per).
 // ---------------------------------------------------------------------------
-#define NASSEG_RP_ELEMS 16
-#define NASSEG_RP_SLICES 16
+#define NASSEG_RP_ELEMS 8
+#define NASSEG_RP_SLICES 32
+__device__ __forceinline__ int rp_elem() { return threadIdx.x % NASSEG_RP_ELEMS; }
+__device__ __forceinline__ int rp_slice() { return threadIdx.x / NASSEG_RP_ELEMS; }
 __device__ __forceinline__ double reduce_partials16(const float* __restrict__ partial, int nblk,
                                                     int64_t per, int64_t e, bool valid,
                                                     double (*red)[NASSEG_RP_ELEMS + 1]) {
-  const int slice = threadIdx.x >> 4;
-  const int el = threadIdx.x & 15;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const int slice = rp_slice();
+  const int el = rp_elem();
+  double s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = 0.0;
   if (valid) {
     int b = slice;
-    for (; b + 3 * NASSEG_RP_SLICES < nblk; b += 4 * NASSEG_RP_SLICES) {
-      const float v0 = partial[(int64_t)b * per + e];
-      const float v1 = partial[(int64_t)(b + NASSEG_RP_SLICES) * per + e];
-      const float v2 = partial[(int64_t)(b + 2 * NASSEG_RP_SLICES) * per + e];
-      const float v3 = partial[(int64_t)(b + 3 * NASSEG_RP_SLICES) * per + e];
-      s0 += (double)v0;
-      s1 += (double)v1;
-      s2 += (double)v2;
-      s3 += (double)v3;
+    for (; b + 7 * NASSEG_RP_SLICES < nblk; b += 8 * NASSEG_RP_SLICES) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = partial[(int64_t)(b + i * NASSEG_RP_SLICES) * per + e];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[i] += (double)v[i];
     }
-    for (; b < nblk; b += NASSEG_RP_SLICES) s0 += (double)partial[(int64_t)b * per + e];
+    for (; b < nblk; b += NASSEG_RP_SLICES) s[0] += (double)partial[(int64_t)b * per + e];
   }
-  red[slice][el] = (s0 + s1) + (s2 + s3);
+  red[slice][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   double tot = 0.0;
   if (slice == 0) {

@@ -1,0 +1,399 @@
+// Dense convolution forward / backward-data (1x1 pointwise and k x k, any stride /
+// dilation) as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32),
+// NHWC, gfx950.
+//
+// Reference call sites: conv1x1 / conv3x3 / conv_bn / conv_bn_relu
+// (src/nn/layer_factory.py:7-24,94-122), the pointwise stage of SepConv /
+// DilConv / InvertedResidual / Pool / Adapt / ConcatReduce (:125-382) and the
+// classifier heads (src/nn/micro_decoders.py:210-227,360-363).
+//
+// fp32 in / fp32 accumulate MFMA is bit-equivalent to an fmaf chain, which is what
+// keeps logits within 1e-4 of the reference.  D[n][pixel] = sum_k W[n][k] * X[pixel][k]:
+// each lane loads one float4 along the (contiguous) reduction axis and feeds its four
+// components to four consecutive MFMAs (the "k" label of an MFMA slot is arbitrary as
+// long as A and B agree); the accumulator then holds four consecutive output channels
+// of one pixel per lane -> float4 stores.  A wave owns MT x NT tiles of 16 pixels x 16
+// channels and all of N for its pixels, so X is read once.  No LDS.
+//
+// Variants (template): GATHER = needs per-tap source-pixel arithmetic (k x k, strided,
+// transposed); KM = how the reduction axis is read (aligned float4 / scalar / "flat"
+// im2col of a small-K conv such as the 3-channel stem); PRO = fused per-input-channel
+// affine+activation prologue; VECN = N % 4 == 0 (float4 epilogue).
+//
+// Packed weight layouts (nasseg_conv_pack_weight):
+//   mode 0 forward       : wp[tap][N][K]    from OIHW (N,K,kh,kw)
+//   mode 1 backward-data : wp[tap][K][N]    (roles of N and K swapped)
+//   mode 2 flat forward  : wp[N][tap*K + k]
+#include "conv_common.h"
+
+namespace {
+
+struct FwdArgs {
+  const float* x;
+  int ldx;
+  const float* w;
+  float* y;
+  int ldy;
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  const float* out_scale;
+  const float* out_shift;
+  int out_act;
+  const float* res;
+  int ldres;
+  int K, N;
+  ConvGeom g;
+};
+
+enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
+
+// 4 floats along the reduction axis starting at k (clamped, always in range); the caller
+// masks what lies beyond K
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* row, int k, int K) {
+  if (VEC) {
+    return ld4(row + (k < K ? k : 0));
+  } else {
+    float4 v;
+    v.x = keep_if(row[k + 0 < K ? k + 0 : 0], k + 0 < K);
+    v.y = keep_if(row[k + 1 < K ? k + 1 : 0], k + 1 < K);
+    v.z = keep_if(row[k + 2 < K ? k + 2 : 0], k + 2 < K);
+    v.w = keep_if(row[k + 3 < K ? k + 3 : 0], k + 3 < K);
+    return v;
+  }
+}
+
+// EPI: any output epilogue (scale / shift(bias) / activation / residual) is present
+template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 15;   // pixel within subtile (B operand col) / n within tile (A operand row)
+  const int kg = lane >> 4;  // k group
+  const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
+  const int m_base = (blockIdx.x * 4 + wave) * (16 * MT);
+  if (m_base >= Mtot) return;
+  const int n_base = blockIdx.y * (16 * NT);
+
+  // destination pixels of this lane (clamped: out-of-range rows compute garbage that is never stored)
+  int pm[MT], pb[MT], py[MT], px[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_base + mt * 16 + j;
+    pm[mt] = m < Mtot ? m : Mtot - 1;
+    if (GATHER) {
+      px[mt] = pm[mt] % a.g.Wo;
+      const int t = pm[mt] / a.g.Wo;
+      py[mt] = t % a.g.Ho;
+      pb[mt] = t / a.g.Ho;
+    }
+  }
+  // weight rows of this lane (clamped + masked)
+  int wn[NT];
+  bool wok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n_base + nt * 16 + j;
+    wok[nt] = n < a.N;
+    wn[nt] = wok[nt] ? n : a.N - 1;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ntaps = a.g.kh * a.g.kw;
+  const int Kq = (KM == KM_FLAT) ? ntaps * a.K : a.K;  // reduction length of one pass
+  const int nk = (Kq + 15) >> 4;
+
+  auto mma = [&](const float4* bv, const float4* av) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        acc[mt][nt] = mfma16(av[nt].x, bv[mt].x, acc[mt][nt]);
+        acc[mt][nt] = mfma16(av[nt].y, bv[mt].y, acc[mt][nt]);
+        acc[mt][nt] = mfma16(av[nt].z, bv[mt].z, acc[mt][nt]);
+        acc[mt][nt] = mfma16(av[nt].w, bv[mt].w, acc[mt][nt]);
+      }
+  };
+
+  if (KM == KM_FLAT) {
+    // im2col on the fly: k' = tap*K + k, every element gathered separately
+    for (int it = 0; it < nk; ++it) {
+      const int k = it * 16 + kg * 4;
+      float4 bv[MT], av[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        float e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int kq = (k + c < Kq) ? k + c : 0;
+          const int tap = kq / a.K, cin = kq - tap * a.K;
+          const int ty = tap / a.g.kw, tx = tap - ty * a.g.kw;
+          const int sp = src_pixel(a.g, pb[mt], py[mt], px[mt], ty, tx);
+          const float v = a.x[(int64_t)(sp < 0 ? 0 : sp) * a.ldx + cin];
+          e[c] = keep_if(v, sp >= 0 && k + c < Kq);
+        }
+        bv[mt] = make_float4(e[0], e[1], e[2], e[3]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        av[nt] = keep_if(load4<false>(a.w + (int64_t)wn[nt] * Kq, k, Kq), wok[nt]);
+      mma(bv, av);
+    }
+  } else {
+    for (int tap = 0; tap < (GATHER ? ntaps : 1); ++tap) {
+      const float* xrow[MT];
+      bool xok[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        if (GATHER) {
+          const int ty = tap / a.g.kw, tx = tap - ty * a.g.kw;
+          const int sp = src_pixel(a.g, pb[mt], py[mt], px[mt], ty, tx);
+          xok[mt] = sp >= 0;
+          xrow[mt] = a.x + (int64_t)(sp < 0 ? 0 : sp) * a.ldx;
+        } else {
+          xok[mt] = true;
+          xrow[mt] = a.x + (int64_t)pm[mt] * a.ldx;
+        }
+      }
+      const float* wrow[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.w + ((int64_t)tap * a.N + wn[nt]) * a.K;
+      for (int it = 0; it < nk; ++it) {
+        const int k = it * 16 + kg * 4;
+        const bool kok = k < a.K;  // (VEC: the whole float4 is in or out)
+        float4 bv[MT], av[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float4 v = load4<KM == KM_VEC>(xrow[mt], k, a.K);
+          if (PRO) {
+            const float4 s = a.in_scale ? load4<KM == KM_VEC>(a.in_scale, k, a.K)
+                                        : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 h = a.in_shift ? load4<KM == KM_VEC>(a.in_shift, k, a.K) : f4zero();
+            v = act_apply4(fma4(v, s, h), a.in_act);
+            if (KM != KM_VEC) {  // restore the zero padding beyond K
+              v.y = keep_if(v.y, k + 1 < a.K);
+              v.z = keep_if(v.z, k + 2 < a.K);
+              v.w = keep_if(v.w, k + 3 < a.K);
+            }
+          }
+          bv[mt] = keep_if(v, xok[mt] && kok);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          av[nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
+        mma(bv, av);
+      }
+    }
+  }
+
+  // epilogue: lane holds pixel j of each subtile, channels n0 + 4*kg + {0..3}
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n_base + nt * 16 + kg * 4;
+    if (VECN && !EPI) {
+      const bool nok = n < a.N;  // N % 4 == 0: all four channels in or out
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + j;
+        const f32x4 c = acc[mt][nt];
+        if (nok && m < Mtot) st4(a.y + (int64_t)m * a.ldy + n, make_float4(c[0], c[1], c[2], c[3]));
+      }
+    } else if (VECN) {
+      const bool nok = n < a.N;
+      const int nc = nok ? n : 0;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+      if (a.out_scale) sc = ld4(a.out_scale + nc);
+      if (a.out_shift) sh = ld4(a.out_shift + nc);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + j;
+        const f32x4 c = acc[mt][nt];
+        float4 o = fma4(make_float4(c[0], c[1], c[2], c[3]), sc, sh);
+        if (a.out_act) o = act_apply4(o, a.out_act);
+        if (a.res) o = add4(o, ld4(a.res + (int64_t)pm[mt] * a.ldres + nc));
+        if (nok && m < Mtot) st4(a.y + (int64_t)m * a.ldy + n, o);
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + j;
+        const f32x4 c = acc[mt][nt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (n + r < a.N) && (m < Mtot);
+          const int nc = (n + r < a.N) ? n + r : 0;
+          float v = c[r];
+          if (a.out_scale) v *= a.out_scale[nc];
+          if (a.out_shift) v += a.out_shift[nc];
+          if (a.out_act) v = act_apply(v, a.out_act);
+          if (a.res) v += a.res[(int64_t)pm[mt] * a.ldres + nc];
+          if (ok) a.y[(int64_t)m * a.ldy + n + r] = v;
+        }
+      }
+    }
+  }
+}
+
+// OIHW (N,K,kh,kw) -> [tap][N][K] (mode 0), [tap][K][N] (mode 1), [N][tap*K+k] (mode 2)
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int N, int K,
+                                 int ntaps, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)ntaps * N * K;
+  if (i >= total) return;
+  int tap, n, k;
+  if (mode == 0) {
+    k = (int)(i % K);
+    int64_t t = i / K;
+    n = (int)(t % N);
+    tap = (int)(t / N);
+  } else if (mode == 1) {
+    n = (int)(i % N);
+    int64_t t = i / N;
+    k = (int)(t % K);
+    tap = (int)(t / K);
+  } else {
+    k = (int)(i % K);
+    int64_t t = i / K;
+    tap = (int)(t % ntaps);
+    n = (int)(t / ntaps);
+  }
+  wp[i] = w[((int64_t)n * K + k) * ntaps + tap];
+}
+
+struct Mode {
+  int km;
+  bool gather, pro, vecn, epi;
+};
+
+template <int MT, int NT>
+int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
+  const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
+  dim3 grid((unsigned)cdiv64(Mtot, 64 * MT), cdiv(a.N, 16 * NT), 1);
+#define GO(KM_, G_, P_, V_)                                                                           \
+  do {                                                                                                \
+    if (md.epi || !(V_))                                                                              \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true>), grid, dim3(256), 0, s, a);  \
+    else                                                                                              \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false>), grid, dim3(256), 0, s, a); \
+  } while (0)
+  if (md.km == KM_FLAT) {
+    if constexpr (NT <= 4) {
+      if (md.vecn) GO(KM_FLAT, true, false, true);
+      else GO(KM_FLAT, true, false, false);
+    } else {
+      return nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_fwd: flat path supports N <= 64");
+    }
+  } else if (!md.vecn) {
+    // class-logit heads (N = 19, 21, 11, 1): always through the gather kernels
+    if constexpr (NT <= 2) {
+      if (md.km == KM_VEC) GO(KM_VEC, true, false, false);
+      else GO(KM_SCALAR, true, false, false);
+    } else {
+      return nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_fwd: N %% 4 != 0 needs N <= 32");
+    }
+  } else if (md.km == KM_SCALAR) {
+    GO(KM_SCALAR, true, false, true);
+  } else if (md.gather) {
+    GO(KM_VEC, true, false, true);
+  } else if (md.pro) {
+    GO(KM_VEC, false, true, true);
+  } else {
+    GO(KM_VEC, false, false, true);
+  }
+#undef GO
+  NASSEG_LAUNCH_CHECK("conv_fwd_kernel");
+  return NASSEG_OK;
+}
+
+// pixel-tile height per wave: as many 16-pixel subtiles as still leave >= ~6
+// workgroups per CU (the op is latency-bound below that)
+template <int NT>
+int launch_small(const FwdArgs& a, const Mode& md, hipStream_t s) {
+  const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
+  if (Mtot >= 64 * 4 * 1536) return launch_one<4, NT>(a, md, s);
+  if (Mtot >= 64 * 2 * 1536) return launch_one<2, NT>(a, md, s);
+  return launch_one<1, NT>(a, md, s);
+}
+template <int NT>
+int launch_mid(const FwdArgs& a, const Mode& md, hipStream_t s) {
+  const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
+  if (Mtot >= 64 * 2 * 1536) return launch_one<2, NT>(a, md, s);
+  return launch_one<1, NT>(a, md, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+// mode 0: [tap][N][K]; mode 1: backward-data [tap][K][N]; mode 2: flat [N][tap*K+k]
+int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int kw, int mode,
+                            void* stream) {
+  NASSEG_REQUIRE(N > 0 && K > 0 && kh > 0 && kw > 0, "conv_pack_weight: bad shape");
+  NASSEG_REQUIRE(mode >= 0 && mode <= 2, "conv_pack_weight: bad mode %d", mode);
+  const int64_t total = (int64_t)N * K * kh * kw;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, wp, N, K, kh * kw, mode);
+  NASSEG_LAUNCH_CHECK("conv_pack_weight");
+  return NASSEG_OK;
+}
+
+// which packing nasseg_conv_fwd expects for a forward (non-transposed) convolution
+int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) {
+  return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0;
+}
+
+// y[dst pixel][n] = out_act(out_scale[n] * sum_{tap,k} w[tap][n][k] *
+//                   in_act(in_scale[k] * x[src pixel(tap)][k] + in_shift[k]) + out_shift[n])
+//                   (+ res[dst pixel][n])
+// transposed == 0: (Hs,Ws) input dims, (Ho,Wo) output dims of a forward conv; wp packed
+//   with mode nasseg_conv_fwd_pack_mode(K,kh,kw).
+// transposed != 0: backward-data; x is the output gradient with dims (Hs,Ws),
+//   y the input gradient with dims (Ho,Wo), wp packed with mode 1, K = forward
+//   N, N = forward K, stride/pad/dil those of the forward conv.
+// The input prologue (in_scale / in_shift / in_act) is available for pointwise
+// (1x1, stride 1) convolutions with K % 4 == 0.
+int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
+                    const float* in_scale, const float* in_shift, int in_act,
+                    const float* out_scale, const float* out_shift, int out_act, const float* res,
+                    int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
+                    int stride, int pad, int dil, int transposed, void* stream) {
+  NASSEG_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "conv_fwd: bad geometry");
+  NASSEG_REQUIRE(K > 0 && N > 0 && ldx >= K && ldy >= N, "conv_fwd: bad channels K=%d N=%d", K, N);
+  NASSEG_REQUIRE((int64_t)B * Hs * Ws < 2147483647LL && (int64_t)B * Ho * Wo < 2147483647LL,
+                 "conv_fwd: too many pixels");
+  FwdArgs a;
+  a.x = x; a.ldx = ldx; a.w = wp; a.y = y; a.ldy = ldy;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
+  a.res = res; a.ldres = ldres; a.K = K; a.N = N;
+  a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
+  a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
+  a.g.transposed = transposed;
+  hipStream_t s = (hipStream_t)stream;
+  Mode md;
+  md.km = (((K & 3) == 0) && ((ldx & 3) == 0)) ? KM_VEC : KM_SCALAR;
+  md.pro = in_scale || in_shift || in_act;
+  md.gather = !(kh == 1 && kw == 1 && stride == 1 && pad == 0 && Hs == Ho && Ws == Wo);
+  md.vecn = ((N & 3) == 0) && ((ldy & 3) == 0) && (!res || (ldres & 3) == 0);
+  md.epi = out_scale || out_shift || out_act || res;
+  if (!transposed && nasseg_conv_fwd_pack_mode(K, kh, kw) == 2) md.km = KM_FLAT;
+  NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
+                 "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
+  const int tiles = cdiv(N, 16);
+  if (tiles <= 1) return launch_small<1>(a, md, s);
+  if (tiles == 2) return launch_small<2>(a, md, s);
+  if (tiles == 3) return launch_small<3>(a, md, s);
+  if (tiles == 4) return launch_small<4>(a, md, s);
+  if (tiles <= 6) return launch_mid<6>(a, md, s);
+  if (tiles <= 8) return launch_mid<8>(a, md, s);
+  if (tiles <= 12) return launch_one<1, 12>(a, md, s);
+  return launch_one<1, 16>(a, md, s);  // N > 256 is covered by grid.y
+}
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+// Dense convolution backward-weight on the fp32 matrix cores, NHWC, gfx950:
+//   dW[n][k][tap] = sum_pixel dY[pixel][n] * X[src(pixel, tap)][k]
+//
+// Reference: autograd of the nn.Conv2d call sites listed in conv_fwd.hip.
+//
+// The reduction axis (pixels) is the slow axis of both operands, so no transposition is
+// needed: lanes load VN floats along n (from dY) and VK floats along k (from X) straight
+// from HBM into MFMA operands, and the rows/cols of the 16x16 MFMA tile are a permutation
+// of (n, k) (row i <-> n = n0 + VN*i + comp).  4 pixels per MFMA; each wave walks a
+// contiguous pixel range 16 pixels at a time (8 vector loads in flight per lane).
+// Per-wave accumulators are combined through LDS in a fixed order, per-workgroup partials
+// [slab][tap][N][K] by a second deterministic pass (reduce_partials16).
+// "Flat" mode gathers (tap, k) of a small-K conv (the 3-channel stem) as one axis.
+#include "conv_common.h"
+
+namespace {
+
+struct WgArgs {
+  const float* x;   // forward input  [B][Hs][Ws][ldx], K channels
+  int ldx;
+  const float* dy;  // grad of forward output [B][Ho][Wo][lddy], N channels
+  int lddy;
+  float* partial;
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  int K, N;
+  int kchunks;     // number of k chunks (16*VK wide)
+  int pix_per_block;  // multiple of 64
+  ConvGeom g;      // non-transposed forward geometry
+};
+
+// out[0..V) = p[i0..i0+V) from a clamped address; caller masks.  AL: V-aligned vector load.
+template <int V, bool AL>
+__device__ __forceinline__ void load_vec(const float* p, int i0, int len, float* out) {
+  if (AL && V == 4) {
+    const float4 v = ld4(p + (i0 < len ? i0 : 0));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  } else if (AL && V == 2) {
+    const float2 v = *reinterpret_cast<const float2*>(p + (i0 < len ? i0 : 0));
+    out[0] = v.x; out[1] = v.y;
+  } else {
+#pragma unroll
+    for (int c = 0; c < V; ++c) out[c] = p[i0 + c < len ? i0 + c : 0];
+  }
+}
+
+// VN / VK: floats per lane along n / k (chunk = 16*V); ALN / ALK: aligned vector loads;
+// GATHER: per-tap source-pixel arithmetic; FLAT: (tap, k) is one gathered axis; PRO: the
+// forward had an input prologue (affine + activation on x), re-applied on load.
+template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+  constexpr int NACC = VN * VK * 4;
+  __shared__ float red[3][NACC][65];  // waves 1..3 park their accumulators here
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 15;  // row/col index inside a 16-wide MFMA tile
+  const int pk = lane >> 4;  // pixel slot 0..3
+  const int ntaps = a.g.kh * a.g.kw;
+  const int tap = FLAT ? 0 : blockIdx.z;
+  const int ty = tap / a.g.kw, tx = tap - ty * a.g.kw;
+  const int nchunk = blockIdx.y / a.kchunks;
+  const int kchunk = blockIdx.y - nchunk * a.kchunks;
+  const int n0 = nchunk * 16 * VN + li * VN;
+  const int k0 = kchunk * 16 * VK + li * VK;
+  const int Kq = FLAT ? ntaps * a.K : a.K;
+  const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
+  const int p_begin = blockIdx.x * a.pix_per_block + wave * (a.pix_per_block >> 2);
+  int p_end = p_begin + (a.pix_per_block >> 2);
+  if (p_end > Mtot) p_end = Mtot;
+
+  f32x4 acc[VN][VK];
+#pragma unroll
+  for (int i = 0; i < VN; ++i)
+#pragma unroll
+    for (int jj = 0; jj < VK; ++jj) acc[i][jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  bool nok[VN], kok[VK];
+#pragma unroll
+  for (int c = 0; c < VN; ++c) nok[c] = n0 + c < a.N;
+#pragma unroll
+  for (int c = 0; c < VK; ++c) kok[c] = k0 + c < Kq;
+  // flat mode: the (tap, channel) each of this lane's k' elements stands for
+  int fty[VK], ftx[VK], fcin[VK];
+  if (FLAT) {
+#pragma unroll
+    for (int c = 0; c < VK; ++c) {
+      const int kq = kok[c] ? k0 + c : 0;
+      const int tp = kq / a.K;
+      fcin[c] = kq - tp * a.K;
+      fty[c] = tp / a.g.kw;
+      ftx[c] = tp - fty[c] * a.g.kw;
+    }
+  }
+  float ps[VK], ph[VK];
+  if (PRO) {
+#pragma unroll
+    for (int c = 0; c < VK; ++c) {
+      const int kc = kok[c] ? k0 + c : 0;
+      ps[c] = a.in_scale ? a.in_scale[kc] : 1.f;
+      ph[c] = a.in_shift ? a.in_shift[kc] : 0.f;
+    }
+  }
+
+  // Loop bounds are wave-uniform; loads are unconditional from clamped addresses and
+  // masked afterwards, so the 2*U vector loads of an iteration are issued back to back.
+  constexpr int U = 4;
+  for (int g0 = p_begin; g0 < p_end; g0 += 4 * U) {
+    float dv[U][VN], xv[U][VK];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int p = g0 + u * 4 + pk;
+      const bool pok = p < p_end;
+      const int pc = pok ? p : p_end - 1;
+      load_vec<VN, ALN>(a.dy + (int64_t)pc * a.lddy, n0, a.N, dv[u]);
+      if (FLAT) {
+        const int ox = pc % a.g.Wo;
+        const int t = pc / a.g.Wo;
+        const int oy = t % a.g.Ho;
+        const int b = t / a.g.Ho;
+#pragma unroll
+        for (int c = 0; c < VK; ++c) {
+          const int sp = src_pixel(a.g, b, oy, ox, fty[c], ftx[c]);
+          const float v = a.x[(int64_t)(sp < 0 ? 0 : sp) * a.ldx + fcin[c]];
+          xv[u][c] = keep_if(v, pok && kok[c] && sp >= 0);
+        }
+#pragma unroll
+        for (int c = 0; c < VN; ++c) dv[u][c] = keep_if(dv[u][c], pok && nok[c]);
+      } else {
+        int sp = pc;
+        if (GATHER) {
+          const int ox = pc % a.g.Wo;
+          const int t = pc / a.g.Wo;
+          const int oy = t % a.g.Ho;
+          const int b = t / a.g.Ho;
+          sp = src_pixel(a.g, b, oy, ox, ty, tx);
+        }
+        const bool ok = pok && sp >= 0;
+        load_vec<VK, ALK>(a.x + (int64_t)(sp < 0 ? 0 : sp) * a.ldx, k0, a.K, xv[u]);
+#pragma unroll
+        for (int c = 0; c < VK; ++c) {
+          float v = xv[u][c];
+          if (PRO) v = act_apply(fmaf(v, ps[c], ph[c]), a.in_act);
+          xv[u][c] = keep_if(v, ok && kok[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < VN; ++c) dv[u][c] = keep_if(dv[u][c], ok && nok[c]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int ca = 0; ca < VN; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < VK; ++cb) acc[ca][cb] = mfma16(dv[u][ca], xv[u][cb], acc[ca][cb]);
+  }
+  // cross-wave reduction through LDS (fixed order -> deterministic)
+  if (wave > 0) {
+#pragma unroll
+    for (int ca = 0; ca < VN; ++ca)
+#pragma unroll
+      for (int cb = 0; cb < VK; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][(ca * VK + cb) * 4 + r][lane] = acc[ca][cb][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* pout = a.partial + (((int64_t)blockIdx.x * (FLAT ? 1 : ntaps) + tap) * a.N) * Kq;
+#pragma unroll
+    for (int ca = 0; ca < VN; ++ca)
+#pragma unroll
+      for (int cb = 0; cb < VK; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = (ca * VK + cb) * 4 + r;
+          const float v = acc[ca][cb][r] + red[0][e][lane] + red[1][e][lane] + red[2][e][lane];
+          // D row i = 4*pk + r  <-> n ; D col = li <-> k
+          const int n = nchunk * 16 * VN + VN * (4 * pk + r) + ca;
+          const int k = kchunk * 16 * VK + VK * li + cb;
+          if (n < a.N && k < Kq) pout[(int64_t)n * Kq + k] = v;
+        }
+  }
+}
+
+// dw (N,K,kh,kw) = sum over slabs of partial.  flat == 0: partial[slab][tap][N][K];
+// flat != 0: partial[slab][N][tap*K + k]
+__global__ __launch_bounds__(256) void conv_wgrad_finalize(const float* __restrict__ partial,
+                                                           float* __restrict__ dw, int nslab,
+                                                           int ntaps, int N, int K, int flat) {
+  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  const int64_t per = (int64_t)ntaps * N * K;
+  const int64_t i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
+  const bool valid = i < per;
+  const double s = reduce_partials16(partial, nslab, per, i, valid, red);
+  if (valid && rp_slice() == 0) {
+    int n, k, tap;
+    if (!flat) {  // i = (tap*N + n)*K + k
+      k = (int)(i % K);
+      const int64_t t = i / K;
+      n = (int)(t % N);
+      tap = (int)(t / N);
+    } else {  // i = n*(ntaps*K) + tap*K + k
+      const int Kq = ntaps * K;
+      n = (int)(i / Kq);
+      const int kq = (int)(i - (int64_t)n * Kq);
+      tap = kq / K;
+      k = kq - tap * K;
+    }
+    dw[((int64_t)n * K + k) * ntaps + tap] = (float)s;
+  }
+}
+
+struct WgMode {
+  bool aln, alk, gather, flat, pro;
+};
+
+template <int VN, int VK>
+int launch_wgrad(const WgArgs& a, dim3 grid, const WgMode& m, hipStream_t s) {
+#define GO(ALN_, ALK_, G_, F_, P_)                                                              \
+  hipLaunchKernelGGL((conv_wgrad_kernel<VN, VK, ALN_, ALK_, G_, F_, P_>), grid, dim3(256), 0, s, a)
+  if (m.flat) {
+    if (m.aln) GO(true, false, true, true, false);
+    else GO(false, false, true, true, false);
+  } else if (m.pro) {
+    // only reachable for pointwise convs with aligned channels (checked by the caller)
+    GO(true, true, false, false, true);
+  } else if (m.aln && m.alk) {
+    if (m.gather) GO(true, true, true, false, false);
+    else GO(true, true, false, false, false);
+  } else if (m.aln) {
+    GO(true, false, true, false, false);
+  } else if (m.alk) {
+    GO(false, true, true, false, false);
+  } else {
+    GO(false, false, true, false, false);
+  }
+#undef GO
+  NASSEG_LAUNCH_CHECK("conv_wgrad_kernel");
+  return NASSEG_OK;
+}
+
+inline int pick_v(int len) { return len > 32 ? 4 : (len > 16 ? 2 : 1); }
+
+struct WgPlan {
+  int vn, vk, nchunks, kchunks, nslab, flat, pix_per_block;
+};
+inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps) {
+  WgPlan p;
+  p.flat = (taps > 1 && taps * K <= 64) ? 1 : 0;
+  const int Kq = p.flat ? taps * K : K;
+  p.vn = pick_v(N);
+  p.vk = pick_v(Kq);
+  p.nchunks = cdiv(N, 16 * p.vn);
+  p.kchunks = cdiv(Kq, 16 * p.vk);
+  const int64_t per = (int64_t)p.nchunks * p.kchunks * (p.flat ? 1 : taps);
+  // ~1536 workgroups in total, >= 256 pixels each, partial buffer <= 16 MiB
+  int64_t s = 1536 / per;
+  if (s < 1) s = 1;
+  int64_t cap_bytes = (int64_t)(16 << 20) / ((int64_t)taps * N * K * 4);
+  if (cap_bytes < 8) cap_bytes = 8;
+  if (s > cap_bytes) s = cap_bytes;
+  if (s > Mtot / 256) s = Mtot / 256;
+  if (s < 1) s = 1;
+  int64_t ppb = cdiv64(Mtot, s);
+  ppb = (ppb + 63) / 64 * 64;
+  p.pix_per_block = (int)ppb;
+  p.nslab = (int)cdiv64(Mtot, ppb);
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// floats of workspace needed by nasseg_conv_wgrad
+int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw) {
+  WgPlan p = wgrad_plan((int64_t)B * Ho * Wo, N, K, kh * kw);
+  return (int64_t)p.nslab * kh * kw * N * K;
+}
+
+// dw (N,K,kh,kw) = sum_pixels dy[pixel][n] * in_act(in_scale*x[src(pixel,tap)][k]+in_shift)
+// (the input prologue is available for pointwise convs with K % 4 == 0 and N % 4 == 0)
+int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+                      const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
+                      int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                      int dil, void* stream) {
+  NASSEG_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "conv_wgrad: bad geometry");
+  NASSEG_REQUIRE(K > 0 && N > 0 && ldx >= K && lddy >= N, "conv_wgrad: bad channels");
+  NASSEG_REQUIRE((int64_t)B * Hs * Ws < 2147483647LL && (int64_t)B * Ho * Wo < 2147483647LL,
+                 "conv_wgrad: too many pixels");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t Mtot = (int64_t)B * Ho * Wo;
+  const int taps = kh * kw;
+  WgPlan p = wgrad_plan(Mtot, N, K, taps);
+  WgMode m;
+  m.flat = p.flat != 0;
+  m.pro = in_scale || in_shift || in_act;
+  m.gather = !(kh == 1 && kw == 1 && stride == 1 && pad == 0 && Hs == Ho && Ws == Wo);
+  m.aln = (N % p.vn == 0) && (lddy % p.vn == 0);
+  m.alk = !m.flat && (K % p.vk == 0) && (ldx % p.vk == 0);
+  NASSEG_REQUIRE(!m.pro || (!m.flat && !m.gather && m.aln && m.alk),
+                 "conv_wgrad: the input prologue needs a pointwise conv with aligned channels");
+  WgArgs a;
+  a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.partial = ws;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  a.K = K; a.N = N;
+  a.kchunks = p.kchunks;
+  a.pix_per_block = p.pix_per_block;
+  a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
+  a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
+  a.g.transposed = 0;
+  dim3 grid(p.nslab, p.nchunks * p.kchunks, p.flat ? 1 : taps);
+  int rc;
+#define WG_CASE(VN_, VK_) \
+  if (p.vn == VN_ && p.vk == VK_) rc = launch_wgrad<VN_, VK_>(a, grid, m, s); else
+  WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1)
+  WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
+  rc = nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_wgrad: no kernel for vn=%d vk=%d", p.vn, p.vk);
+#undef WG_CASE
+  if (rc) return rc;
+  const int64_t per = (int64_t)taps * N * K;
+  hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64(per, NASSEG_RP_ELEMS)), dim3(256), 0,
+                     s, ws, dw, p.nslab, taps, N, K, p.flat);
+  NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
+  return NASSEG_OK;
+}
+
+}  // extern "C"

@@ -17,6 +17,24 @@
 
 namespace {
 
+// keep v where ok, +0.0 elsewhere, without a select the compiler could turn back into
+// a branch around the producing load (mask = all ones / all zeros)
+__device__ __forceinline__ float4 keep_if(float4 v, bool ok) {
+  const unsigned m = 0u - (unsigned)ok;
+  v.x = __uint_as_float(__float_as_uint(v.x) & m);
+  v.y = __uint_as_float(__float_as_uint(v.y) & m);
+  v.z = __uint_as_float(__float_as_uint(v.z) & m);
+  v.w = __uint_as_float(__float_as_uint(v.w) & m);
+  return v;
+}
+
+// Pin a value at this program point: LLVM otherwise sinks the whole FMA chain of an
+// accumulator into the (conditional) block that finally stores it, which keeps every
+// loaded operand alive until the end of the kernel.
+__device__ __forceinline__ void pin(float4& v) {
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
 __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
@@ -35,33 +53,49 @@ __global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // ---------------------------------------------------------------------------
 // forward strip kernel
 // ---------------------------------------------------------------------------
-template <int K, int P, int E>
+// WLDS: keep the K*K per-channel weight vectors in LDS (indexed by channel group,
+// needs C4 <= 64) instead of 4*K*K registers per lane - for 5x5 this is the
+// difference between 1 and 4+ resident waves per SIMD.
+template <int K, int P, int E, bool WLDS, bool RELU>
 __global__ __launch_bounds__(256) void dw_fwd_strip(
     const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ y,
     const float* __restrict__ scale, const float* __restrict__ shift, int H, int W, int C4, int Ho,
-    int Wo, int stride, int pad, int dil, int g, int nchunk, int relu_in, int act) {
+    int Wo, int stride, int pad, int dil, int g, int nchunk, int act) {
+  __shared__ float4 lw[WLDS ? K * K : 1][WLDS ? 64 : 1];
+  const int C = C4 * 4;
+  if (WLDS) {
+    for (int i = threadIdx.x; i < K * K * C4; i += 256) {
+      const int t = i / C4, c = i - t * C4;
+      lw[t][c] = ld4(wt + (size_t)t * C + c * 4);
+    }
+    __syncthreads();
+  }
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Wo * C4) return;
   const int ox = idx / C4;
   const int c4 = idx - ox * C4;
-  const int C = C4 * 4;
   const int b = blockIdx.z;
   const int r = blockIdx.y % g;
   const int chunk = blockIdx.y / g;
   const int oy0 = chunk * (P * g) + r;
   if (oy0 >= Ho) return;
 
-  float4 w[K * K];
+  float4 w[WLDS ? 1 : K * K];
+  if (!WLDS) {
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) w[t] = ld4(wt + (size_t)t * C + c4 * 4);
+    for (int t = 0; t < K * K; ++t) w[t] = ld4(wt + (size_t)t * C + c4 * 4);
+  }
 
+  // Out-of-range taps load from a clamped (always valid) address and are zeroed by a
+  // select afterwards: a load under a branch would be followed by its own
+  // s_waitcnt vmcnt(0) and serialise the whole strip on memory latency.
   int xoff[K];
   bool xok[K];
 #pragma unroll
   for (int tx = 0; tx < K; ++tx) {
-    int ix = ox * stride - pad + tx * dil;
+    const int ix = ox * stride - pad + tx * dil;
     xok[tx] = (ix >= 0) && (ix < W);
-    xoff[tx] = ix * C;
+    xoff[tx] = (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;
   }
   float4 acc[P];
 #pragma unroll
@@ -70,25 +104,38 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   const float* xb = x + (size_t)b * H * W * C + c4 * 4;
   const int iy0 = oy0 * stride - pad;
   constexpr int Q = (P - 1) * E + K;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
+  // One input row ahead: the loads of row q+1 are issued before the FMAs of row q and a
+  // scheduling barrier keeps the compiler from hoisting every load of the (fully
+  // unrolled) strip to the top, which would cost ~4*K*Q registers and all occupancy.
+  auto load_row = [&](int q, float4* v) {
     const int iy = iy0 + q * dil;
     const bool yok = (iy >= 0) && (iy < H);
-    const float* xr = xb + (size_t)iy * W * C;
-    float4 v[K];
+    const float* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
     for (int tx = 0; tx < K; ++tx) {
-      v[tx] = (yok && xok[tx]) ? ld4(xr + xoff[tx]) : f4zero();
-      if (relu_in) v[tx] = relu4(v[tx]);
+      v[tx] = keep_if(ld4(xr + xoff[tx]), yok && xok[tx]);
+      if (RELU) v[tx] = relu4(v[tx]);
     }
+  };
+  float4 vcur[K], vnext[K];
+  load_row(0, vcur);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (q + 1 < Q) load_row(q + 1, vnext);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int ty = q - j * E;
       if (ty >= 0 && ty < K) {
 #pragma unroll
-        for (int tx = 0; tx < K; ++tx) acc[j] = fma4(w[ty * K + tx], v[tx], acc[j]);
+        for (int tx = 0; tx < K; ++tx)
+          acc[j] = fma4(WLDS ? lw[ty * K + tx][c4] : w[WLDS ? 0 : ty * K + tx], vcur[tx], acc[j]);
       }
     }
+#pragma unroll
+    for (int j = 0; j < P; ++j) pin(acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tx = 0; tx < K; ++tx) vcur[tx] = vnext[tx];
   }
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
   if (scale) sc = ld4(scale + c4 * 4);
@@ -101,6 +148,66 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
       o = act_apply4(o, act);
       st4(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4, o);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// backward-data of a stride-2, dilation-1, pad=(K-1)/2 depthwise conv (the only
+// strided form on the path).  One thread produces the 2x2 quad of input-gradient
+// pixels (2a+py, 2b+px): all four read the same small patch of dy, and which
+// taps contribute to which quad position is a compile-time parity pattern:
+//   dx[2a+py] += w[ty] * dy[a + (py+pad-ty)/2]   for ty = (py+pad) mod 2, +2, ...
+// ---------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ dy,
+                                                      const float* __restrict__ wt,
+                                                      float* __restrict__ dx, int B, int Ho, int Wo,
+                                                      int C4, int H, int W) {
+  constexpr int PAD = (K - 1) / 2;
+  // dy rows used by a quad: a + (py+PAD-ty)/2 over all valid (py,ty): [a - LO, a + HI]
+  constexpr int LO = (K - 1 - PAD) / 2;  // largest ty with matching parity, py = 0 side
+  constexpr int HI = (PAD + 1) / 2;
+  constexpr int R = LO + HI + 1;
+  const int C = C4 * 4;
+  const int Hq = (H + 1) >> 1, Wq = (W + 1) >> 1;
+  const int64_t total = (int64_t)B * Hq * Wq * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int bq = (int)(p % Wq);
+    p /= Wq;
+    const int aq = (int)(p % Hq);
+    const int b = (int)(p / Hq);
+    float4 d[R][R];
+#pragma unroll
+    for (int ry = 0; ry < R; ++ry)
+#pragma unroll
+      for (int rx = 0; rx < R; ++rx) {
+        const int oy = aq - LO + ry, ox = bq - LO + rx;
+        d[ry][rx] = (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo)
+                        ? ld4(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + c4 * 4)
+                        : f4zero();
+      }
+    float4 o[2][2];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) o[py][px] = f4zero();
+#pragma unroll
+    for (int ty = 0; ty < K; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < K; ++tx) {
+        const int py = (ty + PAD) & 1, px = (tx + PAD) & 1;  // parity this tap feeds
+        const int ry = (py + PAD - ty) / 2 + LO, rx = (px + PAD - tx) / 2 + LO;
+        o[py][px] = fma4(ld4(wt + (size_t)(ty * K + tx) * C + c4 * 4), d[ry][rx], o[py][px]);
+      }
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        const int iy = 2 * aq + py, ix = 2 * bq + px;
+        if (iy < H && ix < W) st4(dx + (((int64_t)b * H + iy) * W + ix) * C + c4 * 4, o[py][px]);
+      }
   }
 }
 
@@ -166,17 +273,87 @@ __global__ __launch_bounds__(256) void dw_generic(
   }
 }
 
+// Sum acc[t] (t < K*K) over all threads of the workgroup that share a channel group and
+// write out[t][C].  Thread `tid` of a workgroup whose first flattened (x, c/4) index is
+// `base` owns channel group (base + tid) % C4.  With C4 > 256 only the groups present
+// in the workgroup are written (the caller zero-fills the partial buffer).
+template <int K>
+__device__ __forceinline__ void block_reduce_taps(float4 (&acc)[K * K], float4 (*red)[4][64],
+                                                  float* __restrict__ out, int base, int C4) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int C = C4 * 4;
+  const int nown = C4 < 64 ? C4 : 64;
+  if (C4 < 64) {
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      const float4 v = acc[t];
+      float4 s = v;
+      for (int off = C4; off < 64; off += C4) {
+        const int src = lane + off;
+        const bool ok = src < 64;
+        const int sl = ok ? src : lane;
+        const float ax = __shfl(v.x, sl), ay = __shfl(v.y, sl), az = __shfl(v.z, sl),
+                    aw = __shfl(v.w, sl);
+        if (ok) {
+          s.x += ax;
+          s.y += ay;
+          s.z += az;
+          s.w += aw;
+        }
+      }
+      acc[t] = s;
+    }
+  }
+  const int cc = (base + tid) % C4;  // channel group of this lane
+  if (C4 <= 64) {
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+      __syncthreads();
+      if (lane < nown) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) red[u][wave][cc] = acc[r * K + u];
+      }
+      __syncthreads();
+      if (tid < C4) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const float4 s = add4(add4(red[u][0][tid], red[u][1][tid]),
+                                add4(red[u][2][tid], red[u][3][tid]));
+          st4(out + (size_t)(r * K + u) * C + tid * 4, s);
+        }
+      }
+    }
+  } else {
+    // C4 > 64: at most ceil(256 / C4) <= 3 threads of the workgroup share a group, so a
+    // direct strided sum by the first min(C4, 256) threads has no serial tail to speak of
+    float4* flat = &red[0][0][0];  // >= 256 float4
+    const int nsum = C4 < 256 ? C4 : 256;
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      __syncthreads();
+      flat[tid] = acc[t];
+      __syncthreads();
+      if (tid < nsum) {
+        float4 s = f4zero();
+        for (int u = tid; u < 256; u += C4) s = add4(s, flat[u]);
+        st4(out + (size_t)t * C + cc * 4, s);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // backward-weight strip kernel: per-thread K*K float4 accumulators over a set
 // of row chunks, then a per-block reduction over lanes that share a channel
 // group.  partial layout: [block][tap][C].  Deterministic (no atomics).
 // ---------------------------------------------------------------------------
-template <int K, int P, int E>
+template <int K, int P, int E, bool RELU>
 __global__ __launch_bounds__(256) void dw_wgrad_strip(
     const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int B,
-    int H, int W, int C4, int Ho, int Wo, int stride, int pad, int dil, int g, int nchunk,
-    int relu_in) {
-  __shared__ float4 red[256];
+    int H, int W, int C4, int Ho, int Wo, int stride, int pad, int dil, int g, int nchunk) {
+  __shared__ float4 red[K][4][64];
   const int tid = threadIdx.x;
   const int base = blockIdx.x * 256;
   const int idx = base + tid;
@@ -193,9 +370,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
   bool xok[K];
 #pragma unroll
   for (int tx = 0; tx < K; ++tx) {
-    int ix = ox * stride - pad + tx * dil;
+    const int ix = ox * stride - pad + tx * dil;
     xok[tx] = live && (ix >= 0) && (ix < W);
-    xoff[tx] = ix * C;
+    xoff[tx] = (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;  // clamped: loads are unconditional
   }
   constexpr int Q = (P - 1) * E + K;
   const int nwork = B * nchunk * g;
@@ -205,52 +382,51 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
     const int chunk = t2 % nchunk;
     const int b = t2 / nchunk;
     const int oy0 = chunk * (P * g) + r;
-    if (oy0 >= Ho || !live) continue;
+    if (oy0 >= Ho || !live) continue;  // (wave-divergent only in the last x-block)
     float4 d[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int oy = oy0 + j * g;
-      d[j] = (oy < Ho) ? ld4(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4) : f4zero();
+      d[j] = keep_if(ld4(dy + (((size_t)b * Ho + (oy < Ho ? oy : Ho - 1)) * Wo + ox) * C + c4 * 4),
+                     oy < Ho);
     }
     const float* xb = x + (size_t)b * H * W * C + c4 * 4;
     const int iy0 = oy0 * stride - pad;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
+    auto load_row = [&](int q, float4* v) {
       const int iy = iy0 + q * dil;
       const bool yok = (iy >= 0) && (iy < H);
-      const float* xr = xb + (size_t)iy * W * C;
-      float4 v[K];
+      const float* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
       for (int tx = 0; tx < K; ++tx) {
-        v[tx] = (yok && xok[tx]) ? ld4(xr + xoff[tx]) : f4zero();
-        if (relu_in) v[tx] = relu4(v[tx]);
+        v[tx] = keep_if(ld4(xr + xoff[tx]), yok && xok[tx]);
+        if (RELU) v[tx] = relu4(v[tx]);
       }
+    };
+    float4 vcur[K], vnext[K];
+    load_row(0, vcur);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (q + 1 < Q) load_row(q + 1, vnext);
 #pragma unroll
       for (int j = 0; j < P; ++j) {
         const int ty = q - j * E;
         if (ty >= 0 && ty < K) {
 #pragma unroll
-          for (int tx = 0; tx < K; ++tx) acc[ty * K + tx] = fma4(d[j], v[tx], acc[ty * K + tx]);
+          for (int tx = 0; tx < K; ++tx) acc[ty * K + tx] = fma4(d[j], vcur[tx], acc[ty * K + tx]);
         }
       }
-    }
-  }
-  // block reduction: thread t (< min(C4,256)) owns channel group (base+t)%C4
-  float* pout = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(K * K) * C;
-  const int nown = C4 < 256 ? C4 : 256;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) {
-    const float4 a = acc[t];
-    __syncthreads();
-    red[tid] = a;
-    __syncthreads();
-    if (tid < nown) {
-      float4 s = f4zero();
-      for (int u = tid; u < 256; u += C4) s = add4(s, red[u]);
-      const int cc = (base + tid) % C4;
-      st4(pout + (size_t)t * C + cc * 4, s);
+      for (int tx = 0; tx < K; ++tx) vcur[tx] = vnext[tx];
     }
   }
+  // Block reduction without a serial tail.  Lanes l, l+C4, l+2*C4, ... of a wave hold
+  // the same channel group: lanes < C4 gather them with shuffles in a fixed order; the
+  // four waves then meet in a small LDS buffer indexed by channel group, K taps at a
+  // time.  (C4 > 64: every lane of a wave owns a different group, the shuffle step is
+  // the identity and a wave only covers 64 of the groups - see block_reduce_taps.)
+  float* pout = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(K * K) * C;
+  block_reduce_taps<K>(acc, red, pout, base, C4);
 }
 
 // generic backward-weight (any K): same block reduction, one tap at a time.
@@ -299,10 +475,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_finalize(const float* __restrict
                                                          int C) {
   __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
   const int64_t per = (int64_t)KK * C;
-  const int64_t i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + (threadIdx.x & 15);  // tap*C + c
+  const int64_t i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();  // tap*C + c
   const bool valid = i < per;
   const double s = reduce_partials16(partial, nblk, per, i, valid, red);
-  if (valid && (threadIdx.x >> 4) == 0) {
+  if (valid && rp_slice() == 0) {
     const int t = (int)(i / C), c = (int)(i - (int64_t)t * C);
     dw[c * KK + t] = (float)s;
   }
@@ -358,15 +534,31 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* scale,
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(cdiv(Wo * C4, 256), nchunk * sc.g, B);
     NASSEG_REQUIRE(grid.y <= 65535, "dwconv: too many row chunks");
-#define LAUNCH_FWD(KK, EE)                                                                       \
-  hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE>), grid, dim3(256), 0, s, x, wt, y, scale, shift, H, \
-                     W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, relu_in, act)
-    if (K == 3 && sc.e == 1) LAUNCH_FWD(3, 1);
-    else if (K == 3 && sc.e == 2) LAUNCH_FWD(3, 2);
-    else if (K == 5 && sc.e == 1) LAUNCH_FWD(5, 1);
-    else LAUNCH_FWD(5, 2);
+#define LAUNCH_FWD2(KK, EE, WL, RL)                                                               \
+  hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, RL>), grid, dim3(256), 0, s, x, wt, y, scale, shift, \
+                     H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, act)
+#define LAUNCH_FWD(KK, EE, WL) \
+  do { if (relu_in) LAUNCH_FWD2(KK, EE, WL, true); else LAUNCH_FWD2(KK, EE, WL, false); } while (0)
+    const bool wl = C4 <= 64;
+    if (K == 3 && sc.e == 1) LAUNCH_FWD(3, 1, false);
+    else if (K == 3 && sc.e == 2) LAUNCH_FWD(3, 2, false);
+    else if (K == 5 && sc.e == 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
+    else { if (wl) LAUNCH_FWD(5, 2, true); else LAUNCH_FWD(5, 2, false); }
+#undef LAUNCH_FWD2
 #undef LAUNCH_FWD
     NASSEG_LAUNCH_CHECK("dw_fwd_strip");
+    return NASSEG_OK;
+  }
+  if (transposed && stride == 2 && dil == 1 && (K == 3 || K == 5) && pad == (K - 1) / 2 &&
+      !relu_in && !scale && !shift && act == 0) {
+    // (H, W) = dims of dy, (Ho, Wo) = dims of dx in the transposed call
+    const int64_t quads = (int64_t)B * ((Ho + 1) / 2) * ((Wo + 1) / 2) * C4;
+    const int nbq = (int)((quads + 255) / 256 < 65536 * 4 ? (quads + 255) / 256 : 65536 * 4);
+    if (K == 3)
+      hipLaunchKernelGGL((dw_bwd_data_s2<3>), dim3(nbq), dim3(256), 0, s, x, wt, y, B, H, W, C4, Ho, Wo);
+    else
+      hipLaunchKernelGGL((dw_bwd_data_s2<5>), dim3(nbq), dim3(256), 0, s, x, wt, y, B, H, W, C4, Ho, Wo);
+    NASSEG_LAUNCH_CHECK("dw_bwd_data_s2");
     return NASSEG_OK;
   }
   size_t total = (size_t)B * Ho * Wo * C4;
@@ -378,13 +570,21 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* scale,
 }
 
 // workspace (floats) needed by nasseg_dwconv_wgrad
-int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K) {
-  const int C4 = C / 4;
-  int64_t gx = cdiv(Wo * C4, 256);
+// number of workgroup rows (grid.y) of the backward-weight kernels: ~1024 workgroups,
+// but at least ~8 output rows of work per workgroup so that the end-of-block reduction
+// is amortised
+static int64_t wgrad_rows(int B, int C, int Ho, int Wo) {
+  const int64_t gx = cdiv(Wo * (C / 4), 256);
   int64_t gy = 1024 / gx;
+  const int64_t rows = (int64_t)B * Ho;
+  if (gy > rows / 8) gy = rows / 8;
   if (gy < 1) gy = 1;
-  if (gy > (int64_t)B * Ho) gy = (int64_t)B * Ho;
-  return gx * gy * (int64_t)K * K * C;
+  return gy;
+}
+
+int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K) {
+  const int64_t gx = cdiv(Wo * (C / 4), 256);
+  return gx * wgrad_rows(B, C, Ho, Wo) * (int64_t)K * K * C;
 }
 
 // dw (C,1,K,K) = sum over pixels of dy * x_tap; ws must hold
@@ -397,21 +597,26 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, i
   const int C4 = C / 4;
   StripCfg sc = strip_cfg(stride, dil);
   const int gx = cdiv(Wo * C4, 256);
-  int gy = 1024 / gx;
-  if (gy < 1) gy = 1;
-  if ((int64_t)gy > (int64_t)B * Ho) gy = B * Ho;
+  const int gy = (int)wgrad_rows(B, C, Ho, Wo);
+  if (C4 > 256) {
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)gx * gy * K * K * C * sizeof(float), s);
+    if (e != hipSuccess) return nasseg_fail(NASSEG_ERR_LAUNCH, "dwconv_wgrad: memset failed");
+  }
   const bool strip_ok = (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2);
   if (strip_ok) {
     constexpr int P = 4;
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(gx, gy, 1);
-#define LAUNCH_WG(KK, EE)                                                                        \
-  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE>), grid, dim3(256), 0, s, x, dy, ws, B, H, W, C4, \
-                     Ho, Wo, stride, pad, dil, sc.g, nchunk, relu_in)
+#define LAUNCH_WG2(KK, EE, RL)                                                                       \
+  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE, RL>), grid, dim3(256), 0, s, x, dy, ws, B, H, W, C4, \
+                     Ho, Wo, stride, pad, dil, sc.g, nchunk)
+#define LAUNCH_WG(KK, EE) \
+  do { if (relu_in) LAUNCH_WG2(KK, EE, true); else LAUNCH_WG2(KK, EE, false); } while (0)
     if (K == 3 && sc.e == 1) LAUNCH_WG(3, 1);
     else if (K == 3 && sc.e == 2) LAUNCH_WG(3, 2);
     else if (K == 5 && sc.e == 1) LAUNCH_WG(5, 1);
     else LAUNCH_WG(5, 2);
+#undef LAUNCH_WG2
 #undef LAUNCH_WG
     NASSEG_LAUNCH_CHECK("dw_wgrad_strip");
   } else {

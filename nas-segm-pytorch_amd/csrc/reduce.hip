@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void colred_kernel(RedArgs q) {
     const float* pa = q.a + (int64_t)seg * q.R * q.lda + cv * VEC;
     const float* pb = q.b ? q.b + (int64_t)seg * q.R * q.ldb + cv * VEC : nullptr;
     const float* pc = q.c ? q.c + (int64_t)seg * q.R * q.ldc + cv * VEC : nullptr;
-#pragma unroll 4
+#pragma unroll 8
     for (int64_t r = r0 + rr; r < r1; r += rpi) {
       T va = V::ld(pa + r * q.lda);
       if (MODE == RED_SUM) {
@@ -148,10 +148,10 @@ __global__ __launch_bounds__(256) void colred_finalize(const float* __restrict__
   __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
   const int seg = blockIdx.y;
   const int64_t per = 2 * (int64_t)C;  // [2][C] per block, only the first nacc rows are used
-  const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + (threadIdx.x & 15);
+  const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = e < (int64_t)nacc * C;
   const double s = reduce_partials16(partial + (int64_t)seg * nblk * per, nblk, per, e, valid, red);
-  if (valid && (threadIdx.x >> 4) == 0) out[(int64_t)seg * nacc * C + e] = (float)(s * (double)mul);
+  if (valid && rp_slice() == 0) out[(int64_t)seg * nacc * C + e] = (float)(s * (double)mul);
 }
 
 // BatchNorm statistics finalisation (training mode).  Normalisation uses the
@@ -163,13 +163,13 @@ __global__ __launch_bounds__(256) void bn_stats_finalize(
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
     float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* nbt) {
   __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
-  const int c = blockIdx.x * NASSEG_RP_ELEMS + (threadIdx.x & 15);
+  const int c = blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = c < C;
   const int64_t per = 2 * (int64_t)C;
   const double s0 = reduce_partials16(partial, nblk, per, c, valid, red);
   const double s1 = reduce_partials16(partial, nblk, per, (int64_t)C + c, valid, red);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-  if (!valid || (threadIdx.x >> 4) != 0) return;
+  if (!valid || rp_slice() != 0) return;
   const double mu = s0 / M;
   double var = s1 / M - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -212,8 +212,8 @@ struct RedPlan {
 inline RedPlan red_plan(int S, int64_t R, int C, int vec) {
   const int CV = C / vec;
   const int rpi = 256 / CV;
-  int64_t nb = R / ((int64_t)rpi * 8);
-  int64_t cap = 2048 / S;
+  int64_t nb = R / ((int64_t)rpi * 16);
+  int64_t cap = 768 / S;
   if (cap < 1) cap = 1;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
@@ -250,7 +250,7 @@ extern "C" {
 int64_t nasseg_colred_workspace(int S, int64_t R, int C) {
   if (C <= 0 || S <= 0 || R <= 0) return 0;
   // the scalar plan never uses more blocks than the vector plan's cap
-  int64_t cap = 2048 / S;
+  int64_t cap = 768 / S;
   if (cap < 1) cap = 1;
   return (int64_t)S * cap * 2 * C + 16;
 }

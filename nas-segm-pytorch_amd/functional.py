@@ -144,7 +144,10 @@ def depthwise_conv2d(x, weight, stride=1, padding=0, dilation=1, relu_in=False):
 # dense convolution (1x1 and k x k) on the fp32 matrix cores
 # ---------------------------------------------------------------------------
 def _pack_dense(w, mode):
+    """mode 'fwd' picks the layout nasseg_conv_fwd expects for this geometry; 1 = backward-data"""
     N, K, kh, kw = w.shape
+    if mode == "fwd":
+        mode = lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw)
     if kh == 1 and kw == 1 and mode == 0:
         return w  # (N,K,1,1) contiguous already is [tap=0][N][K]
     wp = _vec(w, w.numel())
@@ -165,7 +168,7 @@ class _Conv2d(torch.autograd.Function):
         if Ho <= 0 or Wo <= 0:
             raise NassegError("conv output would be empty")
         y = _new(x, B, N, Ho, Wo)
-        wp = _pack_dense(w, 0)
+        wp = _pack_dense(w, "fwd")
         lib.call("nasseg_conv_fwd", ptr(x), K, ptr(wp), ptr(y), N, None, None, 0, None, ptr(bias),
                  ACT_NONE, None, 0, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0,
                  current_stream())

@@ -290,6 +290,7 @@ def gen_nets():
             # itself, how far every stored gradient moves under two such perturbations;
             # parity tests use it as the tolerance floor.
             sens = {k: 0.0 for k in pick}
+            logit_sens = 0.0
             for ps in (1, 2):
                 net.load_state_dict(sd0)
                 net.train()
@@ -299,6 +300,7 @@ def gen_nets():
                 auxp = []
                 if isinstance(outp, tuple):
                     outp, auxp = outp
+                logit_sens = max(logit_sens, float((outp - output).abs().max()))
                 lp = crit(nn.LogSoftmax(dim=1)(outp), tv)
                 if aux_weight > 0:
                     for a in auxp:
@@ -310,6 +312,7 @@ def gen_nets():
                 for k in pick:
                     sens[k] = max(sens[k], float((named[k].grad - grads[k]).abs().max()))
             rec["grad_sensitivity"] = sens
+            rec["train_logits_sensitivity"] = logit_sens
         meta[name] = rec
     st.save("nets.npz")
     json.dump(meta, open(os.path.join(OUT, "nets_meta.json"), "w"))

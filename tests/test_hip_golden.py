@@ -119,7 +119,11 @@ def test_network(name):
     aux_outs = []
     if isinstance(output, tuple):
         output, aux_outs = output
-    assert_close(output, NETS_NPZ[name + "/logits_train"], 1e-4, 1e-4, "train logits")
+    # train-mode logits go through batch statistics of as few as 40 values per channel at
+    # these sizes; allow 4x what the reference itself moves under a 1e-6 input perturbation
+    # on top of the 1e-4 that the eval-mode logits above are held to
+    tl = 1e-4 + 4.0 * rec["train_logits_sensitivity"]
+    assert_close(output, NETS_NPZ[name + "/logits_train"], tl, 1e-4, "train logits")
     tv = F.nearest_label_resize(target, output.shape[2:])
     loss = F.log_softmax_nll(output, tv, 255)
     if rec["aux_weight"] > 0:
