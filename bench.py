@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="images per GPU")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="debug: all ranks share GPU 0 (with --backend gloo on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -201,10 +204,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+        dist.init_process_group(args.backend, rank=rank, world_size=world)  # nccl = RCCL over xGMI
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     import nas_segm_amd  # noqa: F401

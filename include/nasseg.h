@@ -132,6 +132,13 @@ int nasseg_ce_fwd(const float* logits, const void* target, int elem_size, int64_
 int nasseg_ce_bwd(const float* logits, const void* target, int elem_size, const float* stats,
                   const float* gscale, int64_t P, int C, int ignore, float* dlogits, void* stream);
 
+/* berHu loss of the depth head (BASELINE config 5; absent from the reference - Laina et al.
+ * 2016 eq. 2, "parity unpinned") */
+int nasseg_berhu_fwd(const float* pred, const float* target, int64_t n, float* out, float* ws,
+                     void* stream);
+int nasseg_berhu_bwd(const float* pred, const float* target, const float* stats,
+                     const float* gscale, int64_t n, float* dpred, void* stream);
+
 /* ---- mean-IoU reward: helpers/miou_utils.pyx fast_cm :7-30, compute_iu :32-57,
  * compute_ius_accs :59-90; argmax + up-sampling of engine/inference.py:58-66 ------ */
 int nasseg_fast_cm(const uint8_t* preds, const uint8_t* gt, int64_t P, int n, int64_t* cm,

@@ -90,6 +90,82 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
   }
 }
 
+// ---------------------------------------------------------------------------
+// berHu (reverse Huber) loss for the depth head (BASELINE config 5).  Not present in
+// the reference ("parity unpinned"): Laina et al. 2016, eq. 2 -
+//   B(d) = |d| if |d| <= c else (d^2 + c^2) / (2c),  c = 0.2 * max|d| over the batch,
+// mean over all elements; c is treated as a constant in the backward pass.
+// Three tiny passes: block maxima -> c, block sums -> mean.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void berhu_max_kernel(const float* __restrict__ pred,
+                                                        const float* __restrict__ target, int64_t n,
+                                                        float* __restrict__ partial) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(pred[i] - target[i]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void berhu_sum_kernel(const float* __restrict__ pred,
+                                                        const float* __restrict__ target, int64_t n,
+                                                        const float* __restrict__ maxpart, int nblk,
+                                                        float* __restrict__ partial,
+                                                        float* __restrict__ out) {
+  __shared__ float red[256];
+  __shared__ float cs;
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+    for (int b = 0; b < nblk; ++b) m = fmaxf(m, maxpart[b]);
+    cs = 0.2f * m;
+    if (blockIdx.x == 0) out[1] = cs;
+  }
+  __syncthreads();
+  const float c = cs;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = fabsf(pred[i] - target[i]);
+    acc += (d <= c) ? d : (d * d + c * c) / (2.f * c);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void berhu_finalize_kernel(const float* __restrict__ partial, int nblk, double n,
+                                      float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)partial[b];
+  out[0] = (float)(s / n);
+}
+
+// dpred = g/n * (sign(diff) if |diff| <= c else diff / c)
+__global__ __launch_bounds__(256) void berhu_bwd_kernel(const float* __restrict__ pred,
+                                                        const float* __restrict__ target,
+                                                        const float* __restrict__ stats,
+                                                        const float* __restrict__ gscale, int64_t n,
+                                                        float* __restrict__ dpred) {
+  const float c = stats[1];
+  const float g = (gscale ? gscale[0] : 1.f) / (float)n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = pred[i] - target[i];
+    const float ad = fabsf(d);
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    dpred[i] = g * ((ad <= c) ? sgn : d / c);
+  }
+}
+
 inline int ce_grid(int64_t P) {
   int64_t b = (P + 255) / 256;
   if (b > 1024) b = 1024;
@@ -139,6 +215,32 @@ int nasseg_ce_bwd(const float* logits, const void* target, int elem_size, const 
   else
     return nasseg_fail(NASSEG_ERR_ARG, "ce_bwd: elem_size %d not supported", elem_size);
   NASSEG_LAUNCH_CHECK("ce_bwd");
+  return NASSEG_OK;
+}
+
+// berHu loss (depth head): out[0] = mean loss, out[1] = c = 0.2 * max|pred - target|.
+// pred / target: n fp32 elements, any layout (elementwise).  ws: nasseg_ce_workspace() floats.
+int nasseg_berhu_fwd(const float* pred, const float* target, int64_t n, float* out, float* ws,
+                     void* stream) {
+  NASSEG_REQUIRE(n > 0, "berhu_fwd: empty input");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ce_grid(n);
+  hipLaunchKernelGGL(berhu_max_kernel, dim3(grid), dim3(256), 0, s, pred, target, n, ws);
+  NASSEG_LAUNCH_CHECK("berhu_max");
+  hipLaunchKernelGGL(berhu_sum_kernel, dim3(grid), dim3(256), 0, s, pred, target, n, ws, grid,
+                     ws + 1024, out);
+  NASSEG_LAUNCH_CHECK("berhu_sum");
+  hipLaunchKernelGGL(berhu_finalize_kernel, dim3(1), dim3(64), 0, s, ws + 1024, grid, (double)n, out);
+  NASSEG_LAUNCH_CHECK("berhu_finalize");
+  return NASSEG_OK;
+}
+
+int nasseg_berhu_bwd(const float* pred, const float* target, const float* stats,
+                     const float* gscale, int64_t n, float* dpred, void* stream) {
+  NASSEG_REQUIRE(n > 0, "berhu_bwd: empty input");
+  hipLaunchKernelGGL(berhu_bwd_kernel, dim3(ce_grid(n) * 2), dim3(256), 0, (hipStream_t)stream, pred,
+                     target, stats, gscale, n, dpred);
+  NASSEG_LAUNCH_CHECK("berhu_bwd");
   return NASSEG_OK;
 }
 

@@ -610,6 +610,36 @@ def log_softmax_nll(logits, target, ignore_index=255):
     return _LogSoftmaxNLL.apply(logits, target, ignore_index)
 
 
+class _BerHu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        require_device(pred, target)
+        if pred.dtype != torch.float32 or target.dtype != torch.float32:
+            raise NassegError("berhu: fp32 tensors expected")
+        if pred.shape != target.shape:
+            raise NassegError("berhu: shapes differ")
+        p, t = pred.contiguous(), target.contiguous()
+        out = _vec(p, 2)
+        ws = _ws(p, lib.query("nasseg_ce_workspace"))
+        lib.call("nasseg_berhu_fwd", ptr(p), ptr(t), p.numel(), ptr(out), ptr(ws), current_stream())
+        ctx.save_for_backward(p, t, out)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, out = ctx.saved_tensors
+        g = g.to(torch.float32).contiguous().view(1)
+        d = torch.empty_like(p)
+        lib.call("nasseg_berhu_bwd", ptr(p), ptr(t), ptr(out), ptr(g), p.numel(), ptr(d),
+                 current_stream())
+        return d, None
+
+
+def berhu_loss(pred, target):
+    """Reverse-Huber loss of the depth head (absent from the reference; oracle/losses.py)."""
+    return _BerHu.apply(pred, target)
+
+
 def nearest_label_resize(target, size):
     """F.interpolate(target[:, None].float(), size, mode='nearest').long()[:, 0]."""
     target, esz = _label_tensor(target)

@@ -259,6 +259,22 @@ def test_log_softmax_nll(C, all_ignored):
     assert abs(float(out8) - float(ref)) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 30, 40), (8, 1, 120, 160), (1, 1, 1, 1)])
+def test_berhu_loss_vs_oracle(shape):
+    """parity unpinned in the reference: checked against oracle/losses.py only"""
+    from oracle.losses import berhu
+
+    pred, target = rnd(*shape, seed=31, scale=2.0), rnd(*shape, seed=32, scale=2.0)
+    pc = pred.clone().requires_grad_(True)
+    ref = berhu(pc, target)
+    pg = pred.clone().to(DEV).requires_grad_(True)
+    out = F().berhu_loss(pg, target.to(DEV))
+    assert abs(float(out) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    (ref * 1.3).backward()
+    (out * 1.3).backward()
+    assert_close(pg.grad, pc.grad, 1e-7, 1e-4, "dpred")
+
+
 def test_nearest_label_resize():
     g = torch.Generator().manual_seed(25)
     for (hi, wi), (ho, wo) in [((65, 97), (17, 25)), ((1024, 2048), (256, 512)), ((17, 25), (65, 97)), ((7, 7), (7, 7))]:
