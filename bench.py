@@ -258,7 +258,17 @@ def main():
             top = rows[0]
             total_ms = sum(r["ms"] for r in rows)
             dw = [r for r in rows if r["kernel"] == "nasseg_dwconv"]
+            fam = {"nasseg_conv_fwd": "conv_fwd_kernel", "nasseg_conv_wgrad": "conv_wgrad_kernel(+finalize)",
+                   "nasseg_dwconv": "dw_fwd_strip / dw_bwd_data_s2 / dw_generic",
+                   "nasseg_dwconv_wgrad": "dw_wgrad_strip(+finalize)",
+                   "nasseg_bn_bwd_apply": "bn_bwd_apply_kernel", "nasseg_affine_act": "affine_act_kernel",
+                   "nasseg_bn_stats": "colred_kernel<1>(+bn_stats_finalize)",
+                   "nasseg_bn_bwd_reduce": "colred_kernel<2>(+colred_finalize)"}
             roof = {"bound": "hbm", "kernel": top["kernel"],
+                    "rocprof_kernel_family": fam.get(top["kernel"], top["kernel"]),
+                    "top5": [{"kernel": r["kernel"], "gbs": round(r["gbs"], 1),
+                              "frac": round(r["gbs"] / HBM_PEAK_GBS, 3),
+                              "share": round(r["ms"] / total_ms, 3)} for r in rows[:5]],
                     "achieved": top["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": top["gbs"] / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_ms": top["ms"] / top["launches"], "launches_per_step": top["launches"] / 2,
