@@ -65,7 +65,8 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     const float* in_scale, const float* in_shift, int in_act,
                     const float* out_scale, const float* out_shift, int out_act, const float* res,
                     int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
-                    int stride, int pad, int dil, int transposed, void* stream);
+                    int stride, int pad, int dil, int transposed, float* stats, void* stream);
+int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N);
 int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
@@ -83,6 +84,10 @@ int nasseg_bn_stats(const float* x, int64_t ldx, int64_t M, int C, float eps, fl
                     const float* gamma, const float* beta, float* mean, float* invstd,
                     float* scale, float* shift, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* ws, void* stream);
+int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float eps, float momentum,
+                       const float* gamma, const float* beta, float* mean, float* invstd,
+                       float* scale, float* shift, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, void* stream);
 int nasseg_bn_eval_params(int C, float eps, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, float* mean,
                           float* invstd, float* scale, float* shift, void* stream);

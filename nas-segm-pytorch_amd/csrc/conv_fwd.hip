@@ -42,6 +42,7 @@ struct FwdArgs {
   int out_act;
   const float* res;
   int ldres;
+  float* stats;  // optional [gridDim.x][2][N]: per-workgroup sum / sum of squares of y
   int K, N;
   ConvGeom g;
 };
@@ -64,16 +65,20 @@ __device__ __forceinline__ float4 load4(const float* row, int k, int K) {
   }
 }
 
-// EPI: any output epilogue (scale / shift(bias) / activation / residual) is present
-template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI>
+// EPI: any output epilogue (scale / shift(bias) / activation / residual) is present.
+// STATS: also emit per-workgroup partial sums of y and y^2 per output channel - the
+// BatchNorm batch statistics of the layer that follows, at no extra pass over y.
+template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, bool STATS>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
+  __shared__ float sred[STATS ? 4 : 1][2][STATS ? NT * 16 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15;   // pixel within subtile (B operand col) / n within tile (A operand row)
   const int kg = lane >> 4;  // k group
   const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
   const int m_base = (blockIdx.x * 4 + wave) * (16 * MT);
-  if (m_base >= Mtot) return;
+  const bool active = m_base < Mtot;  // wave-uniform
+  if (!STATS && !active) return;
   const int n_base = blockIdx.y * (16 * NT);
 
   // destination pixels of this lane (clamped: out-of-range rows compute garbage that is never stored)
@@ -238,6 +243,51 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
       }
     }
   }
+
+  if (STATS) {
+    // per-channel sum / sum of squares of the raw accumulators (EPI is off on this path):
+    // over the MT subtiles in registers, over the 16 pixel lanes with xor-shuffles (the
+    // 16-lane group of a k-group holds the same 4 channels), over the 4 waves through LDS
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool ok = active && (m_base + mt * 16 + j < Mtot);
+        const f32x4 c = acc[mt][nt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = keep_if(c[r], ok);
+          sx[r] += v;
+          sq[r] = fmaf(v, v, sq[r]);
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sx[r] += __shfl_xor(sx[r], off);
+          sq[r] += __shfl_xor(sq[r], off);
+        }
+      }
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sred[wave][0][nt * 16 + kg * 4 + r] = sx[r];
+          sred[wave][1][nt * 16 + kg * 4 + r] = sq[r];
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NT * 16; t += 256) {
+      const int n = n_base + t;
+      if (n < a.N) {
+        float* po = a.stats + (int64_t)blockIdx.x * 2 * a.N + n;
+        po[0] = (sred[0][0][t] + sred[1][0][t]) + (sred[2][0][t] + sred[3][0][t]);
+        po[a.N] = (sred[0][1][t] + sred[1][1][t]) + (sred[2][1][t] + sred[3][1][t]);
+      }
+    }
+  }
 }
 
 // OIHW (N,K,kh,kw) -> [tap][N][K] (mode 0), [tap][K][N] (mode 1), [N][tap*K+k] (mode 2)
@@ -268,19 +318,26 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 
 struct Mode {
   int km;
-  bool gather, pro, vecn, epi;
+  bool gather, pro, vecn, epi, stats;
 };
 
 template <int MT, int NT>
 int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
   const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
   dim3 grid((unsigned)cdiv64(Mtot, 64 * MT), cdiv(a.N, 16 * NT), 1);
-#define GO(KM_, G_, P_, V_)                                                                           \
-  do {                                                                                                \
-    if (md.epi || !(V_))                                                                              \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true>), grid, dim3(256), 0, s, a);  \
-    else                                                                                              \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false>), grid, dim3(256), 0, s, a); \
+#define GO(KM_, G_, P_, V_)                                                                       \
+  do {                                                                                            \
+    if (md.stats) {                                                                               \
+      if constexpr (V_)                                                                           \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, true>), grid, dim3(256), \
+                           0, s, a);                                                              \
+    } else if (md.epi || !(V_)) {                                                                 \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true, false>), grid, dim3(256), \
+                         0, s, a);                                                                \
+    } else {                                                                                      \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, false>), grid, dim3(256), \
+                         0, s, a);                                                                \
+    }                                                                                             \
   } while (0)
   if (md.km == KM_FLAT) {
     if constexpr (NT <= 4) {
@@ -313,17 +370,22 @@ int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
 
 // pixel-tile height per wave: as many 16-pixel subtiles as still leave >= ~6
 // workgroups per CU (the op is latency-bound below that)
+inline int pick_mt(int64_t Mtot, int tiles) {
+  if (tiles > 8) return 1;
+  if (tiles > 4) return Mtot >= 64 * 2 * 1536 ? 2 : 1;
+  return Mtot >= 64 * 4 * 1536 ? 4 : (Mtot >= 64 * 2 * 1536 ? 2 : 1);
+}
 template <int NT>
 int launch_small(const FwdArgs& a, const Mode& md, hipStream_t s) {
-  const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
-  if (Mtot >= 64 * 4 * 1536) return launch_one<4, NT>(a, md, s);
-  if (Mtot >= 64 * 2 * 1536) return launch_one<2, NT>(a, md, s);
+  const int mt = pick_mt((int64_t)a.g.B * a.g.Ho * a.g.Wo, NT);
+  if (mt == 4) return launch_one<4, NT>(a, md, s);
+  if (mt == 2) return launch_one<2, NT>(a, md, s);
   return launch_one<1, NT>(a, md, s);
 }
 template <int NT>
 int launch_mid(const FwdArgs& a, const Mode& md, hipStream_t s) {
-  const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
-  if (Mtot >= 64 * 2 * 1536) return launch_one<2, NT>(a, md, s);
+  const int mt = pick_mt((int64_t)a.g.B * a.g.Ho * a.g.Wo, NT);
+  if (mt == 2) return launch_one<2, NT>(a, md, s);
   return launch_one<1, NT>(a, md, s);
 }
 
@@ -343,6 +405,14 @@ int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int
   return NASSEG_OK;
 }
 
+// number of per-workgroup statistic rows nasseg_conv_fwd writes for this geometry
+int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N) {
+  const int64_t Mtot = (int64_t)B * Ho * Wo;
+  const int tiles = cdiv(N, 16);
+  const int nt = tiles <= 4 ? tiles : (tiles <= 6 ? 6 : (tiles <= 8 ? 8 : (tiles <= 12 ? 12 : 16)));
+  return cdiv64(Mtot, 64 * pick_mt(Mtot, nt));
+}
+
 // which packing nasseg_conv_fwd expects for a forward (non-transposed) convolution
 int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) {
   return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0;
@@ -358,11 +428,14 @@ int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) {
 //   N, N = forward K, stride/pad/dil those of the forward conv.
 // The input prologue (in_scale / in_shift / in_act) is available for pointwise
 // (1x1, stride 1) convolutions with K % 4 == 0.
+// stats != null (needs N % 4 == 0 and no output epilogue): also writes
+//   stats[blk][0][n] = sum over the workgroup's pixels of y[.][n], stats[blk][1][n] = sum of y^2
+// for blk < nasseg_conv_fwd_stats_blocks(...) - the partials nasseg_bn_finalize consumes.
 int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     const float* in_scale, const float* in_shift, int in_act,
                     const float* out_scale, const float* out_shift, int out_act, const float* res,
                     int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
-                    int stride, int pad, int dil, int transposed, void* stream) {
+                    int stride, int pad, int dil, int transposed, float* stats, void* stream) {
   NASSEG_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "conv_fwd: bad geometry");
   NASSEG_REQUIRE(K > 0 && N > 0 && ldx >= K && ldy >= N, "conv_fwd: bad channels K=%d N=%d", K, N);
   NASSEG_REQUIRE((int64_t)B * Hs * Ws < 2147483647LL && (int64_t)B * Ho * Wo < 2147483647LL,
@@ -371,7 +444,7 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
   a.x = x; a.ldx = ldx; a.w = wp; a.y = y; a.ldy = ldy;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
-  a.res = res; a.ldres = ldres; a.K = K; a.N = N;
+  a.res = res; a.ldres = ldres; a.stats = stats; a.K = K; a.N = N;
   a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
   a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
   a.g.transposed = transposed;
@@ -382,6 +455,9 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
   md.gather = !(kh == 1 && kw == 1 && stride == 1 && pad == 0 && Hs == Ho && Ws == Wo);
   md.vecn = ((N & 3) == 0) && ((ldy & 3) == 0) && (!res || (ldres & 3) == 0);
   md.epi = out_scale || out_shift || out_act || res;
+  md.stats = stats != nullptr;
+  NASSEG_REQUIRE(!md.stats || (md.vecn && !md.epi),
+                 "conv_fwd: statistics need N %% 4 == 0 and no output epilogue");
   if (!transposed && nasseg_conv_fwd_pack_mode(K, kh, kw) == 2) md.km = KM_FLAT;
   NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
                  "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");

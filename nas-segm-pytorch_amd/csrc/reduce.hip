@@ -300,6 +300,52 @@ int nasseg_bn_stats(const float* x, int64_t ldx, int64_t M, int C, float eps, fl
   return NASSEG_OK;
 }
 
+// sum groups of `rows_per_group` consecutive rows of partial[nblk][per] into out[g][per]
+// (fp32 out, fp64 accumulation, fixed order): first level of a two-level finalisation
+__global__ __launch_bounds__(256) void rows_group_sum(const float* __restrict__ partial,
+                                                      float* __restrict__ out, int nblk, int64_t per,
+                                                      int rows_per_group) {
+  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  const int g = blockIdx.y;
+  const int r0 = g * rows_per_group;
+  int nr = nblk - r0;
+  if (nr > rows_per_group) nr = rows_per_group;
+  const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
+  const bool valid = e < per;
+  const double s = reduce_partials16(partial + (int64_t)r0 * per, nr, per, e, valid, red);
+  if (valid && rp_slice() == 0) out[(int64_t)g * per + e] = (float)s;
+}
+
+// BatchNorm statistics from per-workgroup partials [nblk][2][C] (sum, sum of squares) that a
+// producer kernel (nasseg_conv_fwd with `stats`) already wrote: same outputs as nasseg_bn_stats.
+// The buffer must have room for 64 more rows ([nblk + 64][2][C]) - scratch of the first level
+// of the two-level reduction used when nblk > 512; `partial` is therefore not const in effect.
+int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float eps, float momentum,
+                       const float* gamma, const float* beta, float* mean, float* invstd,
+                       float* scale, float* shift, float* running_mean, float* running_var,
+                       int64_t* num_batches_tracked, void* stream) {
+  NASSEG_REQUIRE(M > 0 && C > 0 && nblk > 0, "bn_finalize: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const float* src = partial;
+  if (nblk > 512) {
+    // two levels: 64 groups of rows first (rows [nblk, nblk+64) of the buffer are scratch)
+    const int G = 64;
+    const int rpg = cdiv(nblk, G);
+    const int groups = cdiv(nblk, rpg);
+    float* lvl = const_cast<float*>(partial) + (int64_t)nblk * 2 * C;
+    hipLaunchKernelGGL(rows_group_sum, dim3(cdiv(2 * C, NASSEG_RP_ELEMS), groups), dim3(256), 0, s,
+                       partial, lvl, nblk, (int64_t)2 * C, rpg);
+    NASSEG_LAUNCH_CHECK("rows_group_sum");
+    src = lvl;
+    nblk = groups;
+  }
+  hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(C, NASSEG_RP_ELEMS)), dim3(256), 0, s, src, nblk, C,
+                     (double)M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean,
+                     running_var, num_batches_tracked);
+  NASSEG_LAUNCH_CHECK("bn_stats_finalize");
+  return NASSEG_OK;
+}
+
 int nasseg_bn_eval_params(int C, float eps, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, float* mean,
                           float* invstd, float* scale, float* shift, void* stream) {

@@ -90,7 +90,27 @@ class FusedSequential(nn.Sequential):
         while i < n:
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
-            if isinstance(m, BatchNorm2d):
+            if (isinstance(m, Conv2d) and m.groups == 1 and m.bias is None and isinstance(nxt, BatchNorm2d)
+                    and nxt.momentum is not None and nxt.track_running_stats
+                    and nxt.weight is not None and m.out_channels % 4 == 0):
+                # dense conv -> BatchNorm [-> ReLU/ReLU6] [+ residual]: one fused node
+                m._check()
+                bn = nxt
+                after = mods[i + 2] if i + 2 < n else None
+                act, step = F.ACT_NONE, 2
+                if isinstance(after, nn.ReLU6):
+                    act, step = F.ACT_RELU6, 3
+                elif isinstance(after, nn.ReLU):
+                    act, step = F.ACT_RELU, 3
+                res = None
+                if not res_used and i + step == n:
+                    res, res_used = residual, True
+                x = F.conv_bn_act(x, m.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked if bn.training else None, bn.training,
+                                  bn.momentum, bn.eps, act, res, m.stride[0], m.padding[0],
+                                  m.dilation[0])
+                i += step
+            elif isinstance(m, BatchNorm2d):
                 act, step = F.ACT_NONE, 1
                 if isinstance(nxt, nn.ReLU6):
                     act, step = F.ACT_RELU6, 2

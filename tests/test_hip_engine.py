@@ -98,7 +98,9 @@ def test_engine_matches_reference_run(name, monkeypatch):
             assert abs(got[k][1] - sa) <= 2e-2 * sa + slack, "{}: {} vs {}".format(k, got[k][1], sa)
     pol = checksums({str(i): a.cpu() for i, a in enumerate(avg_param)})
     for k, (s, sa) in rec["task1_polyak_checksums"].items():
-        assert abs(pol[k][1] - sa) <= 1e-3 * sa + 1e-4, k
+        # the average holds 0.0199 of the post-step weights: same Adam slack, scaled
+        slack = 0.02 * 0.25 * avg_param[int(k)].numel() * 3e-3 * 2
+        assert abs(pol[k][1] - sa) <= 1e-3 * sa + 1e-4 + slack, k
 
     # validation reward of the (slightly different) trained candidate
     vb = [{"image": torch.from_numpy(ENG_NPZ["{}/val/image/{}".format(name, i)]),

@@ -161,6 +161,49 @@ def test_batch_norm_act(shape, act, training, residual):
     assert int(nbt) == (1 if training else 0)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 9, 11, 64, 1, 1, 0, 1), (2, 16, 10, 12, 96, 1, 1, 0, 1),
+                                  (1, 64, 13, 9, 64, 3, 1, 3, 3), (2, 3, 33, 37, 32, 3, 2, 1, 1),
+                                  (3, 24, 1, 1, 24, 1, 1, 0, 1), (1, 24, 40, 40, 144, 1, 1, 0, 1)],
+                         ids=lambda c: "B{}K{}_{}x{}_N{}_k{}s{}p{}d{}".format(*c))
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("residual", [False, True])
+def test_fused_conv_bn_act(case, act, training, residual):
+    """conv -> BN -> act (+res) as one node: statistics come out of the conv epilogue"""
+    B, K, H, W, N, k, s, p, d = case
+    x = rnd(B, K, H, W, seed=40)
+    w = rnd(N, K, k, k, seed=41, scale=1.0 / np.sqrt(K * k * k))
+    gamma = torch.rand(N, generator=torch.Generator().manual_seed(42)) + 0.5
+    beta = rnd(N, seed=43, scale=0.2)
+    rm0, rv0 = rnd(N, seed=44, scale=0.1), torch.rand(N, generator=torch.Generator().manual_seed(45)) + 0.5
+    Ho, Wo = (H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1
+    res = rnd(B, N, Ho, Wo, seed=46) if residual else None
+    rm_c, rv_c, rm_g, rv_g = rm0.clone(), rv0.clone(), rm0.clone().to(DEV), rv0.clone().to(DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+
+    def ref(x, w, g, b, r=None):
+        y = TF.batch_norm(TF.conv2d(x, w, None, s, p, d), rm_c, rv_c, g, b, training, 0.1, 1e-5)
+        y = TF.relu(y) if act == 1 else (TF.hardtanh(y, 0.0, 6.0) if act == 2 else y)
+        return y + r if r is not None else y
+
+    def hip(x, w, g, b, r=None):
+        return F().conv_bn_act(x, w, g, b, rm_g, rv_g, nbt if training else None, training, 0.1, 1e-5,
+                               act, r, s, p, d)
+
+    ins = [x, w, gamma, beta] + ([res] if residual else [])
+    run_pair(hip, ref, ins, fwd_tol=5e-5, grad_rtol=3e-3, names=["x", "w", "gamma", "beta", "res"])
+    assert_close(rm_g, rm_c, 1e-6, 1e-5, "running_mean")
+    assert_close(rv_g, rv_c, 1e-6, 1e-5, "running_var")
+    # inference: one kernel, BN folded into the conv epilogue
+    with torch.no_grad():
+        y_inf = F().conv_bn_act(dev(x), w.to(DEV), gamma.to(DEV), beta.to(DEV), rm_g, rv_g, None, False,
+                                0.1, 1e-5, act, dev(res) if residual else None, s, p, d)
+        y_ref = TF.batch_norm(TF.conv2d(x, w, None, s, p, d), rm_c, rv_c, gamma, beta, False, 0.1, 1e-5)
+        y_ref = TF.relu(y_ref) if act == 1 else (TF.hardtanh(y_ref, 0.0, 6.0) if act == 2 else y_ref)
+        y_ref = y_ref + res if residual else y_ref
+    assert_close(y_inf, y_ref, 5e-5, 5e-5, "inference")
+
+
 def test_batch_norm_single_value_raises_value_error():
     x = dev(rnd(1, 8, 1, 1))
     with pytest.raises(ValueError):
