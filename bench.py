@@ -27,6 +27,16 @@ import torch.distributed as dist  # noqa: E402
 WACV_ARCH0 = [[[3, 0, 1], [4, 1, 1], [3, 1, 1]],
               [[0, 1, 0, 0, 1], [2, 1, 2, 1, 0], [3, 1, 1, 1, 0], [1, 1, 2, 0, 0],
                [3, 0, 2, 0, 0], [5, 3, 2, 1, 0], [0, 5, 0, 1, 0]]]
+WACV_ARCH1 = [[[1, 1, 0], [1, 3, 0], [3, 4, 0]],
+              [[1, 1, 0, 0, 0], [0, 1, 1, 1, 1], [3, 1, 2, 3, 0], [3, 0, 2, 2, 0],
+               [0, 1, 2, 0, 0], [2, 1, 1, 3, 0], [4, 0, 2, 2, 0]]]
+CVPR_ARCH0 = [[8, [0, 0, 5, 2], [0, 2, 8, 8], [0, 5, 1, 4]], [[3, 3], [3, 2], [3, 0]]]
+# name -> (decoder kind, genotype, classes, default batch/GPU, H, W, description)
+WORKLOADS = {
+    "headline": ("template", WACV_ARCH0, 19, 4, 1024, 2048, "WACV arch0 (BASELINE metric)"),
+    "arch1": ("template", WACV_ARCH1, 19, 4, 1024, 2048, "WACV arch1 (BASELINE config 3 shape)"),
+    "cvpr321": ("micro", CVPR_ARCH0, 21, 16, 321, 321, "CVPR arch0 VOC 321x321 bs16 (BASELINE config 2)"),
+}
 NUM_CLASSES = 19
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
@@ -80,22 +90,27 @@ def algorithmic_bytes(name, a):
     return 0
 
 
-def build_model(device):
+def build_model(device, workload="headline"):
     from nas_segm_amd.engine import RankParallel, Segmenter
     from nas_segm_amd.nn.encoders import mbv2
-    from nas_segm_amd.nn.micro_decoders import TemplateDecoder
+    from nas_segm_amd.nn.micro_decoders import MicroDecoder, TemplateDecoder
 
+    kind, genotype, classes = WORKLOADS[workload][:3]
     torch.manual_seed(0)  # random-init weights of the published architecture (no checkpoints offline)
-    enc = mbv2(pretrained=False, return_layers=[1, 2])
-    dec = TemplateDecoder(enc.out_sizes, NUM_CLASSES, WACV_ARCH0, agg_size=64, repeats=2)
+    if kind == "template":
+        enc = mbv2(pretrained=False, return_layers=[1, 2])
+        dec = TemplateDecoder(enc.out_sizes, classes, genotype, agg_size=64, repeats=2)
+    else:
+        enc = mbv2(pretrained=False)
+        dec = MicroDecoder(list(enc.out_sizes), classes, genotype, agg_size=64, repeats=2)
     net = Segmenter(enc, dec).to(device)
     return RankParallel(net), net
 
 
-def synthetic_batch(batch, height, width, rank, device):
+def synthetic_batch(batch, height, width, rank, device, classes=NUM_CLASSES):
     g = torch.Generator().manual_seed(rank)
     image = torch.randn(batch, 3, height, width, generator=g)
-    mask = torch.randint(0, NUM_CLASSES, (batch, height, width), generator=g)
+    mask = torch.randint(0, classes, (batch, height, width), generator=g)
     mask[:, height // 2: height // 2 + 5, :] = 255
     image = image.to(device).contiguous(memory_format=torch.channels_last)
     return image, mask.to(device)
@@ -170,6 +185,22 @@ def cpu_baseline(height, width):
             "fwd_only_images_per_sec": 1.0 / fmed, "cpu_model": cpu_name}
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary
+    (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes of this same command).
+    Units: KB; on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced reads
+    (MI355X_MICROARCH.md, HBM section) and is doubled here.  None if no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_fetch_write_latest.txt")
+    try:
+        for line in open(path):
+            parts = [p.strip() for p in line.split(",")]
+            if len(parts) == 4 and parts[0] == family:
+                return (2.0 * float(parts[2]) + float(parts[3])) * 1024.0
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def roofline_from_profile(summary):
     """Per entry point: launches, total ms, algorithmic GB/s; dominant = most time."""
     rows = []
@@ -186,9 +217,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS),
+                    help="headline = BASELINE.json metric (default); the others are informational")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (0 = the workload's default)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share GPU 0 (with --backend gloo on a 1-GPU box)")
@@ -216,12 +249,16 @@ def main():
     from nas_segm_amd._lib import LaunchProfiler, lib
     from nas_segm_amd.engine.trainer import segmenter_step
 
-    segmenter, net = build_model(device)
+    wl = WORKLOADS[args.workload]
+    args.batch = args.batch or wl[3]
+    args.height = args.height or wl[4]
+    args.width = args.width or wl[5]
+    segmenter, net = build_model(device, args.workload)
     segmenter.train()
     # default_args.py:57-66: SGD(lr 1e-3, mom 0.9, wd 1e-5) encoder, Adam(lr 3e-3, wd 1e-5) decoder
     optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
     optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
-    image, mask = synthetic_batch(args.batch, args.height, args.width, rank, device)
+    image, mask = synthetic_batch(args.batch, args.height, args.width, rank, device, wl[2])
 
     def step():
         return segmenter_step(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1)
@@ -270,7 +307,9 @@ def main():
                               "frac": round(r["gbs"] / HBM_PEAK_GBS, 3),
                               "share": round(r["ms"] / total_ms, 3)} for r in rows[:5]],
                     "achieved": top["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": top["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                    "frac": top["gbs"] / HBM_PEAK_GBS,
+                    "traffic": pmc_traffic(fam.get(top["kernel"], "").split("(")[0].split(" ")[0]),
+                    "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                     "avg_launch_ms": top["ms"] / top["launches"], "launches_per_step": top["launches"] / 2,
                     "share_of_kernel_time": top["ms"] / total_ms,
                     "depthwise_gbs": dw[0]["gbs"] if dw else None,
@@ -295,21 +334,22 @@ def main():
         fence()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "headline":
         cpu = cpu_baseline(args.height, args.width)
 
     if rank == 0:
         imgs = args.batch * world * args.steps
         out = {
-            "metric": "images/sec (fwd+bwd+optimizer step) WACV arch0 {}x{} bs={}/GPU".format(
-                args.width, args.height, args.batch),
+            "metric": "images/sec (fwd+bwd+optimizer step) {} {}x{} bs={}/GPU".format(
+                "WACV arch0" if args.workload == "headline" else args.workload, args.width, args.height,
+                args.batch),
             "value": imgs / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (randn images, randint labels with a 255 band; random-init weights)",
-            "config": {"workload": "headline: WACV arch0 (MobileNetV2[1,2] + TemplateDecoder, 19 classes, "
-                                   "agg 64, sep repeats 2), {}x3x{}x{} per GPU, train_segmenter step".format(
-                                       args.batch, args.height, args.width),
+            "config": {"workload": "{}: {} - MobileNetV2 encoder + searched decoder (agg 64, sep repeats 2), "
+                                   "{}x3x{}x{} per GPU, train_segmenter step".format(
+                                       args.workload, wl[6], args.batch, args.height, args.width),
                        "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
                        "loss": loss_value},
             "roofline": roof, "cpu_baseline": cpu,
