@@ -46,10 +46,10 @@ def algorithmic_bytes(name, a):
     once + outputs written once, SURVEY.md section 8(d) per-primitive formulas).
     `a` is the positional argument tuple of the call (include/nasseg.h order)."""
     if name == "nasseg_dwconv":
-        B, H, W, C, Ho, Wo, K = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
+        B, H, W, C, Ho, Wo, K = a[9], a[10], a[11], a[12], a[13], a[14], a[15]
         return 4 * (B * C * H * W + B * C * Ho * Wo + C * K * K)
     if name == "nasseg_dwconv_wgrad":
-        B, H, W, C, Ho, Wo, K = a[4], a[5], a[6], a[7], a[8], a[9], a[10]
+        B, H, W, C, Ho, Wo, K = a[7], a[8], a[9], a[10], a[11], a[12], a[13]
         return 4 * (B * C * H * W + B * C * Ho * Wo + C * K * K)
     if name == "nasseg_conv_fwd":
         B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[13], a[14], a[15], a[16], a[17], a[18], a[19], a[20], a[21]

@@ -45,13 +45,16 @@ int nasseg_device_count(void);
  * in SepConv / DilConv (layer_factory.py:198-265) and InvertedResidual
  * (layer_factory.py:125-158). */
 int nasseg_dw_pack_weight(const float* w, float* wt, int C, int K, int flip, void* stream);
-int nasseg_dwconv(const float* x, const float* wt, float* y, const float* scale,
-                  const float* shift, int B, int H, int W, int C, int Ho, int Wo, int K, int stride,
-                  int pad, int dil, int transposed, int relu_in, int act, void* stream);
+int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_scale,
+                  const float* in_shift, int in_act, const float* scale, const float* shift, int act,
+                  int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
+                  int transposed, float* stats, void* stream);
+int nasseg_dwconv_strip_ok(int K, int stride, int dil);
+int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil);
 int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K);
-int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int H, int W,
-                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, int relu_in,
-                        void* stream);
+int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
+                        const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
+                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream);
 
 /* ---- dense convolution on the fp32 matrix cores ----------------------------
  * replaces conv1x1 / conv3x3 / conv_bn / conv_bn_relu (layer_factory.py:7-24,

@@ -13,6 +13,14 @@
 // overlap and are served by the vector L1.
 //
 // Packed weight layout used by all kernels here: wt[tap][C] (tap = ty*K+tx).
+//
+// Fusions around the conv (all optional): an input *prologue* act(x*in_scale+in_shift)
+// applied as the taps are loaded - this is how a preceding BatchNorm+ReLU(6) is consumed
+// without ever writing the normalised tensor (and DilConv's leading ReLU); an output
+// affine+act epilogue (inference); and a *statistics* epilogue (per-workgroup sum and sum
+// of squares per channel of y), i.e. the batch statistics of a following BatchNorm.
+#include <math.h>
+
 #include "common.h"
 
 namespace {
@@ -39,6 +47,30 @@ __device__ __forceinline__ float4 relu4(float4 v) {
   return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }
 
+// input prologue of one channel group: clamp(v*sc + sh, lo, hi); (lo, hi) encode the
+// activation (none: -inf..inf, ReLU: 0..inf, ReLU6: 0..6) so there is no branch per tap
+struct Prologue {
+  float4 sc, sh;
+  float lo, hi;
+};
+__device__ __forceinline__ Prologue make_prologue(const float* scale, const float* shift, int act,
+                                                  int c4) {
+  Prologue p;
+  p.sc = scale ? ld4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+  p.sh = shift ? ld4(shift + c4 * 4) : f4zero();
+  p.lo = act ? 0.f : -INFINITY;
+  p.hi = act == NASSEG_ACT_RELU6 ? 6.f : INFINITY;
+  return p;
+}
+__device__ __forceinline__ float4 apply_prologue(float4 v, const Prologue& p) {
+  v = fma4(v, p.sc, p.sh);
+  v.x = fminf(fmaxf(v.x, p.lo), p.hi);
+  v.y = fminf(fmaxf(v.y, p.lo), p.hi);
+  v.z = fminf(fmaxf(v.z, p.lo), p.hi);
+  v.w = fminf(fmaxf(v.w, p.lo), p.hi);
+  return v;
+}
+
 // ---------------------------------------------------------------------------
 // weight packing: (C,1,K,K) -> [tap][C], optional 180-degree flip
 // ---------------------------------------------------------------------------
@@ -50,18 +82,94 @@ __global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
   wt[i] = w[c * KK + ts];
 }
 
+// Sum acc[t] (t < NV) over all threads of the workgroup that share a channel group and
+// write out[t][C], RB values per LDS round (NV % RB == 0).  Thread `tid` of a workgroup whose
+// first flattened (x, c/4) index is `base` owns channel group (base + tid) % C4.  With
+// C4 > 256 only the groups present in the workgroup are written (caller zero-fills).
+// Lanes l, l+C4, l+2*C4, ... of a wave hold the same group: lanes < C4 gather them with
+// shuffles in a fixed order; the four waves then meet in LDS indexed by channel group.
+template <int NV, int RB>
+__device__ __forceinline__ void block_reduce_groups(float4 (&acc)[NV], float4 (*red)[4][64],
+                                                    float* __restrict__ out, int base, int C4) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int C = C4 * 4;
+  const int nown = C4 < 64 ? C4 : 64;
+  if (C4 < 64) {
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const float4 v = acc[t];
+      float4 s = v;
+      for (int off = C4; off < 64; off += C4) {
+        const int src = lane + off;
+        const bool ok = src < 64;
+        const int sl = ok ? src : lane;
+        const float ax = __shfl(v.x, sl), ay = __shfl(v.y, sl), az = __shfl(v.z, sl),
+                    aw = __shfl(v.w, sl);
+        if (ok) {
+          s.x += ax;
+          s.y += ay;
+          s.z += az;
+          s.w += aw;
+        }
+      }
+      acc[t] = s;
+    }
+  }
+  const int cc = (base + tid) % C4;  // channel group of this lane
+  if (C4 <= 64) {
+#pragma unroll
+    for (int r = 0; r < NV / RB; ++r) {
+      __syncthreads();
+      if (lane < nown) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) red[u][wave][cc] = acc[r * RB + u];
+      }
+      __syncthreads();
+      if (tid < C4) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const float4 s = add4(add4(red[u][0][tid], red[u][1][tid]),
+                                add4(red[u][2][tid], red[u][3][tid]));
+          st4(out + (size_t)(r * RB + u) * C + tid * 4, s);
+        }
+      }
+    }
+  } else {
+    // C4 > 64: at most ceil(256 / C4) <= 3 threads of the workgroup share a group, so a
+    // direct strided sum by the first min(C4, 256) threads has no serial tail to speak of
+    float4* flat = &red[0][0][0];  // needs RB * 256 >= 256 float4
+    const int nsum = C4 < 256 ? C4 : 256;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      __syncthreads();
+      flat[tid] = acc[t];
+      __syncthreads();
+      if (tid < nsum) {
+        float4 s = f4zero();
+        for (int u = tid; u < 256; u += C4) s = add4(s, flat[u]);
+        st4(out + (size_t)t * C + cc * 4, s);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // forward strip kernel
 // ---------------------------------------------------------------------------
 // WLDS: keep the K*K per-channel weight vectors in LDS (indexed by channel group,
 // needs C4 <= 64) instead of 4*K*K registers per lane - for 5x5 this is the
 // difference between 1 and 4+ resident waves per SIMD.
-template <int K, int P, int E, bool WLDS, bool RELU>
+// PRO: input prologue; STATS: per-workgroup channel sums of y and y^2 to stats[blk][2][C].
+template <int K, int P, int E, bool WLDS, bool PRO, bool STATS>
 __global__ __launch_bounds__(256) void dw_fwd_strip(
     const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ y,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ scale, const float* __restrict__ shift, int H, int W, int C4, int Ho,
-    int Wo, int stride, int pad, int dil, int g, int nchunk, int act) {
+    int Wo, int stride, int pad, int dil, int g, int nchunk, int act, float* __restrict__ stats) {
   __shared__ float4 lw[WLDS ? K * K : 1][WLDS ? 64 : 1];
+  __shared__ float4 sred[STATS ? 2 : 1][STATS ? 4 : 1][STATS ? 64 : 1];
   const int C = C4 * 4;
   if (WLDS) {
     for (int i = threadIdx.x; i < K * K * C4; i += 256) {
@@ -70,24 +178,30 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     }
     __syncthreads();
   }
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Wo * C4) return;
-  const int ox = idx / C4;
-  const int c4 = idx - ox * C4;
+  const int base = blockIdx.x * 256;
+  const int idx = base + threadIdx.x;
   const int b = blockIdx.z;
   const int r = blockIdx.y % g;
   const int chunk = blockIdx.y / g;
   const int oy0 = chunk * (P * g) + r;
-  if (oy0 >= Ho) return;
+  const bool live = (idx < Wo * C4) && (oy0 < Ho);
+  if (!STATS && !live) return;
+  // (with STATS every thread stays for the workgroup reduction; dead threads work on a
+  //  clamped, valid position and contribute zeros)
+  const int idc = idx < Wo * C4 ? idx : 0;
+  const int ox = idc / C4;
+  const int c4 = idc - ox * C4;
 
   float4 w[WLDS ? 1 : K * K];
   if (!WLDS) {
 #pragma unroll
     for (int t = 0; t < K * K; ++t) w[t] = ld4(wt + (size_t)t * C + c4 * 4);
   }
+  Prologue pro;
+  if (PRO) pro = make_prologue(in_scale, in_shift, in_act, c4);
 
   // Out-of-range taps load from a clamped (always valid) address and are zeroed by a
-  // select afterwards: a load under a branch would be followed by its own
+  // mask afterwards: a load under a branch would be followed by its own
   // s_waitcnt vmcnt(0) and serialise the whole strip on memory latency.
   int xoff[K];
   bool xok[K];
@@ -113,8 +227,9 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     const float* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
     for (int tx = 0; tx < K; ++tx) {
-      v[tx] = keep_if(ld4(xr + xoff[tx]), yok && xok[tx]);
-      if (RELU) v[tx] = relu4(v[tx]);
+      float4 t = ld4(xr + xoff[tx]);
+      if (PRO) t = apply_prologue(t, pro);
+      v[tx] = keep_if(t, yok && xok[tx]);  // zero padding applies to the prologue's output
     }
   };
   float4 vcur[K], vnext[K];
@@ -140,14 +255,23 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
   if (scale) sc = ld4(scale + c4 * 4);
   if (shift) sh = ld4(shift + c4 * 4);
+  float4 ssum[2] = {f4zero(), f4zero()};
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int oy = oy0 + j * g;
-    if (oy < Ho) {
-      float4 o = fma4(acc[j], sc, sh);
-      o = act_apply4(o, act);
-      st4(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4, o);
+    const bool ok = live && oy < Ho;
+    float4 o = fma4(acc[j], sc, sh);
+    if (act) o = act_apply4(o, act);
+    if (STATS) {
+      const float4 m = keep_if(o, ok);
+      ssum[0] = add4(ssum[0], m);
+      ssum[1] = fma4(m, m, ssum[1]);
     }
+    if (ok) st4(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4, o);
+  }
+  if constexpr (STATS) {
+    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    block_reduce_groups<2, 2>(ssum, sred, stats + blk * 2 * C, base, C4);
   }
 }
 
@@ -184,9 +308,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ 
 #pragma unroll
       for (int rx = 0; rx < R; ++rx) {
         const int oy = aq - LO + ry, ox = bq - LO + rx;
-        d[ry][rx] = (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo)
-                        ? ld4(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + c4 * 4)
-                        : f4zero();
+        const bool ok = oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+        const int oyc = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), oxc = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
+        d[ry][rx] = keep_if(ld4(dy + (((int64_t)b * Ho + oyc) * Wo + oxc) * C + c4 * 4), ok);
       }
     float4 o[2][2];
 #pragma unroll
@@ -222,7 +346,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ 
 __global__ __launch_bounds__(256) void dw_generic(
     const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ y,
     const float* __restrict__ scale, const float* __restrict__ shift, int B, int H, int W, int C4,
-    int Ho, int Wo, int K, int stride, int pad, int dil, int transposed, int relu_in, int act) {
+    int Ho, int Wo, int K, int stride, int pad, int dil, int transposed, int relu_in, int act) {  // relu_in: input ReLU
   const int C = C4 * 4;
   const size_t total = (size_t)B * Ho * Wo * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -273,85 +397,15 @@ __global__ __launch_bounds__(256) void dw_generic(
   }
 }
 
-// Sum acc[t] (t < K*K) over all threads of the workgroup that share a channel group and
-// write out[t][C].  Thread `tid` of a workgroup whose first flattened (x, c/4) index is
-// `base` owns channel group (base + tid) % C4.  With C4 > 256 only the groups present
-// in the workgroup are written (the caller zero-fills the partial buffer).
-template <int K>
-__device__ __forceinline__ void block_reduce_taps(float4 (&acc)[K * K], float4 (*red)[4][64],
-                                                  float* __restrict__ out, int base, int C4) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int C = C4 * 4;
-  const int nown = C4 < 64 ? C4 : 64;
-  if (C4 < 64) {
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-      const float4 v = acc[t];
-      float4 s = v;
-      for (int off = C4; off < 64; off += C4) {
-        const int src = lane + off;
-        const bool ok = src < 64;
-        const int sl = ok ? src : lane;
-        const float ax = __shfl(v.x, sl), ay = __shfl(v.y, sl), az = __shfl(v.z, sl),
-                    aw = __shfl(v.w, sl);
-        if (ok) {
-          s.x += ax;
-          s.y += ay;
-          s.z += az;
-          s.w += aw;
-        }
-      }
-      acc[t] = s;
-    }
-  }
-  const int cc = (base + tid) % C4;  // channel group of this lane
-  if (C4 <= 64) {
-#pragma unroll
-    for (int r = 0; r < K; ++r) {
-      __syncthreads();
-      if (lane < nown) {
-#pragma unroll
-        for (int u = 0; u < K; ++u) red[u][wave][cc] = acc[r * K + u];
-      }
-      __syncthreads();
-      if (tid < C4) {
-#pragma unroll
-        for (int u = 0; u < K; ++u) {
-          const float4 s = add4(add4(red[u][0][tid], red[u][1][tid]),
-                                add4(red[u][2][tid], red[u][3][tid]));
-          st4(out + (size_t)(r * K + u) * C + tid * 4, s);
-        }
-      }
-    }
-  } else {
-    // C4 > 64: at most ceil(256 / C4) <= 3 threads of the workgroup share a group, so a
-    // direct strided sum by the first min(C4, 256) threads has no serial tail to speak of
-    float4* flat = &red[0][0][0];  // >= 256 float4
-    const int nsum = C4 < 256 ? C4 : 256;
-#pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-      __syncthreads();
-      flat[tid] = acc[t];
-      __syncthreads();
-      if (tid < nsum) {
-        float4 s = f4zero();
-        for (int u = tid; u < 256; u += C4) s = add4(s, flat[u]);
-        st4(out + (size_t)t * C + cc * 4, s);
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------
 // backward-weight strip kernel: per-thread K*K float4 accumulators over a set
 // of row chunks, then a per-block reduction over lanes that share a channel
 // group.  partial layout: [block][tap][C].  Deterministic (no atomics).
 // ---------------------------------------------------------------------------
-template <int K, int P, int E, bool RELU>
+template <int K, int P, int E, bool PRO>
 __global__ __launch_bounds__(256) void dw_wgrad_strip(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int B,
+    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act, int B,
     int H, int W, int C4, int Ho, int Wo, int stride, int pad, int dil, int g, int nchunk) {
   __shared__ float4 red[K][4][64];
   const int tid = threadIdx.x;
@@ -365,6 +419,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
   float4 acc[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = f4zero();
+  Prologue pro;
+  if (PRO) pro = make_prologue(in_scale, in_shift, in_act, c4);
 
   int xoff[K];
   bool xok[K];
@@ -398,8 +454,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
       const float* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
       for (int tx = 0; tx < K; ++tx) {
-        v[tx] = keep_if(ld4(xr + xoff[tx]), yok && xok[tx]);
-        if (RELU) v[tx] = relu4(v[tx]);
+        float4 t = ld4(xr + xoff[tx]);
+        if (PRO) t = apply_prologue(t, pro);
+        v[tx] = keep_if(t, yok && xok[tx]);
       }
     };
     float4 vcur[K], vnext[K];
@@ -426,7 +483,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
   // time.  (C4 > 64: every lane of a wave owns a different group, the shuffle step is
   // the identity and a wave only covers 64 of the groups - see block_reduce_taps.)
   float* pout = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(K * K) * C;
-  block_reduce_taps<K>(acc, red, pout, base, C4);
+  block_reduce_groups<K * K, K>(acc, red, pout, base, C4);
 }
 
 // generic backward-weight (any K): same block reduction, one tap at a time.
@@ -516,41 +573,58 @@ int nasseg_dw_pack_weight(const float* w, float* wt, int C, int K, int flip, voi
   return NASSEG_OK;
 }
 
-// y = act(scale * dwconv(relu_in ? relu(x) : x) + shift); scale/shift may be null.
-// transposed != 0 computes the backward-data form (x = grad wrt output with
-// dims (H,W), y = grad wrt input with dims (Ho,Wo), un-flipped weights).
-int nasseg_dwconv(const float* x, const float* wt, float* y, const float* scale,
-                  const float* shift, int B, int H, int W, int C, int Ho, int Wo, int K, int stride,
-                  int pad, int dil, int transposed, int relu_in, int act, void* stream) {
+// y = act(scale * dwconv(in_act(in_scale*x + in_shift)) + shift); every pointer of the
+// prologue / epilogue may be null (identity).  transposed != 0 computes the backward-data
+// form (x = grad wrt output with dims (H,W), y = grad wrt input with dims (Ho,Wo),
+// un-flipped weights).  stats != null: also writes stats[blk][2][C] (sum, sum of squares of
+// y per channel) for blk < nasseg_dwconv_stats_blocks(...); forward strip geometries only.
+int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_scale,
+                  const float* in_shift, int in_act, const float* scale, const float* shift, int act,
+                  int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
+                  int transposed, float* stats, void* stream) {
   NASSEG_REQUIRE(C % 4 == 0, "dwconv: C=%d must be a multiple of 4", C);
   NASSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && K > 0 && stride > 0 && dil > 0,
                  "dwconv: bad geometry");
   hipStream_t s = (hipStream_t)stream;
   const int C4 = C / 4;
   StripCfg sc = strip_cfg(stride, dil);
+  const bool pro = in_scale || in_shift || in_act;
   const bool strip_ok = !transposed && (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2) && B <= 65535;
   if (strip_ok) {
     constexpr int P = 4;
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(cdiv(Wo * C4, 256), nchunk * sc.g, B);
     NASSEG_REQUIRE(grid.y <= 65535, "dwconv: too many row chunks");
-#define LAUNCH_FWD2(KK, EE, WL, RL)                                                               \
-  hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, RL>), grid, dim3(256), 0, s, x, wt, y, scale, shift, \
-                     H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, act)
-#define LAUNCH_FWD(KK, EE, WL) \
-  do { if (relu_in) LAUNCH_FWD2(KK, EE, WL, true); else LAUNCH_FWD2(KK, EE, WL, false); } while (0)
+    if (stats && C4 > 256) {
+      hipError_t e = hipMemsetAsync(stats, 0, (size_t)grid.x * grid.y * grid.z * 2 * C * sizeof(float), s);
+      if (e != hipSuccess) return nasseg_fail(NASSEG_ERR_LAUNCH, "dwconv: memset failed");
+    }
+#define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                             \
+  hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
+                     in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, \
+                     act, stats)
+#define LAUNCH_FWD(KK, EE, WL)                                    \
+  do {                                                            \
+    if (pro && stats) LAUNCH_FWD3(KK, EE, WL, true, true);        \
+    else if (pro) LAUNCH_FWD3(KK, EE, WL, true, false);           \
+    else if (stats) LAUNCH_FWD3(KK, EE, WL, false, true);         \
+    else LAUNCH_FWD3(KK, EE, WL, false, false);                   \
+  } while (0)
     const bool wl = C4 <= 64;
     if (K == 3 && sc.e == 1) LAUNCH_FWD(3, 1, false);
     else if (K == 3 && sc.e == 2) LAUNCH_FWD(3, 2, false);
     else if (K == 5 && sc.e == 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
     else { if (wl) LAUNCH_FWD(5, 2, true); else LAUNCH_FWD(5, 2, false); }
-#undef LAUNCH_FWD2
+#undef LAUNCH_FWD3
 #undef LAUNCH_FWD
     NASSEG_LAUNCH_CHECK("dw_fwd_strip");
     return NASSEG_OK;
   }
+  NASSEG_REQUIRE(!stats, "dwconv: the statistics epilogue needs a 3x3 / 5x5 forward strip geometry");
+  NASSEG_REQUIRE(!in_scale && !in_shift && in_act <= NASSEG_ACT_RELU,
+                 "dwconv: only an input ReLU is supported as prologue on the generic path");
   if (transposed && stride == 2 && dil == 1 && (K == 3 || K == 5) && pad == (K - 1) / 2 &&
-      !relu_in && !scale && !shift && act == 0) {
+      !in_act && !scale && !shift && act == 0) {
     // (H, W) = dims of dy, (Ho, Wo) = dims of dx in the transposed call
     const int64_t quads = (int64_t)B * ((Ho + 1) / 2) * ((Wo + 1) / 2) * C4;
     const int nbq = (int)((quads + 255) / 256 < 65536 * 4 ? (quads + 255) / 256 : 65536 * 4);
@@ -564,12 +638,25 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* scale,
   size_t total = (size_t)B * Ho * Wo * C4;
   int nb = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
   hipLaunchKernelGGL(dw_generic, dim3(nb), dim3(256), 0, s, x, wt, y, scale, shift, B, H, W, C4,
-                     Ho, Wo, K, stride, pad, dil, transposed, relu_in, act);
+                     Ho, Wo, K, stride, pad, dil, transposed, in_act, act);
   NASSEG_LAUNCH_CHECK("dw_generic");
   return NASSEG_OK;
 }
 
-// workspace (floats) needed by nasseg_dwconv_wgrad
+// 1 when nasseg_dwconv / nasseg_dwconv_wgrad take the fast strip path for this geometry,
+// i.e. when the full input prologue and the statistics epilogue are available
+int nasseg_dwconv_strip_ok(int K, int stride, int dil) {
+  StripCfg sc = strip_cfg(stride, dil);
+  return ((K == 3 || K == 5) && (sc.e == 1 || sc.e == 2)) ? 1 : 0;
+}
+
+// number of statistic rows nasseg_dwconv writes (0 when the geometry has no stats support)
+int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil) {
+  if (!nasseg_dwconv_strip_ok(K, stride, dil)) return 0;
+  StripCfg sc = strip_cfg(stride, dil);
+  return (int64_t)cdiv(Wo * (C / 4), 256) * cdiv(Ho, 4 * sc.g) * sc.g * B;
+}
+
 // number of workgroup rows (grid.y) of the backward-weight kernels: ~1024 workgroups,
 // but at least ~8 output rows of work per workgroup so that the end-of-block reduction
 // is amortised
@@ -587,11 +674,11 @@ int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K) {
   return gx * wgrad_rows(B, C, Ho, Wo) * (int64_t)K * K * C;
 }
 
-// dw (C,1,K,K) = sum over pixels of dy * x_tap; ws must hold
+// dw (C,1,K,K) = sum over pixels of dy * in_act(in_scale*x_tap + in_shift); ws must hold
 // nasseg_dwconv_wgrad_workspace() floats.
-int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, int B, int H, int W,
-                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, int relu_in,
-                        void* stream) {
+int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
+                        const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
+                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream) {
   NASSEG_REQUIRE(C % 4 == 0, "dwconv_wgrad: C=%d must be a multiple of 4", C);
   hipStream_t s = (hipStream_t)stream;
   const int C4 = C / 4;
@@ -602,16 +689,17 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, i
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)gx * gy * K * K * C * sizeof(float), s);
     if (e != hipSuccess) return nasseg_fail(NASSEG_ERR_LAUNCH, "dwconv_wgrad: memset failed");
   }
+  const bool pro = in_scale || in_shift || in_act;
   const bool strip_ok = (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2);
   if (strip_ok) {
     constexpr int P = 4;
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(gx, gy, 1);
-#define LAUNCH_WG2(KK, EE, RL)                                                                       \
-  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE, RL>), grid, dim3(256), 0, s, x, dy, ws, B, H, W, C4, \
-                     Ho, Wo, stride, pad, dil, sc.g, nchunk)
+#define LAUNCH_WG2(KK, EE, PR)                                                                    \
+  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE, PR>), grid, dim3(256), 0, s, x, dy, ws, in_scale, \
+                     in_shift, in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk)
 #define LAUNCH_WG(KK, EE) \
-  do { if (relu_in) LAUNCH_WG2(KK, EE, true); else LAUNCH_WG2(KK, EE, false); } while (0)
+  do { if (pro) LAUNCH_WG2(KK, EE, true); else LAUNCH_WG2(KK, EE, false); } while (0)
     if (K == 3 && sc.e == 1) LAUNCH_WG(3, 1);
     else if (K == 3 && sc.e == 2) LAUNCH_WG(3, 2);
     else if (K == 5 && sc.e == 1) LAUNCH_WG(5, 1);
@@ -620,8 +708,10 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws, i
 #undef LAUNCH_WG
     NASSEG_LAUNCH_CHECK("dw_wgrad_strip");
   } else {
+    NASSEG_REQUIRE(!in_scale && !in_shift && in_act <= NASSEG_ACT_RELU,
+                   "dwconv_wgrad: only an input ReLU is supported as prologue on the generic path");
     hipLaunchKernelGGL(dw_wgrad_generic, dim3(gx, gy, 1), dim3(256), 0, s, x, dy, ws, B, H, W, C4,
-                       Ho, Wo, K, stride, pad, dil, relu_in);
+                       Ho, Wo, K, stride, pad, dil, in_act);
     NASSEG_LAUNCH_CHECK("dw_wgrad_generic");
   }
   hipLaunchKernelGGL(dw_wgrad_finalize, dim3(cdiv(K * K * C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws,

@@ -96,8 +96,8 @@ class _DepthwiseConv(torch.autograd.Function):
         wt = _vec(x, K * K * C)
         lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
         y = _new(x, B, C, Ho, Wo)
-        lib.call("nasseg_dwconv", ptr(x), ptr(wt), ptr(y), None, None, B, H, W, C, Ho, Wo, K,
-                 stride, pad, dil, 0, int(relu_in), ACT_NONE, s)
+        lib.call("nasseg_dwconv", ptr(x), ptr(wt), ptr(y), None, None, ACT_RELU if relu_in else ACT_NONE,
+                 None, None, ACT_NONE, B, H, W, C, Ho, Wo, K, stride, pad, dil, 0, None, s)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, dil, bool(relu_in))
         return y
@@ -119,19 +119,19 @@ class _DepthwiseConv(torch.autograd.Function):
             if stride == 1 and padb >= 0:
                 # correlation with the 180-degree rotated kernel
                 lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 1, s)
-                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, B, Ho, Wo, C, H, W,
-                         K, 1, padb, dil, 0, 0, ACT_NONE, s)
+                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+                         ACT_NONE, B, Ho, Wo, C, H, W, K, 1, padb, dil, 0, None, s)
             else:
                 lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
-                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, B, Ho, Wo, C, H, W,
-                         K, stride, pad, dil, 1, 0, ACT_NONE, s)
+                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+                         ACT_NONE, B, Ho, Wo, C, H, W, K, stride, pad, dil, 1, None, s)
             if relu_in:
                 dx = _act_bwd(dx, x, ACT_RELU)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws = _ws(x, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, K))
-            lib.call("nasseg_dwconv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), B, H, W, C, Ho, Wo,
-                     K, stride, pad, dil, int(relu_in), s)
+            lib.call("nasseg_dwconv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), None, None,
+                     ACT_RELU if relu_in else ACT_NONE, B, H, W, C, Ho, Wo, K, stride, pad, dil, s)
         return dx, dw, None, None, None, None
 
 
@@ -317,6 +317,236 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
     return _ConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
                             bool(training), momentum, eps, int(act), residual, int(stride),
                             int(padding), int(dilation))
+
+
+# ---------------------------------------------------------------------------
+# conv -> BN -> act chains with "normalise on read"
+# ---------------------------------------------------------------------------
+def _dw_backward_data(dz, w, x_shape, stride, pad, dil):
+    B, C, H, W = x_shape
+    K = w.shape[-1]
+    Ho, Wo = dz.shape[2], dz.shape[3]
+    s = current_stream()
+    wt = _vec(dz, K * K * C)
+    dx = _new(dz, B, C, H, W)
+    padb = dil * (K - 1) - pad
+    if stride == 1 and padb >= 0:
+        lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 1, s)
+        lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+                 ACT_NONE, B, Ho, Wo, C, H, W, K, 1, padb, dil, 0, None, s)
+    else:
+        lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
+        lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+                 ACT_NONE, B, Ho, Wo, C, H, W, K, stride, pad, dil, 1, None, s)
+    return dx
+
+
+class _ConvChain(torch.autograd.Function):
+    """A run of convolutions (dense on the MFMA path or depthwise), each optionally followed
+    by BatchNorm (+ReLU/ReLU6), as ONE autograd node in which a normalised activation that
+    only feeds the next convolution is never written: the producer emits the raw conv output
+    z plus the BatchNorm statistics (epilogue), the consumer applies act(scale*z + shift) as
+    it loads its operand (prologue), backward recomputes the same on load.  Only the chain's
+    final output is materialised (with the block's residual add fused in).
+
+    cfg = (in_act0, ops); ops[i] = (kind, stride, pad, dil, has_bn, act, training, momentum, eps)
+    with kind 'dense' | 'dw'; tensors = per op (weight, gamma, beta, running_mean,
+    running_var, num_batches_tracked) with None where absent.
+    """
+
+    @staticmethod
+    def forward(ctx, cfg, x, residual, *tensors):
+        in_act0, ops = cfg
+        x = _cl(x)
+        s = current_stream()
+        needs_grad = any(ctx.needs_input_grad)
+        res = _cl(residual) if residual is not None else None
+        cur, pend = x, ((None, None, in_act0) if in_act0 else None)
+        saved, meta = [], []
+        n_ops = len(ops)
+        for i, (kind, stride, pad, dil, has_bn, act, training, momentum, eps) in enumerate(ops):
+            w, gamma, beta, rm, rv, nbt = tensors[6 * i:6 * i + 6]
+            w = w.contiguous()
+            B, K, H, W = cur.shape
+            last = i == n_ops - 1
+            if kind == "dw":
+                k = w.shape[-1]
+                if w.shape[0] != K or w.shape[1] != 1:
+                    raise NassegError("depthwise weight {} does not match C={}".format(tuple(w.shape), K))
+                N, kh, kw = K, k, k
+                strip = bool(lib.query("nasseg_dwconv_strip_ok", k, stride, dil))
+                pro_ok = strip or (pend is not None and pend[0] is None and pend[2] == ACT_RELU)
+                stats_ok = strip
+            else:
+                N, Kw, kh, kw = w.shape
+                if Kw != K:
+                    raise NassegError("conv weight {} does not match C_in={}".format(tuple(w.shape), K))
+                pointwise = kh == 1 and kw == 1 and stride == 1 and pad == 0
+                pro_ok = pointwise and K % 4 == 0 and N % 4 == 0
+                stats_ok = N % 4 == 0
+            Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
+            if Ho <= 0 or Wo <= 0:
+                raise NassegError("conv output would be empty")
+            if pend is not None and not pro_ok:
+                cur = (_affine_act(cur, pend[0], pend[1], None, pend[2]) if pend[0] is not None
+                       else _axpby(cur, None, None, None, pend[2]))
+                pend = None
+            psc, psh, pact = pend if pend is not None else (None, None, ACT_NONE)
+            M = B * Ho * Wo
+            z = _new(cur, B, N, Ho, Wo)
+            fold = has_bn and not training and not needs_grad and not (kind == "dw" and last and res is not None)
+            stats = part = None
+            nblk = 0
+            if has_bn:
+                if training and M <= 1:
+                    raise ValueError("Expected more than 1 value per channel when training, got input "
+                                     "size {}".format((B, N, Ho, Wo)))
+                stats = _vec(cur, 4 * N)  # mean | invstd | scale | shift
+                mean, invstd, scale, shift = (stats[0:N], stats[N:2 * N], stats[2 * N:3 * N],
+                                              stats[3 * N:])
+                if not training:
+                    lib.call("nasseg_bn_eval_params", N, float(eps), ptr(gamma), ptr(beta), ptr(rm),
+                             ptr(rv), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
+                elif stats_ok:
+                    nblk = (lib.query("nasseg_dwconv_stats_blocks", B, N, Ho, Wo, kh, stride, dil)
+                            if kind == "dw" else lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N))
+                    part = _ws(cur, (nblk + 64) * 2 * N)
+            o_sc = o_sh = o_res = None
+            o_act = ACT_NONE
+            if fold:  # inference: BN (+act, +residual) folded into the conv's epilogue
+                o_sc, o_sh, o_act = scale, shift, act
+                if last and res is not None:
+                    o_res = res
+            if kind == "dw":
+                wt = _vec(cur, kh * kw * K)
+                lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), K, kh, 0, s)
+                lib.call("nasseg_dwconv", ptr(cur), ptr(wt), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
+                         ptr(o_sh), o_act, B, H, W, K, Ho, Wo, kh, stride, pad, dil, 0, ptr(part), s)
+            else:
+                wp = _pack_dense(w, "fwd")
+                lib.call("nasseg_conv_fwd", ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh), pact,
+                         ptr(o_sc), ptr(o_sh), o_act, ptr(o_res), N, B, H, W, K, Ho, Wo, N, kh, kw,
+                         stride, pad, dil, 0, ptr(part), s)
+            if needs_grad:
+                saved.extend([cur, psc, psh, z, stats, w])
+                meta.append((pact,))
+            if fold:
+                cur, pend = z, None
+                if last and res is not None:
+                    res = None  # consumed by the epilogue
+                continue
+            if has_bn:
+                if training:
+                    if part is not None:
+                        lib.call("nasseg_bn_finalize", ptr(part), nblk, M, N, float(eps), float(momentum),
+                                 ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                 ptr(rm), ptr(rv), ptr(nbt), s)
+                    else:
+                        ws = _ws(cur, lib.query("nasseg_colred_workspace", 1, M, N))
+                        lib.call("nasseg_bn_stats", ptr(z), N, M, N, float(eps), float(momentum),
+                                 ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                 ptr(rm), ptr(rv), ptr(nbt), ptr(ws), s)
+                cur, pend = z, (scale, shift, act)
+            else:
+                cur, pend = z, None
+        if pend is not None:
+            y = _affine_act(cur, pend[0], pend[1], res, pend[2])
+        elif res is not None:
+            y = _axpby(cur, res, None, None)
+        else:
+            y = cur
+        if needs_grad:
+            ctx.save_for_backward(*[t for t in saved])
+            ctx.meta = (cfg, meta, residual is not None, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg, meta, has_res, x_shape = ctx.meta
+        in_act0, ops = cfg
+        sv = ctx.saved_tensors
+        g = _cl(dy)
+        s = current_stream()
+        n_ops = len(ops)
+        grads = [None] * (6 * n_ops)
+        dres = g if (has_res and ctx.needs_input_grad[2]) else None
+        for i in range(n_ops - 1, -1, -1):
+            kind, stride, pad, dil, has_bn, act, training, momentum, eps = ops[i]
+            cur, psc, psh, z, stats, w = sv[6 * i:6 * i + 6]
+            (pact,) = meta[i]
+            B, N, Ho, Wo = z.shape
+            M = B * Ho * Wo
+            need_dw = ctx.needs_input_grad[3 + 6 * i]
+            need_dx = i > 0 or ctx.needs_input_grad[1]
+            if has_bn:
+                mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
+                sums = _vec(z, 2 * N)
+                ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
+                lib.call("nasseg_bn_bwd_reduce", ptr(g), N, ptr(z), N, M, N, ptr(scale), ptr(shift),
+                         ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
+                if ctx.needs_input_grad[3 + 6 * i + 1]:
+                    grads[6 * i + 1] = sums[N:2 * N]
+                if ctx.needs_input_grad[3 + 6 * i + 2]:
+                    grads[6 * i + 2] = sums[0:N]
+                if not (need_dw or need_dx):
+                    g = None
+                    break
+                dz = torch.empty_like(z)
+                lib.call("nasseg_bn_bwd_apply", ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean),
+                         ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
+            else:
+                dz = g
+                if not (need_dw or need_dx):
+                    g = None
+                    break
+            Bc, K, H, W = cur.shape
+            if kind == "dw":
+                k = w.shape[-1]
+                if need_dw:
+                    dwt = torch.empty_like(w)
+                    ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", Bc, K, Ho, Wo, k))
+                    lib.call("nasseg_dwconv_wgrad", ptr(cur), ptr(dz), ptr(dwt), ptr(ws), ptr(psc),
+                             ptr(psh), pact, Bc, H, W, K, Ho, Wo, k, stride, pad, dil, s)
+                    grads[6 * i] = dwt
+                g = _dw_backward_data(dz, w, (Bc, K, H, W), stride, pad, dil) if need_dx else None
+            else:
+                _, _, kh, kw = w.shape
+                if need_dw:
+                    dwt = torch.empty_like(w)
+                    ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", Bc, Ho, Wo, N, K, kh, kw))
+                    lib.call("nasseg_conv_wgrad", ptr(cur), K, ptr(dz), N, ptr(dwt), ptr(ws), ptr(psc),
+                             ptr(psh), pact, Bc, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
+                    grads[6 * i] = dwt
+                g = None
+                if need_dx:
+                    g = _new(cur, Bc, K, H, W)
+                    wp = _pack_dense(w, 1)
+                    lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wp), ptr(g), K, None, None, 0, None, None,
+                             ACT_NONE, None, 0, Bc, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None, s)
+        dx = None
+        if g is not None and ctx.needs_input_grad[1]:
+            dx = g
+            if in_act0:
+                # the chain started with an activation applied on load (DilConv's ReLU)
+                dx = _act_bwd(dx, sv[0], in_act0)
+        return (None, dx, dres) + tuple(grads)
+
+
+def conv_chain(x, ops, in_act0=ACT_NONE, residual=None):
+    """ops: list of (weight, stride, padding, dilation, depthwise, bn, act) where ``bn`` is None
+    or (gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps)."""
+    cfg_ops, tensors = [], []
+    for weight, stride, padding, dilation, depthwise, bn, act in ops:
+        if bn is None:
+            cfg_ops.append(("dw" if depthwise else "dense", int(stride), int(padding), int(dilation),
+                            False, ACT_NONE, False, 0.0, 0.0))
+            tensors.extend([weight, None, None, None, None, None])
+        else:
+            gamma, beta, rm, rv, nbt, training, momentum, eps = bn
+            cfg_ops.append(("dw" if depthwise else "dense", int(stride), int(padding), int(dilation),
+                            True, int(act), bool(training), float(momentum), float(eps)))
+            tensors.extend([weight, gamma, beta, rm, rv, nbt if training else None])
+    return _ConvChain.apply((int(in_act0), tuple(cfg_ops)), x, residual, *tensors)
 
 
 # ---------------------------------------------------------------------------

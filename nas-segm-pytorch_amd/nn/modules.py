@@ -79,37 +79,74 @@ class AvgPool2d(nn.AvgPool2d):
         return F.avg_pool2d(x, self.kernel_size, self.stride, self.padding)
 
 
+def _flatten(mods):
+    out = []
+    for m in mods:
+        if isinstance(m, FusedSequential):
+            out.extend(_flatten(m._modules.values()))
+        else:
+            out.append(m)
+    return out
+
+
+def _chainable(m):
+    """a conv the fused chain node can run: bias-free, dense with N % 4 == 0 or depthwise"""
+    if not isinstance(m, Conv2d) or m.bias is not None:
+        return False
+    if m.is_depthwise:
+        return m.in_channels % 4 == 0
+    return m.groups == 1 and m.out_channels % 4 == 0
+
+
+def _bn_fusable(m):
+    return (isinstance(m, BatchNorm2d) and m.momentum is not None and m.track_running_stats
+            and m.weight is not None)
+
+
 class FusedSequential(nn.Sequential):
-    """nn.Sequential with BN+act(+residual) and ReLU+depthwise peephole fusion."""
+    """nn.Sequential whose forward runs maximal runs of [conv (BN (ReLU|ReLU6)?)?]+ as one fused
+    autograd node (functional.conv_chain: statistics in the conv epilogue, normalise-on-read
+    between the convs, residual add in the last normalise pass).  Nested FusedSequentials
+    (SepConv stages) are flattened first; anything else runs module by module."""
 
     def forward(self, x, residual=None):
-        mods = list(self._modules.values())
+        mods = _flatten(self._modules.values())
         n = len(mods)
         i = 0
         res_used = residual is None
         while i < n:
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
-            if (isinstance(m, Conv2d) and m.groups == 1 and m.bias is None and isinstance(nxt, BatchNorm2d)
-                    and nxt.momentum is not None and nxt.track_running_stats
-                    and nxt.weight is not None and m.out_channels % 4 == 0):
-                # dense conv -> BatchNorm [-> ReLU/ReLU6] [+ residual]: one fused node
-                m._check()
-                bn = nxt
-                after = mods[i + 2] if i + 2 < n else None
-                act, step = F.ACT_NONE, 2
-                if isinstance(after, nn.ReLU6):
-                    act, step = F.ACT_RELU6, 3
-                elif isinstance(after, nn.ReLU):
-                    act, step = F.ACT_RELU, 3
+            in_act0 = F.ACT_NONE
+            if (isinstance(m, nn.ReLU) and not isinstance(m, nn.ReLU6) and _chainable(nxt)
+                    and nxt.is_depthwise):
+                in_act0 = F.ACT_RELU  # DilConv: ReLU applied as the depthwise conv loads
+                i += 1
+                m = mods[i]
+            if _chainable(m):
+                ops = []
+                while i < n and _chainable(mods[i]):
+                    conv = mods[i]
+                    conv._check()
+                    i += 1
+                    bn, act = None, F.ACT_NONE
+                    if i < n and _bn_fusable(mods[i]):
+                        b = mods[i]
+                        i += 1
+                        if i < n and isinstance(mods[i], nn.ReLU6):
+                            act = F.ACT_RELU6
+                            i += 1
+                        elif i < n and isinstance(mods[i], nn.ReLU):
+                            act = F.ACT_RELU
+                            i += 1
+                        bn = (b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked,
+                              b.training, b.momentum, b.eps)
+                    ops.append((conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0],
+                                conv.is_depthwise, bn, act))
                 res = None
-                if not res_used and i + step == n:
+                if not res_used and i == n:
                     res, res_used = residual, True
-                x = F.conv_bn_act(x, m.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked if bn.training else None, bn.training,
-                                  bn.momentum, bn.eps, act, res, m.stride[0], m.padding[0],
-                                  m.dilation[0])
-                i += step
+                x = F.conv_chain(x, ops, in_act0, res)
             elif isinstance(m, BatchNorm2d):
                 act, step = F.ACT_NONE, 1
                 if isinstance(nxt, nn.ReLU6):
@@ -121,10 +158,6 @@ class FusedSequential(nn.Sequential):
                     res, res_used = residual, True
                 x = m(x, act=act, residual=res)
                 i += step
-            elif (isinstance(m, nn.ReLU) and not isinstance(m, nn.ReLU6)
-                  and isinstance(nxt, Conv2d) and nxt.is_depthwise):
-                x = nxt(x, relu_in=True)
-                i += 2
             else:
                 x = m(x)
                 i += 1

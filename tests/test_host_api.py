@@ -41,7 +41,8 @@ def test_error_convention_is_runtime_error():
 
     assert issubclass(NassegError, RuntimeError)
     with pytest.raises(RuntimeError) as e:  # argument validation happens before any launch
-        lib.call("nasseg_dwconv", None, None, None, None, None, 1, 4, 4, 6, 4, 4, 3, 1, 1, 1, 0, 0, 0, None)
+        lib.call("nasseg_dwconv", None, None, None, None, None, 0, None, None, 0, 1, 4, 4, 6, 4, 4, 3, 1, 1, 1,
+                 0, None, None)
     assert "multiple of 4" in str(e.value)
 
 
