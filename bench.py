@@ -225,6 +225,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share GPU 0 (with --backend gloo on a 1-GPU box)")
+    ap.add_argument("--graph", type=int, default=0, choices=(0, 1, 2),
+                    help="0 = launch every kernel from the host; 1 = replay forward+loss+backward from a "
+                         "hipGraph (all-reduce, clip, optimisers outside); 2 = whole step in the graph (1 GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -257,11 +260,21 @@ def main():
     segmenter.train()
     # default_args.py:57-66: SGD(lr 1e-3, mom 0.9, wd 1e-5) encoder, Adam(lr 3e-3, wd 1e-5) decoder
     optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
-    optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+    optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5,
+                                 capturable=args.graph == 2)
     image, mask = synthetic_batch(args.batch, args.height, args.width, rank, device, wl[2])
 
-    def step():
+    def eager_step():
         return segmenter_step(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1)
+
+    step = eager_step
+    if args.graph:
+        from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+        graphed = GraphedSegmenterStep(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
+                                       capture_optimisers=args.graph == 2)
+
+        def step():
+            return graphed.step(image, mask)
 
     def fence():
         if world > 1:
@@ -286,8 +299,8 @@ def main():
     rows = []
     if not args.no_roofline and rank == 0:
         lib.profiler = LaunchProfiler()
-        step()
-        step()
+        eager_step()
+        eager_step()
         summary = lib.profiler.summary()
         rows = roofline_from_profile(summary)
         lib.profiler = None
@@ -351,7 +364,8 @@ def main():
                                    "{}x3x{}x{} per GPU, train_segmenter step".format(
                                        args.workload, wl[6], args.batch, args.height, args.width),
                        "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
-                       "loss": loss_value},
+                       "loss": loss_value,
+                       "launch": ("host", "hipGraph(fwd+loss+bwd)", "hipGraph(whole step)")[args.graph]},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu:

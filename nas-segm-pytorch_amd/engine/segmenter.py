@@ -36,6 +36,7 @@ class RankParallel(nn.Module):
         self.process_group = process_group
         self._flat = None
         self._views = None
+        self._used = None
         if broadcast:
             self.broadcast_parameters()
 
@@ -55,27 +56,31 @@ class RankParallel(nn.Module):
             for t in list(self.module.parameters()) + list(self.module.buffers()):
                 dist.broadcast(t.data, src, group=self.process_group)
 
-    def _ensure_bucket(self):
-        params = [p for p in self.module.parameters() if p.requires_grad]
-        if self._flat is not None and len(params) == len(self._views):
-            return params
-        total = sum(p.numel() for p in params)
-        ref = params[0]
+    def _build_bucket(self, used):
+        total = sum(p.numel() for p in used)
+        ref = used[0]
         self._flat = torch.zeros(total, device=ref.device, dtype=ref.dtype)
+        self._used = used
         self._views = []
         off = 0
-        for p in params:
-            v = self._flat[off:off + p.numel()].view_as(p)
-            self._views.append(v)
+        for p in used:
+            self._views.append(self._flat[off:off + p.numel()].view_as(p))
             off += p.numel()
-        return params
 
     def attach_flat_grads(self):
-        """Point every ``param.grad`` into the flat bucket (zeroed).  Call instead
-        of ``optimizer.zero_grad()``; autograd then accumulates in place."""
-        params = self._ensure_bucket()
+        """Call instead of ``optimizer.zero_grad()``.  The first call only clears the
+        gradients: which parameters a candidate's loss actually reaches is discovered from
+        that first backward (``sync_gradients``), because parameters autograd never touches
+        must keep ``grad is None`` - the optimisers skip those, as they do under the
+        reference's nn.DataParallel - rather than receive a zero gradient plus weight decay.
+        From then on every reached ``param.grad`` is a view into one zeroed flat bucket and
+        autograd accumulates in place."""
+        if self._flat is None:
+            for p in self.module.parameters():
+                p.grad = None
+            return None
         self._flat.zero_()
-        for p, v in zip(params, self._views):
+        for p, v in zip(self._used, self._views):
             p.grad = v
         return self._flat
 
@@ -84,12 +89,15 @@ class RankParallel(nn.Module):
         ws = self.world_size
         if ws == 1:
             return
-        params = self._ensure_bucket()
+        if self._flat is None:
+            # static per architecture, hence identical on every rank
+            self._build_bucket([p for p in self.module.parameters()
+                                if p.requires_grad and p.grad is not None])
         aliased = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
-                      for p, v in zip(params, self._views))
+                      for p, v in zip(self._used, self._views))
         if not aliased:
-            # grads were (re)allocated by autograd / zero_grad(set_to_none): pack them
-            for p, v in zip(params, self._views):
+            # first step, or grads were re-allocated (zero_grad(set_to_none)): pack them
+            for p, v in zip(self._used, self._views):
                 if p.grad is None:
                     v.zero_()
                 else:
@@ -97,7 +105,7 @@ class RankParallel(nn.Module):
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.process_group)
         self._flat.div_(ws)
         if not aliased:
-            for p, v in zip(params, self._views):
+            for p, v in zip(self._used, self._views):
                 p.grad = v
 
     def reduce_confusion(self, cm):

@@ -28,20 +28,28 @@ def _worker(rank, world, port, q):
 
         torch.manual_seed(100 + rank)  # different init per rank: broadcast must fix it
         net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3), torch.nn.Linear(3, 2))
+        net.register_parameter("never_reached", torch.nn.Parameter(torch.ones(3)))  # e.g. unused aux head
         dp = RankParallel(net)
         first = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
         gathered = [torch.zeros_like(first) for _ in range(world)]
         dist.all_gather(gathered, first)
         same_params = all(torch.equal(gathered[0], g) for g in gathered)
 
-        # path 1: grads alias the flat bucket
-        dp.attach_flat_grads()
+        # step 1 discovers which parameters the loss reaches; step 2 accumulates straight
+        # into the flat bucket (path 1: grads alias it)
         x = torch.full((5, 4), float(rank + 1))
+        assert dp.attach_flat_grads() is None
         net(x).sum().backward()
-        local = [p.grad.clone() for p in net.parameters()]
         dp.sync_gradients()
-        ok_alias = True
-        for p, l in zip(net.parameters(), local):
+        reached = [p for p in net.parameters() if p is not net.never_reached]
+        flat = dp.attach_flat_grads()
+        assert flat is not None and flat.numel() == sum(p.numel() for p in reached)
+        net(x).sum().backward()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(reached, dp._views))
+        local = [p.grad.clone() for p in reached]
+        dp.sync_gradients()
+        ok_alias = net.never_reached.grad is None
+        for p, l in zip(reached, local):
             allg = [torch.zeros_like(l) for _ in range(world)]
             dist.all_gather(allg, l)
             ok_alias &= torch.allclose(p.grad, sum(allg) / world, atol=1e-6)
@@ -49,10 +57,10 @@ def _worker(rank, world, port, q):
         for p in net.parameters():
             p.grad = None
         net(x * 2).sum().backward()
-        local = [p.grad.clone() for p in net.parameters()]
+        local = [p.grad.clone() for p in reached]
         dp.sync_gradients()
-        ok_pack = True
-        for p, l in zip(net.parameters(), local):
+        ok_pack = net.never_reached.grad is None
+        for p, l in zip(reached, local):
             allg = [torch.zeros_like(l) for _ in range(world)]
             dist.all_gather(allg, l)
             ok_pack &= torch.allclose(p.grad, sum(allg) / world, atol=1e-6)

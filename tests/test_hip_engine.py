@@ -228,3 +228,41 @@ def test_candidate_evaluation_with_controller_samples():
     r2 = evaluate_candidates(cv, make_batches, ctrl_version="cvpr", num_classes=19, agg_size=48,
                              aux_cell=True, repeats=1, omit_classes=())
     assert len(r2) == 1 and np.isfinite(r2[0]) and 0.0 <= r2[0] <= 1.0
+
+
+@pytest.mark.parametrize("net_name,capture_opt", [("wacv_arch0", False), ("wacv_arch0", True),
+                                                    ("cvpr_arch0", False)])
+def test_graphed_step_equals_eager_step(net_name, capture_opt):
+    """hipGraph replay of forward+loss+backward (optionally clip+optimisers) leaves exactly the
+    parameters, running statistics and losses the eager step sequence leaves (bit for bit:
+    same kernels, same order, no float atomics), over changing batches."""
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    rec = load_json("nets_meta.json")[net_name]
+    aux_w = 0.15 if rec["kind"] != "template" else -1
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(2, 3, 97, 129, generator=g).to(DEV).contiguous(memory_format=torch.channels_last),
+                torch.randint(0, rec["classes"], (2, 97, 129), generator=g).to(DEV)) for _ in range(3)]
+
+    def run(graphed):
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+        oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5, capturable=True)
+        losses = []
+        if graphed:
+            stepper = GraphedSegmenterStep(net, batches[0][0], batches[0][1], oe, od, 255, 3.0, 3.0, aux_w,
+                                           capture_optimisers=capture_opt)
+            assert stepper.capture_optimisers == capture_opt
+            for x, t in batches:
+                losses.append(float(stepper.step(x, t)))
+        else:
+            for x, t in batches:
+                losses.append(float(segmenter_step(net, x, t, oe, od, 255, 3.0, 3.0, aux_w)))
+        return losses, _cpu_sd(net)
+
+    l0, sd0 = run(False)
+    l1, sd1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k

@@ -27,6 +27,18 @@ if [[ "$WHAT" == "all" || "$WHAT" == "bench" ]]; then
   echo "bench exit $?" >> $OUT/summary.log
   cat $OUT/bench.json >> $OUT/summary.log
 fi
+if [[ "$WHAT" == "all" || "$WHAT" == "graph" ]]; then
+  for g in 1 2; do
+    timeout 300 python bench.py --steps 8 --warmup 2 --graph $g --no-cpu-baseline --no-roofline > $OUT/bench_graph$g.json 2> $OUT/bench_graph$g.err
+    echo "bench --graph $g exit $?" >> $OUT/summary.log; cat $OUT/bench_graph$g.json >> $OUT/summary.log
+  done
+  for wl in arch1 cvpr321; do
+    for g in 0 2; do
+      timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --graph $g --no-cpu-baseline > $OUT/bench_${wl}_g$g.json 2> $OUT/bench_${wl}_g$g.err
+      echo "bench $wl --graph $g exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_g$g.json >> $OUT/summary.log
+    done
+  done
+fi
 if [[ "$WHAT" == "all" || "$WHAT" == "prof" ]]; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o run -- \
      python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > "$OLDPWD/$OUT/prof.log" 2>&1)
