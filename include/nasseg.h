@@ -63,6 +63,10 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
  * output affine/bias+act(+residual) epilogue. */
 int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int kw, int mode,
                             void* stream);
+/* several weights (dense and depthwise) re-packed by one launch: dims[5*i..] =
+ * N, K, kh, kw, kind; kind 0/1/2 as mode above, 3 / 4 = depthwise plain / flipped */
+int nasseg_pack_weights(int count, const float* const* w, float* const* wp, const int* dims,
+                        void* stream);
 int nasseg_conv_fwd_pack_mode(int K, int kh, int kw);
 int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     const float* in_scale, const float* in_shift, int in_act,

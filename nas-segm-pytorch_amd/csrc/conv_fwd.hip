@@ -13,7 +13,10 @@
 // components to four consecutive MFMAs (the "k" label of an MFMA slot is arbitrary as
 // long as A and B agree); the accumulator then holds four consecutive output channels
 // of one pixel per lane -> float4 stores.  A wave owns MT x NT tiles of 16 pixels x 16
-// channels and all of N for its pixels, so X is read once.  No LDS.
+// channels.  Up to N = 64 a wave computes all of N for its own pixels; above that (WS) the
+// four waves of a workgroup share the same 16*MT pixels and split N between them, which
+// keeps the per-wave weight traffic (L1) and accumulator count independent of N.  Either
+// way X comes from HBM once.  No LDS.
 //
 // Variants (template): GATHER = needs per-tap source-pixel arithmetic (k x k, strided,
 // transposed); KM = how the reduction axis is read (aligned float4 / scalar / "flat"
@@ -68,18 +71,19 @@ __device__ __forceinline__ float4 load4(const float* row, int k, int K) {
 // EPI: any output epilogue (scale / shift(bias) / activation / residual) is present.
 // STATS: also emit per-workgroup partial sums of y and y^2 per output channel - the
 // BatchNorm batch statistics of the layer that follows, at no extra pass over y.
-template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, bool STATS>
+template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, bool STATS, bool WS>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
-  __shared__ float sred[STATS ? 4 : 1][2][STATS ? NT * 16 : 1];
+  __shared__ float sred[(STATS && !WS) ? 4 : 1][2][(STATS && !WS) ? NT * 16 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15;   // pixel within subtile (B operand col) / n within tile (A operand row)
   const int kg = lane >> 4;  // k group
   const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
-  const int m_base = (blockIdx.x * 4 + wave) * (16 * MT);
+  const int m_base = WS ? blockIdx.x * (16 * MT) : (blockIdx.x * 4 + wave) * (16 * MT);
   const bool active = m_base < Mtot;  // wave-uniform
-  if (!STATS && !active) return;
-  const int n_base = blockIdx.y * (16 * NT);
+  if ((!STATS || WS) && !active) return;
+  const int n_base = WS ? (blockIdx.y * 4 + wave) * (16 * NT) : blockIdx.y * (16 * NT);
+  if (WS && n_base >= a.N) return;  // (no workgroup barrier on the WS path)
 
   // destination pixels of this lane (clamped: out-of-range rows compute garbage that is never stored)
   int pm[MT], pb[MT], py[MT], px[MT];
@@ -270,7 +274,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
           sq[r] += __shfl_xor(sq[r], off);
         }
       }
-      if (j == 0) {
+      if (WS) {
+        // this wave alone owns these channels of the workgroup's pixels
+        const int n = n_base + nt * 16 + kg * 4;
+        if (j == 0 && n < a.N) {
+          float* po = a.stats + (int64_t)blockIdx.x * 2 * a.N + n;
+          st4(po, make_float4(sx[0], sx[1], sx[2], sx[3]));
+          st4(po + a.N, make_float4(sq[0], sq[1], sq[2], sq[3]));
+        }
+      } else if (j == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           sred[wave][0][nt * 16 + kg * 4 + r] = sx[r];
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
         }
       }
     }
+    if (WS) return;
     __syncthreads();
     for (int t = threadIdx.x; t < NT * 16; t += 256) {
       const int n = n_base + t;
@@ -316,31 +329,75 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
   wp[i] = w[((int64_t)n * K + k) * ntaps + tap];
 }
 
+// Several weight tensors re-packed by ONE launch (a chain of convolutions packs the
+// forward and backward-data layouts of all its weights together: launches, not bytes, are
+// what small layers pay for).  kind 0..2 = dense modes above; 3 = depthwise [tap][C],
+// 4 = depthwise flipped by 180 degrees (N = C, K = 1).
+struct PackDesc {
+  const float* w;
+  float* wp;
+  int N, K, ntaps, kind;
+};
+constexpr int kPackMax = 16;
+struct PackTable {
+  PackDesc d[kPackMax];
+};
+
+__global__ void pack_multi_kernel(PackTable t) {
+  const PackDesc d = t.d[blockIdx.y];
+  const int total = d.ntaps * d.N * d.K;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int tap, n, k;
+    if (d.kind == 0) {
+      k = i % d.K;
+      const int q = i / d.K;
+      n = q % d.N;
+      tap = q / d.N;
+    } else if (d.kind == 1) {
+      n = i % d.N;
+      const int q = i / d.N;
+      k = q % d.K;
+      tap = q / d.K;
+    } else if (d.kind == 2) {
+      k = i % d.K;
+      const int q = i / d.K;
+      tap = q % d.ntaps;
+      n = q / d.ntaps;
+    } else {
+      n = i % d.N;
+      k = 0;
+      tap = i / d.N;
+      if (d.kind == 4) tap = d.ntaps - 1 - tap;
+    }
+    d.wp[i] = d.w[((int64_t)n * d.K + k) * d.ntaps + tap];
+  }
+}
+
 struct Mode {
   int km;
   bool gather, pro, vecn, epi, stats;
 };
 
-template <int MT, int NT>
+template <int MT, int NT, bool WS = false>
 int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
   const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
-  dim3 grid((unsigned)cdiv64(Mtot, 64 * MT), cdiv(a.N, 16 * NT), 1);
+  dim3 grid((unsigned)cdiv64(Mtot, (WS ? 16 : 64) * MT), cdiv(a.N, (WS ? 64 : 16) * NT), 1);
 #define GO(KM_, G_, P_, V_)                                                                       \
   do {                                                                                            \
     if (md.stats) {                                                                               \
       if constexpr (V_)                                                                           \
-        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, true>), grid, dim3(256), \
-                           0, s, a);                                                              \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, true, WS>), grid,     \
+                           dim3(256), 0, s, a);                                                   \
     } else if (md.epi || !(V_)) {                                                                 \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true, false>), grid, dim3(256), \
-                         0, s, a);                                                                \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true, false, WS>), grid,       \
+                         dim3(256), 0, s, a);                                                     \
     } else {                                                                                      \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, false>), grid, dim3(256), \
-                         0, s, a);                                                                \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, false, WS>), grid,      \
+                         dim3(256), 0, s, a);                                                     \
     }                                                                                             \
   } while (0)
   if (md.km == KM_FLAT) {
-    if constexpr (NT <= 4) {
+    if constexpr (NT <= 4 && !WS) {
       if (md.vecn) GO(KM_FLAT, true, false, true);
       else GO(KM_FLAT, true, false, false);
     } else {
@@ -348,7 +405,7 @@ int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
     }
   } else if (!md.vecn) {
     // class-logit heads (N = 19, 21, 11, 1): always through the gather kernels
-    if constexpr (NT <= 2) {
+    if constexpr (NT <= 2 && !WS) {
       if (md.km == KM_VEC) GO(KM_VEC, true, false, false);
       else GO(KM_SCALAR, true, false, false);
     } else {
@@ -371,22 +428,15 @@ int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
 // pixel-tile height per wave: as many 16-pixel subtiles as still leave >= ~6
 // workgroups per CU (the op is latency-bound below that)
 inline int pick_mt(int64_t Mtot, int tiles) {
-  if (tiles > 8) return 1;
-  if (tiles > 4) return Mtot >= 64 * 2 * 1536 ? 2 : 1;
+  if (tiles > 4) return Mtot >= 16 * 4 * 1536 ? 4 : (Mtot >= 16 * 2 * 1536 ? 2 : 1);  // wave-split N
   return Mtot >= 64 * 4 * 1536 ? 4 : (Mtot >= 64 * 2 * 1536 ? 2 : 1);
 }
-template <int NT>
+template <int NT, bool WS = false>
 int launch_small(const FwdArgs& a, const Mode& md, hipStream_t s) {
-  const int mt = pick_mt((int64_t)a.g.B * a.g.Ho * a.g.Wo, NT);
-  if (mt == 4) return launch_one<4, NT>(a, md, s);
-  if (mt == 2) return launch_one<2, NT>(a, md, s);
-  return launch_one<1, NT>(a, md, s);
-}
-template <int NT>
-int launch_mid(const FwdArgs& a, const Mode& md, hipStream_t s) {
-  const int mt = pick_mt((int64_t)a.g.B * a.g.Ho * a.g.Wo, NT);
-  if (mt == 2) return launch_one<2, NT>(a, md, s);
-  return launch_one<1, NT>(a, md, s);
+  const int mt = pick_mt((int64_t)a.g.B * a.g.Ho * a.g.Wo, WS ? 5 : NT);
+  if (mt == 4) return launch_one<4, NT, WS>(a, md, s);
+  if (mt == 2) return launch_one<2, NT, WS>(a, md, s);
+  return launch_one<1, NT, WS>(a, md, s);
 }
 
 }  // namespace
@@ -405,12 +455,46 @@ int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int
   return NASSEG_OK;
 }
 
+// count tensors in one launch.  w[i] / wp[i]: device pointers (host arrays of pointers);
+// dims[5*i..] = N, K, kh, kw, kind with kind 0/1/2 = the dense modes of
+// nasseg_conv_pack_weight and 3 / 4 = depthwise (C = N, K = 1) plain / flipped, i.e.
+// nasseg_dw_pack_weight(flip = 0 / 1).
+int nasseg_pack_weights(int count, const float* const* w, float* const* wp, const int* dims,
+                        void* stream) {
+  NASSEG_REQUIRE(count >= 0 && (count == 0 || (w && wp && dims)), "pack_weights: bad arguments");
+  for (int base = 0; base < count; base += kPackMax) {
+    const int n = count - base < kPackMax ? count - base : kPackMax;
+    PackTable t;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+      const int* d = dims + 5 * (base + i);
+      NASSEG_REQUIRE(d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] >= 0 && d[4] <= 4,
+                     "pack_weights: bad descriptor %d", base + i);
+      NASSEG_REQUIRE(d[4] < 3 || d[1] == 1, "pack_weights: depthwise weights have K = 1");
+      NASSEG_REQUIRE(w[base + i] && wp[base + i], "pack_weights: null tensor %d", base + i);
+      t.d[i].w = w[base + i];
+      t.d[i].wp = wp[base + i];
+      t.d[i].N = d[0];
+      t.d[i].K = d[1];
+      t.d[i].ntaps = d[2] * d[3];
+      t.d[i].kind = d[4];
+      const int64_t total = (int64_t)d[0] * d[1] * d[2] * d[3];
+      NASSEG_REQUIRE(total < 2147483647LL, "pack_weights: tensor %d too large", base + i);
+      if (total > most) most = total;
+    }
+    int64_t gx = cdiv64(most, 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)gx, n), dim3(256), 0, (hipStream_t)stream, t);
+    NASSEG_LAUNCH_CHECK("pack_weights");
+  }
+  return NASSEG_OK;
+}
+
 // number of per-workgroup statistic rows nasseg_conv_fwd writes for this geometry
 int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N) {
   const int64_t Mtot = (int64_t)B * Ho * Wo;
   const int tiles = cdiv(N, 16);
-  const int nt = tiles <= 4 ? tiles : (tiles <= 6 ? 6 : (tiles <= 8 ? 8 : (tiles <= 12 ? 12 : 16)));
-  return cdiv64(Mtot, 64 * pick_mt(Mtot, nt));
+  return cdiv64(Mtot, (tiles > 4 ? 16 : 64) * pick_mt(Mtot, tiles));
 }
 
 // which packing nasseg_conv_fwd expects for a forward (non-transposed) convolution
@@ -466,10 +550,10 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
   if (tiles == 2) return launch_small<2>(a, md, s);
   if (tiles == 3) return launch_small<3>(a, md, s);
   if (tiles == 4) return launch_small<4>(a, md, s);
-  if (tiles <= 6) return launch_mid<6>(a, md, s);
-  if (tiles <= 8) return launch_mid<8>(a, md, s);
-  if (tiles <= 12) return launch_one<1, 12>(a, md, s);
-  return launch_one<1, 16>(a, md, s);  // N > 256 is covered by grid.y
+  // N > 64: the four waves of a workgroup split N (2, 3 or 4 tiles each)
+  if (tiles <= 8) return launch_small<2, true>(a, md, s);
+  if (tiles <= 12) return launch_small<3, true>(a, md, s);
+  return launch_small<4, true>(a, md, s);  // N > 256 is covered by grid.y
 }
 
 }  // extern "C"

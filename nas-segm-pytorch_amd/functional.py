@@ -155,6 +155,42 @@ def _pack_dense(w, mode):
     return wp
 
 
+def _pack_many(like, items):
+    """Re-pack several weights with ONE launch.  items: [(weight, kind)], kind 'fwd' | 0 | 1 | 2
+    for dense weights (as _pack_dense), 'dw' | 'dwflip' for depthwise ones.  Returns the packed
+    tensors in order (the weight itself where its layout already is the packed one)."""
+    import ctypes
+
+    out, descs, off = [], [], 0
+    for w, kind in items:
+        if kind in ("dw", "dwflip"):
+            C, _, k, _ = w.shape
+            d = (C, 1, k, k, 3 if kind == "dw" else 4)
+        else:
+            N, K, kh, kw = w.shape
+            mode = lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) if kind == "fwd" else int(kind)
+            if kh == 1 and kw == 1 and mode == 0:
+                out.append(w)
+                continue
+            d = (N, K, kh, kw, mode)
+        out.append(None)
+        descs.append((len(out) - 1, w, d, off))
+        off += (w.numel() + 3) // 4 * 4  # keep every packed tensor 16-byte aligned
+    if descs:
+        buf = _vec(like, off)
+        n = len(descs)
+        src = (ctypes.c_void_p * n)(*[ptr(w) for _, w, _, _ in descs])
+        dst = (ctypes.c_void_p * n)()
+        dims = (ctypes.c_int * (5 * n))()
+        for j, (pos, w, d, o) in enumerate(descs):
+            t = buf[o:o + w.numel()]
+            out[pos] = t
+            dst[j] = ptr(t)
+            dims[5 * j:5 * j + 5] = d
+        lib.call("nasseg_pack_weights", n, src, dst, dims, current_stream())
+    return out
+
+
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil):
@@ -322,20 +358,17 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
 # ---------------------------------------------------------------------------
 # conv -> BN -> act chains with "normalise on read"
 # ---------------------------------------------------------------------------
-def _dw_backward_data(dz, w, x_shape, stride, pad, dil):
+def _dw_backward_data(dz, wt, K, x_shape, stride, pad, dil):
+    """wt: the packed weight - flipped when the stride-1 correlation form applies, plain otherwise"""
     B, C, H, W = x_shape
-    K = w.shape[-1]
     Ho, Wo = dz.shape[2], dz.shape[3]
     s = current_stream()
-    wt = _vec(dz, K * K * C)
     dx = _new(dz, B, C, H, W)
     padb = dil * (K - 1) - pad
     if stride == 1 and padb >= 0:
-        lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 1, s)
         lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
                  ACT_NONE, B, Ho, Wo, C, H, W, K, 1, padb, dil, 0, None, s)
     else:
-        lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
         lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
                  ACT_NONE, B, Ho, Wo, C, H, W, K, stride, pad, dil, 1, None, s)
     return dx
@@ -364,9 +397,30 @@ class _ConvChain(torch.autograd.Function):
         cur, pend = x, ((None, None, in_act0) if in_act0 else None)
         saved, meta = [], []
         n_ops = len(ops)
+        # every layout of every weight of the chain (forward now, backward-data later) is
+        # produced by one launch
+        weights = [tensors[6 * i].contiguous() for i in range(n_ops)]
+        items, bwd_slot = [], [None] * n_ops
+        for i, op in enumerate(ops):
+            items.append((weights[i], "dw" if op[0] == "dw" else "fwd"))
+        if needs_grad:
+            for i, (kind, stride, pad, dil) in enumerate(o[:4] for o in ops):
+                if i == 0 and not ctx.needs_input_grad[1]:
+                    continue
+                if kind == "dw":
+                    k = weights[i].shape[-1]
+                    if stride == 1 and dil * (k - 1) - pad >= 0:
+                        bwd_slot[i] = len(items)
+                        items.append((weights[i], "dwflip"))
+                    else:
+                        bwd_slot[i] = i  # transposed gather reads the forward layout
+                else:
+                    bwd_slot[i] = len(items)
+                    items.append((weights[i], 1))
+        packed = _pack_many(x, items)
         for i, (kind, stride, pad, dil, has_bn, act, training, momentum, eps) in enumerate(ops):
             w, gamma, beta, rm, rv, nbt = tensors[6 * i:6 * i + 6]
-            w = w.contiguous()
+            w = weights[i]
             B, K, H, W = cur.shape
             last = i == n_ops - 1
             if kind == "dw":
@@ -417,18 +471,17 @@ class _ConvChain(torch.autograd.Function):
                 o_sc, o_sh, o_act = scale, shift, act
                 if last and res is not None:
                     o_res = res
+            wp = packed[i]
             if kind == "dw":
-                wt = _vec(cur, kh * kw * K)
-                lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), K, kh, 0, s)
-                lib.call("nasseg_dwconv", ptr(cur), ptr(wt), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
+                lib.call("nasseg_dwconv", ptr(cur), ptr(wp), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
                          ptr(o_sh), o_act, B, H, W, K, Ho, Wo, kh, stride, pad, dil, 0, ptr(part), s)
             else:
-                wp = _pack_dense(w, "fwd")
                 lib.call("nasseg_conv_fwd", ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh), pact,
                          ptr(o_sc), ptr(o_sh), o_act, ptr(o_res), N, B, H, W, K, Ho, Wo, N, kh, kw,
                          stride, pad, dil, 0, ptr(part), s)
             if needs_grad:
-                saved.extend([cur, psc, psh, z, stats, w])
+                saved.extend([cur, psc, psh, z, stats, w,
+                              packed[bwd_slot[i]] if bwd_slot[i] is not None else None])
                 meta.append((pact,))
             if fold:
                 cur, pend = z, None
@@ -472,7 +525,7 @@ class _ConvChain(torch.autograd.Function):
         dres = g if (has_res and ctx.needs_input_grad[2]) else None
         for i in range(n_ops - 1, -1, -1):
             kind, stride, pad, dil, has_bn, act, training, momentum, eps = ops[i]
-            cur, psc, psh, z, stats, w = sv[6 * i:6 * i + 6]
+            cur, psc, psh, z, stats, w, wb = sv[7 * i:7 * i + 7]
             (pact,) = meta[i]
             B, N, Ho, Wo = z.shape
             M = B * Ho * Wo
@@ -508,7 +561,7 @@ class _ConvChain(torch.autograd.Function):
                     lib.call("nasseg_dwconv_wgrad", ptr(cur), ptr(dz), ptr(dwt), ptr(ws), ptr(psc),
                              ptr(psh), pact, Bc, H, W, K, Ho, Wo, k, stride, pad, dil, s)
                     grads[6 * i] = dwt
-                g = _dw_backward_data(dz, w, (Bc, K, H, W), stride, pad, dil) if need_dx else None
+                g = _dw_backward_data(dz, wb, k, (Bc, K, H, W), stride, pad, dil) if need_dx else None
             else:
                 _, _, kh, kw = w.shape
                 if need_dw:
@@ -520,8 +573,7 @@ class _ConvChain(torch.autograd.Function):
                 g = None
                 if need_dx:
                     g = _new(cur, Bc, K, H, W)
-                    wp = _pack_dense(w, 1)
-                    lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wp), ptr(g), K, None, None, 0, None, None,
+                    lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(g), K, None, None, 0, None, None,
                              ACT_NONE, None, 0, Bc, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None, s)
         dx = None
         if g is not None and ctx.needs_input_grad[1]:

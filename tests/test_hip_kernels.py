@@ -384,3 +384,31 @@ def test_cpu_tensors_fail_loudly():
         F().relu(rnd(1, 4, 2, 2))
     with pytest.raises(RuntimeError):
         F().conv2d(rnd(1, 4, 2, 2), rnd(4, 4, 1, 1))
+
+
+def test_pack_weights_single_launch_matches_the_per_tensor_packers():
+    """nasseg_pack_weights (one launch for a whole chain) is bit-identical to
+    nasseg_conv_pack_weight / nasseg_dw_pack_weight, for more tensors than one table holds"""
+    f = F()
+    g = torch.Generator().manual_seed(3)
+    dense = [torch.randn(n, k, kh, kh, generator=g).to(DEV) for n, k, kh in
+             [(19, 64, 3), (64, 24, 1), (32, 3, 3), (48, 16, 1), (8, 8, 3)]]
+    dws = [torch.randn(c, 1, k, k, generator=g).to(DEV) for c, k in [(24, 3), (64, 5), (8, 7)]]
+    items = []
+    for w in dense:
+        items += [(w, "fwd"), (w, 1), (w, 0)]
+    for w in dws:
+        items += [(w, "dw"), (w, "dwflip")]
+    items = items * 2  # 42 descriptors > kPackMax
+    got = f._pack_many(dense[0], items)
+    s = f.current_stream()
+    for (w, kind), t in zip(items, got):
+        if kind in ("dw", "dwflip"):
+            C, _, k, _ = w.shape
+            want = torch.empty(k * k * C, device=DEV)
+            f.lib.call("nasseg_dw_pack_weight", f.ptr(w), f.ptr(want), C, k, int(kind == "dwflip"), s)
+            assert torch.equal(t, want)
+        else:
+            want = f._pack_dense(w, kind)
+            assert torch.equal(t.reshape(-1), want.reshape(-1))
+            assert t.data_ptr() % 16 == 0
