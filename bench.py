@@ -55,6 +55,12 @@ def algorithmic_bytes(name, a):
         B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[13], a[14], a[15], a[16], a[17], a[18], a[19], a[20], a[21]
         res = B * Ho * Wo * N if a[11] else 0
         return 4 * (B * Hs * Ws * K + B * Ho * Wo * N + N * K * kh * kw + res)
+    if name == "nasseg_conv_bwd_data_bn":  # dy read, g written, z read once (fused BN-backward sums)
+        B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[12], a[13], a[14], a[15], a[16], a[17], a[18], a[19], a[20]
+        return 4 * (B * Hs * Ws * K + 2 * B * Ho * Wo * N + N * K * kh * kw)
+    if name == "nasseg_dwconv_bwd_data_bn":
+        B, H, W, C, Ho, Wo, K = a[9], a[10], a[11], a[12], a[13], a[14], a[15]
+        return 4 * (B * C * H * W + 2 * B * C * Ho * Wo + C * K * K)
     if name == "nasseg_conv_wgrad":
         B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17]
         return 4 * (B * Hs * Ws * K + B * Ho * Wo * N + N * K * kh * kw)
@@ -310,6 +316,7 @@ def main():
             dw = [r for r in rows if r["kernel"] == "nasseg_dwconv"]
             fam = {"nasseg_conv_fwd": "conv_fwd_kernel", "nasseg_conv_wgrad": "conv_wgrad_kernel(+finalize)",
                    "nasseg_dwconv": "dw_fwd_strip / dw_bwd_data_s2 / dw_generic",
+                   "nasseg_conv_bwd_data_bn": "conv_fwd_kernel", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
                    "nasseg_dwconv_wgrad": "dw_wgrad_strip(+finalize)",
                    "nasseg_bn_bwd_apply": "bn_bwd_apply_kernel", "nasseg_affine_act": "affine_act_kernel",
                    "nasseg_bn_stats": "colred_kernel<1>(+bn_stats_finalize)",

@@ -51,6 +51,16 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_sca
                   int transposed, float* stats, void* stream);
 int nasseg_dwconv_strip_ok(int K, int stride, int dil);
 int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil);
+/* backward-data fused with the first half of the backward of the BatchNorm whose
+ * normalised output act(scale*z+shift) the conv read (normalise-on-read chains): writes
+ * g = act'(..) * dwconv_backward_data(dy) and per-workgroup rows of {sum g, sum g*xhat} */
+int nasseg_dwconv_bwd_data_bn(const float* dy, const float* wt, float* g, const float* z,
+                              const float* scale, const float* shift, const float* mean,
+                              const float* invstd, int act, int B, int H, int W, int C, int Ho,
+                              int Wo, int K, int stride, int pad, int dil, int transposed,
+                              float* stats, void* stream);
+int64_t nasseg_dwconv_bwd_data_bn_blocks(int B, int C, int Ho, int Wo, int K, int stride, int pad,
+                                         int dil, int transposed);
 int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K);
 int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
                         const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
@@ -74,6 +84,12 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
                     int stride, int pad, int dil, int transposed, float* stats, void* stream);
 int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N);
+/* dense twin of nasseg_dwconv_bwd_data_bn (arguments as nasseg_conv_fwd, transposed) */
+int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
+                            const float* z, int ldz, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, int act, int B, int Hs, int Ws,
+                            int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                            int dil, float* stats, void* stream);
 int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
@@ -101,6 +117,8 @@ int nasseg_bn_eval_params(int C, float eps, const float* gamma, const float* bet
 int nasseg_bn_bwd_reduce(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t M,
                          int C, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int act, float* sums, float* ws, void* stream);
+/* sums[cols] = sum of the rows of partial[nblk][cols] (buffer needs nblk + 64 rows) */
+int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* stream);
 int nasseg_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
                         int C, int train, int act, float* dx, void* stream);

@@ -45,7 +45,16 @@ struct FwdArgs {
   int out_act;
   const float* res;
   int ldres;
-  float* stats;  // optional [gridDim.x][2][N]: per-workgroup sum / sum of squares of y
+  float* stats;  // optional [gridDim.x][2][N]: per-workgroup partial sums (see STATS)
+  // STATS == 2: the BatchNorm whose backward statistics are gathered (y is the gradient
+  // w.r.t. act(b_scale*bz + b_shift))
+  const float* bz;
+  int ldbz;
+  const float* b_scale;
+  const float* b_shift;
+  const float* b_mean;
+  const float* b_invstd;
+  int b_act;
   int K, N;
   ConvGeom g;
 };
@@ -69,11 +78,16 @@ __device__ __forceinline__ float4 load4(const float* row, int k, int K) {
 }
 
 // EPI: any output epilogue (scale / shift(bias) / activation / residual) is present.
-// STATS: also emit per-workgroup partial sums of y and y^2 per output channel - the
+// STATS == 1: also emit per-workgroup partial sums of y and y^2 per output channel - the
 // BatchNorm batch statistics of the layer that follows, at no extra pass over y.
-template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, bool STATS, bool WS>
+// STATS == 2 (backward-data calls): y is the gradient g w.r.t. a = act(b_scale*z + b_shift),
+// the normalised activation this conv read in the forward pass.  The epilogue multiplies g
+// by act'(...) (so the masked gradient is what gets stored) and emits the partial sums of
+// g' and g'*xhat, xhat = (z - mean)*invstd: the first half of that BatchNorm's backward at
+// the price of one read of z instead of a separate pass over g and z.
+template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, int STATS, bool WS>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
-  __shared__ float sred[(STATS && !WS) ? 4 : 1][2][(STATS && !WS) ? NT * 16 : 1];
+  __shared__ float sred[(STATS != 0 && !WS) ? 4 : 1][2][(STATS != 0 && !WS) ? NT * 16 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15;   // pixel within subtile (B operand col) / n within tile (A operand row)
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
   const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
   const int m_base = WS ? blockIdx.x * (16 * MT) : (blockIdx.x * 4 + wave) * (16 * MT);
   const bool active = m_base < Mtot;  // wave-uniform
-  if ((!STATS || WS) && !active) return;
+  if ((STATS == 0 || WS) && !active) return;
   const int n_base = WS ? (blockIdx.y * 4 + wave) * (16 * NT) : blockIdx.y * (16 * NT);
   if (WS && n_base >= a.N) return;  // (no workgroup barrier on the WS path)
 
@@ -201,6 +215,85 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     }
   }
 
+  if (STATS != 0) {
+    // per-channel partial sums over the MT subtiles in registers, over the 16 pixel lanes with
+    // xor-shuffles (the 16-lane group of a k-group holds the same 4 channels), over the 4
+    // waves through LDS (EPI is off on this path)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+      float bsc[4], bsh[4], bmu[4], bis[4];
+      const int nb = n_base + nt * 16 + kg * 4;
+      const int nbc = nb < a.N ? nb : 0;
+      if (STATS == 2) {
+        const float4 t0 = ld4(a.b_scale + nbc), t1 = ld4(a.b_shift + nbc), t2 = ld4(a.b_mean + nbc),
+                     t3 = ld4(a.b_invstd + nbc);
+        bsc[0] = t0.x; bsc[1] = t0.y; bsc[2] = t0.z; bsc[3] = t0.w;
+        bsh[0] = t1.x; bsh[1] = t1.y; bsh[2] = t1.z; bsh[3] = t1.w;
+        bmu[0] = t2.x; bmu[1] = t2.y; bmu[2] = t2.z; bmu[3] = t2.w;
+        bis[0] = t3.x; bis[1] = t3.y; bis[2] = t3.z; bis[3] = t3.w;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool ok = active && (m_base + mt * 16 + j < Mtot);
+        if (STATS == 2) {
+          const float4 z4 = ld4(a.bz + (int64_t)pm[mt] * a.ldbz + nbc);
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g = acc[mt][nt][r] * act_mask(fmaf(zz[r], bsc[r], bsh[r]), a.b_act);
+            acc[mt][nt][r] = g;
+            const float v = keep_if(g, ok);
+            sx[r] += v;
+            sq[r] = fmaf(v, (zz[r] - bmu[r]) * bis[r], sq[r]);
+          }
+        } else {
+          const f32x4 c = acc[mt][nt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = keep_if(c[r], ok);
+            sx[r] += v;
+            sq[r] = fmaf(v, v, sq[r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sx[r] += __shfl_xor(sx[r], off);
+          sq[r] += __shfl_xor(sq[r], off);
+        }
+      }
+      if (WS) {
+        // this wave alone owns these channels of the workgroup's pixels
+        if (j == 0 && nb < a.N) {
+          float* po = a.stats + (int64_t)blockIdx.x * 2 * a.N + nb;
+          st4(po, make_float4(sx[0], sx[1], sx[2], sx[3]));
+          st4(po + a.N, make_float4(sq[0], sq[1], sq[2], sq[3]));
+        }
+      } else if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sred[wave][0][nt * 16 + kg * 4 + r] = sx[r];
+          sred[wave][1][nt * 16 + kg * 4 + r] = sq[r];
+        }
+      }
+    }
+    if (!WS) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < NT * 16; t += 256) {
+        const int n = n_base + t;
+        if (n < a.N) {
+          float* po = a.stats + (int64_t)blockIdx.x * 2 * a.N + n;
+          po[0] = (sred[0][0][t] + sred[1][0][t]) + (sred[2][0][t] + sred[3][0][t]);
+          po[a.N] = (sred[0][1][t] + sred[1][1][t]) + (sred[2][1][t] + sred[3][1][t]);
+        }
+      }
+      if (!active) return;
+    }
+  }
+
   // epilogue: lane holds pixel j of each subtile, channels n0 + 4*kg + {0..3}
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -248,59 +341,6 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     }
   }
 
-  if (STATS) {
-    // per-channel sum / sum of squares of the raw accumulators (EPI is off on this path):
-    // over the MT subtiles in registers, over the 16 pixel lanes with xor-shuffles (the
-    // 16-lane group of a k-group holds the same 4 channels), over the 4 waves through LDS
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bool ok = active && (m_base + mt * 16 + j < Mtot);
-        const f32x4 c = acc[mt][nt];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = keep_if(c[r], ok);
-          sx[r] += v;
-          sq[r] = fmaf(v, v, sq[r]);
-        }
-      }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sx[r] += __shfl_xor(sx[r], off);
-          sq[r] += __shfl_xor(sq[r], off);
-        }
-      }
-      if (WS) {
-        // this wave alone owns these channels of the workgroup's pixels
-        const int n = n_base + nt * 16 + kg * 4;
-        if (j == 0 && n < a.N) {
-          float* po = a.stats + (int64_t)blockIdx.x * 2 * a.N + n;
-          st4(po, make_float4(sx[0], sx[1], sx[2], sx[3]));
-          st4(po + a.N, make_float4(sq[0], sq[1], sq[2], sq[3]));
-        }
-      } else if (j == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sred[wave][0][nt * 16 + kg * 4 + r] = sx[r];
-          sred[wave][1][nt * 16 + kg * 4 + r] = sq[r];
-        }
-      }
-    }
-    if (WS) return;
-    __syncthreads();
-    for (int t = threadIdx.x; t < NT * 16; t += 256) {
-      const int n = n_base + t;
-      if (n < a.N) {
-        float* po = a.stats + (int64_t)blockIdx.x * 2 * a.N + n;
-        po[0] = (sred[0][0][t] + sred[1][0][t]) + (sred[2][0][t] + sred[3][0][t]);
-        po[a.N] = (sred[0][1][t] + sred[1][1][t]) + (sred[2][1][t] + sred[3][1][t]);
-      }
-    }
-  }
 }
 
 // OIHW (N,K,kh,kw) -> [tap][N][K] (mode 0), [tap][K][N] (mode 1), [N][tap*K+k] (mode 2)
@@ -375,7 +415,8 @@ __global__ void pack_multi_kernel(PackTable t) {
 
 struct Mode {
   int km;
-  bool gather, pro, vecn, epi, stats;
+  bool gather, pro, vecn, epi;
+  int stats;  // 0 none, 1 forward BN statistics, 2 BN-backward statistics
 };
 
 template <int MT, int NT, bool WS = false>
@@ -384,15 +425,19 @@ int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
   dim3 grid((unsigned)cdiv64(Mtot, (WS ? 16 : 64) * MT), cdiv(a.N, (WS ? 64 : 16) * NT), 1);
 #define GO(KM_, G_, P_, V_)                                                                       \
   do {                                                                                            \
-    if (md.stats) {                                                                               \
+    if (md.stats == 2) {                                                                          \
+      if constexpr ((V_) && !(P_) && KM_ != KM_FLAT)                                              \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 2, WS>), grid,        \
+                           dim3(256), 0, s, a);                                                   \
+    } else if (md.stats) {                                                                        \
       if constexpr (V_)                                                                           \
-        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, true, WS>), grid,     \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 1, WS>), grid,        \
                            dim3(256), 0, s, a);                                                   \
     } else if (md.epi || !(V_)) {                                                                 \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true, false, WS>), grid,       \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true, 0, WS>), grid,           \
                          dim3(256), 0, s, a);                                                     \
     } else {                                                                                      \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, false, WS>), grid,      \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 0, WS>), grid,          \
                          dim3(256), 0, s, a);                                                     \
     }                                                                                             \
   } while (0)
@@ -437,6 +482,39 @@ int launch_small(const FwdArgs& a, const Mode& md, hipStream_t s) {
   if (mt == 4) return launch_one<4, NT, WS>(a, md, s);
   if (mt == 2) return launch_one<2, NT, WS>(a, md, s);
   return launch_one<1, NT, WS>(a, md, s);
+}
+
+inline int fwd_pack_mode(int K, int kh, int kw) { return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0; }
+
+int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
+  const int K = a.K, N = a.N;
+  const ConvGeom& g = a.g;
+  NASSEG_REQUIRE(g.B > 0 && g.Hs > 0 && g.Ws > 0 && g.Ho > 0 && g.Wo > 0, "conv_fwd: bad geometry");
+  NASSEG_REQUIRE(K > 0 && N > 0 && a.ldx >= K && a.ldy >= N, "conv_fwd: bad channels K=%d N=%d", K, N);
+  NASSEG_REQUIRE((int64_t)g.B * g.Hs * g.Ws < 2147483647LL && (int64_t)g.B * g.Ho * g.Wo < 2147483647LL,
+                 "conv_fwd: too many pixels");
+  Mode md;
+  md.km = (((K & 3) == 0) && ((a.ldx & 3) == 0)) ? KM_VEC : KM_SCALAR;
+  md.pro = a.in_scale || a.in_shift || a.in_act;
+  md.gather = !(g.kh == 1 && g.kw == 1 && g.stride == 1 && g.pad == 0 && g.Hs == g.Ho && g.Ws == g.Wo);
+  md.vecn = ((N & 3) == 0) && ((a.ldy & 3) == 0) && (!a.res || (a.ldres & 3) == 0);
+  md.epi = a.out_scale || a.out_shift || a.out_act || a.res;
+  md.stats = stats_mode;
+  NASSEG_REQUIRE(!md.stats || (md.vecn && !md.epi),
+                 "conv_fwd: statistics need N %% 4 == 0 and no output epilogue");
+  NASSEG_REQUIRE(md.stats != 2 || !md.pro, "conv_bwd_data_bn: no input prologue on this path");
+  if (!g.transposed && fwd_pack_mode(K, g.kh, g.kw) == 2) md.km = KM_FLAT;
+  NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
+                 "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
+  const int tiles = cdiv(N, 16);
+  if (tiles <= 1) return launch_small<1>(a, md, s);
+  if (tiles == 2) return launch_small<2>(a, md, s);
+  if (tiles == 3) return launch_small<3>(a, md, s);
+  if (tiles == 4) return launch_small<4>(a, md, s);
+  // N > 64: the four waves of a workgroup split N (2, 3 or 4 tiles each)
+  if (tiles <= 8) return launch_small<2, true>(a, md, s);
+  if (tiles <= 12) return launch_small<3, true>(a, md, s);
+  return launch_small<4, true>(a, md, s);  // N > 256 is covered by grid.y
 }
 
 }  // namespace
@@ -498,9 +576,7 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N) {
 }
 
 // which packing nasseg_conv_fwd expects for a forward (non-transposed) convolution
-int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) {
-  return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0;
-}
+int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) { return fwd_pack_mode(K, kh, kw); }
 
 // y[dst pixel][n] = out_act(out_scale[n] * sum_{tap,k} w[tap][n][k] *
 //                   in_act(in_scale[k] * x[src pixel(tap)][k] + in_shift[k]) + out_shift[n])
@@ -520,11 +596,7 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     const float* out_scale, const float* out_shift, int out_act, const float* res,
                     int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
                     int stride, int pad, int dil, int transposed, float* stats, void* stream) {
-  NASSEG_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "conv_fwd: bad geometry");
-  NASSEG_REQUIRE(K > 0 && N > 0 && ldx >= K && ldy >= N, "conv_fwd: bad channels K=%d N=%d", K, N);
-  NASSEG_REQUIRE((int64_t)B * Hs * Ws < 2147483647LL && (int64_t)B * Ho * Wo < 2147483647LL,
-                 "conv_fwd: too many pixels");
-  FwdArgs a;
+  FwdArgs a = {};
   a.x = x; a.ldx = ldx; a.w = wp; a.y = y; a.ldy = ldy;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   a.out_scale = out_scale; a.out_shift = out_shift; a.out_act = out_act;
@@ -532,28 +604,35 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
   a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
   a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
   a.g.transposed = transposed;
-  hipStream_t s = (hipStream_t)stream;
-  Mode md;
-  md.km = (((K & 3) == 0) && ((ldx & 3) == 0)) ? KM_VEC : KM_SCALAR;
-  md.pro = in_scale || in_shift || in_act;
-  md.gather = !(kh == 1 && kw == 1 && stride == 1 && pad == 0 && Hs == Ho && Ws == Wo);
-  md.vecn = ((N & 3) == 0) && ((ldy & 3) == 0) && (!res || (ldres & 3) == 0);
-  md.epi = out_scale || out_shift || out_act || res;
-  md.stats = stats != nullptr;
-  NASSEG_REQUIRE(!md.stats || (md.vecn && !md.epi),
-                 "conv_fwd: statistics need N %% 4 == 0 and no output epilogue");
-  if (!transposed && nasseg_conv_fwd_pack_mode(K, kh, kw) == 2) md.km = KM_FLAT;
-  NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
-                 "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
-  const int tiles = cdiv(N, 16);
-  if (tiles <= 1) return launch_small<1>(a, md, s);
-  if (tiles == 2) return launch_small<2>(a, md, s);
-  if (tiles == 3) return launch_small<3>(a, md, s);
-  if (tiles == 4) return launch_small<4>(a, md, s);
-  // N > 64: the four waves of a workgroup split N (2, 3 or 4 tiles each)
-  if (tiles <= 8) return launch_small<2, true>(a, md, s);
-  if (tiles <= 12) return launch_small<3, true>(a, md, s);
-  return launch_small<4, true>(a, md, s);  // N > 256 is covered by grid.y
+  return conv_dispatch(a, stats ? 1 : 0, (hipStream_t)stream);
+}
+
+// Backward-data of a dense conv whose forward input was the normalised activation
+// a = act(scale*z + shift) of a BatchNorm (never materialised - see the input prologue),
+// fused with the first half of that BatchNorm's backward:
+//   g[p][k]  = act'(scale[k]*z[p][k] + shift[k]) * sum_{tap,n} w[tap][n][k] * dy[src(p,tap)][n]
+//   stats[blk][0][k] = sum_p g[p][k],  stats[blk][1][k] = sum_p g[p][k]*(z[p][k]-mean[k])*invstd[k]
+// over the pixels p of workgroup blk < nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N).
+// Arguments as nasseg_conv_fwd with transposed != 0: dy has dims (Hs,Ws) and K channels (the
+// forward conv's output channels), g and z dims (Ho,Wo) and N channels (N % 4 == 0), wp packed
+// with mode 1.  Summing the stats rows (nasseg_rows_sum) gives what nasseg_bn_bwd_reduce
+// returns; nasseg_bn_bwd_apply then takes g as its dy.
+int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
+                            const float* z, int ldz, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, int act, int B, int Hs, int Ws,
+                            int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                            int dil, float* stats, void* stream) {
+  NASSEG_REQUIRE(z && scale && shift && mean && invstd && stats, "conv_bwd_data_bn: null argument");
+  NASSEG_REQUIRE((ldz & 3) == 0 && ldz >= N, "conv_bwd_data_bn: bad ldz");
+  FwdArgs a = {};
+  a.x = dy; a.ldx = lddy; a.w = wp; a.y = g; a.ldy = ldg;
+  a.stats = stats; a.K = K; a.N = N;
+  a.bz = z; a.ldbz = ldz; a.b_scale = scale; a.b_shift = shift; a.b_mean = mean;
+  a.b_invstd = invstd; a.b_act = act;
+  a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
+  a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
+  a.g.transposed = 1;
+  return conv_dispatch(a, 2, (hipStream_t)stream);
 }
 
 }  // extern "C"

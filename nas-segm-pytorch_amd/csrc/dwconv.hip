@@ -71,6 +71,43 @@ __device__ __forceinline__ float4 apply_prologue(float4 v, const Prologue& p) {
   return v;
 }
 
+// BatchNorm whose backward statistics a backward-data kernel gathers in its epilogue: the
+// value written is g' = g * act'(scale*z + shift) and the workgroup's partial sums of g' and
+// g' * (z - mean) * invstd go to stats[blk][2][C] (see nasseg_dwconv_bwd_data_bn).
+struct BnBwd {
+  const float* z;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  int act;
+};
+struct BnBwdLane {
+  float4 sc, sh, mu, is;
+};
+__device__ __forceinline__ BnBwdLane bnbwd_lane(const BnBwd& bn, int c4) {
+  BnBwdLane l;
+  l.sc = ld4(bn.scale + c4 * 4);
+  l.sh = ld4(bn.shift + c4 * 4);
+  l.mu = ld4(bn.mean + c4 * 4);
+  l.is = ld4(bn.invstd + c4 * 4);
+  return l;
+}
+// masks g in place; adds keep_if(g', ok) and its product with xhat to ssum[0], ssum[1]
+__device__ __forceinline__ void bnbwd_accumulate(float4& g, float4 z, const BnBwdLane& l, int act,
+                                                 bool ok, float4 (&ssum)[2]) {
+  const float4 yv = fma4(z, l.sc, l.sh);
+  g.x *= act_mask(yv.x, act);
+  g.y *= act_mask(yv.y, act);
+  g.z *= act_mask(yv.z, act);
+  g.w *= act_mask(yv.w, act);
+  const float4 v = keep_if(g, ok);
+  const float4 xh = make_float4((z.x - l.mu.x) * l.is.x, (z.y - l.mu.y) * l.is.y,
+                                (z.z - l.mu.z) * l.is.z, (z.w - l.mu.w) * l.is.w);
+  ssum[0] = add4(ssum[0], v);
+  ssum[1] = fma4(v, xh, ssum[1]);
+}
+
 // ---------------------------------------------------------------------------
 // weight packing: (C,1,K,K) -> [tap][C], optional 180-degree flip
 // ---------------------------------------------------------------------------
@@ -161,13 +198,15 @@ __device__ __forceinline__ void block_reduce_groups(float4 (&acc)[NV], float4 (*
 // WLDS: keep the K*K per-channel weight vectors in LDS (indexed by channel group,
 // needs C4 <= 64) instead of 4*K*K registers per lane - for 5x5 this is the
 // difference between 1 and 4+ resident waves per SIMD.
-// PRO: input prologue; STATS: per-workgroup channel sums of y and y^2 to stats[blk][2][C].
-template <int K, int P, int E, bool WLDS, bool PRO, bool STATS>
+// PRO: input prologue; STATS == 1: per-workgroup channel sums of y and y^2 to
+// stats[blk][2][C]; STATS == 2: BatchNorm-backward statistics of `bn` (y is a gradient).
+template <int K, int P, int E, bool WLDS, bool PRO, int STATS>
 __global__ __launch_bounds__(256) void dw_fwd_strip(
     const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ y,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ scale, const float* __restrict__ shift, int H, int W, int C4, int Ho,
-    int Wo, int stride, int pad, int dil, int g, int nchunk, int act, float* __restrict__ stats) {
+    int Wo, int stride, int pad, int dil, int g, int nchunk, int act, float* __restrict__ stats,
+    BnBwd bn) {
   __shared__ float4 lw[WLDS ? K * K : 1][WLDS ? 64 : 1];
   __shared__ float4 sred[STATS ? 2 : 1][STATS ? 4 : 1][STATS ? 64 : 1];
   const int C = C4 * 4;
@@ -256,20 +295,27 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   if (scale) sc = ld4(scale + c4 * 4);
   if (shift) sh = ld4(shift + c4 * 4);
   float4 ssum[2] = {f4zero(), f4zero()};
+  BnBwdLane bl;
+  if (STATS == 2) bl = bnbwd_lane(bn, c4);
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int oy = oy0 + j * g;
     const bool ok = live && oy < Ho;
     float4 o = fma4(acc[j], sc, sh);
     if (act) o = act_apply4(o, act);
-    if (STATS) {
+    if (STATS == 1) {
       const float4 m = keep_if(o, ok);
       ssum[0] = add4(ssum[0], m);
       ssum[1] = fma4(m, m, ssum[1]);
     }
+    if (STATS == 2) {
+      const int oyc = oy < Ho ? oy : Ho - 1;  // (unconditional load from a valid address)
+      const float4 z = ld4(bn.z + (((size_t)b * Ho + oyc) * Wo + ox) * C + c4 * 4);
+      bnbwd_accumulate(o, z, bl, bn.act, ok, ssum);
+    }
     if (ok) st4(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4, o);
   }
-  if constexpr (STATS) {
+  if constexpr (STATS != 0) {
     const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     block_reduce_groups<2, 2>(ssum, sred, stats + blk * 2 * C, base, C4);
   }
@@ -282,11 +328,18 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
 // taps contribute to which quad position is a compile-time parity pattern:
 //   dx[2a+py] += w[ty] * dy[a + (py+pad-ty)/2]   for ty = (py+pad) mod 2, +2, ...
 // ---------------------------------------------------------------------------
-template <int K>
+// BST: BatchNorm-backward statistics epilogue (the host makes gridDim.x * 256 a multiple of
+// C4 so that a thread keeps its channel group over the grid-stride loop).
+template <int K, bool BST>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ dy,
                                                       const float* __restrict__ wt,
                                                       float* __restrict__ dx, int B, int Ho, int Wo,
-                                                      int C4, int H, int W) {
+                                                      int C4, int H, int W, float* __restrict__ stats,
+                                                      BnBwd bn) {
+  __shared__ float4 sred[BST ? 2 : 1][BST ? 4 : 1][BST ? 64 : 1];
+  float4 ssum[2] = {f4zero(), f4zero()};
+  BnBwdLane bl;
+  if (BST) bl = bnbwd_lane(bn, (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % C4));
   constexpr int PAD = (K - 1) / 2;
   // dy rows used by a quad: a + (py+PAD-ty)/2 over all valid (py,ty): [a - LO, a + HI]
   constexpr int LO = (K - 1 - PAD) / 2;  // largest ty with matching parity, py = 0 side
@@ -330,9 +383,17 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ 
 #pragma unroll
       for (int px = 0; px < 2; ++px) {
         const int iy = 2 * aq + py, ix = 2 * bq + px;
-        if (iy < H && ix < W) st4(dx + (((int64_t)b * H + iy) * W + ix) * C + c4 * 4, o[py][px]);
+        const bool ok = iy < H && ix < W;
+        if (BST) {
+          const int iyc = iy < H ? iy : H - 1, ixc = ix < W ? ix : W - 1;
+          const float4 z = ld4(bn.z + (((int64_t)b * H + iyc) * W + ixc) * C + c4 * 4);
+          bnbwd_accumulate(o[py][px], z, bl, bn.act, ok, ssum);
+        }
+        if (ok) st4(dx + (((int64_t)b * H + iy) * W + ix) * C + c4 * 4, o[py][px]);
       }
   }
+  if constexpr (BST)
+    block_reduce_groups<2, 2>(ssum, sred, stats + (size_t)blockIdx.x * 2 * C4 * 4, blockIdx.x * 256, C4);
 }
 
 // ---------------------------------------------------------------------------
@@ -573,19 +634,31 @@ int nasseg_dw_pack_weight(const float* w, float* wt, int C, int K, int flip, voi
   return NASSEG_OK;
 }
 
-// y = act(scale * dwconv(in_act(in_scale*x + in_shift)) + shift); every pointer of the
-// prologue / epilogue may be null (identity).  transposed != 0 computes the backward-data
-// form (x = grad wrt output with dims (H,W), y = grad wrt input with dims (Ho,Wo),
-// un-flipped weights).  stats != null: also writes stats[blk][2][C] (sum, sum of squares of
-// y per channel) for blk < nasseg_dwconv_stats_blocks(...); forward strip geometries only.
-int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_scale,
-                  const float* in_shift, int in_act, const float* scale, const float* shift, int act,
-                  int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
-                  int transposed, float* stats, void* stream) {
+int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil);
+int64_t nasseg_dwconv_bwd_data_bn_blocks(int B, int C, int Ho, int Wo, int K, int stride, int pad,
+                                         int dil, int transposed);
+
+// grid of the stride-2 backward-data kernel; with the statistics epilogue it is capped (a
+// grid-stride loop does the rest) and made a multiple of C4 / gcd(C4, 256)
+static int s2_blocks(int B, int Hd, int Wd, int C4, bool bst) {
+  const int64_t quads = (int64_t)B * ((Hd + 1) / 2) * ((Wd + 1) / 2) * C4;
+  int64_t nb = (quads + 255) / 256;
+  if (!bst) return (int)(nb < 65536 * 4 ? nb : 65536 * 4);
+  if (nb > 4096) nb = 4096;
+  int gcd = C4, t = 256;
+  while (t) { const int r = gcd % t; gcd = t; t = r; }
+  const int m = C4 / gcd;
+  return (int)((nb + m - 1) / m * m);
+}
+
+static int dwconv_impl(const float* x, const float* wt, float* y, const float* in_scale,
+                       const float* in_shift, int in_act, const float* scale, const float* shift,
+                       int act, int B, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                       int pad, int dil, int transposed, float* stats, int stats_mode, BnBwd bn,
+                       hipStream_t s) {
   NASSEG_REQUIRE(C % 4 == 0, "dwconv: C=%d must be a multiple of 4", C);
   NASSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && K > 0 && stride > 0 && dil > 0,
                  "dwconv: bad geometry");
-  hipStream_t s = (hipStream_t)stream;
   const int C4 = C / 4;
   StripCfg sc = strip_cfg(stride, dil);
   const bool pro = in_scale || in_shift || in_act;
@@ -595,6 +668,7 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_sca
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(cdiv(Wo * C4, 256), nchunk * sc.g, B);
     NASSEG_REQUIRE(grid.y <= 65535, "dwconv: too many row chunks");
+    NASSEG_REQUIRE(stats_mode != 2 || !pro, "dwconv_bwd_data_bn: no input prologue on this path");
     if (stats && C4 > 256) {
       hipError_t e = hipMemsetAsync(stats, 0, (size_t)grid.x * grid.y * grid.z * 2 * C * sizeof(float), s);
       if (e != hipSuccess) return nasseg_fail(NASSEG_ERR_LAUNCH, "dwconv: memset failed");
@@ -602,13 +676,14 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_sca
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                             \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, \
-                     act, stats)
+                     act, stats, bn)
 #define LAUNCH_FWD(KK, EE, WL)                                    \
   do {                                                            \
-    if (pro && stats) LAUNCH_FWD3(KK, EE, WL, true, true);        \
-    else if (pro) LAUNCH_FWD3(KK, EE, WL, true, false);           \
-    else if (stats) LAUNCH_FWD3(KK, EE, WL, false, true);         \
-    else LAUNCH_FWD3(KK, EE, WL, false, false);                   \
+    if (stats_mode == 2) LAUNCH_FWD3(KK, EE, WL, false, 2);       \
+    else if (pro && stats) LAUNCH_FWD3(KK, EE, WL, true, 1);      \
+    else if (pro) LAUNCH_FWD3(KK, EE, WL, true, 0);               \
+    else if (stats) LAUNCH_FWD3(KK, EE, WL, false, 1);            \
+    else LAUNCH_FWD3(KK, EE, WL, false, 0);                       \
   } while (0)
     const bool wl = C4 <= 64;
     if (K == 3 && sc.e == 1) LAUNCH_FWD(3, 1, false);
@@ -620,27 +695,69 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_sca
     NASSEG_LAUNCH_CHECK("dw_fwd_strip");
     return NASSEG_OK;
   }
-  NASSEG_REQUIRE(!stats, "dwconv: the statistics epilogue needs a 3x3 / 5x5 forward strip geometry");
   NASSEG_REQUIRE(!in_scale && !in_shift && in_act <= NASSEG_ACT_RELU,
                  "dwconv: only an input ReLU is supported as prologue on the generic path");
   if (transposed && stride == 2 && dil == 1 && (K == 3 || K == 5) && pad == (K - 1) / 2 &&
       !in_act && !scale && !shift && act == 0) {
     // (H, W) = dims of dy, (Ho, Wo) = dims of dx in the transposed call
-    const int64_t quads = (int64_t)B * ((Ho + 1) / 2) * ((Wo + 1) / 2) * C4;
-    const int nbq = (int)((quads + 255) / 256 < 65536 * 4 ? (quads + 255) / 256 : 65536 * 4);
-    if (K == 3)
-      hipLaunchKernelGGL((dw_bwd_data_s2<3>), dim3(nbq), dim3(256), 0, s, x, wt, y, B, H, W, C4, Ho, Wo);
-    else
-      hipLaunchKernelGGL((dw_bwd_data_s2<5>), dim3(nbq), dim3(256), 0, s, x, wt, y, B, H, W, C4, Ho, Wo);
+    const bool bst = stats_mode == 2;
+    const int nbq = s2_blocks(B, Ho, Wo, C4, bst);
+    if (bst && C4 > 256) {
+      hipError_t e = hipMemsetAsync(stats, 0, (size_t)nbq * 2 * C * sizeof(float), s);
+      if (e != hipSuccess) return nasseg_fail(NASSEG_ERR_LAUNCH, "dwconv: memset failed");
+    }
+#define LAUNCH_S2(KK, BS) \
+  hipLaunchKernelGGL((dw_bwd_data_s2<KK, BS>), dim3(nbq), dim3(256), 0, s, x, wt, y, B, H, W, C4, Ho, Wo, stats, bn)
+    if (K == 3) { if (bst) LAUNCH_S2(3, true); else LAUNCH_S2(3, false); }
+    else { if (bst) LAUNCH_S2(5, true); else LAUNCH_S2(5, false); }
+#undef LAUNCH_S2
     NASSEG_LAUNCH_CHECK("dw_bwd_data_s2");
     return NASSEG_OK;
   }
+  NASSEG_REQUIRE(!stats, "dwconv: the statistics epilogues need a 3x3 / 5x5 strip or stride-2 geometry");
   size_t total = (size_t)B * Ho * Wo * C4;
   int nb = (int)((total + 255) / 256 < 65536 * 4 ? (total + 255) / 256 : 65536 * 4);
   hipLaunchKernelGGL(dw_generic, dim3(nb), dim3(256), 0, s, x, wt, y, scale, shift, B, H, W, C4,
                      Ho, Wo, K, stride, pad, dil, transposed, in_act, act);
   NASSEG_LAUNCH_CHECK("dw_generic");
   return NASSEG_OK;
+}
+
+// y = act(scale * dwconv(in_act(in_scale*x + in_shift)) + shift); every pointer of the
+// prologue / epilogue may be null (identity).  transposed != 0 computes the backward-data
+// form (x = grad wrt output with dims (H,W), y = grad wrt input with dims (Ho,Wo),
+// un-flipped weights).  stats != null: also writes stats[blk][2][C] (sum, sum of squares of
+// y per channel) for blk < nasseg_dwconv_stats_blocks(...); forward strip geometries only.
+int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_scale,
+                  const float* in_shift, int in_act, const float* scale, const float* shift, int act,
+                  int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
+                  int transposed, float* stats, void* stream) {
+  NASSEG_REQUIRE(!stats || transposed == 0, "dwconv: statistics are a forward epilogue");
+  BnBwd bn = {};
+  return dwconv_impl(x, wt, y, in_scale, in_shift, in_act, scale, shift, act, B, H, W, C, Ho, Wo, K,
+                     stride, pad, dil, transposed, stats, stats ? 1 : 0, bn, (hipStream_t)stream);
+}
+
+// Backward-data of a depthwise conv whose forward input was the normalised activation
+// a = act(scale*z + shift) of a BatchNorm, fused with the first half of that BatchNorm's
+// backward (the depthwise twin of nasseg_conv_bwd_data_bn): writes
+//   g = act'(scale*z + shift) * dwconv_backward_data(dy)
+// and stats[blk][0][c] = sum g, stats[blk][1][c] = sum g*(z-mean)*invstd over the pixels of
+// workgroup blk < nasseg_dwconv_bwd_data_bn_blocks(...).  Geometry arguments exactly as the
+// nasseg_dwconv call that computes the same backward-data: either the correlation form
+// (transposed == 0, stride 1, flipped weights, pad' = dil*(K-1) - pad) or the transposed
+// stride-2 form; g and z have dims (Ho, Wo).
+int nasseg_dwconv_bwd_data_bn(const float* dy, const float* wt, float* g, const float* z,
+                              const float* scale, const float* shift, const float* mean,
+                              const float* invstd, int act, int B, int H, int W, int C, int Ho,
+                              int Wo, int K, int stride, int pad, int dil, int transposed,
+                              float* stats, void* stream) {
+  NASSEG_REQUIRE(z && scale && shift && mean && invstd && stats, "dwconv_bwd_data_bn: null argument");
+  NASSEG_REQUIRE(nasseg_dwconv_bwd_data_bn_blocks(B, C, Ho, Wo, K, stride, pad, dil, transposed) > 0,
+                 "dwconv_bwd_data_bn: geometry has no fused path");
+  BnBwd bn = {z, scale, shift, mean, invstd, act};
+  return dwconv_impl(dy, wt, g, nullptr, nullptr, 0, nullptr, nullptr, 0, B, H, W, C, Ho, Wo, K,
+                     stride, pad, dil, transposed, stats, 2, bn, (hipStream_t)stream);
 }
 
 // 1 when nasseg_dwconv / nasseg_dwconv_wgrad take the fast strip path for this geometry,
@@ -655,6 +772,17 @@ int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stri
   if (!nasseg_dwconv_strip_ok(K, stride, dil)) return 0;
   StripCfg sc = strip_cfg(stride, dil);
   return (int64_t)cdiv(Wo * (C / 4), 256) * cdiv(Ho, 4 * sc.g) * sc.g * B;
+}
+
+// rows of statistics nasseg_dwconv_bwd_data_bn writes for this call (0: no fused path, use
+// nasseg_dwconv + nasseg_bn_bwd_reduce)
+int64_t nasseg_dwconv_bwd_data_bn_blocks(int B, int C, int Ho, int Wo, int K, int stride, int pad,
+                                         int dil, int transposed) {
+  if (C % 4 != 0 || B > 65535) return 0;
+  if (!transposed) return nasseg_dwconv_stats_blocks(B, C, Ho, Wo, K, stride, dil);
+  if (stride == 2 && dil == 1 && (K == 3 || K == 5) && pad == (K - 1) / 2)
+    return s2_blocks(B, Ho, Wo, C / 4, true);
+  return 0;
 }
 
 // number of workgroup rows (grid.y) of the backward-weight kernels: ~1024 workgroups,

@@ -346,6 +346,31 @@ int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float e
   return NASSEG_OK;
 }
 
+// out[e] = sum over rows of partial[nblk][cols] (fp64 accumulation, fixed order): turns the
+// per-workgroup rows written by nasseg_conv_bwd_data_bn / nasseg_dwconv_bwd_data_bn into the
+// sums[2][C] that nasseg_bn_bwd_reduce produces.  Like nasseg_bn_finalize the buffer needs room
+// for 64 extra rows (first level of the two-level reduction when nblk > 512).
+int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* stream) {
+  NASSEG_REQUIRE(nblk > 0 && cols > 0 && partial && out, "rows_sum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const float* src = partial;
+  if (nblk > 512) {
+    const int G = 64;
+    const int rpg = cdiv(nblk, G);
+    const int groups = cdiv(nblk, rpg);
+    float* lvl = const_cast<float*>(partial) + (int64_t)nblk * cols;
+    hipLaunchKernelGGL(rows_group_sum, dim3(cdiv(cols, NASSEG_RP_ELEMS), groups), dim3(256), 0, s,
+                       partial, lvl, nblk, (int64_t)cols, rpg);
+    NASSEG_LAUNCH_CHECK("rows_group_sum");
+    src = lvl;
+    nblk = groups;
+  }
+  hipLaunchKernelGGL(rows_group_sum, dim3(cdiv(cols, NASSEG_RP_ELEMS), 1), dim3(256), 0, s, src, out,
+                     nblk, (int64_t)cols, nblk);
+  NASSEG_LAUNCH_CHECK("rows_group_sum");
+  return NASSEG_OK;
+}
+
 int nasseg_bn_eval_params(int C, float eps, const float* gamma, const float* beta,
                           const float* running_mean, const float* running_var, float* mean,
                           float* invstd, float* scale, float* shift, void* stream) {

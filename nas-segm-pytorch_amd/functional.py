@@ -358,20 +358,31 @@ def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_t
 # ---------------------------------------------------------------------------
 # conv -> BN -> act chains with "normalise on read"
 # ---------------------------------------------------------------------------
-def _dw_backward_data(dz, wt, K, x_shape, stride, pad, dil):
-    """wt: the packed weight - flipped when the stride-1 correlation form applies, plain otherwise"""
+def _dw_backward_data(dz, wt, K, x_shape, stride, pad, dil, bn=None):
+    """wt: the packed weight - flipped when the stride-1 correlation form applies, plain otherwise.
+    bn = (z, scale, shift, mean, invstd, act) of the BatchNorm whose normalised output this conv
+    read: the kernel then also masks the gradient with act' and emits the BatchNorm-backward
+    partial sums.  Returns (dx, None | (rows buffer, number of rows))."""
     B, C, H, W = x_shape
     Ho, Wo = dz.shape[2], dz.shape[3]
     s = current_stream()
     dx = _new(dz, B, C, H, W)
     padb = dil * (K - 1) - pad
     if stride == 1 and padb >= 0:
-        lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
-                 ACT_NONE, B, Ho, Wo, C, H, W, K, 1, padb, dil, 0, None, s)
+        geom = (B, Ho, Wo, C, H, W, K, 1, padb, dil, 0)
     else:
-        lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
-                 ACT_NONE, B, Ho, Wo, C, H, W, K, stride, pad, dil, 1, None, s)
-    return dx
+        geom = (B, Ho, Wo, C, H, W, K, stride, pad, dil, 1)
+    if bn is not None:
+        nb = lib.query("nasseg_dwconv_bwd_data_bn_blocks", B, C, H, W, K, geom[7], geom[8], dil, geom[10])
+        if nb > 0:
+            z, scale, shift, mean, invstd, act = bn
+            part = _ws(dz, (nb + 64) * 2 * C)
+            lib.call("nasseg_dwconv_bwd_data_bn", ptr(dz), ptr(wt), ptr(dx), ptr(z), ptr(scale),
+                     ptr(shift), ptr(mean), ptr(invstd), act, *geom, ptr(part), s)
+            return dx, (part, nb)
+    lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+             ACT_NONE, *geom, None, s)
+    return dx, None
 
 
 class _ConvChain(torch.autograd.Function):
@@ -523,6 +534,7 @@ class _ConvChain(torch.autograd.Function):
         n_ops = len(ops)
         grads = [None] * (6 * n_ops)
         dres = g if (has_res and ctx.needs_input_grad[2]) else None
+        pre = None  # BatchNorm-backward partial rows of op i that came with g (fused dgrad epilogue)
         for i in range(n_ops - 1, -1, -1):
             kind, stride, pad, dil, has_bn, act, training, momentum, eps = ops[i]
             cur, psc, psh, z, stats, w, wb = sv[7 * i:7 * i + 7]
@@ -534,9 +546,13 @@ class _ConvChain(torch.autograd.Function):
             if has_bn:
                 mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
                 sums = _vec(z, 2 * N)
-                ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
-                lib.call("nasseg_bn_bwd_reduce", ptr(g), N, ptr(z), N, M, N, ptr(scale), ptr(shift),
-                         ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
+                if pre is not None:
+                    # g arrived masked, with its per-workgroup {sum g, sum g*xhat} rows
+                    lib.call("nasseg_rows_sum", ptr(pre[0]), pre[1], 2 * N, ptr(sums), s)
+                else:
+                    ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
+                    lib.call("nasseg_bn_bwd_reduce", ptr(g), N, ptr(z), N, M, N, ptr(scale),
+                             ptr(shift), ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
                 if ctx.needs_input_grad[3 + 6 * i + 1]:
                     grads[6 * i + 1] = sums[N:2 * N]
                 if ctx.needs_input_grad[3 + 6 * i + 2]:
@@ -553,6 +569,13 @@ class _ConvChain(torch.autograd.Function):
                     g = None
                     break
             Bc, K, H, W = cur.shape
+            pre = None
+            bn_prev = None
+            if need_dx and i > 0 and ops[i - 1][4] and K % 4 == 0:
+                # the producer of this conv's input is a BatchNorm of the chain: fuse the first
+                # half of ITS backward into the backward-data kernel below
+                zp, stp = sv[7 * (i - 1) + 3], sv[7 * (i - 1) + 4]
+                bn_prev = (zp, stp[2 * K:3 * K], stp[3 * K:], stp[0:K], stp[K:2 * K], ops[i - 1][5])
             if kind == "dw":
                 k = w.shape[-1]
                 if need_dw:
@@ -561,7 +584,9 @@ class _ConvChain(torch.autograd.Function):
                     lib.call("nasseg_dwconv_wgrad", ptr(cur), ptr(dz), ptr(dwt), ptr(ws), ptr(psc),
                              ptr(psh), pact, Bc, H, W, K, Ho, Wo, k, stride, pad, dil, s)
                     grads[6 * i] = dwt
-                g = _dw_backward_data(dz, wb, k, (Bc, K, H, W), stride, pad, dil) if need_dx else None
+                g = None
+                if need_dx:
+                    g, pre = _dw_backward_data(dz, wb, k, (Bc, K, H, W), stride, pad, dil, bn_prev)
             else:
                 _, _, kh, kw = w.shape
                 if need_dw:
@@ -573,8 +598,18 @@ class _ConvChain(torch.autograd.Function):
                 g = None
                 if need_dx:
                     g = _new(cur, Bc, K, H, W)
-                    lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(g), K, None, None, 0, None, None,
-                             ACT_NONE, None, 0, Bc, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None, s)
+                    if bn_prev is not None:
+                        nb = lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K)
+                        part = _ws(cur, (nb + 64) * 2 * K)
+                        zp, psc_, psh_, pmu_, pis_, pact_ = bn_prev
+                        lib.call("nasseg_conv_bwd_data_bn", ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
+                                 ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
+                                 K, kh, kw, stride, pad, dil, ptr(part), s)
+                        pre = (part, nb)
+                    else:
+                        lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(g), K, None, None, 0, None,
+                                 None, ACT_NONE, None, 0, Bc, Ho, Wo, N, H, W, K, kh, kw, stride, pad,
+                                 dil, 1, None, s)
         dx = None
         if g is not None and ctx.needs_input_grad[1]:
             dx = g

@@ -412,3 +412,90 @@ def test_pack_weights_single_launch_matches_the_per_tensor_packers():
             want = f._pack_dense(w, kind)
             assert torch.equal(t.reshape(-1), want.reshape(-1))
             assert t.data_ptr() % 16 == 0
+
+
+def _bn_vectors(C, seed):
+    g = torch.Generator().manual_seed(seed)
+    scale = (torch.rand(C, generator=g) + 0.5) * torch.where(torch.rand(C, generator=g) < 0.2, -1.0, 1.0)
+    shift = torch.randn(C, generator=g) * 0.3
+    mean = torch.randn(C, generator=g) * 0.2
+    invstd = torch.rand(C, generator=g) + 0.5
+    return [t.to(DEV) for t in (scale, shift, mean, invstd)]
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W (dims of g / z), C_in of fwd conv (= channels of g), N_out of fwd conv, k, stride, pad, dil
+    (2, 13, 17, 24, 64, 1, 1, 0, 1), (2, 16, 16, 144, 24, 1, 1, 0, 1), (1, 9, 11, 224, 64, 1, 1, 0, 1),
+    (2, 12, 10, 64, 19, 3, 1, 1, 1), (2, 15, 13, 32, 48, 3, 2, 1, 1), (4, 64, 64, 96, 16, 1, 1, 0, 1)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_dense_backward_data_with_bn_backward_statistics(case, act):
+    """nasseg_conv_bwd_data_bn == nasseg_conv_fwd(transposed) followed by the act' mask, and its
+    summed rows == nasseg_bn_bwd_reduce of the unmasked gradient"""
+    f = F()
+    B, H, W, K, N, k, stride, pad, dil = case
+    Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    w = rnd(N, K, k, k, seed=1, scale=0.2).to(DEV)
+    dy = dev(rnd(B, N, Ho, Wo, seed=2))
+    z = dev(rnd(B, K, H, W, seed=3))
+    scale, shift, mean, invstd = _bn_vectors(K, 4)
+    s = f.current_stream()
+    wp = f._pack_dense(w, 1)
+    g_ref = dev(torch.empty(B, K, H, W))
+    f.lib.call("nasseg_conv_fwd", f.ptr(dy), N, f.ptr(wp), f.ptr(g_ref), K, None, None, 0, None, None, 0,
+               None, 0, B, Ho, Wo, N, H, W, K, k, k, stride, pad, dil, 1, None, s)
+    sums_ref = torch.empty(2 * K, device=DEV)
+    ws = torch.empty(f.lib.query("nasseg_colred_workspace", 1, B * H * W, K), device=DEV)
+    f.lib.call("nasseg_bn_bwd_reduce", f.ptr(g_ref), K, f.ptr(z), K, B * H * W, K, f.ptr(scale), f.ptr(shift),
+               f.ptr(mean), f.ptr(invstd), act, f.ptr(sums_ref), f.ptr(ws), s)
+    nb = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, K)
+    part = torch.full(((nb + 64) * 2 * K,), float("nan"), device=DEV)
+    g = dev(torch.empty(B, K, H, W))
+    f.lib.call("nasseg_conv_bwd_data_bn", f.ptr(dy), N, f.ptr(wp), f.ptr(g), K, f.ptr(z), K, f.ptr(scale),
+               f.ptr(shift), f.ptr(mean), f.ptr(invstd), act, B, Ho, Wo, N, H, W, K, k, k, stride, pad, dil,
+               f.ptr(part), s)
+    sums = torch.empty(2 * K, device=DEV)
+    f.lib.call("nasseg_rows_sum", f.ptr(part), nb, 2 * K, f.ptr(sums), s)
+    yv = z * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    mask = torch.ones_like(yv) if act == 0 else ((yv > 0) if act == 1 else ((yv > 0) & (yv < 6))).float()
+    assert torch.equal(g, g_ref * mask)
+    tol = 1e-5 * float(B * H * W) ** 0.5 * float(g_ref.abs().max()) * float(invstd.max()) * 4
+    assert_close(sums, sums_ref, tol, 1e-4, "bn backward sums")
+
+
+@pytest.mark.parametrize("case", [
+    # B, C, H, W (dims of the conv INPUT = of g / z), K, stride, pad, dil
+    (2, 24, 13, 17, 3, 1, 1, 1), (2, 32, 16, 20, 5, 1, 2, 1), (2, 16, 21, 19, 3, 1, 3, 3),
+    (2, 32, 30, 33, 5, 1, 12, 6), (2, 24, 17, 23, 3, 2, 1, 1), (2, 16, 18, 22, 5, 2, 2, 1),
+    (1, 96, 32, 64, 3, 2, 1, 1), (2, 144, 9, 8, 3, 2, 1, 1), (1, 8, 9, 11, 7, 1, 3, 1)])
+@pytest.mark.parametrize("act", [0, 2])
+def test_depthwise_backward_data_with_bn_backward_statistics(case, act):
+    f = F()
+    B, C, H, W, K, stride, pad, dil = case
+    Ho, Wo = (H + 2 * pad - dil * (K - 1) - 1) // stride + 1, (W + 2 * pad - dil * (K - 1) - 1) // stride + 1
+    w = rnd(C, 1, K, K, seed=1, scale=0.3).to(DEV)
+    dy = dev(rnd(B, C, Ho, Wo, seed=2))
+    z = dev(rnd(B, C, H, W, seed=3))
+    scale, shift, mean, invstd = _bn_vectors(C, 5)
+    flip = stride == 1 and dil * (K - 1) - pad >= 0
+    (wt,) = f._pack_many(dy, [(w, "dwflip" if flip else "dw")])
+    g_ref, pre = f._dw_backward_data(dy, wt, K, (B, C, H, W), stride, pad, dil)
+    assert pre is None
+    g, pre = f._dw_backward_data(dy, wt, K, (B, C, H, W), stride, pad, dil,
+                                 (z, scale, shift, mean, invstd, act))
+    yv = z * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    mask = torch.ones_like(yv) if act == 0 else ((yv > 0) & (yv < 6)).float()
+    if K == 7:
+        assert pre is None  # generic geometry: no fused path, the caller reduces separately
+        assert torch.equal(g, g_ref)
+        return
+    assert pre is not None
+    assert torch.equal(g, g_ref * mask)
+    s = f.current_stream()
+    sums = torch.empty(2 * C, device=DEV)
+    f.lib.call("nasseg_rows_sum", f.ptr(pre[0]), pre[1], 2 * C, f.ptr(sums), s)
+    sums_ref = torch.empty(2 * C, device=DEV)
+    ws = torch.empty(f.lib.query("nasseg_colred_workspace", 1, B * H * W, C), device=DEV)
+    f.lib.call("nasseg_bn_bwd_reduce", f.ptr(g_ref), C, f.ptr(z), C, B * H * W, C, f.ptr(scale), f.ptr(shift),
+               f.ptr(mean), f.ptr(invstd), act, f.ptr(sums_ref), f.ptr(ws), s)
+    tol = 1e-5 * float(B * H * W) ** 0.5 * float(g_ref.abs().max()) * float(invstd.max()) * 4
+    assert_close(sums, sums_ref, tol, 1e-4, "bn backward sums")
