@@ -27,6 +27,8 @@
 //   mode 0 forward       : wp[tap][N][K]    from OIHW (N,K,kh,kw)
 //   mode 1 backward-data : wp[tap][K][N]    (roles of N and K swapped)
 //   mode 2 flat forward  : wp[N][tap*K + k]
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace {
@@ -369,10 +371,166 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
   wp[i] = w[((int64_t)n * K + k) * ntaps + tap];
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 stride-1 convolution (dilation 1 or 2) with the input tile staged in LDS.
+// The gather kernel above re-reads X once per tap through L1/L2 (9x the tensor), which
+// is what bounds the 64->19 class head and its backward-data; here a workgroup owns an
+// 8 x 32 patch of output pixels, stages the (8+2d) x (32+2d) input patch of a 32-channel
+// slice in LDS once (zero-filled outside the image and beyond K) and serves all nine taps
+// from there: ds_read_b128 per lane, pixel stride padded to 36 floats so that the 16 pixel
+// lanes of a k-group hit distinct banks.  MFMA operand mapping, weight layout (mode 0,
+// [tap][N][K]) and epilogue as in conv_fwd_kernel; weights come from L1.
+// Backward-data of such a conv is the same kernel on dy with flipped, role-swapped
+// weights (pack kind 5) and pad' = d*(k-1) - pad.
+// ---------------------------------------------------------------------------
+constexpr int kLdsTH = 8, kLdsTW = 32, kLdsKC = 32, kLdsKS = kLdsKC + 4;
+
+template <int NT, bool VECN, bool VECK>
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
+  extern __shared__ float tile[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int j = lane & 15;
+  const int kg = lane >> 4;
+  const int dil = a.g.dil;
+  const int TR = kLdsTH + 2 * dil, TC = kLdsTW + 2 * dil;
+  const int b = blockIdx.z;
+  const int oy0 = blockIdx.y * kLdsTH, ox0 = blockIdx.x * kLdsTW;
+  const int iy0 = oy0 - a.g.pad, ix0 = ox0 - a.g.pad;
+  const int H = a.g.Hs, W = a.g.Ws;
+
+  int wn[NT];
+  bool wok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + j;
+    wok[nt] = n < a.N;
+    wn[nt] = wok[nt] ? n : a.N - 1;
+  }
+  // this lane's pixel in each of the wave's four 16-pixel subtiles: rows 2w, 2w+1; two halves
+  int toff[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) toff[mt] = ((2 * wave + (mt >> 1)) * TC + (mt & 1) * 16 + j) * kLdsKS;
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* xb = a.x + (int64_t)b * H * W * a.ldx;
+  for (int kc0 = 0; kc0 < a.K; kc0 += kLdsKC) {
+    if (kc0) __syncthreads();
+    for (int idx = threadIdx.x; idx < TR * TC * (kLdsKC / 4); idx += 256) {
+      const int q = idx % (kLdsKC / 4);
+      const int p = idx / (kLdsKC / 4);
+      const int pc = p % TC, pr = p / TC;
+      const int iy = iy0 + pr, ix = ix0 + pc;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+      const int k = kc0 + q * 4;
+      const float* src = xb + ((int64_t)iyc * W + ixc) * a.ldx;
+      float4 v = load4<VECK>(src, k, a.K);
+      if (!VECK) {
+        v.y = keep_if(v.y, k + 1 < a.K);
+        v.z = keep_if(v.z, k + 2 < a.K);
+        v.w = keep_if(v.w, k + 3 < a.K);
+      }
+      *reinterpret_cast<float4*>(&tile[p * kLdsKS + q * 4]) = keep_if(v, ok && k < a.K);
+    }
+    __syncthreads();
+    const int nks = (a.K - kc0 >= kLdsKC) ? kLdsKC / 16 : (a.K - kc0 + 15) / 16;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ty = tap / 3, tx = tap - ty * 3;
+      const int tsh = (ty * dil * TC + tx * dil) * kLdsKS;
+      const float* wrow[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.w + ((int64_t)tap * a.N + wn[nt]) * a.K;
+      for (int ks = 0; ks < nks; ++ks) {
+        const int kl = ks * 16 + kg * 4;
+        const int k = kc0 + kl;
+        float4 bv[4], av[NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          bv[mt] = *reinterpret_cast<const float4*>(&tile[toff[mt] + tsh + kl]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float4 v = load4<VECK>(wrow[nt], k, a.K);
+          if (!VECK) {
+            v.y = keep_if(v.y, k + 1 < a.K);
+            v.z = keep_if(v.z, k + 2 < a.K);
+            v.w = keep_if(v.w, k + 3 < a.K);
+          }
+          av[nt] = keep_if(v, wok[nt] && k < a.K);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = mfma16(av[nt].x, bv[mt].x, acc[mt][nt]);
+            acc[mt][nt] = mfma16(av[nt].y, bv[mt].y, acc[mt][nt]);
+            acc[mt][nt] = mfma16(av[nt].z, bv[mt].z, acc[mt][nt]);
+            acc[mt][nt] = mfma16(av[nt].w, bv[mt].w, acc[mt][nt]);
+          }
+      }
+    }
+  }
+
+  // epilogue: lane holds pixel j of each subtile, channels nt*16 + 4*kg + {0..3}
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + (mt & 1) * 16 + j;
+    const bool pok = oy < a.g.Ho && ox < a.g.Wo;
+    const int64_t m = ((int64_t)b * a.g.Ho + (oy < a.g.Ho ? oy : a.g.Ho - 1)) * a.g.Wo +
+                      (ox < a.g.Wo ? ox : a.g.Wo - 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + kg * 4;
+      const f32x4 c = acc[mt][nt];
+      if (VECN) {
+        const bool nok = n < a.N;
+        const int nc = nok ? n : 0;
+        float4 o = make_float4(c[0], c[1], c[2], c[3]);
+        if (a.out_scale) o = fma4(o, ld4(a.out_scale + nc), f4zero());
+        if (a.out_shift) o = add4(o, ld4(a.out_shift + nc));
+        if (a.out_act) o = act_apply4(o, a.out_act);
+        if (a.res) o = add4(o, ld4(a.res + m * a.ldres + nc));
+        if (nok && pok) st4(a.y + m * a.ldy + n, o);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = (n + r < a.N) && pok;
+          const int nc = (n + r < a.N) ? n + r : 0;
+          float v = c[r];
+          if (a.out_scale) v *= a.out_scale[nc];
+          if (a.out_shift) v += a.out_shift[nc];
+          if (a.out_act) v = act_apply(v, a.out_act);
+          if (a.res) v += a.res[m * a.ldres + nc];
+          if (ok) a.y[m * a.ldy + n + r] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+int launch_lds3x3(const FwdArgs& a, bool vecn, bool veck, hipStream_t s) {
+  const int dil = a.g.dil;
+  const size_t lds = (size_t)(kLdsTH + 2 * dil) * (kLdsTW + 2 * dil) * kLdsKS * sizeof(float);
+  dim3 grid(cdiv(a.g.Wo, kLdsTW), cdiv(a.g.Ho, kLdsTH), a.g.B);
+#define GO3(V_, K_) hipLaunchKernelGGL((conv3x3_lds_kernel<NT, V_, K_>), grid, dim3(256), lds, s, a)
+  if (vecn) { if (veck) GO3(true, true); else GO3(true, false); }
+  else { if (veck) GO3(false, true); else GO3(false, false); }
+#undef GO3
+  NASSEG_LAUNCH_CHECK("conv3x3_lds_kernel");
+  return NASSEG_OK;
+}
+
 // Several weight tensors re-packed by ONE launch (a chain of convolutions packs the
 // forward and backward-data layouts of all its weights together: launches, not bytes, are
 // what small layers pay for).  kind 0..2 = dense modes above; 3 = depthwise [tap][C],
-// 4 = depthwise flipped by 180 degrees (N = C, K = 1).
+// 4 = depthwise flipped by 180 degrees (N = C, K = 1); 5 = mode 1 with the taps flipped
+// (backward-data of a stride-1 conv computed as a forward conv over dy).
 struct PackDesc {
   const float* w;
   float* wp;
@@ -393,11 +551,12 @@ __global__ void pack_multi_kernel(PackTable t) {
       const int q = i / d.K;
       n = q % d.N;
       tap = q / d.N;
-    } else if (d.kind == 1) {
+    } else if (d.kind == 1 || d.kind == 5) {
       n = i % d.N;
       const int q = i / d.N;
       k = q % d.K;
       tap = q / d.K;
+      if (d.kind == 5) tap = d.ntaps - 1 - tap;
     } else if (d.kind == 2) {
       k = i % d.K;
       const int q = i / d.K;
@@ -484,6 +643,11 @@ int launch_small(const FwdArgs& a, const Mode& md, hipStream_t s) {
   return launch_one<1, NT, WS>(a, md, s);
 }
 
+inline bool lds3x3_disabled() {
+  static const bool off = getenv("NASSEG_NO_LDS3X3") != nullptr;  // (A/B measurements)
+  return off;
+}
+
 inline int fwd_pack_mode(int K, int kh, int kw) { return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0; }
 
 int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
@@ -507,6 +671,16 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
                  "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
   const int tiles = cdiv(N, 16);
+  // 3x3, stride 1, dilation <= 2, maps at least one tile large: input patch staged in LDS
+  if (!g.transposed && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.dil <= 2 && md.km != KM_FLAT &&
+      !md.pro && !md.stats && tiles <= 4 && g.Wo >= kLdsTW && g.Ho >= kLdsTH && g.B <= 65535 &&
+      g.pad >= 0 && g.pad <= 2 * g.dil && !lds3x3_disabled()) {
+    const bool veck = md.km == KM_VEC;
+    if (tiles <= 1) return launch_lds3x3<1>(a, md.vecn, veck, s);
+    if (tiles == 2) return launch_lds3x3<2>(a, md.vecn, veck, s);
+    if (tiles == 3) return launch_lds3x3<3>(a, md.vecn, veck, s);
+    return launch_lds3x3<4>(a, md.vecn, veck, s);
+  }
   if (tiles <= 1) return launch_small<1>(a, md, s);
   if (tiles == 2) return launch_small<2>(a, md, s);
   if (tiles == 3) return launch_small<3>(a, md, s);
@@ -536,7 +710,7 @@ int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int
 // count tensors in one launch.  w[i] / wp[i]: device pointers (host arrays of pointers);
 // dims[5*i..] = N, K, kh, kw, kind with kind 0/1/2 = the dense modes of
 // nasseg_conv_pack_weight and 3 / 4 = depthwise (C = N, K = 1) plain / flipped, i.e.
-// nasseg_dw_pack_weight(flip = 0 / 1).
+// nasseg_dw_pack_weight(flip = 0 / 1); 5 = [K_fwd-major rows] mode 1 with flipped taps.
 int nasseg_pack_weights(int count, const float* const* w, float* const* wp, const int* dims,
                         void* stream) {
   NASSEG_REQUIRE(count >= 0 && (count == 0 || (w && wp && dims)), "pack_weights: bad arguments");
@@ -546,9 +720,9 @@ int nasseg_pack_weights(int count, const float* const* w, float* const* wp, cons
     int64_t most = 0;
     for (int i = 0; i < n; ++i) {
       const int* d = dims + 5 * (base + i);
-      NASSEG_REQUIRE(d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] >= 0 && d[4] <= 4,
+      NASSEG_REQUIRE(d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] >= 0 && d[4] <= 5,
                      "pack_weights: bad descriptor %d", base + i);
-      NASSEG_REQUIRE(d[4] < 3 || d[1] == 1, "pack_weights: depthwise weights have K = 1");
+      NASSEG_REQUIRE(d[4] < 3 || d[4] == 5 || d[1] == 1, "pack_weights: depthwise weights have K = 1");
       NASSEG_REQUIRE(w[base + i] && wp[base + i], "pack_weights: null tensor %d", base + i);
       t.d[i].w = w[base + i];
       t.d[i].wp = wp[base + i];

@@ -11,6 +11,8 @@
 // Per-wave accumulators are combined through LDS in a fixed order, per-workgroup partials
 // [slab][tap][N][K] by a second deterministic pass (reduce_partials16).
 // "Flat" mode gathers (tap, k) of a small-K conv (the 3-channel stem) as one axis.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace {
@@ -254,12 +256,14 @@ inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps) {
   p.kchunks = cdiv(Kq, 16 * p.vk);
   const int64_t per = (int64_t)p.nchunks * p.kchunks * (p.flat ? 1 : taps);
   // ~1536 workgroups in total, >= 256 pixels each, partial buffer <= 16 MiB
-  int64_t s = 1536 / per;
+  static const int kBlocks = getenv("NASSEG_WG_BLOCKS") ? atoi(getenv("NASSEG_WG_BLOCKS")) : 1536;
+  static const int kMinPix = getenv("NASSEG_WG_MINPIX") ? atoi(getenv("NASSEG_WG_MINPIX")) : 256;
+  int64_t s = kBlocks / per;
   if (s < 1) s = 1;
   int64_t cap_bytes = (int64_t)(16 << 20) / ((int64_t)taps * N * K * 4);
   if (cap_bytes < 8) cap_bytes = 8;
   if (s > cap_bytes) s = cap_bytes;
-  if (s > Mtot / 256) s = Mtot / 256;
+  if (s > Mtot / kMinPix) s = Mtot / kMinPix;
   if (s < 1) s = 1;
   int64_t ppb = cdiv64(Mtot, s);
   ppb = (ppb + 63) / 64 * 64;

@@ -157,7 +157,8 @@ def _pack_dense(w, mode):
 
 def _pack_many(like, items):
     """Re-pack several weights with ONE launch.  items: [(weight, kind)], kind 'fwd' | 0 | 1 | 2
-    for dense weights (as _pack_dense), 'dw' | 'dwflip' for depthwise ones.  Returns the packed
+    for dense weights (as _pack_dense; 5 = mode 1 with flipped taps, see _dense_backward_data),
+    'dw' | 'dwflip' for depthwise ones.  Returns the packed
     tensors in order (the weight itself where its layout already is the packed one)."""
     import ctypes
 
@@ -169,6 +170,8 @@ def _pack_many(like, items):
         else:
             N, K, kh, kw = w.shape
             mode = lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) if kind == "fwd" else int(kind)
+            if kh == 1 and kw == 1 and mode == 5:
+                mode = 1
             if kh == 1 and kw == 1 and mode == 0:
                 out.append(w)
                 continue
@@ -189,6 +192,42 @@ def _pack_many(like, items):
             dims[5 * j:5 * j + 5] = d
         lib.call("nasseg_pack_weights", n, src, dst, dims, current_stream())
     return out
+
+
+def _dgrad_form(kh, kw, stride, pad, dil):
+    """Backward-data of a stride-1 k x k conv is a forward conv over dy with flipped,
+    role-swapped weights (pack kind 5) and pad' = dil*(k-1) - pad - the form the LDS-tiled
+    3x3 kernel serves; everything else uses the transposed gather (pack kind 1)."""
+    if stride == 1 and kh == kw and kh > 1 and dil * (kh - 1) - pad >= 0:
+        return 5
+    return 1
+
+
+def _dense_dgrad_form(w, stride, pad, dil):
+    """_dgrad_form for weight ``w`` (N,K,kh,kw); a forward conv over dy whose reduction
+    axis (N) is so short that nasseg_conv_fwd would take its flat-packed path keeps the
+    transposed form."""
+    N, _, kh, kw = w.shape
+    form = _dgrad_form(kh, kw, stride, pad, dil)
+    if form == 5 and lib.query("nasseg_conv_fwd_pack_mode", N, kh, kw) != 0:
+        return 1
+    return form
+
+
+def _dense_backward_data(dz, wb, form, x_shape, N, kh, kw, stride, pad, dil):
+    """dx of a dense conv; wb packed with kind ``form`` (_dgrad_form)."""
+    B, K, H, W = x_shape
+    Ho, Wo = dz.shape[2], dz.shape[3]
+    dx = _new(dz, B, K, H, W)
+    if form == 5:
+        lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
+                 ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, 1, dil * (kh - 1) - pad, dil, 0,
+                 None, current_stream())
+    else:
+        lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
+                 ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None,
+                 current_stream())
+    return dx
 
 
 class _Conv2d(torch.autograd.Function):
@@ -223,10 +262,9 @@ class _Conv2d(torch.autograd.Function):
         s = current_stream()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _new(x, B, K, H, W)
-            wp = _pack_dense(w, 1)
-            lib.call("nasseg_conv_fwd", ptr(dy), N, ptr(wp), ptr(dx), K, None, None, 0, None, None,
-                     ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None, s)
+            form = _dense_dgrad_form(w, stride, pad, dil)
+            (wp,) = _pack_many(dy, [(w, form)])
+            dx = _dense_backward_data(dy, wp, form, (B, K, H, W), N, kh, kw, stride, pad, dil)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
@@ -250,10 +288,9 @@ def _conv_backward(x, w, dz, stride, pad, dil, need_dx, need_dw):
     s = current_stream()
     dx = dw = None
     if need_dx:
-        dx = _new(x, B, K, H, W)
-        wp = _pack_dense(w, 1)
-        lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wp), ptr(dx), K, None, None, 0, None, None,
-                 ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None, s)
+        form = _dense_dgrad_form(w, stride, pad, dil)
+        (wp,) = _pack_many(dz, [(w, form)])
+        dx = _dense_backward_data(dz, wp, form, (B, K, H, W), N, kh, kw, stride, pad, dil)
     if need_dw:
         dw = torch.empty_like(w)
         ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
@@ -426,8 +463,10 @@ class _ConvChain(torch.autograd.Function):
                     else:
                         bwd_slot[i] = i  # transposed gather reads the forward layout
                 else:
+                    # (a chain whose producer is a BatchNorm uses the fused transposed kernel)
+                    fused = i > 0 and ops[i - 1][4] and weights[i].shape[1] % 4 == 0
                     bwd_slot[i] = len(items)
-                    items.append((weights[i], 1))
+                    items.append((weights[i], 1 if fused else _dense_dgrad_form(weights[i], stride, pad, dil)))
         packed = _pack_many(x, items)
         for i, (kind, stride, pad, dil, has_bn, act, training, momentum, eps) in enumerate(ops):
             w, gamma, beta, rm, rv, nbt = tensors[6 * i:6 * i + 6]
@@ -597,8 +636,8 @@ class _ConvChain(torch.autograd.Function):
                     grads[6 * i] = dwt
                 g = None
                 if need_dx:
-                    g = _new(cur, Bc, K, H, W)
                     if bn_prev is not None:
+                        g = _new(cur, Bc, K, H, W)
                         nb = lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K)
                         part = _ws(cur, (nb + 64) * 2 * K)
                         zp, psc_, psh_, pmu_, pis_, pact_ = bn_prev
@@ -607,9 +646,8 @@ class _ConvChain(torch.autograd.Function):
                                  K, kh, kw, stride, pad, dil, ptr(part), s)
                         pre = (part, nb)
                     else:
-                        lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(g), K, None, None, 0, None,
-                                 None, ACT_NONE, None, 0, Bc, Ho, Wo, N, H, W, K, kh, kw, stride, pad,
-                                 dil, 1, None, s)
+                        g = _dense_backward_data(dz, wb, _dense_dgrad_form(w, stride, pad, dil),
+                                                 (Bc, K, H, W), N, kh, kw, stride, pad, dil)
         dx = None
         if g is not None and ctx.needs_input_grad[1]:
             dx = g

@@ -108,6 +108,14 @@ CONV_CASES = [
     (2, 8, 13, 17, 16, 3, 2, 12, 12, False),
     (3, 64, 1, 1, 64, 1, 1, 0, 1, False),
     (1, 20, 5, 5, 12, 1, 1, 0, 1, False),
+    # maps at least 8 x 32: the LDS-tiled 3x3 kernel (forward, and backward-data as a forward conv
+    # over dy with flipped weights), ragged tiles, K / N not multiples of 4, dilation 2, pad 0 / 2
+    (2, 64, 20, 70, 19, 3, 1, 1, 1, True),
+    (1, 19, 17, 45, 64, 3, 1, 1, 1, False),
+    (2, 32, 9, 33, 48, 3, 1, 2, 2, False),
+    (2, 16, 12, 40, 32, 3, 1, 0, 1, True),
+    (1, 40, 8, 32, 21, 3, 1, 2, 1, True),
+    (2, 64, 64, 64, 64, 3, 1, 1, 1, False),
 ]
 
 

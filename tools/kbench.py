@@ -36,6 +36,7 @@ CONV = [  # B, K, H, W, N, k, stride, pad, dil
     (4, 96, 512, 1024, 16, 1, 1, 0, 1), (4, 32, 128, 256, 32, 1, 1, 0, 1), (4, 64, 32, 64, 64, 1, 1, 0, 1),
     (4, 32, 512, 1024, 32, 1, 1, 0, 1), (4, 64, 256, 512, 19, 3, 1, 1, 1), (4, 3, 1024, 2048, 32, 3, 2, 1, 1),
     (4, 32, 128, 256, 192, 1, 1, 0, 1), (4, 192, 128, 256, 32, 1, 1, 0, 1),
+    (4, 64, 256, 512, 20, 3, 1, 1, 1), (4, 64, 256, 512, 32, 3, 1, 1, 1), (4, 64, 256, 512, 16, 3, 1, 1, 1),
 ]
 DW = [  # B, C, H, W, K, stride, pad, dil
     (4, 32, 128, 256, 5, 1, 2, 1), (4, 24, 256, 512, 5, 1, 2, 1), (4, 32, 128, 256, 5, 1, 12, 6),
@@ -87,6 +88,8 @@ def bench_dw(which):
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["all"]
+    if os.environ.get("KBENCH_ONLY_3X3"):
+        CONV[:] = [c for c in CONV if c[5] == 3 and c[1] == 64]
     print("env:", {k: v for k, v in os.environ.items() if k.startswith("NASSEG_")})
     for w in what:
         if w in ("conv", "wgrad", "dgrad", "all"):
