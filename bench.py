@@ -313,7 +313,10 @@ def main():
         if rows:
             top = rows[0]
             total_ms = sum(r["ms"] for r in rows)
-            dw = [r for r in rows if r["kernel"] == "nasseg_dwconv"]
+            # depthwise forward + backward-data launches (plain and with the fused BN-backward sums)
+            dwr = [r for r in rows if r["kernel"] in ("nasseg_dwconv", "nasseg_dwconv_bwd_data_bn")]
+            dw = ([{"gbs": sum(r["bytes"] for r in dwr) / 1e9 / (sum(r["ms"] for r in dwr) / 1e3)}]
+                  if dwr and sum(r["ms"] for r in dwr) > 0 else [])
             fam = {"nasseg_conv_fwd": "conv_fwd_kernel", "nasseg_conv_wgrad": "conv_wgrad_kernel(+finalize)",
                    "nasseg_dwconv": "dw_fwd_strip / dw_bwd_data_s2 / dw_generic",
                    "nasseg_conv_bwd_data_bn": "conv_fwd_kernel", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
