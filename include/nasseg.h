@@ -73,9 +73,10 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
  * output affine/bias+act(+residual) epilogue. */
 int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int kw, int mode,
                             void* stream);
-/* several weights (dense and depthwise) re-packed by one launch: dims[5*i..] =
- * N, K, kh, kw, kind; kind 0/1/2 as mode above, 3 / 4 = depthwise plain / flipped,
- * 5 = mode 1 with flipped taps (backward-data of a stride-1 conv as a forward conv over dy) */
+/* several weights (dense and depthwise) re-packed by one launch: dims[7*i..] =
+ * N, K, kh, kw, kind, Ksrc, koff; kind 0/1/2 as mode above, 3 / 4 = depthwise plain / flipped,
+ * 5 = mode 1 with flipped taps (backward-data of a stride-1 conv as a forward conv over dy);
+ * Ksrc > 0 packs only input channels [koff, koff+K) of a weight with Ksrc input channels */
 int nasseg_pack_weights(int count, const float* const* w, float* const* wp, const int* dims,
                         void* stream);
 int nasseg_conv_fwd_pack_mode(int K, int kh, int kw);

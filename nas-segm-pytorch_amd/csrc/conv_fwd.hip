@@ -535,6 +535,7 @@ struct PackDesc {
   const float* w;
   float* wp;
   int N, K, ntaps, kind;
+  int Ksrc, koff;  // the K channels packed are [koff, koff+K) of a source with Ksrc input channels
 };
 constexpr int kPackMax = 16;
 struct PackTable {
@@ -568,7 +569,7 @@ __global__ void pack_multi_kernel(PackTable t) {
       tap = i / d.N;
       if (d.kind == 4) tap = d.ntaps - 1 - tap;
     }
-    d.wp[i] = d.w[((int64_t)n * d.K + k) * d.ntaps + tap];
+    d.wp[i] = d.w[((int64_t)n * d.Ksrc + d.koff + k) * d.ntaps + tap];
   }
 }
 
@@ -708,7 +709,9 @@ int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int
 }
 
 // count tensors in one launch.  w[i] / wp[i]: device pointers (host arrays of pointers);
-// dims[5*i..] = N, K, kh, kw, kind with kind 0/1/2 = the dense modes of
+// dims[7*i..] = N, K, kh, kw, kind, Ksrc, koff: the K input channels [koff, koff+K) of a source
+// weight with Ksrc input channels are packed (Ksrc = 0 means the whole weight: Ksrc = K, koff = 0
+// - a slice lets ConcatReduce's 1x1 over a concatenation run as two convs); kind 0/1/2 = the dense modes of
 // nasseg_conv_pack_weight and 3 / 4 = depthwise (C = N, K = 1) plain / flipped, i.e.
 // nasseg_dw_pack_weight(flip = 0 / 1); 5 = [K_fwd-major rows] mode 1 with flipped taps.
 int nasseg_pack_weights(int count, const float* const* w, float* const* wp, const int* dims,
@@ -719,7 +722,7 @@ int nasseg_pack_weights(int count, const float* const* w, float* const* wp, cons
     PackTable t;
     int64_t most = 0;
     for (int i = 0; i < n; ++i) {
-      const int* d = dims + 5 * (base + i);
+      const int* d = dims + 7 * (base + i);
       NASSEG_REQUIRE(d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0 && d[4] >= 0 && d[4] <= 5,
                      "pack_weights: bad descriptor %d", base + i);
       NASSEG_REQUIRE(d[4] < 3 || d[4] == 5 || d[1] == 1, "pack_weights: depthwise weights have K = 1");
@@ -730,6 +733,10 @@ int nasseg_pack_weights(int count, const float* const* w, float* const* wp, cons
       t.d[i].K = d[1];
       t.d[i].ntaps = d[2] * d[3];
       t.d[i].kind = d[4];
+      t.d[i].Ksrc = d[5] > 0 ? d[5] : d[1];
+      t.d[i].koff = d[5] > 0 ? d[6] : 0;
+      NASSEG_REQUIRE(t.d[i].koff >= 0 && t.d[i].koff + d[1] <= t.d[i].Ksrc, "pack_weights: bad slice %d",
+                     base + i);
       const int64_t total = (int64_t)d[0] * d[1] * d[2] * d[3];
       NASSEG_REQUIRE(total < 2147483647LL, "pack_weights: tensor %d too large", base + i);
       if (total > most) most = total;

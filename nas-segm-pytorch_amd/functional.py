@@ -156,40 +156,45 @@ def _pack_dense(w, mode):
 
 
 def _pack_many(like, items):
-    """Re-pack several weights with ONE launch.  items: [(weight, kind)], kind 'fwd' | 0 | 1 | 2
-    for dense weights (as _pack_dense; 5 = mode 1 with flipped taps, see _dense_backward_data),
-    'dw' | 'dwflip' for depthwise ones.  Returns the packed
-    tensors in order (the weight itself where its layout already is the packed one)."""
+    """Re-pack several weights with ONE launch.  items: [(weight, kind)] or, for a slice of the
+    input channels of a dense weight, [(weight, kind, koff, K)]; kind 'fwd' | 0 | 1 | 2 for dense
+    weights (as _pack_dense; 5 = mode 1 with flipped taps, see _dense_backward_data), 'dw' |
+    'dwflip' for depthwise ones.  Returns the packed tensors in order (the weight itself where
+    its layout already is the packed one)."""
     import ctypes
 
     out, descs, off = [], [], 0
-    for w, kind in items:
+    for item in items:
+        w, kind = item[0], item[1]
         if kind in ("dw", "dwflip"):
             C, _, k, _ = w.shape
-            d = (C, 1, k, k, 3 if kind == "dw" else 4)
+            d = (C, 1, k, k, 3 if kind == "dw" else 4, 0, 0)
+            numel = w.numel()
         else:
-            N, K, kh, kw = w.shape
+            N, Ksrc, kh, kw = w.shape
+            koff, K = (item[2], item[3]) if len(item) > 2 else (0, Ksrc)
             mode = lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) if kind == "fwd" else int(kind)
             if kh == 1 and kw == 1 and mode == 5:
                 mode = 1
-            if kh == 1 and kw == 1 and mode == 0:
+            if kh == 1 and kw == 1 and mode == 0 and K == Ksrc:
                 out.append(w)
                 continue
-            d = (N, K, kh, kw, mode)
+            d = (N, K, kh, kw, mode, Ksrc if K != Ksrc else 0, koff)
+            numel = N * K * kh * kw
         out.append(None)
-        descs.append((len(out) - 1, w, d, off))
-        off += (w.numel() + 3) // 4 * 4  # keep every packed tensor 16-byte aligned
+        descs.append((len(out) - 1, w, d, off, numel))
+        off += (numel + 3) // 4 * 4  # keep every packed tensor 16-byte aligned
     if descs:
         buf = _vec(like, off)
         n = len(descs)
-        src = (ctypes.c_void_p * n)(*[ptr(w) for _, w, _, _ in descs])
+        src = (ctypes.c_void_p * n)(*[ptr(w) for _, w, _, _, _ in descs])
         dst = (ctypes.c_void_p * n)()
-        dims = (ctypes.c_int * (5 * n))()
-        for j, (pos, w, d, o) in enumerate(descs):
-            t = buf[o:o + w.numel()]
+        dims = (ctypes.c_int * (7 * n))()
+        for j, (pos, w, d, o, numel) in enumerate(descs):
+            t = buf[o:o + numel]
             out[pos] = t
             dst[j] = ptr(t)
-            dims[5 * j:5 * j + 5] = d
+            dims[7 * j:7 * j + 7] = d
         lib.call("nasseg_pack_weights", n, src, dst, dims, current_stream())
     return out
 
@@ -866,6 +871,119 @@ class _ConcatResize(torch.autograd.Function):
 
 def concat_resize(tensors, size, relu=False):
     return _ConcatResize.apply(int(size[0]), int(size[1]), ACT_RELU if relu else ACT_NONE, *tensors)
+
+
+class _CatBNReluConv(torch.autograd.Function):
+    """ConcatReduce's tail, cat(x, y) -> BatchNorm(2C) -> ReLU -> 1x1 conv (2C -> N)
+    (src/nn/layer_factory.py:369-382), WITHOUT the concatenation: BatchNorm is per channel and
+    the 1x1 conv is linear in its input channels, so
+
+        out = W[:, :C] . relu(bn_lo(x)) + W[:, C:] . relu(bn_hi(y))
+
+    Two pointwise convs, each applying its half of the BatchNorm on load (the second adds the
+    first's output in its epilogue); neither the 2C-channel slab nor its normalised copy is ever
+    written, and the backward needs no slicing: each half's backward-data kernel emits the
+    masked gradient with its BatchNorm-backward sums.  Used for large maps (a few more, smaller
+    launches than the slab path)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, beta, rm, rv, nbt, weight, training, momentum, eps):
+        x, y = _cl(x), _cl(y)
+        B, C, H, W = x.shape
+        N = weight.shape[0]
+        w = weight.contiguous()
+        if tuple(y.shape) != (B, C, H, W) or tuple(w.shape) != (N, 2 * C, 1, 1):
+            raise NassegError("cat_bn_relu_conv: shapes {} {} {}".format(
+                tuple(x.shape), tuple(y.shape), tuple(w.shape)))
+        M = B * H * W
+        s = current_stream()
+        needs_grad = any(ctx.needs_input_grad)
+        stats = _vec(x, 8 * C)  # [mean | invstd | scale | shift] x [2C]
+        mean, invstd, scale, shift = (stats[0:2 * C], stats[2 * C:4 * C], stats[4 * C:6 * C],
+                                      stats[6 * C:8 * C])
+        if training:
+            if M <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input "
+                                 "size {}".format((B, 2 * C, H, W)))
+            ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
+            for h, t in enumerate((x, y)):
+                lo, hi = h * C, (h + 1) * C
+                lib.call("nasseg_bn_stats", ptr(t), C, M, C, float(eps), float(momentum), ptr(gamma[lo:hi]),
+                         ptr(beta[lo:hi]), ptr(mean[lo:hi]), ptr(invstd[lo:hi]), ptr(scale[lo:hi]),
+                         ptr(shift[lo:hi]), ptr(rm[lo:hi]) if rm is not None else None,
+                         ptr(rv[lo:hi]) if rv is not None else None,
+                         ptr(nbt) if (nbt is not None and h == 0) else None, ptr(ws), s)
+        else:
+            lib.call("nasseg_bn_eval_params", 2 * C, float(eps), ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+                     ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
+        items = [(w, 0, 0, C), (w, 0, C, C)]
+        if needs_grad:
+            items += [(w, 1, 0, C), (w, 1, C, C)]
+        packed = _pack_many(x, items)
+        y1 = _new(x, B, N, H, W)
+        lib.call("nasseg_conv_fwd", ptr(x), C, ptr(packed[0]), ptr(y1), N, ptr(scale[0:C]), ptr(shift[0:C]),
+                 ACT_RELU, None, None, ACT_NONE, None, 0, B, H, W, C, H, W, N, 1, 1, 1, 0, 1, 0, None, s)
+        out = _new(x, B, N, H, W)
+        lib.call("nasseg_conv_fwd", ptr(y), C, ptr(packed[1]), ptr(out), N, ptr(scale[C:]), ptr(shift[C:]),
+                 ACT_RELU, None, None, ACT_NONE, ptr(y1), N, B, H, W, C, H, W, N, 1, 1, 1, 0, 1, 0, None, s)
+        if needs_grad:
+            ctx.save_for_backward(x, y, stats, packed[2], packed[3])
+            ctx.cfg = (bool(training), N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, stats, wb_lo, wb_hi = ctx.saved_tensors
+        training, N = ctx.cfg
+        dout = _cl(dout)
+        B, C, H, W = x.shape
+        M = B * H * W
+        s = current_stream()
+        mean, invstd, scale, shift = (stats[0:2 * C], stats[2 * C:4 * C], stats[4 * C:6 * C],
+                                      stats[6 * C:8 * C])
+        need_w = ctx.needs_input_grad[7]
+        need_bn = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        dbn = _vec(x, 4 * C) if need_bn else None  # [dbeta(2C) | dgamma(2C)]
+        dw = torch.empty((N, 2 * C, 1, 1), device=x.device, dtype=x.dtype) if need_w else None
+        nb = lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, C)
+        grads_in = [None, None]
+        for h, (t, wb) in enumerate(((x, wb_lo), (y, wb_hi))):
+            lo, hi = h * C, (h + 1) * C
+            need_dx = ctx.needs_input_grad[h]
+            sc, sh, mu, isd = scale[lo:hi], shift[lo:hi], mean[lo:hi], invstd[lo:hi]
+            if need_dx or need_bn:
+                g = _new(x, B, C, H, W)
+                part = _ws(x, (nb + 64) * 2 * C)
+                lib.call("nasseg_conv_bwd_data_bn", ptr(dout), N, ptr(wb), ptr(g), C, ptr(t), C, ptr(sc),
+                         ptr(sh), ptr(mu), ptr(isd), ACT_RELU, B, H, W, N, H, W, C, 1, 1, 1, 0, 1,
+                         ptr(part), s)
+                sums = _vec(x, 2 * C)
+                lib.call("nasseg_rows_sum", ptr(part), nb, 2 * C, ptr(sums), s)
+                if need_bn:  # sums = [sum g | sum g*xhat] -> rows (dbeta, dgamma) of dbn at columns lo..hi
+                    lib.call("nasseg_chan_copy", ptr(sums), C, 0, ptr(dbn), 2 * C, lo, None, 0, 0, 2, C,
+                             ACT_NONE, ACT_NONE, s)
+                if need_dx:
+                    dz = torch.empty_like(t)
+                    lib.call("nasseg_bn_bwd_apply", ptr(g), ptr(t), ptr(sc), ptr(sh), ptr(mu), ptr(isd),
+                             ptr(sums), M, C, int(training), ACT_RELU, ptr(dz), s)
+                    grads_in[h] = dz
+            if need_w:
+                dwh = _vec(x, N * C)
+                ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, H, W, N, C, 1, 1))
+                lib.call("nasseg_conv_wgrad", ptr(t), C, ptr(dout), N, ptr(dwh), ptr(ws), ptr(sc), ptr(sh),
+                         ACT_RELU, B, H, W, C, H, W, N, 1, 1, 1, 0, 1, s)
+                lib.call("nasseg_chan_copy", ptr(dwh), C, 0, ptr(dw), 2 * C, lo, None, 0, 0, N, C, ACT_NONE,
+                         ACT_NONE, s)
+        dgamma = dbn[2 * C:4 * C] if ctx.needs_input_grad[2] else None
+        dbeta = dbn[0:2 * C] if ctx.needs_input_grad[3] else None
+        return (grads_in[0], grads_in[1], dgamma, dbeta, None, None, None, dw, None, None, None)
+
+
+def cat_bn_relu_conv(x, y, gamma, beta, running_mean, running_var, num_batches_tracked, weight,
+                     training, momentum=0.1, eps=1e-5):
+    """conv1x1(relu(batch_norm(cat([x, y], 1)))) without materialising the concatenation."""
+    return _CatBNReluConv.apply(x, y, gamma, beta, running_mean, running_var, num_batches_tracked,
+                                weight, bool(training), float(momentum), float(eps))
 
 
 # ---------------------------------------------------------------------------

@@ -251,6 +251,11 @@ class ParamSum(nn.Module):
         return F.param_sum(x, y, self.a, self.b)
 
 
+# elements per input above which ConcatReduce skips the concatenation (F.cat_bn_relu_conv);
+# below it the slab path's fewer launches win
+_SPLIT_CAT_MIN = 1 << 24
+
+
 class ConcatReduce(nn.Module):
     """cat -> BN(2C) -> ReLU -> 1x1 (2C -> C) (layer_factory.py:369-382)."""
 
@@ -268,6 +273,15 @@ class ConcatReduce(nn.Module):
         if tuple(x.shape[2:]) != tuple(y.shape[2:]):
             # torch.cat would refuse; same exception class so try_except scores the candidate 0
             raise RuntimeError("Sizes of tensors must match except in dimension 1")
+        bn, conv = self.conv1x1[0], self.conv1x1[2]
+        C = x.shape[1]
+        if (x.shape[0] * x.shape[2] * x.shape[3] * C >= _SPLIT_CAT_MIN and C % 4 == 0
+                and conv.weight.shape[0] % 4 == 0 and bn.affine and bn.momentum is not None
+                and bn.track_running_stats and tuple(x.shape) == tuple(y.shape)):
+            # large maps: no slab, two pointwise convs with the BatchNorm halves applied on load
+            return F.cat_bn_relu_conv(x, y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      bn.num_batches_tracked if bn.training else None, conv.weight,
+                                      bn.training, bn.momentum, bn.eps)
         z = F.concat_resize([x, y], x.shape[2:])
         return self.conv1x1(z)
 

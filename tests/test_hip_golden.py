@@ -61,10 +61,17 @@ def test_registry_op(case):
         assert_close(after[k], v, 1e-5, 1e-5, "buffer " + k)
 
 
+@pytest.mark.parametrize("split_cat", [False, True], ids=["slab", "split"])
 @pytest.mark.parametrize("case", [c for c in OPS_CASES if c["kind"] == "agg"], ids=lambda c: c["case"])
-def test_registry_agg(case):
+def test_registry_agg(case, split_cat, monkeypatch):
+    from nas_segm_amd.nn import layer_factory
     from nas_segm_amd.nn.layer_factory import AGG_OPS
 
+    if split_cat:
+        if case["name"] != "cat":
+            pytest.skip("only ConcatReduce has a split (no-concatenation) path")
+        # the path large maps take: two pointwise convs instead of cat -> BN -> ReLU -> conv
+        monkeypatch.setattr(layer_factory, "_SPLIT_CAT_MIN", 0)
     name = case["case"]
     mod = AGG_OPS[case["name"]](case["C_in0"], case["C_in1"], case["C_out"], True, 2, case["larger"])
     sd = sub_dict(OPS_NPZ, name + "/sd")
