@@ -5,9 +5,12 @@ rewards are gathered back to rank 0 where ``train_agent`` consumes them
 (src/main_search.py:490-513,543-660; src/rl/agent.py:73-77).  No gradient exchange is
 needed in this mode - candidates are independent.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
+from ..helpers.utils import compute_params
 from ..nn.encoders import create_encoder
 from ..nn.micro_decoders import MicroDecoder, TemplateDecoder
 from .inference import validate
@@ -32,7 +35,7 @@ def build_candidate(config, ctrl_version="wacv", num_classes=19, agg_size=48, au
 
 def evaluate_candidate(config, train_batches, val_batches, ctrl_version="wacv", num_classes=19,
                        agg_size=48, aux_cell=True, repeats=1, epochs=1, aux_weight=0.15,
-                       omit_classes=(0,), device="cuda"):
+                       omit_classes=(0,), device="cuda", stats=None):
     """Train the candidate on ``train_batches`` (lists of {"image", "mask"}) for ``epochs``
     passes and return its validation reward; failures score 0 like in the reference."""
     try:
@@ -51,6 +54,8 @@ def evaluate_candidate(config, train_batches, val_batches, ctrl_version="wacv", 
             return 0.0
     reward = validate(segmenter, val_batches, 0, 0, num_classes=num_classes, print_every=10 ** 9,
                       omit_classes=list(omit_classes))
+    if stats is not None:
+        stats["params"] = compute_params(segmenter)[1]
     return float(reward)
 
 
@@ -72,3 +77,65 @@ def evaluate_candidates(configs, make_batches, **kwargs):
     for part in gathered:
         merged.update(part)
     return [merged[i] for i in range(len(configs))]
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def search_loop(sample_fn, train_agent_fn, evaluate_fn, n_iterations, arch_writer=None, logger=None,
+                first_epoch=0):
+    """Outer loop of the search with one candidate per GPU (BASELINE config 4).
+
+    The reference evaluates ONE sampled architecture per outer epoch on all GPUs
+    (src/main_search.py:543-674); here every outer iteration evaluates ``world`` of them, one
+    per rank, and the controller takes ``world`` policy-gradient steps:
+
+      rank 0   : ``sample_fn()`` x world -> (config, entropy, log_prob) each (the reference's
+                 ``agent.controller.sample()``, micro_controllers.py:136-139) - the controller
+                 and its RNG live on rank 0 only;
+      all ranks: receive their config (broadcast of python lists), ``evaluate_fn(config)`` ->
+                 reward or (reward, n_params) (``evaluate_candidate``: RuntimeError => 0);
+      rank 0   : gathers the rewards and calls ``train_agent_fn((config, reward, entropy,
+                 log_prob))`` once per candidate, in sampling order (rl/agent.py:73-77: REINFORCE
+                 step or PPO RolloutStorage insert), and appends the reference's genotype log
+                 line per candidate (main_search.py:664-674; the format helpers/num_uq.py parses).
+
+    Returns, on rank 0, the list of (config, reward) in evaluation order; None elsewhere.
+    """
+    world, rank = _world()
+    history = []
+    for it in range(n_iterations):
+        t0 = time.time()
+        samples = [sample_fn() for _ in range(world)] if rank == 0 else None
+        if world > 1:
+            box = [[s[0] for s in samples]] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=0)
+            config = box[0][rank]
+        else:
+            config = samples[0][0]
+        result = evaluate_fn(config)
+        reward, params = result if isinstance(result, tuple) else (result, -1)
+        mine = (float(reward), int(params))
+        if world > 1:
+            gathered = [None] * world if rank == 0 else None
+            dist.gather_object(mine, gathered, dst=0)
+        else:
+            gathered = [mine]
+        if rank != 0:
+            continue
+        per_arch = (time.time() - t0)
+        for k, ((cfg, entropy, log_prob), (rew, par)) in enumerate(zip(samples, gathered)):
+            train_agent_fn((cfg, rew, entropy, log_prob))
+            epoch = first_epoch + it * world + k
+            if logger is not None:
+                logger.info(" Decoder: {}".format(cfg))
+            if arch_writer is not None:
+                arch_writer.write(
+                    "reward: {:.4f}, epoch: {}, params: {}, epoch_time: {:.4f}, genotype: {}\n".format(
+                        rew, epoch, par, per_arch, cfg))
+                arch_writer.flush()
+            history.append((cfg, rew))
+    return history if rank == 0 else None

@@ -89,10 +89,15 @@ class RankParallel(nn.Module):
         ws = self.world_size
         if ws == 1:
             return
-        if self._flat is None:
-            # static per architecture, hence identical on every rank
-            self._build_bucket([p for p in self.module.parameters()
-                                if p.requires_grad and p.grad is not None])
+        # the parameters this backward reached: static per architecture and training stage
+        # (decoder only on cached features, everything end to end), hence identical on every
+        # rank; the bucket is rebuilt when the stage changes
+        have = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
+        if (self._flat is None or len(have) != len(self._used)
+                or any(a is not b for a, b in zip(have, self._used))):
+            if not have:
+                return
+            self._build_bucket(have)
         aliased = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
                       for p, v in zip(self._used, self._views))
         if not aliased:

@@ -162,6 +162,10 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
                 loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
         optim_dec.zero_grad()
         loss.backward()
+        if getattr(segmenter, "world_size", 1) > 1:
+            # the feature cache is sharded: every rank steps on its own cached samples and the
+            # decoder gradients are averaged (the reference runs this stage on one GPU)
+            segmenter.sync_gradients()
         _clip_and_step([(list(decoder.parameters()), dec_grad_clip, optim_dec)])
         losses.update(loss.item())
         batch_time.update(time.time() - start)

@@ -98,3 +98,72 @@ def test_rank_parallel_single_process_is_a_noop():
     g = net.weight.grad.clone()
     dp.sync_gradients()
     assert torch.equal(net.weight.grad, g)
+
+
+def _search_worker(rank, world, port, q, log_path):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nas_segm_amd.engine.search import search_loop
+
+        counter = {"n": 0}
+        trained = []
+
+        def sample_fn():  # only ever called on rank 0 (the controller lives there)
+            assert rank == 0
+            counter["n"] += 1
+            n = counter["n"]
+            return [[n, n + 1, 0], [[0, 1, n % 3, 0, 1]]], 0.5 * n, -1.0 * n
+
+        def evaluate_fn(config):  # stands in for evaluate_candidate: reward depends on the genotype
+            return 0.01 * config[0][0] + 0.001 * rank, 1000 + config[0][0]
+
+        writer = open(log_path, "w") if rank == 0 else None
+        hist = search_loop(sample_fn, trained.append, evaluate_fn, 2, arch_writer=writer, first_epoch=5)
+        if writer:
+            writer.close()
+        q.put((rank, hist, trained))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_search_loop_one_candidate_per_rank_gloo(tmp_path):
+    """config-4 outer loop: rank 0 samples `world` genotypes per iteration, every rank evaluates
+    its own, rank 0 trains the controller once per candidate in sampling order and writes the
+    reference's genotype log format"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    log_path = str(tmp_path / "genotypes.out")
+    procs = [ctx.Process(target=_search_worker, args=(r, world, port, q, log_path)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict((r[0], r[1:]) for r in [q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    hist, trained = results[0]
+    assert results[1] == (None, [])
+    assert [c[0][0] for c, _ in hist] == [1, 2, 3, 4]
+    # candidate k of an iteration ran on rank k: reward = 0.01*n + 0.001*rank
+    assert [round(r, 4) for _, r in hist] == [0.01, 0.021, 0.03, 0.041]
+    assert [(t[0][0][0], round(t[1], 4), t[2], t[3]) for t in trained] == [
+        (1, 0.01, 0.5, -1.0), (2, 0.021, 1.0, -2.0), (3, 0.03, 1.5, -3.0), (4, 0.041, 2.0, -4.0)]
+    lines = open(log_path).read().strip().split("\n")
+    assert len(lines) == 4
+    assert lines[0].startswith("reward: 0.0100, epoch: 5, params: 1001, epoch_time: ")
+    assert lines[3].startswith("reward: 0.0410, epoch: 8, params: 1004, epoch_time: ")
+    assert lines[1].endswith("genotype: [[2, 3, 0], [[0, 1, 2, 0, 1]]]")
+
+
+def test_search_loop_single_process():
+    from nas_segm_amd.engine.search import search_loop
+
+    seen = []
+    hist = search_loop(lambda: ([[1]], 0.1, -0.2), seen.append, lambda cfg: 0.5, 3)
+    assert hist == [([[1]], 0.5)] * 3 and seen == [([[1]], 0.5, 0.1, -0.2)] * 3

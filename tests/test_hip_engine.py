@@ -266,3 +266,36 @@ def test_graphed_step_equals_eager_step(net_name, capture_opt):
     assert l0 == l1, (l0, l1)
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+
+
+def test_search_loop_with_real_candidates(tmp_path):
+    """outer loop (config 4) on one GPU: genotypes + entropy/log-prob recorded from the reference
+    controller feed search_loop; every candidate is built, trained and validated by
+    evaluate_candidate and logged in the reference's genotype-log format"""
+    from nas_segm_amd.engine.search import evaluate_candidate, search_loop
+
+    samples = iter(load_json("controller.json")["wacv"]["samples"][:3])
+    g = torch.Generator().manual_seed(4)
+    train = [{"image": torch.randn(2, 3, 65, 97, generator=g),
+              "mask": torch.randint(0, 19, (2, 65, 97), generator=g).to(torch.uint8)} for _ in range(2)]
+    val = train[:1]
+
+    def sample_fn():
+        s = next(samples)
+        return s["config"], float(s.get("entropy", 0.0)), float(s.get("log_prob", 0.0))
+
+    def evaluate_fn(config):
+        stats = {}
+        r = evaluate_candidate(config, train, val, ctrl_version="wacv", num_classes=19, agg_size=48,
+                               aux_cell=False, repeats=1, omit_classes=(), stats=stats)
+        return r, stats.get("params", -1)
+
+    trained = []
+    path = tmp_path / "genotypes.out"
+    with open(path, "w") as fo:
+        hist = search_loop(sample_fn, trained.append, evaluate_fn, 3, arch_writer=fo)
+    assert len(hist) == 3 and len(trained) == 3
+    assert all(0.0 <= r <= 1.0 for _, r in hist)
+    lines = open(path).read().strip().split("\n")
+    assert len(lines) == 3 and all(l.startswith("reward: ") and ", genotype: [[" in l for l in lines)
+    assert all(int(l.split("params: ")[1].split(",")[0]) > 50000 for l in lines)
