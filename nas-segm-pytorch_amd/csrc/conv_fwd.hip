@@ -27,8 +27,6 @@
 //   mode 0 forward       : wp[tap][N][K]    from OIHW (N,K,kh,kw)
 //   mode 1 backward-data : wp[tap][K][N]    (roles of N and K swapped)
 //   mode 2 flat forward  : wp[N][tap*K + k]
-#include <stdlib.h>
-
 #include "conv_common.h"
 
 namespace {
@@ -644,11 +642,6 @@ int launch_small(const FwdArgs& a, const Mode& md, hipStream_t s) {
   return launch_one<1, NT, WS>(a, md, s);
 }
 
-inline bool lds3x3_disabled() {
-  static const bool off = getenv("NASSEG_NO_LDS3X3") != nullptr;  // (A/B measurements)
-  return off;
-}
-
 inline int fwd_pack_mode(int K, int kh, int kw) { return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0; }
 
 int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
@@ -675,7 +668,7 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   // 3x3, stride 1, dilation <= 2, maps at least one tile large: input patch staged in LDS
   if (!g.transposed && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.dil <= 2 && md.km != KM_FLAT &&
       !md.pro && !md.stats && tiles <= 4 && g.Wo >= kLdsTW && g.Ho >= kLdsTH && g.B <= 65535 &&
-      g.pad >= 0 && g.pad <= 2 * g.dil && !lds3x3_disabled()) {
+      g.pad >= 0 && g.pad <= 2 * g.dil) {
     const bool veck = md.km == KM_VEC;
     if (tiles <= 1) return launch_lds3x3<1>(a, md.vecn, veck, s);
     if (tiles == 2) return launch_lds3x3<2>(a, md.vecn, veck, s);

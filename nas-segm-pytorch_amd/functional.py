@@ -427,6 +427,23 @@ def _dw_backward_data(dz, wt, K, x_shape, stride, pad, dil, bn=None):
     return dx, None
 
 
+_IDENTITY = {}
+
+
+def _identity_vectors(like, n):
+    """(ones, zeros) of at least n floats on like's device - the "BatchNorm" that turns the fused
+    backward-data epilogue into a plain act' mask (scale 1, shift 0, mean 0, invstd 1).  Created
+    once per device and size class, never written."""
+    key = (like.device, (n + 1023) // 1024)
+    ent = _IDENTITY.get(key)
+    if ent is None:
+        m = key[1] * 1024
+        ent = (torch.ones(m, device=like.device, dtype=torch.float32),
+               torch.zeros(m, device=like.device, dtype=torch.float32))
+        _IDENTITY[key] = ent
+    return ent
+
+
 class _ConvChain(torch.autograd.Function):
     """A run of convolutions (dense on the MFMA path or depthwise), each optionally followed
     by BatchNorm (+ReLU/ReLU6), as ONE autograd node in which a normalised activation that
@@ -469,7 +486,7 @@ class _ConvChain(torch.autograd.Function):
                         bwd_slot[i] = i  # transposed gather reads the forward layout
                 else:
                     # (a chain whose producer is a BatchNorm uses the fused transposed kernel)
-                    fused = i > 0 and ops[i - 1][4] and weights[i].shape[1] % 4 == 0
+                    fused = ((i > 0 and ops[i - 1][4]) or (i == 0 and in_act0)) and weights[i].shape[1] % 4 == 0
                     bwd_slot[i] = len(items)
                     items.append((weights[i], 1 if fused else _dense_dgrad_form(weights[i], stride, pad, dil)))
         packed = _pack_many(x, items)
@@ -573,6 +590,7 @@ class _ConvChain(torch.autograd.Function):
         cfg, meta, has_res, x_shape = ctx.meta
         in_act0, ops = cfg
         sv = ctx.saved_tensors
+        fused_in0 = bool(in_act0)  # (forward packed op 0's backward-data weights for the fused kernel)
         g = _cl(dy)
         s = current_stream()
         n_ops = len(ops)
@@ -620,6 +638,12 @@ class _ConvChain(torch.autograd.Function):
                 # half of ITS backward into the backward-data kernel below
                 zp, stp = sv[7 * (i - 1) + 3], sv[7 * (i - 1) + 4]
                 bn_prev = (zp, stp[2 * K:3 * K], stp[3 * K:], stp[0:K], stp[K:2 * K], ops[i - 1][5])
+            elif need_dx and i == 0 and in_act0 and K % 4 == 0 and (kind == "dw" or fused_in0):
+                # the chain's input went through an activation on load (ReLU ahead of DilConv's
+                # depthwise conv, of pre_clf's 1x1): the same epilogue with an identity BatchNorm
+                # multiplies dx by act'(x) - no separate pass over dx and x
+                one, zero = _identity_vectors(cur, K)
+                bn_prev = (cur, one, zero, zero, one, in_act0)
             if kind == "dw":
                 k = w.shape[-1]
                 if need_dw:
@@ -656,8 +680,9 @@ class _ConvChain(torch.autograd.Function):
         dx = None
         if g is not None and ctx.needs_input_grad[1]:
             dx = g
-            if in_act0:
-                # the chain started with an activation applied on load (DilConv's ReLU)
+            if in_act0 and pre is None:
+                # the chain started with an activation applied on load and the backward-data
+                # kernel had no fused mask for this geometry
                 dx = _act_bwd(dx, sv[0], in_act0)
         return (None, dx, dres) + tuple(grads)
 

@@ -223,8 +223,9 @@ class MicroDecoder(nn.Module):
             merged = cell(maps[a], maps[b])
             maps.append(merged)
             aux_outs.append(head(merged))
-        out = collect_all(maps, self.collect_inds, relu=True)
-        return self.conv_clf(self.pre_clf(out)), aux_outs
+        # F.relu(collect_all(...)) of the reference: the ReLU is applied as pre_clf loads
+        out = collect_all(maps, self.collect_inds)
+        return self.conv_clf(self.pre_clf(out, relu_in=True)), aux_outs
 
 
 class TemplateDecoder(nn.Module):
@@ -321,5 +322,6 @@ class TemplateDecoder(nn.Module):
                 # the next repeat consumes (previous right input, previous output)
                 left, right = right, merged
             maps.append(merged)
-        out = collect_all(maps, self._collect_inds, relu=True)
-        return self.conv_clf(self.pre_clf(out))
+        # F.relu(collect_all(...)) of the reference: the ReLU is applied as pre_clf loads
+        out = collect_all(maps, self._collect_inds)
+        return self.conv_clf(self.pre_clf(out, relu_in=True))

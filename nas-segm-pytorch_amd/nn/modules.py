@@ -109,15 +109,19 @@ class FusedSequential(nn.Sequential):
     between the convs, residual add in the last normalise pass).  Nested FusedSequentials
     (SepConv stages) are flattened first; anything else runs module by module."""
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, relu_in=False):
+        """relu_in: the input is to be passed through a ReLU first (the decoders' F.relu ahead of
+        pre_clf); fused into the first conv's loads when the sequence starts with a conv."""
         mods = _flatten(self._modules.values())
         n = len(mods)
         i = 0
         res_used = residual is None
+        if relu_in and not (n and _chainable(mods[0])):
+            x, relu_in = F.relu(x), False
         while i < n:
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
-            in_act0 = F.ACT_NONE
+            in_act0 = F.ACT_RELU if (relu_in and i == 0) else F.ACT_NONE
             if (isinstance(m, nn.ReLU) and not isinstance(m, nn.ReLU6) and _chainable(nxt)
                     and nxt.is_depthwise):
                 in_act0 = F.ACT_RELU  # DilConv: ReLU applied as the depthwise conv loads

@@ -1,5 +1,5 @@
 """Micro-benchmark of single C-ABI entry points at headline shapes (GPU box).
-usage: python tools/kbench.py [conv|wgrad|dw|dwwgrad|red] ...   (env knobs are read by the library)"""
+usage: python tools/kbench.py [conv|wgrad|dw|dwwgrad|red] ...   """
 import os
 import sys
 

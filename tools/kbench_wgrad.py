@@ -1,5 +1,5 @@
 """Direct (no autograd) timing of nasseg_conv_wgrad at the small / mid shapes of the headline step.
-usage: python tools/kbench_wgrad.py          (NASSEG_WG_* env knobs are read by the library)"""
+usage: python tools/kbench_wgrad.py          """
 import os
 import sys
 
