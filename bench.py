@@ -85,7 +85,7 @@ def algorithmic_bytes(name, a):
         B, Hi, Wi, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
         return 4 * B * C * (Hi * Wi + Ho * Wo)
     if name == "nasseg_bilinear_bwd":
-        B, Hi, Wi, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
+        B, Hi, Wi, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]  # (ws, stream follow)
         return 4 * B * C * (Hi * Wi + Ho * Wo)
     if name == "nasseg_colred":
         n = a[9] * a[10] * a[11]

@@ -151,8 +151,9 @@ int nasseg_pool_bwd(int mode, const float* dy, const uint8_t* idx, float* dx, in
  * 236-238,245-247; inference.py:58-60) and nearest label resize (trainer.py:43-49,236-238). */
 int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream);
+int64_t nasseg_bilinear_bwd_workspace(int B, int Hi, int Wi, int C, int Ho, int Wo);
 int nasseg_bilinear_bwd(const float* dy, int64_t lddy, int dyoff, float* dx, int B, int Hi, int Wi,
-                        int C, int Ho, int Wo, void* stream);
+                        int C, int Ho, int Wo, float* ws, void* stream);
 int nasseg_nearest_label(const void* x, int elem_size, int64_t* y, int B, int Hi, int Wi, int Ho,
                          int Wo, void* stream);
 

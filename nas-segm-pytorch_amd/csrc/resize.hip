@@ -102,6 +102,15 @@ __global__ __launch_bounds__(256) void bilinear_fwd_scalar_kernel(const float* _
   }
 }
 
+__device__ __forceinline__ float4 keep_if4(float4 v, bool ok) {
+  const unsigned m = 0u - (unsigned)ok;
+  v.x = __uint_as_float(__float_as_uint(v.x) & m);
+  v.y = __uint_as_float(__float_as_uint(v.y) & m);
+  v.z = __uint_as_float(__float_as_uint(v.z) & m);
+  v.w = __uint_as_float(__float_as_uint(v.w) & m);
+  return v;
+}
+
 // conservative destination range [lo, hi] whose source footprint can touch index i
 __device__ __forceinline__ void dst_range(int i, float scale, int out_size, int& lo, int& hi) {
   // src(o) in [i-1, i+1)  <=>  o in [(i-0.5)/scale - 0.5, (i+1.5)/scale - 0.5)
@@ -163,6 +172,50 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
   }
 }
 
+// Separable form of the backward for large up-sampling factors (the footprint of one source
+// pixel is ~(2f+2)^2 destination pixels: 324 taps at f = 8 in the joint gather, 2 x 18 here):
+//   pass 1  tmp[b][oy][ix][c] = sum_ox wx(ox, ix) * dy[b][oy][ox][c]
+//   pass 2  dx[b][iy][ix][c]  = sum_oy wy(oy, iy) * tmp[b][oy][ix][c]
+// One axis per kernel (AXIS 1 = x, 0 = y); the destination window is walked without branches
+// (clamped loads, zero weights drop out).
+template <int AXIS>
+__global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const float* __restrict__ src,
+                                                                int64_t lds, int soff,
+                                                                float* __restrict__ dst, int B,
+                                                                int H, int Wsrc, int Wdst, int C4,
+                                                                int Hdst, float scale) {
+  // AXIS 1: src [B][H][Wsrc][lds], dst [B][H][Wdst][C] (reduce along x: Wsrc = Wo, Wdst = Wi)
+  // AXIS 0: src [B][H][Wsrc][C] with H = Ho, dst [B][Hdst][Wsrc][C]   (reduce along y)
+  const int C = C4 * 4;
+  const int rows_out = AXIS == 1 ? H : Hdst;
+  const int cols_out = AXIS == 1 ? Wdst : Wsrc;
+  const int64_t total = (int64_t)B * rows_out * cols_out * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int x = (int)(p % cols_out);
+    p /= cols_out;
+    const int y = (int)(p % rows_out);
+    const int b = (int)(p / rows_out);
+    const int idx = AXIS == 1 ? x : y;             // source-grid index this thread gathers for
+    const int n_in = AXIS == 1 ? Wdst : Hdst;      // size of the low-resolution axis
+    const int n_out = AXIS == 1 ? Wsrc : H;        // size of the high-resolution axis
+    int lo, hi;
+    dst_range(idx, scale, n_out, lo, hi);
+    float4 g = f4zero();
+    for (int o = lo; o <= hi; ++o) {
+      const float w = lin_weight(o, idx, scale, n_in, n_out);
+      const int64_t pix = AXIS == 1 ? ((int64_t)b * H + y) * Wsrc + o : ((int64_t)b * H + o) * Wsrc + x;
+      const float4 d = keep_if4(ld4(src + pix * lds + soff + c4 * 4), w != 0.f);
+      g.x = fmaf(w, d.x, g.x);
+      g.y = fmaf(w, d.y, g.y);
+      g.z = fmaf(w, d.z, g.z);
+      g.w = fmaf(w, d.w, g.w);
+    }
+    st4(dst + i * 4, g);
+  }
+}
+
 // nearest resize of integer label maps (torch 'nearest': src = min(floor(dst*in/out), in-1))
 template <typename TI>
 __global__ __launch_bounds__(256) void nearest_label_kernel(const TI* __restrict__ x,
@@ -206,13 +259,30 @@ int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, 
   return NASSEG_OK;
 }
 
-// dx [B][Hi][Wi][C] = transpose of the forward map applied to dy[..., dyoff:dyoff+C]
+// floats of workspace nasseg_bilinear_bwd wants for this geometry (0: single-pass gather)
+int64_t nasseg_bilinear_bwd_workspace(int B, int Hi, int Wi, int C, int Ho, int Wo) {
+  if (C % 4 != 0 || Ho < 3 * Hi || Wo < 3 * Wi) return 0;
+  return (int64_t)B * Ho * Wi * C;
+}
+
+// dx [B][Hi][Wi][C] = transpose of the forward map applied to dy[..., dyoff:dyoff+C].
+// ws: nasseg_bilinear_bwd_workspace() floats, or null (then always the single-pass gather).
 int nasseg_bilinear_bwd(const float* dy, int64_t lddy, int dyoff, float* dx, int B, int Hi, int Wi,
-                        int C, int Ho, int Wo, void* stream) {
+                        int C, int Ho, int Wo, float* ws, void* stream) {
   NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad shape");
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   hipStream_t s = (hipStream_t)stream;
-  if (C % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0)
+  const bool vec = C % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0;
+  if (ws && vec && nasseg_bilinear_bwd_workspace(B, Hi, Wi, C, Ho, Wo) > 0) {
+    // up-sampling by >= 3 in both directions: separable two-pass form
+    hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1>), dim3(rs_grid((int64_t)B * Ho * Wi * (C / 4))),
+                       dim3(256), 0, s, dy, lddy, dyoff, ws, B, Ho, Wo, Wi, C / 4, 0, sw);
+    hipLaunchKernelGGL((bilinear_bwd_axis_kernel<0>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
+                       dim3(256), 0, s, ws, (int64_t)C, 0, dx, B, Ho, Wi, Wi, C / 4, Hi, sh);
+    NASSEG_LAUNCH_CHECK("bilinear_bwd_axis");
+    return NASSEG_OK;
+  }
+  if (vec)
     hipLaunchKernelGGL((bilinear_bwd_kernel<4>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
                        dim3(256), 0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
   else

@@ -825,8 +825,9 @@ class _Bilinear(torch.autograd.Function):
         B, C, H, W = ctx.shape
         dy = _cl(dy)
         dx = _new(dy, B, C, H, W)
+        nws = lib.query("nasseg_bilinear_bwd_workspace", B, H, W, C, dy.shape[2], dy.shape[3])
         lib.call("nasseg_bilinear_bwd", ptr(dy), C, 0, ptr(dx), B, H, W, C, dy.shape[2],
-                 dy.shape[3], current_stream())
+                 dy.shape[3], ptr(_ws(dy, nws)) if nws else None, current_stream())
         return dx, None, None
 
 
@@ -888,7 +889,9 @@ class _ConcatResize(torch.autograd.Function):
                 lib.call("nasseg_chan_copy", ptr(dy), Ct, off, ptr(dx), C, 0, None, 0, 0,
                          B * Ho * Wo, C, ACT_NONE, ACT_NONE, s)
             else:
-                lib.call("nasseg_bilinear_bwd", ptr(dy), Ct, off, ptr(dx), B, H, W, C, Ho, Wo, s)
+                nws = lib.query("nasseg_bilinear_bwd_workspace", B, H, W, C, Ho, Wo)
+                lib.call("nasseg_bilinear_bwd", ptr(dy), Ct, off, ptr(dx), B, H, W, C, Ho, Wo,
+                         ptr(_ws(dy, nws)) if nws else None, s)
             grads.append(dx)
             off += C
         return (None, None, None) + tuple(grads)

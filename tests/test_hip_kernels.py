@@ -259,6 +259,16 @@ def test_concat_resize_with_relu():
                                                           align_corners=False), c], 1), [a, b, c])
 
 
+def test_concat_resize_large_factor_uses_the_separable_backward():
+    """x8 up-sampling into a slab: the backward reads its channel slice of the slab's gradient
+    through the two-pass (x then y) gather"""
+    a, b = rnd(2, 8, 32, 40, seed=17), rnd(2, 12, 4, 5, seed=18)
+    assert F().lib.query("nasseg_bilinear_bwd_workspace", 2, 4, 5, 12, 32, 40) > 0
+    run_pair(lambda a, b: F().concat_resize([a, b], (32, 40), relu=True),
+             lambda a, b: TF.relu(torch.cat([a, TF.interpolate(b, size=(32, 40), mode="bilinear",
+                                                               align_corners=False)], 1)), [a, b])
+
+
 def test_add_relu_paramsum_repeat():
     x, y = rnd(2, 16, 9, 11, seed=17), rnd(2, 16, 9, 11, seed=18)
     a = torch.rand(16, generator=torch.Generator().manual_seed(19)) + 0.5
