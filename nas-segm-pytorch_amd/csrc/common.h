@@ -46,6 +46,29 @@ __device__ __forceinline__ float4 act_apply4(float4 v, int act) {
   v.w = act_apply(v.w, act);
   return v;
 }
+// Activation of a fused prologue inside a hot loop: the run-time `act` becomes two loop-invariant
+// scalars (is there a clamp, and its upper bound) and a select, instead of a branch per element.
+struct ActSel {
+  bool on;
+  float hi;
+};
+__device__ __forceinline__ ActSel act_sel(int act) {
+  ActSel s;
+  s.on = act != NASSEG_ACT_NONE;
+  s.hi = act == NASSEG_ACT_RELU6 ? 6.f : __builtin_inff();
+  return s;
+}
+__device__ __forceinline__ float act_apply(float v, const ActSel& s) {
+  const float r = fminf(fmaxf(v, 0.f), s.hi);
+  return s.on ? r : v;
+}
+__device__ __forceinline__ float4 act_apply4(float4 v, const ActSel& s) {
+  v.x = act_apply(v.x, s);
+  v.y = act_apply(v.y, s);
+  v.z = act_apply(v.z, s);
+  v.w = act_apply(v.w, s);
+  return v;
+}
 // derivative mask of the activation evaluated at pre-activation value z
 __device__ __forceinline__ float act_mask(float z, int act) {
   if (act == NASSEG_ACT_RELU) return z > 0.f ? 1.f : 0.f;

@@ -85,9 +85,12 @@ __device__ __forceinline__ float4 load4(const float* row, int k, int K) {
 // by act'(...) (so the masked gradient is what gets stored) and emits the partial sums of
 // g' and g'*xhat, xhat = (z - mean)*invstd: the first half of that BatchNorm's backward at
 // the price of one read of z instead of a separate pass over g and z.
+// STATS == 3: only the act' mask of STATS == 2 (b_scale / b_shift may be null = identity): the
+// backward of an activation that was applied on load, without a pass over dx and x.
 template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, int STATS, bool WS>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
-  __shared__ float sred[(STATS != 0 && !WS) ? 4 : 1][2][(STATS != 0 && !WS) ? NT * 16 : 1];
+  constexpr bool kSums = STATS == 1 || STATS == 2;
+  __shared__ float sred[(kSums && !WS) ? 4 : 1][2][(kSums && !WS) ? NT * 16 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15;   // pixel within subtile (B operand col) / n within tile (A operand row)
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
   const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
   const int m_base = WS ? blockIdx.x * (16 * MT) : (blockIdx.x * 4 + wave) * (16 * MT);
   const bool active = m_base < Mtot;  // wave-uniform
-  if ((STATS == 0 || WS) && !active) return;
+  if ((!kSums || WS) && !active) return;
   const int n_base = WS ? (blockIdx.y * 4 + wave) * (16 * NT) : blockIdx.y * (16 * NT);
   if (WS && n_base >= a.N) return;  // (no workgroup barrier on the WS path)
 
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int ntaps = a.g.kh * a.g.kw;
+  const ActSel pact = act_sel(a.in_act);
   const int Kq = (KM == KM_FLAT) ? ntaps * a.K : a.K;  // reduction length of one pass
   const int nk = (Kq + 15) >> 4;
 
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
             const float4 s = a.in_scale ? load4<KM == KM_VEC>(a.in_scale, k, a.K)
                                         : make_float4(1.f, 1.f, 1.f, 1.f);
             const float4 h = a.in_shift ? load4<KM == KM_VEC>(a.in_shift, k, a.K) : f4zero();
-            v = act_apply4(fma4(v, s, h), a.in_act);
+            v = act_apply4(fma4(v, s, h), pact);
             if (KM != KM_VEC) {  // restore the zero padding beyond K
               v.y = keep_if(v.y, k + 1 < a.K);
               v.z = keep_if(v.z, k + 2 < a.K);
@@ -225,6 +229,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
       float bsc[4], bsh[4], bmu[4], bis[4];
       const int nb = n_base + nt * 16 + kg * 4;
       const int nbc = nb < a.N ? nb : 0;
+      if (STATS == 3) {
+        const float4 t0 = a.b_scale ? ld4(a.b_scale + nbc) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 t1 = a.b_shift ? ld4(a.b_shift + nbc) : f4zero();
+        bsc[0] = t0.x; bsc[1] = t0.y; bsc[2] = t0.z; bsc[3] = t0.w;
+        bsh[0] = t1.x; bsh[1] = t1.y; bsh[2] = t1.z; bsh[3] = t1.w;
+      }
       if (STATS == 2) {
         const float4 t0 = ld4(a.b_scale + nbc), t1 = ld4(a.b_shift + nbc), t2 = ld4(a.b_mean + nbc),
                      t3 = ld4(a.b_invstd + nbc);
@@ -236,7 +246,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const bool ok = active && (m_base + mt * 16 + j < Mtot);
-        if (STATS == 2) {
+        if (STATS == 3) {
+          const float4 z4 = ld4(a.bz + (int64_t)pm[mt] * a.ldbz + nbc);
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][nt][r] *= act_mask(fmaf(zz[r], bsc[r], bsh[r]), a.b_act);
+        } else if (STATS == 2) {
           const float4 z4 = ld4(a.bz + (int64_t)pm[mt] * a.ldbz + nbc);
           const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
@@ -257,6 +272,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
           }
         }
       }
+      if (!kSums) continue;
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) {
 #pragma unroll
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
         }
       }
     }
-    if (!WS) {
+    if (kSums && !WS) {
       __syncthreads();
       for (int t = threadIdx.x; t < NT * 16; t += 256) {
         const int n = n_base + t;
@@ -574,7 +590,7 @@ __global__ void pack_multi_kernel(PackTable t) {
 struct Mode {
   int km;
   bool gather, pro, vecn, epi;
-  int stats;  // 0 none, 1 forward BN statistics, 2 BN-backward statistics
+  int stats;  // 0 none, 1 forward BN statistics, 2 BN-backward statistics, 3 act' mask only
 };
 
 template <int MT, int NT, bool WS = false>
@@ -586,6 +602,10 @@ int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
     if (md.stats == 2) {                                                                          \
       if constexpr ((V_) && !(P_) && KM_ != KM_FLAT)                                              \
         hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 2, WS>), grid,        \
+                           dim3(256), 0, s, a);                                                   \
+    } else if (md.stats == 3) {                                                                   \
+      if constexpr ((V_) && !(P_) && KM_ != KM_FLAT)                                              \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 3, WS>), grid,        \
                            dim3(256), 0, s, a);                                                   \
     } else if (md.stats) {                                                                        \
       if constexpr (V_)                                                                           \
@@ -660,7 +680,7 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   md.stats = stats_mode;
   NASSEG_REQUIRE(!md.stats || (md.vecn && !md.epi),
                  "conv_fwd: statistics need N %% 4 == 0 and no output epilogue");
-  NASSEG_REQUIRE(md.stats != 2 || !md.pro, "conv_bwd_data_bn: no input prologue on this path");
+  NASSEG_REQUIRE(md.stats < 2 || !md.pro, "conv_bwd_data_bn: no input prologue on this path");
   if (!g.transposed && fwd_pack_mode(K, g.kh, g.kw) == 2) md.km = KM_FLAT;
   NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
                  "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
@@ -791,12 +811,14 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
 // forward conv's output channels), g and z dims (Ho,Wo) and N channels (N % 4 == 0), wp packed
 // with mode 1.  Summing the stats rows (nasseg_rows_sum) gives what nasseg_bn_bwd_reduce
 // returns; nasseg_bn_bwd_apply then takes g as its dy.
+// stats == null: only the act' mask (scale / shift may then be null = identity, mean / invstd are
+// unused) - the backward of an activation applied on load, e.g. the ReLU ahead of pre_clf.
 int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
                             const float* z, int ldz, const float* scale, const float* shift,
                             const float* mean, const float* invstd, int act, int B, int Hs, int Ws,
                             int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
                             int dil, float* stats, void* stream) {
-  NASSEG_REQUIRE(z && scale && shift && mean && invstd && stats, "conv_bwd_data_bn: null argument");
+  NASSEG_REQUIRE(z && (!stats || (scale && shift && mean && invstd)), "conv_bwd_data_bn: null argument");
   NASSEG_REQUIRE((ldz & 3) == 0 && ldz >= N, "conv_bwd_data_bn: bad ldz");
   FwdArgs a = {};
   a.x = dy; a.ldx = lddy; a.w = wp; a.y = g; a.ldy = ldg;
@@ -806,7 +828,7 @@ int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g
   a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
   a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
   a.g.transposed = 1;
-  return conv_dispatch(a, 2, (hipStream_t)stream);
+  return conv_dispatch(a, stats ? 2 : 3, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
       ftx[c] = tp - fty[c] * a.g.kw;
     }
   }
+  const ActSel pact = act_sel(a.in_act);
   float ps[VK], ph[VK];
   if (PRO) {
 #pragma unroll
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int c = 0; c < VK; ++c) {
           float v = xv[u][c];
-          if (PRO) v = act_apply(fmaf(v, ps[c], ph[c]), a.in_act);
+          if (PRO) v = act_apply(fmaf(v, ps[c], ph[c]), pact);
           xv[u][c] = keep_if(v, ok && kok[c]);
         }
 #pragma unroll

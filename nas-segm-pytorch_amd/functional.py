@@ -642,8 +642,11 @@ class _ConvChain(torch.autograd.Function):
                 # the chain's input went through an activation on load (ReLU ahead of DilConv's
                 # depthwise conv, of pre_clf's 1x1): the same epilogue with an identity BatchNorm
                 # multiplies dx by act'(x) - no separate pass over dx and x
-                one, zero = _identity_vectors(cur, K)
-                bn_prev = (cur, one, zero, zero, one, in_act0)
+                if kind == "dw":
+                    one, zero = _identity_vectors(cur, K)
+                    bn_prev = (cur, one, zero, zero, one, in_act0)
+                else:
+                    bn_prev = (cur, None, None, None, None, in_act0)  # mask-only epilogue
             if kind == "dw":
                 k = w.shape[-1]
                 if need_dw:
@@ -667,9 +670,9 @@ class _ConvChain(torch.autograd.Function):
                 if need_dx:
                     if bn_prev is not None:
                         g = _new(cur, Bc, K, H, W)
-                        nb = lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K)
-                        part = _ws(cur, (nb + 64) * 2 * K)
                         zp, psc_, psh_, pmu_, pis_, pact_ = bn_prev
+                        nb = lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K) if pmu_ is not None else 0
+                        part = _ws(cur, (nb + 64) * 2 * K) if nb else None
                         lib.call("nasseg_conv_bwd_data_bn", ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
                                  ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
                                  K, kh, kw, stride, pad, dil, ptr(part), s)

@@ -517,3 +517,24 @@ def test_depthwise_backward_data_with_bn_backward_statistics(case, act):
                f.ptr(mean), f.ptr(invstd), act, f.ptr(sums_ref), f.ptr(ws), s)
     tol = 1e-5 * float(B * H * W) ** 0.5 * float(g_ref.abs().max()) * float(invstd.max()) * 4
     assert_close(sums, sums_ref, tol, 1e-4, "bn backward sums")
+
+
+@pytest.mark.parametrize("N,act", [(64, 1), (224, 1), (24, 2)])
+def test_dense_backward_data_mask_only(N, act):
+    """nasseg_conv_bwd_data_bn without a statistics buffer: only the act' mask (identity scale/shift) -
+    the backward of a ReLU applied as the conv loaded its input"""
+    f = F()
+    B, H, W, K = 2, 16, 24, 64  # K = output channels of the forward conv, N = its input channels
+    w = rnd(K, N, 1, 1, seed=1, scale=0.2).to(DEV)
+    dy = dev(rnd(B, K, H, W, seed=2))
+    x = dev(rnd(B, N, H, W, seed=3) * 4)
+    s = f.current_stream()
+    wp = f._pack_dense(w, 1)
+    g_ref = dev(torch.empty(B, N, H, W))
+    f.lib.call("nasseg_conv_fwd", f.ptr(dy), K, f.ptr(wp), f.ptr(g_ref), N, None, None, 0, None, None, 0,
+               None, 0, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, 1, None, s)
+    g = dev(torch.empty(B, N, H, W))
+    f.lib.call("nasseg_conv_bwd_data_bn", f.ptr(dy), K, f.ptr(wp), f.ptr(g), N, f.ptr(x), N, None, None,
+               None, None, act, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, None, s)
+    mask = ((x > 0) if act == 1 else ((x > 0) & (x < 6))).float()
+    assert torch.equal(g, g_ref * mask)
