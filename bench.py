@@ -303,11 +303,14 @@ def main():
 
     roof = None
     rows = []
-    if not args.no_roofline and rank == 0:
-        lib.profiler = LaunchProfiler()
+    if not args.no_roofline:
+        # two extra untimed steps with per-launch HIP events; every rank takes them (the step
+        # contains the gradient all-reduce), only rank 0 records
+        if rank == 0:
+            lib.profiler = LaunchProfiler()
         eager_step()
         eager_step()
-        summary = lib.profiler.summary()
+        summary = lib.profiler.summary() if rank == 0 else {}
         rows = roofline_from_profile(summary)
         lib.profiler = None
         if rows:
