@@ -12,9 +12,10 @@ step.  What stays outside the graph is what genuinely needs the host or the
 network: copying the next batch into the static input buffers, the RCCL gradient
 all-reduce, and (unless ``capture_optimisers``) clipping + optimiser steps.
 
-Gradients are accumulated by autograd into ONE flat fp32 bucket that aliases the
-``param.grad`` of every parameter the loss reaches, zeroed by a memset node at the
-head of the graph and all-reduced with one collective when data parallel.
+Gradients are cleared (``grad = None``) before the capture, so backward writes them as
+fresh tensors of the graph's private pool: every replay refills the same addresses and no
+accumulation kernels are recorded.  When data parallel they are packed into one flat fp32
+bucket (one multi-tensor copy) and all-reduced with one collective after the replay.
 """
 import torch
 import torch.distributed as dist
@@ -60,13 +61,13 @@ class GraphedSegmenterStep(object):
                                        and _capturable(optim_enc) and _capturable(optim_dec))
         self.image = image.detach().clone(memory_format=torch.channels_last)
         self.target = target.detach().clone()
-        self.flat = None
+        self.flat = self._views = self._used = None
         self._capture(warmup)
 
     # -- the captured region ---------------------------------------------------------
     def _fwd_bwd(self, with_optimisers):
-        if self.flat is not None:
-            self.flat.zero_()
+        for p in self.model.parameters():
+            p.grad = None
         output = self.segmenter(self.image)
         aux_outs = []
         if isinstance(output, tuple):
@@ -81,21 +82,6 @@ class GraphedSegmenterStep(object):
         if with_optimisers:
             _clip_and_step(self.groups)
         return loss.detach()
-
-    def _attach_bucket(self):
-        """One flat fp32 bucket over the parameters the loss reaches (found by a first
-        backward from ``grad is None``); the others keep ``grad is None`` so the optimisers
-        skip them exactly as in the eager step."""
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        for p in params:
-            p.grad = None
-        self._fwd_bwd(False)
-        used = [p for p in params if p.grad is not None]
-        self.flat = torch.zeros(sum(p.numel() for p in used), device=used[0].device, dtype=used[0].dtype)
-        off = 0
-        for p in used:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
 
     def _bn_buffers(self):
         return [b for m in self.model.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)
@@ -113,7 +99,6 @@ class GraphedSegmenterStep(object):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._attach_bucket()
             for _ in range(max(1, warmup)):
                 self._fwd_bwd(self.capture_optimisers)
         torch.cuda.current_stream().wait_stream(side)
@@ -132,12 +117,25 @@ class GraphedSegmenterStep(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._fwd_bwd(self.capture_optimisers)
-        # capturing executes nothing: state is exactly as restored above
+        # capturing executes nothing: state is exactly as restored above.  The gradients the
+        # capture left in ``param.grad`` are the static tensors every replay refills.
+        self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
+        if self.world > 1:
+            used = [p for p, _ in self._static_grads]
+            self.flat = torch.zeros(sum(p.numel() for p in used), device=used[0].device,
+                                    dtype=used[0].dtype)
+            self._views, off = [], 0
+            for p in used:
+                self._views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
 
     def _all_reduce(self):
+        torch._foreach_copy_(self._views, [g for _, g in self._static_grads])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM,
                         group=getattr(self.segmenter, "process_group", None))
         self.flat.div_(self.world)
+        for (p, _), v in zip(self._static_grads, self._views):
+            p.grad = v
 
     # -- per step ----------------------------------------------------------------------
     def step(self, image=None, target=None):
@@ -146,6 +144,8 @@ class GraphedSegmenterStep(object):
         if target is not None and target.data_ptr() != self.target.data_ptr():
             self.target.copy_(target, non_blocking=True)
         self.graph.replay()
+        for p, g in self._static_grads:  # (an eager step in between may have re-pointed them)
+            p.grad = g
         if not self.capture_optimisers:
             if self.world > 1:
                 self._all_reduce()

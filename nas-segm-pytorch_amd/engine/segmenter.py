@@ -23,8 +23,9 @@ class RankParallel(nn.Module):
     Keeps the ``.module`` attribute engine code reaches through
     (``segmenter.module.encoder`` / ``.decoder``).  Each rank runs the full
     replica on its own shard of the batch; after backward, ``sync_gradients()``
-    all-reduces ONE flat fp32 bucket that aliases every ``param.grad`` (no
-    per-parameter collectives, no copy in or out) and divides by the world size.
+    packs the gradients into ONE flat fp32 bucket (one multi-tensor copy), all-reduces it
+    (no per-parameter collectives), divides by the world size and leaves every
+    ``param.grad`` pointing into the bucket.
     BatchNorm statistics stay per rank, as under nn.DataParallel; parameters and
     buffers are broadcast from rank 0 when a candidate is (re)built.
     Works un-initialised too (world size 1): every collective becomes a no-op.
@@ -68,24 +69,19 @@ class RankParallel(nn.Module):
             off += p.numel()
 
     def attach_flat_grads(self):
-        """Call instead of ``optimizer.zero_grad()``.  The first call only clears the
-        gradients: which parameters a candidate's loss actually reaches is discovered from
-        that first backward (``sync_gradients``), because parameters autograd never touches
-        must keep ``grad is None`` - the optimisers skip those, as they do under the
-        reference's nn.DataParallel - rather than receive a zero gradient plus weight decay.
-        From then on every reached ``param.grad`` is a view into one zeroed flat bucket and
-        autograd accumulates in place."""
-        if self._flat is None:
-            for p in self.module.parameters():
-                p.grad = None
-            return None
-        self._flat.zero_()
-        for p, v in zip(self._used, self._views):
-            p.grad = v
-        return self._flat
+        """Call instead of ``optimizer.zero_grad()``: clears every gradient so that autograd
+        writes fresh tensors in backward (accumulating into pre-attached views would cost one
+        small add kernel per parameter and step).  Which parameters the loss reaches is read off
+        those fresh gradients in ``sync_gradients``: parameters autograd never touches keep
+        ``grad is None`` - the optimisers skip those, as under the reference's nn.DataParallel."""
+        for p in self.module.parameters():
+            p.grad = None
+        return None
 
     def sync_gradients(self):
-        """Sum gradients across ranks and average (one collective)."""
+        """Average the gradients over the ranks with ONE collective: the fresh gradients are
+        packed into a flat fp32 bucket by one multi-tensor copy, the bucket is all-reduced and
+        every reached ``param.grad`` is re-pointed at its slice of it."""
         ws = self.world_size
         if ws == 1:
             return
@@ -98,20 +94,17 @@ class RankParallel(nn.Module):
             if not have:
                 return
             self._build_bucket(have)
-        aliased = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
-                      for p, v in zip(self._used, self._views))
-        if not aliased:
-            # first step, or grads were re-allocated (zero_grad(set_to_none)): pack them
-            for p, v in zip(self._used, self._views):
-                if p.grad is None:
-                    v.zero_()
-                else:
-                    v.copy_(p.grad)
+        src, dst = [], []
+        for p, v in zip(self._used, self._views):
+            if p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.process_group)
         self._flat.div_(ws)
-        if not aliased:
-            for p, v in zip(self._used, self._views):
-                p.grad = v
+        for p, v in zip(self._used, self._views):
+            p.grad = v
 
     def reduce_confusion(self, cm):
         """Sum the int64 confusion matrix over ranks at the end of validation."""

@@ -35,19 +35,16 @@ def _worker(rank, world, port, q):
         dist.all_gather(gathered, first)
         same_params = all(torch.equal(gathered[0], g) for g in gathered)
 
-        # step 1 discovers which parameters the loss reaches; step 2 accumulates straight
-        # into the flat bucket (path 1: grads alias it)
+        # autograd writes fresh gradients; sync packs them into the flat bucket (one multi-tensor
+        # copy), all-reduces it and leaves every reached param.grad pointing into the bucket
         x = torch.full((5, 4), float(rank + 1))
-        assert dp.attach_flat_grads() is None
+        assert dp.attach_flat_grads() is None and all(p.grad is None for p in net.parameters())
         net(x).sum().backward()
-        dp.sync_gradients()
         reached = [p for p in net.parameters() if p is not net.never_reached]
-        flat = dp.attach_flat_grads()
-        assert flat is not None and flat.numel() == sum(p.numel() for p in reached)
-        net(x).sum().backward()
-        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(reached, dp._views))
         local = [p.grad.clone() for p in reached]
         dp.sync_gradients()
+        assert dp._flat.numel() == sum(p.numel() for p in reached)
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(reached, dp._views))
         ok_alias = net.never_reached.grad is None
         for p, l in zip(reached, local):
             allg = [torch.zeros_like(l) for _ in range(world)]
