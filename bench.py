@@ -234,6 +234,8 @@ def main():
     ap.add_argument("--graph", type=int, default=0, choices=(0, 1, 2),
                     help="0 = launch every kernel from the host; 1 = replay forward+loss+backward from a "
                          "hipGraph (all-reduce, clip, optimisers outside); 2 = whole step in the graph (1 GPU)")
+    ap.add_argument("--fused-optim", type=int, default=0, choices=(0, 1),
+                    help="torch.optim fused=True implementations of SGD / Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -265,9 +267,12 @@ def main():
     segmenter, net = build_model(device, args.workload)
     segmenter.train()
     # default_args.py:57-66: SGD(lr 1e-3, mom 0.9, wd 1e-5) encoder, Adam(lr 3e-3, wd 1e-5) decoder
-    optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    # (torch.optim is the reference's optimiser too - SURVEY section 8a O1; `fused` selects its
+    # single-kernel multi-tensor implementation instead of the foreach one)
+    fused = dict(fused=True) if args.fused_optim else {}
+    optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5, **fused)
     optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5,
-                                 capturable=args.graph == 2)
+                                 capturable=args.graph == 2, **fused)
     image, mask = synthetic_batch(args.batch, args.height, args.width, rank, device, wl[2])
 
     def eager_step():

@@ -61,6 +61,12 @@ struct FwdArgs {
 
 enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
 
+// k-steps fetched per iteration of the reduction loop (compile-time; 2 was measured: requesting
+// both halves of a 128-byte line of X back to back costs more occupancy than it saves in L1)
+#ifndef NASSEG_CONV_KU
+#define NASSEG_CONV_KU 1
+#endif
+
 // 4 floats along the reduction axis starting at k (clamped, always in range); the caller
 // masks what lies beyond K
 template <bool VEC>
@@ -132,6 +138,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int ntaps = a.g.kh * a.g.kw;
+  constexpr int KU = (KM == KM_VEC) ? NASSEG_CONV_KU : 1;
   const ActSel pact = act_sel(a.in_act);
   const int Kq = (KM == KM_FLAT) ? ntaps * a.K : a.K;  // reduction length of one pass
   const int nk = (Kq + 15) >> 4;
@@ -191,30 +198,34 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
       const float* wrow[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.w + ((int64_t)tap * a.N + wn[nt]) * a.K;
-      for (int it = 0; it < nk; ++it) {
-        const int k = it * 16 + kg * 4;
-        const bool kok = k < a.K;  // (VEC: the whole float4 is in or out)
-        float4 bv[MT], av[NT];
+      for (int it = 0; it < nk; it += KU) {
+        float4 bv[KU][MT], av[KU][NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          float4 v = load4<KM == KM_VEC>(xrow[mt], k, a.K);
-          if (PRO) {
-            const float4 s = a.in_scale ? load4<KM == KM_VEC>(a.in_scale, k, a.K)
-                                        : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 h = a.in_shift ? load4<KM == KM_VEC>(a.in_shift, k, a.K) : f4zero();
-            v = act_apply4(fma4(v, s, h), pact);
-            if (KM != KM_VEC) {  // restore the zero padding beyond K
-              v.y = keep_if(v.y, k + 1 < a.K);
-              v.z = keep_if(v.z, k + 2 < a.K);
-              v.w = keep_if(v.w, k + 3 < a.K);
+        for (int u = 0; u < KU; ++u) {
+          const int k = (it + u) * 16 + kg * 4;
+          const bool kok = k < a.K;  // (VEC: the whole float4 is in or out)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            float4 v = load4<KM == KM_VEC>(xrow[mt], k, a.K);
+            if (PRO) {
+              const float4 s = a.in_scale ? load4<KM == KM_VEC>(a.in_scale, k, a.K)
+                                          : make_float4(1.f, 1.f, 1.f, 1.f);
+              const float4 h = a.in_shift ? load4<KM == KM_VEC>(a.in_shift, k, a.K) : f4zero();
+              v = act_apply4(fma4(v, s, h), pact);
+              if (KM != KM_VEC) {  // restore the zero padding beyond K
+                v.y = keep_if(v.y, k + 1 < a.K);
+                v.z = keep_if(v.z, k + 2 < a.K);
+                v.w = keep_if(v.w, k + 3 < a.K);
+              }
             }
+            bv[u][mt] = keep_if(v, xok[mt] && kok);
           }
-          bv[mt] = keep_if(v, xok[mt] && kok);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            av[u][nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          av[nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
-        mma(bv, av);
+        for (int u = 0; u < KU; ++u) mma(bv[u], av[u]);
       }
     }
   }
