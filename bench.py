@@ -31,11 +31,17 @@ WACV_ARCH1 = [[[1, 1, 0], [1, 3, 0], [3, 4, 0]],
               [[1, 1, 0, 0, 0], [0, 1, 1, 1, 1], [3, 1, 2, 3, 0], [3, 0, 2, 2, 0],
                [0, 1, 2, 0, 0], [2, 1, 1, 3, 0], [4, 0, 2, 2, 0]]]
 CVPR_ARCH0 = [[8, [0, 0, 5, 2], [0, 2, 8, 8], [0, 5, 1, 4]], [[3, 3], [3, 2], [3, 0]]]
+CVPR_ARCH2_DEPTH = [[5, [0, 0, 4, 1], [3, 2, 0, 1], [5, 6, 5, 0]], [[1, 3], [4, 3], [2, 2]]]
 # name -> (decoder kind, genotype, classes, default batch/GPU, H, W, description)
 WORKLOADS = {
     "headline": ("template", WACV_ARCH0, 19, 4, 1024, 2048, "WACV arch0 (BASELINE metric)"),
     "arch1": ("template", WACV_ARCH1, 19, 4, 1024, 2048, "WACV arch1 (BASELINE config 3 shape)"),
     "cvpr321": ("micro", CVPR_ARCH0, 21, 16, 321, 321, "CVPR arch0 VOC 321x321 bs16 (BASELINE config 2)"),
+    # one genotype sampled by the reference controller per rank (tests/golden/controller.json), search
+    # defaults (agg 48, sep repeats 1); the reward of one batch is computed with the HIP mIoU kernels
+    "search713": ("sampled", None, 19, 8, 713, 713, "sampled WACV cell per GPU, 713x713 bs8 (BASELINE config 4)"),
+    # 1-channel depth head, berHu loss (fp32 - the bf16 variant of BASELINE config 5 does not exist yet)
+    "depth480": ("micro", CVPR_ARCH2_DEPTH, 1, 8, 480, 640, "CVPR depth arch, berHu, 480x640 bs8 (BASELINE config 5, fp32)"),
 }
 NUM_CLASSES = 19
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -103,13 +109,21 @@ def build_model(device, workload="headline"):
 
     kind, genotype, classes = WORKLOADS[workload][:3]
     torch.manual_seed(0)  # random-init weights of the published architecture (no checkpoints offline)
-    if kind == "template":
+    if kind == "sampled":
+        with open(os.path.join(ROOT, "tests", "golden", "controller.json")) as fh:
+            samples = json.load(fh)["wacv"]["samples"]
+        genotype = samples[int(os.environ.get("RANK", "0")) % len(samples)]["config"]
+        enc = mbv2(pretrained=False, return_layers=[1, 2])
+        dec = TemplateDecoder(enc.out_sizes, classes, genotype, agg_size=48, repeats=1)
+    elif kind == "template":
         enc = mbv2(pretrained=False, return_layers=[1, 2])
         dec = TemplateDecoder(enc.out_sizes, classes, genotype, agg_size=64, repeats=2)
     else:
         enc = mbv2(pretrained=False)
         dec = MicroDecoder(list(enc.out_sizes), classes, genotype, agg_size=64, repeats=2)
     net = Segmenter(enc, dec).to(device)
+    if kind == "sampled":
+        return net, net  # independent candidates: nothing is broadcast or all-reduced
     return RankParallel(net), net
 
 
@@ -278,7 +292,30 @@ def main():
     def eager_step():
         return segmenter_step(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1)
 
+    if args.workload == "depth480":
+        from nas_segm_amd import functional as NF
+        from nas_segm_amd.engine.trainer import _clip_and_step, _zero_grads
+
+        with torch.no_grad():
+            probe = segmenter(image)
+            probe = probe[0] if isinstance(probe, tuple) else probe
+        depth = torch.rand(probe.shape, device=device).contiguous(memory_format=torch.channels_last) * 10.0
+        del probe
+
+        def eager_step():  # noqa: F811 - regression head: berHu instead of softmax/NLL
+            out = segmenter(image)
+            out = out[0] if isinstance(out, tuple) else out
+            loss = NF.berhu_loss(out, depth)
+            _zero_grads(segmenter, (optim_enc, optim_dec))
+            loss.backward()
+            segmenter.sync_gradients()
+            _clip_and_step([(list(net.encoder.parameters()), 3.0, optim_enc),
+                            (list(net.decoder.parameters()), 3.0, optim_dec)])
+            return loss
+
     step = eager_step
+    if args.graph and args.workload == "depth480":
+        raise SystemExit("--graph replays the softmax/NLL step; depth480 runs from the host")
     if args.graph:
         from nas_segm_amd.engine.graphed import GraphedSegmenterStep
         graphed = GraphedSegmenterStep(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
@@ -305,6 +342,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_value = float(loss.item())
+    reward = None
+    if args.workload == "search713":
+        # the candidate's reward on one batch: fused upsample -> argmax -> confusion matrix on the GPU,
+        # IoU arithmetic of the Cython module on the host (engine/inference.py)
+        from nas_segm_amd.engine.inference import validate
+        reward = float(validate(segmenter, [{"image": image, "mask": mask.to(torch.uint8)}], 0, 0,
+                                num_classes=wl[2], print_every=10 ** 9, omit_classes=[]))
+        segmenter.train()
 
     roof = None
     rows = []
@@ -378,11 +423,11 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (randn images, randint labels with a 255 band; random-init weights)",
-            "config": {"workload": "{}: {} - MobileNetV2 encoder + searched decoder (agg 64, sep repeats 2), "
+            "config": {"workload": "{}: {} - MobileNetV2 encoder + searched decoder, "
                                    "{}x3x{}x{} per GPU, train_segmenter step".format(
                                        args.workload, wl[6], args.batch, args.height, args.width),
                        "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
-                       "loss": loss_value,
+                       "loss": loss_value, "reward": reward,
                        "launch": ("host", "hipGraph(fwd+loss+bwd)", "hipGraph(whole step)")[args.graph]},
             "roofline": roof, "cpu_baseline": cpu,
         }
