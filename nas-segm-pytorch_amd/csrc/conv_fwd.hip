@@ -61,8 +61,9 @@ struct FwdArgs {
 
 enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
 
-// k-steps fetched per iteration of the reduction loop (compile-time; 2 was measured: requesting
-// both halves of a 128-byte line of X back to back costs more occupancy than it saves in L1)
+// k-steps of X fetched per iteration of the reduction loop (compile-time).  Measured: 2 and 4 are
+// both slower than 1 (224->64: 205 -> 253 us, 16->96: 228 -> 378 us at 4) - the extra operand
+// registers cost occupancy, and thread-level parallelism is what hides HBM latency here
 #ifndef NASSEG_CONV_KU
 #define NASSEG_CONV_KU 1
 #endif
@@ -199,7 +200,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.w + ((int64_t)tap * a.N + wn[nt]) * a.K;
       for (int it = 0; it < nk; it += KU) {
-        float4 bv[KU][MT], av[KU][NT];
+        // X operands of KU k-steps are requested together (bytes in flight per wave are what
+        // bounds a latency-limited stream); the weights (L1 hits) follow step by step
+        float4 bv[KU][MT];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
           const int k = (it + u) * 16 + kg * 4;
@@ -220,12 +223,18 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
             }
             bv[u][mt] = keep_if(v, xok[mt] && kok);
           }
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            av[u][nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
         }
 #pragma unroll
-        for (int u = 0; u < KU; ++u) mma(bv[u], av[u]);
+        for (int u = 0; u < KU; ++u) {
+          const int k = (it + u) * 16 + kg * 4;
+          const bool kok = k < a.K;
+          float4 av[NT];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            av[nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
+          mma(bv[u], av);
+          if (KU > 1) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
