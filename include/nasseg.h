@@ -181,6 +181,81 @@ int nasseg_argmax_cm(const float* logits, const uint8_t* gt, uint8_t* preds, int
 /* host-side (cm, iu, n_pixels, accs are HOST pointers) */
 int nasseg_compute_ius_accs(const int64_t* cm, int n, double* iu, int64_t* n_pixels, double* accs);
 
+
+/* ---- bfloat16 activation storage --------------------------------------------
+ * Every entry point above that reads or writes ACTIVATIONS (feature maps and their gradients)
+ * has a twin nasseg_bf16_<op> with the same arguments in which those tensors are stored as
+ * bfloat16 (BASELINE config 5).  Only storage changes: values are widened to fp32 on load and
+ * rounded to nearest-even on store; arithmetic, MFMA accumulation, BatchNorm statistics,
+ * parameters, parameter gradients, workspaces and every per-channel vector stay fp32, and the
+ * size / workspace queries are shared with the fp32 entry points. */
+typedef uint16_t nasseg_bf16_t;
+int nasseg_bf16_affine_act(const nasseg_bf16_t* x, const float* scale, const float* shift, const nasseg_bf16_t* res,
+                      nasseg_bf16_t* y, int64_t n, int C, int act, void* stream);
+int nasseg_bf16_bn_bwd_apply(const nasseg_bf16_t* dy, const nasseg_bf16_t* x, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* sums, int64_t M,
+                        int C, int train, int act, nasseg_bf16_t* dx, void* stream);
+int nasseg_bf16_axpby(const nasseg_bf16_t* a, const nasseg_bf16_t* b, const float* alpha, const float* beta, nasseg_bf16_t* y,
+                 int64_t n, int C, int act, void* stream);
+int nasseg_bf16_act_bwd(const nasseg_bf16_t* dy, const nasseg_bf16_t* ref, nasseg_bf16_t* dx, int64_t n, int act, void* stream);
+int nasseg_bf16_fill(nasseg_bf16_t* y, int64_t n, float v, void* stream);
+int nasseg_bf16_chan_copy(const nasseg_bf16_t* x, int64_t ldx, int xoff, nasseg_bf16_t* y, int64_t ldy, int yoff,
+                     const nasseg_bf16_t* mref, int64_t ldm, int moff, int64_t P, int C, int act, int mact,
+                     void* stream);
+int nasseg_bf16_chan_fold(const nasseg_bf16_t* dy, nasseg_bf16_t* dx, int64_t P, int C, int rep, void* stream);
+int nasseg_bf16_pool_fwd(int mode, const nasseg_bf16_t* x, nasseg_bf16_t* y, uint8_t* idx, int B, int H, int W, int C,
+                    int Ho, int Wo, int K, int stride, int pad, void* stream);
+int nasseg_bf16_pool_bwd(int mode, const nasseg_bf16_t* dy, const uint8_t* idx, nasseg_bf16_t* dx, int B, int H, int W,
+                    int C, int Ho, int Wo, int K, int stride, int pad, void* stream);
+int nasseg_bf16_bilinear_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
+                        int C, int Ho, int Wo, int act, void* stream);
+int nasseg_bf16_bilinear_bwd(const nasseg_bf16_t* dy, int64_t lddy, int dyoff, nasseg_bf16_t* dx, int B, int Hi, int Wi,
+                        int C, int Ho, int Wo, float* ws, void* stream);
+int nasseg_bf16_ce_fwd(const nasseg_bf16_t* logits, const void* target, int elem_size, int64_t P, int C,
+                  int ignore, float* out, float* ws, void* stream);
+int nasseg_bf16_ce_bwd(const nasseg_bf16_t* logits, const void* target, int elem_size, const float* stats,
+                  const float* gscale, int64_t P, int C, int ignore, nasseg_bf16_t* dlogits, void* stream);
+int nasseg_bf16_berhu_fwd(const nasseg_bf16_t* pred, const nasseg_bf16_t* target, int64_t n, float* out, float* ws,
+                     void* stream);
+int nasseg_bf16_berhu_bwd(const nasseg_bf16_t* pred, const nasseg_bf16_t* target, const float* stats,
+                     const float* gscale, int64_t n, nasseg_bf16_t* dpred, void* stream);
+int nasseg_bf16_colred(int mode, const nasseg_bf16_t* a, int64_t lda, const nasseg_bf16_t* b, int64_t ldb,
+                  const nasseg_bf16_t* c, int64_t ldc, float* out, float* ws, int S, int64_t R, int C,
+                  float mul, void* stream);
+int nasseg_bf16_bn_stats(const nasseg_bf16_t* x, int64_t ldx, int64_t M, int C, float eps, float momentum,
+                    const float* gamma, const float* beta, float* mean, float* invstd,
+                    float* scale, float* shift, float* running_mean, float* running_var,
+                    int64_t* num_batches_tracked, float* ws, void* stream);
+int nasseg_bf16_bn_bwd_reduce(const nasseg_bf16_t* dy, int64_t lddy, const nasseg_bf16_t* x, int64_t ldx, int64_t M,
+                         int C, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, int act, float* sums, float* ws, void* stream);
+int nasseg_bf16_dwconv(const nasseg_bf16_t* x, const float* wt, nasseg_bf16_t* y, const float* in_scale,
+                  const float* in_shift, int in_act, const float* scale, const float* shift, int act,
+                  int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
+                  int transposed, float* stats, void* stream);
+int nasseg_bf16_dwconv_bwd_data_bn(const nasseg_bf16_t* dy, const float* wt, nasseg_bf16_t* g, const nasseg_bf16_t* z,
+                              const float* scale, const float* shift, const float* mean,
+                              const float* invstd, int act, int B, int H, int W, int C, int Ho,
+                              int Wo, int K, int stride, int pad, int dil, int transposed,
+                              float* stats, void* stream);
+int nasseg_bf16_dwconv_wgrad(const nasseg_bf16_t* x, const nasseg_bf16_t* dy, float* dw, float* ws,
+                        const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
+                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream);
+int nasseg_bf16_conv_fwd(const nasseg_bf16_t* x, int ldx, const float* wp, nasseg_bf16_t* y, int ldy,
+                    const float* in_scale, const float* in_shift, int in_act,
+                    const float* out_scale, const float* out_shift, int out_act, const nasseg_bf16_t* res,
+                    int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
+                    int stride, int pad, int dil, int transposed, float* stats, void* stream);
+int nasseg_bf16_conv_bwd_data_bn(const nasseg_bf16_t* dy, int lddy, const float* wp, nasseg_bf16_t* g, int ldg,
+                            const nasseg_bf16_t* z, int ldz, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, int act, int B, int Hs, int Ws,
+                            int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                            int dil, float* stats, void* stream);
+int nasseg_bf16_conv_wgrad(const nasseg_bf16_t* x, int ldx, const nasseg_bf16_t* dy, int lddy, float* dw, float* ws,
+                      const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
+                      int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                      int dil, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,11 +31,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-    deps = [src, os.path.join(CSRC, "common.h"), os.path.abspath(__file__)]
+# sources whose entry points never touch activations: compiled once (fp32 build only)
+FP32_ONLY_SOURCES = ("capi.cpp", "miou.hip")
+
+
+def _compile(job):
+    """job = (source, bf16): every kernel source is compiled twice - activations stored as fp32
+    (nasseg_<op>) and as bfloat16 (-DNASSEG_BF16, nasseg_bf16_<op>); see csrc/common.h."""
+    src, bf16 = job
+    obj = os.path.join(OBJ_DIR, os.path.basename(src) + (".bf16.o" if bf16 else ".o"))
+    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
+            os.path.abspath(__file__)]
     if _stale(obj, deps):
-        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + (["-DNASSEG_BF16"] if bf16 else []) + ["-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for {}:\n{}\n{}".format(src, r.stdout, r.stderr))
@@ -49,8 +57,10 @@ def build_library(force=False, verbose=False):
         for f in os.listdir(OBJ_DIR):
             os.remove(os.path.join(OBJ_DIR, f))
     srcs = sources()
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
+    jobs = [(f, False) for f in srcs] + [(f, True) for f in srcs
+                                         if os.path.basename(f) not in FP32_ONLY_SOURCES]
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        objs = list(ex.map(_compile, jobs))
     if force or _stale(LIB_PATH, objs):
         cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB_PATH] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,6 +1,6 @@
 // Shared device/host helpers for the nasseg gfx950 kernels.
-// All activations are fp32 NHWC ("channels_last"): element (b, y, x, c) of a
-// tensor with pixel stride ld lives at ((b*H + y)*W + x)*ld + c.
+// All activations are NHWC ("channels_last"), fp32 or bf16 storage (act_t below): element
+// (b, y, x, c) of a tensor with pixel stride ld lives at ((b*H + y)*W + x)*ld + c.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -77,6 +77,51 @@ __device__ __forceinline__ float act_mask(float z, int act) {
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------
+// Storage type of ACTIVATIONS (feature maps and their gradients).  Every source file is
+// compiled twice: act_t = float exports nasseg_<op>, act_t = bfloat16 (-DNASSEG_BF16) exports
+// the twin nasseg_bf16_<op> with identical arguments.  Only storage changes: values are
+// widened to fp32 on load and rounded to nearest-even on store; all arithmetic, the MFMA
+// accumulation, statistics, parameters, parameter gradients and workspaces stay fp32.
+// bf16_t is a struct so that an activation can never be read as a number by accident.
+// ---------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+#ifdef NASSEG_BF16
+typedef bf16_t act_t;
+#define NASSEG_FN(name) nasseg_bf16_##name
+#define NASSEG_FP32_ONLY 0
+#else
+typedef float act_t;
+#define NASSEG_FN(name) nasseg_##name
+#define NASSEG_FP32_ONLY 1  // entry points that never touch activations exist once, in this build
+#endif
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
+  const uint32_t u = __float_as_uint(f);
+  const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;  // round to nearest even
+  return (f != f) ? 0x7fc0u : r;                                // (NaN stays NaN)
+}
+__device__ __forceinline__ float lda1(const float* p) { return *p; }
+__device__ __forceinline__ float lda1(const bf16_t* p) { return bf16_to_f32(p->v); }
+__device__ __forceinline__ void sta1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void sta1(bf16_t* p, float v) { p->v = (uint16_t)f32_to_bf16(v); }
+__device__ __forceinline__ float4 lda4(const float* p) { return ld4(p); }
+__device__ __forceinline__ float4 lda4(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void sta4(float* p, float4 v) { st4(p, v); }
+__device__ __forceinline__ void sta4(bf16_t* p, float4 v) {
+  uint2 u;
+  u.x = f32_to_bf16(v.x) | (f32_to_bf16(v.y) << 16);
+  u.y = f32_to_bf16(v.z) | (f32_to_bf16(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
   c.x = fmaf(a.x, b.x, c.x);

@@ -32,10 +32,10 @@
 namespace {
 
 struct FwdArgs {
-  const float* x;
+  const act_t* x;  // activations: fp32 or bf16 storage (common.h)
   int ldx;
   const float* w;
-  float* y;
+  act_t* y;
   int ldy;
   const float* in_scale;
   const float* in_shift;
@@ -43,12 +43,12 @@ struct FwdArgs {
   const float* out_scale;
   const float* out_shift;
   int out_act;
-  const float* res;
+  const act_t* res;
   int ldres;
   float* stats;  // optional [gridDim.x][2][N]: per-workgroup partial sums (see STATS)
   // STATS == 2: the BatchNorm whose backward statistics are gathered (y is the gradient
   // w.r.t. act(b_scale*bz + b_shift))
-  const float* bz;
+  const act_t* bz;
   int ldbz;
   const float* b_scale;
   const float* b_shift;
@@ -73,7 +73,7 @@ enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
 template <bool VEC>
 __device__ __forceinline__ float4 load4(const float* row, int k, int K) {
   if (VEC) {
-    return ld4(row + (k < K ? k : 0));
+    return lda4(row + (k < K ? k : 0));
   } else {
     float4 v;
     v.x = keep_if(row[k + 0 < K ? k + 0 : 0], k + 0 < K);
@@ -83,6 +83,22 @@ __device__ __forceinline__ float4 load4(const float* row, int k, int K) {
     return v;
   }
 }
+
+#ifdef NASSEG_BF16
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const bf16_t* row, int k, int K) {
+  if (VEC) {
+    return lda4(row + (k < K ? k : 0));
+  } else {
+    float4 v;
+    v.x = keep_if(lda1(row + (k + 0 < K ? k + 0 : 0)), k + 0 < K);
+    v.y = keep_if(lda1(row + (k + 1 < K ? k + 1 : 0)), k + 1 < K);
+    v.z = keep_if(lda1(row + (k + 2 < K ? k + 2 : 0)), k + 2 < K);
+    v.w = keep_if(lda1(row + (k + 3 < K ? k + 3 : 0)), k + 3 < K);
+    return v;
+  }
+}
+#endif
 
 // EPI: any output epilogue (scale / shift(bias) / activation / residual) is present.
 // STATS == 1: also emit per-workgroup partial sums of y and y^2 per output channel - the
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
           const int tap = kq / a.K, cin = kq - tap * a.K;
           const int ty = tap / a.g.kw, tx = tap - ty * a.g.kw;
           const int sp = src_pixel(a.g, pb[mt], py[mt], px[mt], ty, tx);
-          const float v = a.x[(int64_t)(sp < 0 ? 0 : sp) * a.ldx + cin];
+          const float v = lda1(a.x + (int64_t)(sp < 0 ? 0 : sp) * a.ldx + cin);
           e[c] = keep_if(v, sp >= 0 && k + c < Kq);
         }
         bv[mt] = make_float4(e[0], e[1], e[2], e[3]);
@@ -182,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     }
   } else {
     for (int tap = 0; tap < (GATHER ? ntaps : 1); ++tap) {
-      const float* xrow[MT];
+      const act_t* xrow[MT];
       bool xok[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -250,14 +266,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
       const int nb = n_base + nt * 16 + kg * 4;
       const int nbc = nb < a.N ? nb : 0;
       if (STATS == 3) {
-        const float4 t0 = a.b_scale ? ld4(a.b_scale + nbc) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float4 t1 = a.b_shift ? ld4(a.b_shift + nbc) : f4zero();
+        const float4 t0 = a.b_scale ? lda4(a.b_scale + nbc) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 t1 = a.b_shift ? lda4(a.b_shift + nbc) : f4zero();
         bsc[0] = t0.x; bsc[1] = t0.y; bsc[2] = t0.z; bsc[3] = t0.w;
         bsh[0] = t1.x; bsh[1] = t1.y; bsh[2] = t1.z; bsh[3] = t1.w;
       }
       if (STATS == 2) {
-        const float4 t0 = ld4(a.b_scale + nbc), t1 = ld4(a.b_shift + nbc), t2 = ld4(a.b_mean + nbc),
-                     t3 = ld4(a.b_invstd + nbc);
+        const float4 t0 = lda4(a.b_scale + nbc), t1 = lda4(a.b_shift + nbc), t2 = lda4(a.b_mean + nbc),
+                     t3 = lda4(a.b_invstd + nbc);
         bsc[0] = t0.x; bsc[1] = t0.y; bsc[2] = t0.z; bsc[3] = t0.w;
         bsh[0] = t1.x; bsh[1] = t1.y; bsh[2] = t1.z; bsh[3] = t1.w;
         bmu[0] = t2.x; bmu[1] = t2.y; bmu[2] = t2.z; bmu[3] = t2.w;
@@ -267,12 +283,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
       for (int mt = 0; mt < MT; ++mt) {
         const bool ok = active && (m_base + mt * 16 + j < Mtot);
         if (STATS == 3) {
-          const float4 z4 = ld4(a.bz + (int64_t)pm[mt] * a.ldbz + nbc);
+          const float4 z4 = lda4(a.bz + (int64_t)pm[mt] * a.ldbz + nbc);
           const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[mt][nt][r] *= act_mask(fmaf(zz[r], bsc[r], bsh[r]), a.b_act);
         } else if (STATS == 2) {
-          const float4 z4 = ld4(a.bz + (int64_t)pm[mt] * a.ldbz + nbc);
+          const float4 z4 = lda4(a.bz + (int64_t)pm[mt] * a.ldbz + nbc);
           const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -305,18 +321,20 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
         // this wave alone owns these channels of the workgroup's pixels
         if (j == 0 && nb < a.N) {
           float* po = a.stats + (int64_t)blockIdx.x * 2 * a.N + nb;
-          st4(po, make_float4(sx[0], sx[1], sx[2], sx[3]));
-          st4(po + a.N, make_float4(sq[0], sq[1], sq[2], sq[3]));
+          sta4(po, make_float4(sx[0], sx[1], sx[2], sx[3]));
+          sta4(po + a.N, make_float4(sq[0], sq[1], sq[2], sq[3]));
         }
-      } else if (j == 0) {
+      } else if constexpr (kSums) {
+        if (j == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sred[wave][0][nt * 16 + kg * 4 + r] = sx[r];
-          sred[wave][1][nt * 16 + kg * 4 + r] = sq[r];
+          for (int r = 0; r < 4; ++r) {
+            sred[wave][0][nt * 16 + kg * 4 + r] = sx[r];
+            sred[wave][1][nt * 16 + kg * 4 + r] = sq[r];
+          }
         }
       }
     }
-    if (kSums && !WS) {
+    if constexpr (kSums && !WS) {
       __syncthreads();
       for (int t = threadIdx.x; t < NT * 16; t += 256) {
         const int n = n_base + t;
@@ -340,22 +358,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
       for (int mt = 0; mt < MT; ++mt) {
         const int m = m_base + mt * 16 + j;
         const f32x4 c = acc[mt][nt];
-        if (nok && m < Mtot) st4(a.y + (int64_t)m * a.ldy + n, make_float4(c[0], c[1], c[2], c[3]));
+        if (nok && m < Mtot) sta4(a.y + (int64_t)m * a.ldy + n, make_float4(c[0], c[1], c[2], c[3]));
       }
     } else if (VECN) {
       const bool nok = n < a.N;
       const int nc = nok ? n : 0;
       float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
-      if (a.out_scale) sc = ld4(a.out_scale + nc);
-      if (a.out_shift) sh = ld4(a.out_shift + nc);
+      if (a.out_scale) sc = lda4(a.out_scale + nc);
+      if (a.out_shift) sh = lda4(a.out_shift + nc);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = m_base + mt * 16 + j;
         const f32x4 c = acc[mt][nt];
         float4 o = fma4(make_float4(c[0], c[1], c[2], c[3]), sc, sh);
         if (a.out_act) o = act_apply4(o, a.out_act);
-        if (a.res) o = add4(o, ld4(a.res + (int64_t)pm[mt] * a.ldres + nc));
-        if (nok && m < Mtot) st4(a.y + (int64_t)m * a.ldy + n, o);
+        if (a.res) o = add4(o, lda4(a.res + (int64_t)pm[mt] * a.ldres + nc));
+        if (nok && m < Mtot) sta4(a.y + (int64_t)m * a.ldy + n, o);
       }
     } else {
 #pragma unroll
@@ -370,8 +388,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
           if (a.out_scale) v *= a.out_scale[nc];
           if (a.out_shift) v += a.out_shift[nc];
           if (a.out_act) v = act_apply(v, a.out_act);
-          if (a.res) v += a.res[(int64_t)pm[mt] * a.ldres + nc];
-          if (ok) a.y[(int64_t)m * a.ldy + n + r] = v;
+          if (a.res) v += lda1(a.res + (int64_t)pm[mt] * a.ldres + nc);
+          if (ok) sta1(a.y + (int64_t)m * a.ldy + n + r, v);
         }
       }
     }
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float* xb = a.x + (int64_t)b * H * W * a.ldx;
+  const act_t* xb = a.x + (int64_t)b * H * W * a.ldx;
   for (int kc0 = 0; kc0 < a.K; kc0 += kLdsKC) {
     if (kc0) __syncthreads();
     for (int idx = threadIdx.x; idx < TR * TC * (kLdsKC / 4); idx += 256) {
@@ -463,7 +481,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
       const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
       const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
       const int k = kc0 + q * 4;
-      const float* src = xb + ((int64_t)iyc * W + ixc) * a.ldx;
+      const act_t* src = xb + ((int64_t)iyc * W + ixc) * a.ldx;
       float4 v = load4<VECK>(src, k, a.K);
       if (!VECK) {
         v.y = keep_if(v.y, k + 1 < a.K);
@@ -525,11 +543,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
         const bool nok = n < a.N;
         const int nc = nok ? n : 0;
         float4 o = make_float4(c[0], c[1], c[2], c[3]);
-        if (a.out_scale) o = fma4(o, ld4(a.out_scale + nc), f4zero());
-        if (a.out_shift) o = add4(o, ld4(a.out_shift + nc));
+        if (a.out_scale) o = fma4(o, lda4(a.out_scale + nc), f4zero());
+        if (a.out_shift) o = add4(o, lda4(a.out_shift + nc));
         if (a.out_act) o = act_apply4(o, a.out_act);
-        if (a.res) o = add4(o, ld4(a.res + m * a.ldres + nc));
-        if (nok && pok) st4(a.y + m * a.ldy + n, o);
+        if (a.res) o = add4(o, lda4(a.res + m * a.ldres + nc));
+        if (nok && pok) sta4(a.y + m * a.ldy + n, o);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -539,8 +557,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
           if (a.out_scale) v *= a.out_scale[nc];
           if (a.out_shift) v += a.out_shift[nc];
           if (a.out_act) v = act_apply(v, a.out_act);
-          if (a.res) v += a.res[m * a.ldres + nc];
-          if (ok) a.y[m * a.ldy + n + r] = v;
+          if (a.res) v += lda1(a.res + m * a.ldres + nc);
+          if (ok) sta1(a.y + m * a.ldy + n + r, v);
         }
       }
     }
@@ -729,6 +747,7 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
 
 extern "C" {
 
+#if NASSEG_FP32_ONLY
 // mode 0: [tap][N][K]; mode 1: backward-data [tap][K][N]; mode 2: flat [N][tap*K+k]
 int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int kw, int mode,
                             void* stream) {
@@ -740,7 +759,9 @@ int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int
   NASSEG_LAUNCH_CHECK("conv_pack_weight");
   return NASSEG_OK;
 }
+#endif  // NASSEG_FP32_ONLY
 
+#if NASSEG_FP32_ONLY
 // count tensors in one launch.  w[i] / wp[i]: device pointers (host arrays of pointers);
 // dims[7*i..] = N, K, kh, kw, kind, Ksrc, koff: the K input channels [koff, koff+K) of a source
 // weight with Ksrc input channels are packed (Ksrc = 0 means the whole weight: Ksrc = K, koff = 0
@@ -781,16 +802,21 @@ int nasseg_pack_weights(int count, const float* const* w, float* const* wp, cons
   }
   return NASSEG_OK;
 }
+#endif  // NASSEG_FP32_ONLY
 
+#if NASSEG_FP32_ONLY
 // number of per-workgroup statistic rows nasseg_conv_fwd writes for this geometry
 int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N) {
   const int64_t Mtot = (int64_t)B * Ho * Wo;
   const int tiles = cdiv(N, 16);
   return cdiv64(Mtot, (tiles > 4 ? 16 : 64) * pick_mt(Mtot, tiles));
 }
+#endif  // NASSEG_FP32_ONLY
 
+#if NASSEG_FP32_ONLY
 // which packing nasseg_conv_fwd expects for a forward (non-transposed) convolution
 int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) { return fwd_pack_mode(K, kh, kw); }
+#endif  // NASSEG_FP32_ONLY
 
 // y[dst pixel][n] = out_act(out_scale[n] * sum_{tap,k} w[tap][n][k] *
 //                   in_act(in_scale[k] * x[src pixel(tap)][k] + in_shift[k]) + out_shift[n])
@@ -805,9 +831,9 @@ int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) { return fwd_pack_mode(K, k
 // stats != null (needs N % 4 == 0 and no output epilogue): also writes
 //   stats[blk][0][n] = sum over the workgroup's pixels of y[.][n], stats[blk][1][n] = sum of y^2
 // for blk < nasseg_conv_fwd_stats_blocks(...) - the partials nasseg_bn_finalize consumes.
-int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
+int NASSEG_FN(conv_fwd)(const act_t* x, int ldx, const float* wp, act_t* y, int ldy,
                     const float* in_scale, const float* in_shift, int in_act,
-                    const float* out_scale, const float* out_shift, int out_act, const float* res,
+                    const float* out_scale, const float* out_shift, int out_act, const act_t* res,
                     int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
                     int stride, int pad, int dil, int transposed, float* stats, void* stream) {
   FwdArgs a = {};
@@ -833,8 +859,8 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
 // returns; nasseg_bn_bwd_apply then takes g as its dy.
 // stats == null: only the act' mask (scale / shift may then be null = identity, mean / invstd are
 // unused) - the backward of an activation applied on load, e.g. the ReLU ahead of pre_clf.
-int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
-                            const float* z, int ldz, const float* scale, const float* shift,
+int NASSEG_FN(conv_bwd_data_bn)(const act_t* dy, int lddy, const float* wp, act_t* g, int ldg,
+                            const act_t* z, int ldz, const float* scale, const float* shift,
                             const float* mean, const float* invstd, int act, int B, int Hs, int Ws,
                             int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
                             int dil, float* stats, void* stream) {

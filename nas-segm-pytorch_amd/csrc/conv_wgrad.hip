@@ -16,9 +16,9 @@
 namespace {
 
 struct WgArgs {
-  const float* x;   // forward input  [B][Hs][Ws][ldx], K channels
+  const act_t* x;  // activations: fp32 or bf16 storage (common.h)   // forward input  [B][Hs][Ws][ldx], K channels
   int ldx;
-  const float* dy;  // grad of forward output [B][Ho][Wo][lddy], N channels
+  const act_t* dy;  // grad of forward output [B][Ho][Wo][lddy], N channels
   int lddy;
   float* partial;
   const float* in_scale;
@@ -31,10 +31,26 @@ struct WgArgs {
 };
 
 // out[0..V) = p[i0..i0+V) from a clamped address; caller masks.  AL: V-aligned vector load.
+#ifdef NASSEG_BF16
+template <int V, bool AL>
+__device__ __forceinline__ void load_vec(const bf16_t* p, int i0, int len, float* out) {
+  if (AL && V == 4) {
+    const float4 v = lda4(p + (i0 < len ? i0 : 0));
+    out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+  } else if (AL && V == 2) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p + (i0 < len ? i0 : 0));
+    out[0] = __uint_as_float(u << 16);
+    out[1] = __uint_as_float(u & 0xffff0000u);
+  } else {
+#pragma unroll
+    for (int c = 0; c < V; ++c) out[c] = lda1(p + (i0 + c < len ? i0 + c : 0));
+  }
+}
+#endif
 template <int V, bool AL>
 __device__ __forceinline__ void load_vec(const float* p, int i0, int len, float* out) {
   if (AL && V == 4) {
-    const float4 v = ld4(p + (i0 < len ? i0 : 0));
+    const float4 v = lda4(p + (i0 < len ? i0 : 0));
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
   } else if (AL && V == 2) {
     const float2 v = *reinterpret_cast<const float2*>(p + (i0 < len ? i0 : 0));
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int c = 0; c < VK; ++c) {
           const int sp = src_pixel(a.g, b, oy, ox, fty[c], ftx[c]);
-          const float v = a.x[(int64_t)(sp < 0 ? 0 : sp) * a.ldx + fcin[c]];
+          const float v = lda1(a.x + (int64_t)(sp < 0 ? 0 : sp) * a.ldx + fcin[c]);
           xv[u][c] = keep_if(v, pok && kok[c] && sp >= 0);
         }
 #pragma unroll
@@ -275,15 +291,17 @@ inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps) {
 
 extern "C" {
 
+#if NASSEG_FP32_ONLY
 // floats of workspace needed by nasseg_conv_wgrad
 int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw) {
   WgPlan p = wgrad_plan((int64_t)B * Ho * Wo, N, K, kh * kw);
   return (int64_t)p.nslab * kh * kw * N * K;
 }
+#endif  // NASSEG_FP32_ONLY
 
 // dw (N,K,kh,kw) = sum_pixels dy[pixel][n] * in_act(in_scale*x[src(pixel,tap)][k]+in_shift)
 // (the input prologue is available for pointwise convs with K % 4 == 0 and N % 4 == 0)
-int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
+int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
                       int dil, void* stream) {

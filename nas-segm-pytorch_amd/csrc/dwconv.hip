@@ -56,8 +56,8 @@ struct Prologue {
 __device__ __forceinline__ Prologue make_prologue(const float* scale, const float* shift, int act,
                                                   int c4) {
   Prologue p;
-  p.sc = scale ? ld4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-  p.sh = shift ? ld4(shift + c4 * 4) : f4zero();
+  p.sc = scale ? lda4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+  p.sh = shift ? lda4(shift + c4 * 4) : f4zero();
   p.lo = act ? 0.f : -INFINITY;
   p.hi = act == NASSEG_ACT_RELU6 ? 6.f : INFINITY;
   return p;
@@ -75,7 +75,7 @@ __device__ __forceinline__ float4 apply_prologue(float4 v, const Prologue& p) {
 // value written is g' = g * act'(scale*z + shift) and the workgroup's partial sums of g' and
 // g' * (z - mean) * invstd go to stats[blk][2][C] (see nasseg_dwconv_bwd_data_bn).
 struct BnBwd {
-  const float* z;
+  const act_t* z;
   const float* scale;
   const float* shift;
   const float* mean;
@@ -87,10 +87,10 @@ struct BnBwdLane {
 };
 __device__ __forceinline__ BnBwdLane bnbwd_lane(const BnBwd& bn, int c4) {
   BnBwdLane l;
-  l.sc = ld4(bn.scale + c4 * 4);
-  l.sh = ld4(bn.shift + c4 * 4);
-  l.mu = ld4(bn.mean + c4 * 4);
-  l.is = ld4(bn.invstd + c4 * 4);
+  l.sc = lda4(bn.scale + c4 * 4);
+  l.sh = lda4(bn.shift + c4 * 4);
+  l.mu = lda4(bn.mean + c4 * 4);
+  l.is = lda4(bn.invstd + c4 * 4);
   return l;
 }
 // masks g in place; adds keep_if(g', ok) and its product with xhat to ssum[0], ssum[1]
@@ -169,7 +169,7 @@ __device__ __forceinline__ void block_reduce_groups(float4 (&acc)[NV], float4 (*
         for (int u = 0; u < RB; ++u) {
           const float4 s = add4(add4(red[u][0][tid], red[u][1][tid]),
                                 add4(red[u][2][tid], red[u][3][tid]));
-          st4(out + (size_t)(r * RB + u) * C + tid * 4, s);
+          sta4(out + (size_t)(r * RB + u) * C + tid * 4, s);
         }
       }
     }
@@ -186,7 +186,7 @@ __device__ __forceinline__ void block_reduce_groups(float4 (&acc)[NV], float4 (*
       if (tid < nsum) {
         float4 s = f4zero();
         for (int u = tid; u < 256; u += C4) s = add4(s, flat[u]);
-        st4(out + (size_t)t * C + cc * 4, s);
+        sta4(out + (size_t)t * C + cc * 4, s);
       }
     }
   }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void block_reduce_groups(float4 (&acc)[NV], float4 (*
 // stats[blk][2][C]; STATS == 2: BatchNorm-backward statistics of `bn` (y is a gradient).
 template <int K, int P, int E, bool WLDS, bool PRO, int STATS>
 __global__ __launch_bounds__(256) void dw_fwd_strip(
-    const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ y,
+    const act_t* __restrict__ x, const float* __restrict__ wt, act_t* __restrict__ y,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ scale, const float* __restrict__ shift, int H, int W, int C4, int Ho,
     int Wo, int stride, int pad, int dil, int g, int nchunk, int act, float* __restrict__ stats,
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   if (WLDS) {
     for (int i = threadIdx.x; i < K * K * C4; i += 256) {
       const int t = i / C4, c = i - t * C4;
-      lw[t][c] = ld4(wt + (size_t)t * C + c * 4);
+      lw[t][c] = lda4(wt + (size_t)t * C + c * 4);
     }
     __syncthreads();
   }
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   float4 w[WLDS ? 1 : K * K];
   if (!WLDS) {
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) w[t] = ld4(wt + (size_t)t * C + c4 * 4);
+    for (int t = 0; t < K * K; ++t) w[t] = lda4(wt + (size_t)t * C + c4 * 4);
   }
   Prologue pro;
   if (PRO) pro = make_prologue(in_scale, in_shift, in_act, c4);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
 #pragma unroll
   for (int j = 0; j < P; ++j) acc[j] = f4zero();
 
-  const float* xb = x + (size_t)b * H * W * C + c4 * 4;
+  const act_t* xb = x + (size_t)b * H * W * C + c4 * 4;
   const int iy0 = oy0 * stride - pad;
   constexpr int Q = (P - 1) * E + K;
   // One input row ahead: the loads of row q+1 are issued before the FMAs of row q and a
@@ -263,10 +263,10 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   auto load_row = [&](int q, float4* v) {
     const int iy = iy0 + q * dil;
     const bool yok = (iy >= 0) && (iy < H);
-    const float* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
+    const act_t* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
     for (int tx = 0; tx < K; ++tx) {
-      float4 t = ld4(xr + xoff[tx]);
+      float4 t = lda4(xr + xoff[tx]);
       if (PRO) t = apply_prologue(t, pro);
       v[tx] = keep_if(t, yok && xok[tx]);  // zero padding applies to the prologue's output
     }
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     for (int tx = 0; tx < K; ++tx) vcur[tx] = vnext[tx];
   }
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
-  if (scale) sc = ld4(scale + c4 * 4);
-  if (shift) sh = ld4(shift + c4 * 4);
+  if (scale) sc = lda4(scale + c4 * 4);
+  if (shift) sh = lda4(shift + c4 * 4);
   float4 ssum[2] = {f4zero(), f4zero()};
   BnBwdLane bl;
   if (STATS == 2) bl = bnbwd_lane(bn, c4);
@@ -310,10 +310,10 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     }
     if (STATS == 2) {
       const int oyc = oy < Ho ? oy : Ho - 1;  // (unconditional load from a valid address)
-      const float4 z = ld4(bn.z + (((size_t)b * Ho + oyc) * Wo + ox) * C + c4 * 4);
+      const float4 z = lda4(bn.z + (((size_t)b * Ho + oyc) * Wo + ox) * C + c4 * 4);
       bnbwd_accumulate(o, z, bl, bn.act, ok, ssum);
     }
-    if (ok) st4(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4, o);
+    if (ok) sta4(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4, o);
   }
   if constexpr (STATS != 0) {
     const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -331,9 +331,9 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
 // BST: BatchNorm-backward statistics epilogue (the host makes gridDim.x * 256 a multiple of
 // C4 so that a thread keeps its channel group over the grid-stride loop).
 template <int K, bool BST>
-__global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void dw_bwd_data_s2(const act_t* __restrict__ dy,
                                                       const float* __restrict__ wt,
-                                                      float* __restrict__ dx, int B, int Ho, int Wo,
+                                                      act_t* __restrict__ dx, int B, int Ho, int Wo,
                                                       int C4, int H, int W, float* __restrict__ stats,
                                                       BnBwd bn) {
   __shared__ float4 sred[BST ? 2 : 1][BST ? 4 : 1][BST ? 64 : 1];
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ 
         const int oy = aq - LO + ry, ox = bq - LO + rx;
         const bool ok = oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
         const int oyc = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), oxc = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
-        d[ry][rx] = keep_if(ld4(dy + (((int64_t)b * Ho + oyc) * Wo + oxc) * C + c4 * 4), ok);
+        d[ry][rx] = keep_if(lda4(dy + (((int64_t)b * Ho + oyc) * Wo + oxc) * C + c4 * 4), ok);
       }
     float4 o[2][2];
 #pragma unroll
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ 
       for (int tx = 0; tx < K; ++tx) {
         const int py = (ty + PAD) & 1, px = (tx + PAD) & 1;  // parity this tap feeds
         const int ry = (py + PAD - ty) / 2 + LO, rx = (px + PAD - tx) / 2 + LO;
-        o[py][px] = fma4(ld4(wt + (size_t)(ty * K + tx) * C + c4 * 4), d[ry][rx], o[py][px]);
+        o[py][px] = fma4(lda4(wt + (size_t)(ty * K + tx) * C + c4 * 4), d[ry][rx], o[py][px]);
       }
 #pragma unroll
     for (int py = 0; py < 2; ++py)
@@ -386,10 +386,10 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ 
         const bool ok = iy < H && ix < W;
         if (BST) {
           const int iyc = iy < H ? iy : H - 1, ixc = ix < W ? ix : W - 1;
-          const float4 z = ld4(bn.z + (((int64_t)b * H + iyc) * W + ixc) * C + c4 * 4);
+          const float4 z = lda4(bn.z + (((int64_t)b * H + iyc) * W + ixc) * C + c4 * 4);
           bnbwd_accumulate(o[py][px], z, bl, bn.act, ok, ssum);
         }
-        if (ok) st4(dx + (((int64_t)b * H + iy) * W + ix) * C + c4 * 4, o[py][px]);
+        if (ok) sta4(dx + (((int64_t)b * H + iy) * W + ix) * C + c4 * 4, o[py][px]);
       }
   }
   if constexpr (BST)
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2(const float* __restrict__ 
 // (H, W) are the dims of the tensor read, (Ho, Wo) of the tensor written.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dw_generic(
-    const float* __restrict__ x, const float* __restrict__ wt, float* __restrict__ y,
+    const act_t* __restrict__ x, const float* __restrict__ wt, act_t* __restrict__ y,
     const float* __restrict__ scale, const float* __restrict__ shift, int B, int H, int W, int C4,
     int Ho, int Wo, int K, int stride, int pad, int dil, int transposed, int relu_in, int act) {  // relu_in: input ReLU
   const int C = C4 * 4;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void dw_generic(
     p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    const float* xb = x + (size_t)b * H * W * C + c4 * 4;
+    const act_t* xb = x + (size_t)b * H * W * C + c4 * 4;
     float4 acc = f4zero();
     for (int ty = 0; ty < K; ++ty) {
       int iy;
@@ -445,16 +445,16 @@ __global__ __launch_bounds__(256) void dw_generic(
           ok = ok && ix < W;
         }
         if (!ok) continue;
-        float4 v = ld4(xb + ((size_t)iy * W + ix) * C);
+        float4 v = lda4(xb + ((size_t)iy * W + ix) * C);
         if (relu_in) v = relu4(v);
-        acc = fma4(ld4(wt + (size_t)(ty * K + tx) * C + c4 * 4), v, acc);
+        acc = fma4(lda4(wt + (size_t)(ty * K + tx) * C + c4 * 4), v, acc);
       }
     }
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
-    if (scale) sc = ld4(scale + c4 * 4);
-    if (shift) sh = ld4(shift + c4 * 4);
+    if (scale) sc = lda4(scale + c4 * 4);
+    if (shift) sh = lda4(shift + c4 * 4);
     float4 o = act_apply4(fma4(acc, sc, sh), act);
-    st4(y + i * 4, o);
+    sta4(y + i * 4, o);
   }
 }
 
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void dw_generic(
 // ---------------------------------------------------------------------------
 template <int K, int P, int E, bool PRO>
 __global__ __launch_bounds__(256) void dw_wgrad_strip(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+    const act_t* __restrict__ x, const act_t* __restrict__ dy, float* __restrict__ partial,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act, int B,
     int H, int W, int C4, int Ho, int Wo, int stride, int pad, int dil, int g, int nchunk) {
   __shared__ float4 red[K][4][64];
@@ -504,18 +504,18 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int oy = oy0 + j * g;
-      d[j] = keep_if(ld4(dy + (((size_t)b * Ho + (oy < Ho ? oy : Ho - 1)) * Wo + ox) * C + c4 * 4),
+      d[j] = keep_if(lda4(dy + (((size_t)b * Ho + (oy < Ho ? oy : Ho - 1)) * Wo + ox) * C + c4 * 4),
                      oy < Ho);
     }
-    const float* xb = x + (size_t)b * H * W * C + c4 * 4;
+    const act_t* xb = x + (size_t)b * H * W * C + c4 * 4;
     const int iy0 = oy0 * stride - pad;
     auto load_row = [&](int q, float4* v) {
       const int iy = iy0 + q * dil;
       const bool yok = (iy >= 0) && (iy < H);
-      const float* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
+      const act_t* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
       for (int tx = 0; tx < K; ++tx) {
-        float4 t = ld4(xr + xoff[tx]);
+        float4 t = lda4(xr + xoff[tx]);
         if (PRO) t = apply_prologue(t, pro);
         v[tx] = keep_if(t, yok && xok[tx]);
       }
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
 
 // generic backward-weight (any K): same block reduction, one tap at a time.
 __global__ __launch_bounds__(256) void dw_wgrad_generic(
-    const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial, int B,
+    const act_t* __restrict__ x, const act_t* __restrict__ dy, float* __restrict__ partial, int B,
     int H, int W, int C4, int Ho, int Wo, int K, int stride, int pad, int dil, int relu_in) {
   __shared__ float4 red[256];
   const int tid = threadIdx.x;
@@ -570,9 +570,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_generic(
           const int oy = wk % Ho, b = wk / Ho;
           const int iy = oy * stride - pad + ty * dil;
           if (iy < 0 || iy >= H) continue;
-          float4 v = ld4(x + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
+          float4 v = lda4(x + (((size_t)b * H + iy) * W + ix) * C + c4 * 4);
           if (relu_in) v = relu4(v);
-          a = fma4(ld4(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4), v, a);
+          a = fma4(lda4(dy + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4), v, a);
         }
       }
       __syncthreads();
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_generic(
         float4 s = f4zero();
         for (int u = tid; u < 256; u += C4) s = add4(s, red[u]);
         const int cc = (base + tid) % C4;
-        st4(pout + (size_t)(ty * K + tx) * C + cc * 4, s);
+        sta4(pout + (size_t)(ty * K + tx) * C + cc * 4, s);
       }
     }
 }
@@ -624,6 +624,7 @@ inline StripCfg strip_cfg(int stride, int dil) {
 
 extern "C" {
 
+#if NASSEG_FP32_ONLY
 // wt[tap][C] <- w (C,1,K,K); flip != 0 rotates the kernel by 180 degrees.
 int nasseg_dw_pack_weight(const float* w, float* wt, int C, int K, int flip, void* stream) {
   NASSEG_REQUIRE(C > 0 && K > 0, "dw_pack_weight: bad shape C=%d K=%d", C, K);
@@ -633,6 +634,7 @@ int nasseg_dw_pack_weight(const float* w, float* wt, int C, int K, int flip, voi
   NASSEG_LAUNCH_CHECK("dw_pack_weight");
   return NASSEG_OK;
 }
+#endif  // NASSEG_FP32_ONLY
 
 int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil);
 int64_t nasseg_dwconv_bwd_data_bn_blocks(int B, int C, int Ho, int Wo, int K, int stride, int pad,
@@ -651,7 +653,7 @@ static int s2_blocks(int B, int Hd, int Wd, int C4, bool bst) {
   return (int)((nb + m - 1) / m * m);
 }
 
-static int dwconv_impl(const float* x, const float* wt, float* y, const float* in_scale,
+static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* in_scale,
                        const float* in_shift, int in_act, const float* scale, const float* shift,
                        int act, int B, int H, int W, int C, int Ho, int Wo, int K, int stride,
                        int pad, int dil, int transposed, float* stats, int stats_mode, BnBwd bn,
@@ -728,7 +730,7 @@ static int dwconv_impl(const float* x, const float* wt, float* y, const float* i
 // form (x = grad wrt output with dims (H,W), y = grad wrt input with dims (Ho,Wo),
 // un-flipped weights).  stats != null: also writes stats[blk][2][C] (sum, sum of squares of
 // y per channel) for blk < nasseg_dwconv_stats_blocks(...); forward strip geometries only.
-int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_scale,
+int NASSEG_FN(dwconv)(const act_t* x, const float* wt, act_t* y, const float* in_scale,
                   const float* in_shift, int in_act, const float* scale, const float* shift, int act,
                   int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
                   int transposed, float* stats, void* stream) {
@@ -747,7 +749,7 @@ int nasseg_dwconv(const float* x, const float* wt, float* y, const float* in_sca
 // nasseg_dwconv call that computes the same backward-data: either the correlation form
 // (transposed == 0, stride 1, flipped weights, pad' = dil*(K-1) - pad) or the transposed
 // stride-2 form; g and z have dims (Ho, Wo).
-int nasseg_dwconv_bwd_data_bn(const float* dy, const float* wt, float* g, const float* z,
+int NASSEG_FN(dwconv_bwd_data_bn)(const act_t* dy, const float* wt, act_t* g, const act_t* z,
                               const float* scale, const float* shift, const float* mean,
                               const float* invstd, int act, int B, int H, int W, int C, int Ho,
                               int Wo, int K, int stride, int pad, int dil, int transposed,
@@ -760,20 +762,25 @@ int nasseg_dwconv_bwd_data_bn(const float* dy, const float* wt, float* g, const 
                      stride, pad, dil, transposed, stats, 2, bn, (hipStream_t)stream);
 }
 
+#if NASSEG_FP32_ONLY
 // 1 when nasseg_dwconv / nasseg_dwconv_wgrad take the fast strip path for this geometry,
 // i.e. when the full input prologue and the statistics epilogue are available
 int nasseg_dwconv_strip_ok(int K, int stride, int dil) {
   StripCfg sc = strip_cfg(stride, dil);
   return ((K == 3 || K == 5) && (sc.e == 1 || sc.e == 2)) ? 1 : 0;
 }
+#endif  // NASSEG_FP32_ONLY
 
+#if NASSEG_FP32_ONLY
 // number of statistic rows nasseg_dwconv writes (0 when the geometry has no stats support)
 int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil) {
   if (!nasseg_dwconv_strip_ok(K, stride, dil)) return 0;
   StripCfg sc = strip_cfg(stride, dil);
   return (int64_t)cdiv(Wo * (C / 4), 256) * cdiv(Ho, 4 * sc.g) * sc.g * B;
 }
+#endif  // NASSEG_FP32_ONLY
 
+#if NASSEG_FP32_ONLY
 // rows of statistics nasseg_dwconv_bwd_data_bn writes for this call (0: no fused path, use
 // nasseg_dwconv + nasseg_bn_bwd_reduce)
 int64_t nasseg_dwconv_bwd_data_bn_blocks(int B, int C, int Ho, int Wo, int K, int stride, int pad,
@@ -784,6 +791,7 @@ int64_t nasseg_dwconv_bwd_data_bn_blocks(int B, int C, int Ho, int Wo, int K, in
     return s2_blocks(B, Ho, Wo, C / 4, true);
   return 0;
 }
+#endif  // NASSEG_FP32_ONLY
 
 // number of workgroup rows (grid.y) of the backward-weight kernels: ~1024 workgroups,
 // but at least ~8 output rows of work per workgroup so that the end-of-block reduction
@@ -797,14 +805,16 @@ static int64_t wgrad_rows(int B, int C, int Ho, int Wo) {
   return gy;
 }
 
+#if NASSEG_FP32_ONLY
 int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K) {
   const int64_t gx = cdiv(Wo * (C / 4), 256);
   return gx * wgrad_rows(B, C, Ho, Wo) * (int64_t)K * K * C;
 }
+#endif  // NASSEG_FP32_ONLY
 
 // dw (C,1,K,K) = sum over pixels of dy * in_act(in_scale*x_tap + in_shift); ws must hold
 // nasseg_dwconv_wgrad_workspace() floats.
-int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
+int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* ws,
                         const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
                         int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream) {
   NASSEG_REQUIRE(C % 4 == 0, "dwconv_wgrad: C=%d must be a multiple of 4", C);

@@ -19,16 +19,16 @@ inline int ew_grid(int64_t n) {
 
 // y = act(x*scale[c] + shift[c]) (+ res)
 __global__ __launch_bounds__(256) void affine_act_kernel(
-    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ res, float* __restrict__ y, int64_t n4, int C4, int act) {
+    const act_t* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const act_t* __restrict__ res, act_t* __restrict__ y, int64_t n4, int C4, int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
-    float4 v = ld4(x + i * 4);
-    float4 s = scale ? ld4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-    float4 h = shift ? ld4(shift + c4 * 4) : f4zero();
+    float4 v = lda4(x + i * 4);
+    float4 s = scale ? lda4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 h = shift ? lda4(shift + c4 * 4) : f4zero();
     v = act_apply4(fma4(v, s, h), act);
-    if (res) v = add4(v, ld4(res + i * 4));
-    st4(y + i * 4, v);
+    if (res) v = add4(v, lda4(res + i * 4));
+    sta4(y + i * 4, v);
   }
 }
 
@@ -36,95 +36,95 @@ __global__ __launch_bounds__(256) void affine_act_kernel(
 //   g = dy * act'(x*scale+shift);  xhat = (x-mean)*invstd
 //   train: dx = scale * (g - sums0/M - xhat*sums1/M)     eval: dx = scale * g
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ scale,
+    const act_t* __restrict__ dy, const act_t* __restrict__ x, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ sums, float invM, int train,
-    int act, float* __restrict__ dx, int64_t n4, int C4) {
+    int act, act_t* __restrict__ dx, int64_t n4, int C4) {
   const int C = C4 * 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
-    const float4 d = ld4(dy + i * 4);
-    const float4 v = ld4(x + i * 4);
-    const float4 s = ld4(scale + c4 * 4);
-    const float4 h = ld4(shift + c4 * 4);
+    const float4 d = lda4(dy + i * 4);
+    const float4 v = lda4(x + i * 4);
+    const float4 s = lda4(scale + c4 * 4);
+    const float4 h = lda4(shift + c4 * 4);
     const float4 z = fma4(v, s, h);
     float4 g = make_float4(d.x * act_mask(z.x, act), d.y * act_mask(z.y, act),
                            d.z * act_mask(z.z, act), d.w * act_mask(z.w, act));
     if (train) {
-      const float4 mu = ld4(mean + c4 * 4);
-      const float4 is = ld4(invstd + c4 * 4);
-      const float4 s0 = ld4(sums + c4 * 4);
-      const float4 s1 = ld4(sums + C + c4 * 4);
+      const float4 mu = lda4(mean + c4 * 4);
+      const float4 is = lda4(invstd + c4 * 4);
+      const float4 s0 = lda4(sums + c4 * 4);
+      const float4 s1 = lda4(sums + C + c4 * 4);
       g.x = g.x - s0.x * invM - (v.x - mu.x) * is.x * s1.x * invM;
       g.y = g.y - s0.y * invM - (v.y - mu.y) * is.y * s1.y * invM;
       g.z = g.z - s0.z * invM - (v.z - mu.z) * is.z * s1.z * invM;
       g.w = g.w - s0.w * invM - (v.w - mu.w) * is.w * s1.w * invM;
     }
-    st4(dx + i * 4, mul4(g, s));
+    sta4(dx + i * 4, mul4(g, s));
   }
 }
 
 // y = act(alpha[c]*a + beta[c]*b); alpha / beta null = 1; b null = absent
-__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a,
-                                                    const float* __restrict__ b,
+__global__ __launch_bounds__(256) void axpby_kernel(const act_t* __restrict__ a,
+                                                    const act_t* __restrict__ b,
                                                     const float* __restrict__ alpha,
                                                     const float* __restrict__ beta,
-                                                    float* __restrict__ y, int64_t n4, int C4,
+                                                    act_t* __restrict__ y, int64_t n4, int C4,
                                                     int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
-    float4 v = ld4(a + i * 4);
-    if (alpha) v = mul4(v, ld4(alpha + c4 * 4));
+    float4 v = lda4(a + i * 4);
+    if (alpha) v = mul4(v, lda4(alpha + c4 * 4));
     if (b) {
-      float4 w = ld4(b + i * 4);
-      if (beta) w = mul4(w, ld4(beta + c4 * 4));
+      float4 w = lda4(b + i * 4);
+      if (beta) w = mul4(w, lda4(beta + c4 * 4));
       v = add4(v, w);
     }
-    st4(y + i * 4, act_apply4(v, act));
+    sta4(y + i * 4, act_apply4(v, act));
   }
 }
 
 // dx = dy * act'(y_or_z)  (ReLU: ref > 0; ReLU6: 0 < ref < 6)
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy,
-                                                      const float* __restrict__ ref,
-                                                      float* __restrict__ dx, int64_t n4, int act) {
+__global__ __launch_bounds__(256) void act_bwd_kernel(const act_t* __restrict__ dy,
+                                                      const act_t* __restrict__ ref,
+                                                      act_t* __restrict__ dx, int64_t n4, int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const float4 d = ld4(dy + i * 4);
-    const float4 r = ld4(ref + i * 4);
-    st4(dx + i * 4, make_float4(d.x * act_mask(r.x, act), d.y * act_mask(r.y, act),
+    const float4 d = lda4(dy + i * 4);
+    const float4 r = lda4(ref + i * 4);
+    sta4(dx + i * 4, make_float4(d.x * act_mask(r.x, act), d.y * act_mask(r.y, act),
                                 d.z * act_mask(r.z, act), d.w * act_mask(r.w, act)));
   }
 }
 
-__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ y, int64_t n, float v) {
+__global__ __launch_bounds__(256) void fill_kernel(act_t* __restrict__ y, int64_t n, float v) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    y[i] = v;
+    sta1(y + i, v);
 }
 
 // strided channel-block copy: y[p][yoff + c] = act(x[p][xoff + c]) * (mask_ref ? act'(mask_ref[p][moff+c]) : 1)
 // for c < C; covers torch.cat (write into a slab), its backward (slice out of a
 // slab, optionally masked by the ReLU that followed the cat) and Skip's repeat.
 __global__ __launch_bounds__(256) void chan_copy_kernel(
-    const float* __restrict__ x, int64_t ldx, int xoff, float* __restrict__ y, int64_t ldy,
-    int yoff, const float* __restrict__ mref, int64_t ldm, int moff, int64_t P, int C4, int act,
+    const act_t* __restrict__ x, int64_t ldx, int xoff, act_t* __restrict__ y, int64_t ldy,
+    int yoff, const act_t* __restrict__ mref, int64_t ldm, int moff, int64_t P, int C4, int act,
     int mact) {
   const int64_t n4 = P * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
     const int64_t p = i / C4;
-    float4 v = act_apply4(ld4(x + p * ldx + xoff + c4 * 4), act);
+    float4 v = act_apply4(lda4(x + p * ldx + xoff + c4 * 4), act);
     if (mref) {
-      const float4 r = ld4(mref + p * ldm + moff + c4 * 4);
+      const float4 r = lda4(mref + p * ldm + moff + c4 * 4);
       v = make_float4(v.x * act_mask(r.x, mact), v.y * act_mask(r.y, mact),
                       v.z * act_mask(r.z, mact), v.w * act_mask(r.w, mact));
     }
-    st4(y + p * ldy + yoff + c4 * 4, v);
+    sta4(y + p * ldy + yoff + c4 * 4, v);
   }
 }
 
 // dx[p][c] = sum_r dy[p][r*C + c]   (backward of the channel repeat in Skip)
-__global__ __launch_bounds__(256) void chan_fold_kernel(const float* __restrict__ dy,
-                                                        float* __restrict__ dx, int64_t P, int C4,
+__global__ __launch_bounds__(256) void chan_fold_kernel(const act_t* __restrict__ dy,
+                                                        act_t* __restrict__ dx, int64_t P, int C4,
                                                         int rep) {
   const int64_t n4 = P * C4;
   const int C = C4 * 4;
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void chan_fold_kernel(const float* __restrict_
     const int c4 = (int)(i % C4);
     const int64_t p = i / C4;
     float4 s = f4zero();
-    for (int r = 0; r < rep; ++r) s = add4(s, ld4(dy + (p * rep + r) * C + c4 * 4));
-    st4(dx + i * 4, s);
+    for (int r = 0; r < rep; ++r) s = add4(s, lda4(dy + (p * rep + r) * C + c4 * 4));
+    sta4(dx + i * 4, s);
   }
 }
 
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void chan_fold_kernel(const float* __restrict_
 extern "C" {
 
 // y = act(x*scale[c] + shift[c]) (+ res); x, y, res dense [n/C][C]; scale/shift/res may be null
-int nasseg_affine_act(const float* x, const float* scale, const float* shift, const float* res,
-                      float* y, int64_t n, int C, int act, void* stream) {
+int NASSEG_FN(affine_act)(const act_t* x, const float* scale, const float* shift, const act_t* res,
+                      act_t* y, int64_t n, int C, int act, void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0 && n % C == 0, "affine_act: bad shape n=%lld C=%d",
                  (long long)n, C);
   if (n == 0) return NASSEG_OK;
@@ -153,9 +153,9 @@ int nasseg_affine_act(const float* x, const float* scale, const float* shift, co
   return NASSEG_OK;
 }
 
-int nasseg_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
+int NASSEG_FN(bn_bwd_apply)(const act_t* dy, const act_t* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
-                        int C, int train, int act, float* dx, void* stream) {
+                        int C, int train, int act, act_t* dx, void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0 && M > 0, "bn_bwd_apply: bad shape");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(M * C / 4)), dim3(256), 0,
                      (hipStream_t)stream, dy, x, scale, shift, mean, invstd, sums,
@@ -165,7 +165,7 @@ int nasseg_bn_bwd_apply(const float* dy, const float* x, const float* scale, con
 }
 
 // y = act(alpha[c]*a + beta[c]*b)
-int nasseg_axpby(const float* a, const float* b, const float* alpha, const float* beta, float* y,
+int NASSEG_FN(axpby)(const act_t* a, const act_t* b, const float* alpha, const float* beta, act_t* y,
                  int64_t n, int C, int act, void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0 && n % C == 0, "axpby: bad shape");
   if (n == 0) return NASSEG_OK;
@@ -175,7 +175,7 @@ int nasseg_axpby(const float* a, const float* b, const float* alpha, const float
   return NASSEG_OK;
 }
 
-int nasseg_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int act, void* stream) {
+int NASSEG_FN(act_bwd)(const act_t* dy, const act_t* ref, act_t* dx, int64_t n, int act, void* stream) {
   NASSEG_REQUIRE(n % 4 == 0, "act_bwd: n must be a multiple of 4");
   if (n == 0) return NASSEG_OK;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, dy,
@@ -184,15 +184,15 @@ int nasseg_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int 
   return NASSEG_OK;
 }
 
-int nasseg_fill(float* y, int64_t n, float v, void* stream) {
+int NASSEG_FN(fill)(act_t* y, int64_t n, float v, void* stream) {
   if (n <= 0) return NASSEG_OK;
   hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, y, n, v);
   NASSEG_LAUNCH_CHECK("fill");
   return NASSEG_OK;
 }
 
-int nasseg_chan_copy(const float* x, int64_t ldx, int xoff, float* y, int64_t ldy, int yoff,
-                     const float* mref, int64_t ldm, int moff, int64_t P, int C, int act, int mact,
+int NASSEG_FN(chan_copy)(const act_t* x, int64_t ldx, int xoff, act_t* y, int64_t ldy, int yoff,
+                     const act_t* mref, int64_t ldm, int moff, int64_t P, int C, int act, int mact,
                      void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && xoff % 4 == 0 &&
                      yoff % 4 == 0 && (!mref || (ldm % 4 == 0 && moff % 4 == 0)),
@@ -204,7 +204,7 @@ int nasseg_chan_copy(const float* x, int64_t ldx, int xoff, float* y, int64_t ld
   return NASSEG_OK;
 }
 
-int nasseg_chan_fold(const float* dy, float* dx, int64_t P, int C, int rep, void* stream) {
+int NASSEG_FN(chan_fold)(const act_t* dy, act_t* dx, int64_t P, int C, int rep, void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0 && rep > 0, "chan_fold: bad shape");
   if (P <= 0) return NASSEG_OK;
   hipLaunchKernelGGL(chan_fold_kernel, dim3(ew_grid(P * C / 4)), dim3(256), 0, (hipStream_t)stream,

@@ -15,7 +15,7 @@
 namespace {
 
 template <typename TL>
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits,
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const act_t* __restrict__ logits,
                                                      const TL* __restrict__ target, int64_t P,
                                                      int C, int ignore, float* __restrict__ partial) {
   __shared__ float red_l[256];
@@ -24,13 +24,13 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ l
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
     const int64_t t = (int64_t)target[p];
     if (t == ignore || t < 0 || t >= C) continue;  // out-of-range labels are skipped, never read
-    const float* lp = logits + p * C;
-    float m = lp[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, lp[c]);
+    const act_t* lp = logits + p * C;
+    float m = lda1(lp);
+    for (int c = 1; c < C; ++c) m = fmaxf(m, lda1(lp + c));
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += expf(lp[c] - m);
+    for (int c = 0; c < C; ++c) s += expf(lda1(lp + c) - m);
     const float lse = m + logf(s);
-    loss += lse - lp[t];
+    loss += lse - lda1(lp + t);
     cnt += 1.f;
   }
   red_l[threadIdx.x] = loss;
@@ -64,28 +64,28 @@ __global__ void ce_finalize_kernel(const float* __restrict__ partial, int nblk,
 
 // dlogits[p][c] = gscale[0] * (softmax(p)[c] - [c == target]) / nvalid   (0 for ignored pixels)
 template <typename TL>
-__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits,
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const act_t* __restrict__ logits,
                                                      const TL* __restrict__ target,
                                                      const float* __restrict__ stats,
                                                      const float* __restrict__ gscale, int64_t P,
-                                                     int C, int ignore, float* __restrict__ dlogits) {
+                                                     int C, int ignore, act_t* __restrict__ dlogits) {
   const float g = (gscale ? gscale[0] : 1.f) / stats[1];
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
     const int64_t t = (int64_t)target[p];
-    const float* lp = logits + p * C;
-    float* dp = dlogits + p * C;
+    const act_t* lp = logits + p * C;
+    act_t* dp = dlogits + p * C;
     if (t == ignore || t < 0 || t >= C) {
-      for (int c = 0; c < C; ++c) dp[c] = 0.f;
+      for (int c = 0; c < C; ++c) sta1(dp + c, 0.f);
       continue;
     }
-    float m = lp[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, lp[c]);
+    float m = lda1(lp);
+    for (int c = 1; c < C; ++c) m = fmaxf(m, lda1(lp + c));
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += expf(lp[c] - m);
+    for (int c = 0; c < C; ++c) s += expf(lda1(lp + c) - m);
     const float inv = 1.f / s;
     for (int c = 0; c < C; ++c) {
-      float sm = expf(lp[c] - m) * inv;
-      dp[c] = g * (sm - ((int64_t)c == t ? 1.f : 0.f));
+      float sm = expf(lda1(lp + c) - m) * inv;
+      sta1(dp + c, g * (sm - ((int64_t)c == t ? 1.f : 0.f)));
     }
   }
 }
@@ -97,13 +97,13 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ l
 // mean over all elements; c is treated as a constant in the backward pass.
 // Three tiny passes: block maxima -> c, block sums -> mean.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void berhu_max_kernel(const float* __restrict__ pred,
-                                                        const float* __restrict__ target, int64_t n,
+__global__ __launch_bounds__(256) void berhu_max_kernel(const act_t* __restrict__ pred,
+                                                        const act_t* __restrict__ target, int64_t n,
                                                         float* __restrict__ partial) {
   __shared__ float red[256];
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    m = fmaxf(m, fabsf(pred[i] - target[i]));
+    m = fmaxf(m, fabsf(lda1(pred + i) - lda1(target + i)));
   red[threadIdx.x] = m;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void berhu_max_kernel(const float* __restrict_
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(256) void berhu_sum_kernel(const float* __restrict__ pred,
-                                                        const float* __restrict__ target, int64_t n,
+__global__ __launch_bounds__(256) void berhu_sum_kernel(const act_t* __restrict__ pred,
+                                                        const act_t* __restrict__ target, int64_t n,
                                                         const float* __restrict__ maxpart, int nblk,
                                                         float* __restrict__ partial,
                                                         float* __restrict__ out) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void berhu_sum_kernel(const float* __restrict_
   const float c = cs;
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float d = fabsf(pred[i] - target[i]);
+    const float d = fabsf(lda1(pred + i) - lda1(target + i));
     acc += (d <= c) ? d : (d * d + c * c) / (2.f * c);
   }
   red[threadIdx.x] = acc;
@@ -151,18 +151,18 @@ __global__ void berhu_finalize_kernel(const float* __restrict__ partial, int nbl
 }
 
 // dpred = g/n * (sign(diff) if |diff| <= c else diff / c)
-__global__ __launch_bounds__(256) void berhu_bwd_kernel(const float* __restrict__ pred,
-                                                        const float* __restrict__ target,
+__global__ __launch_bounds__(256) void berhu_bwd_kernel(const act_t* __restrict__ pred,
+                                                        const act_t* __restrict__ target,
                                                         const float* __restrict__ stats,
                                                         const float* __restrict__ gscale, int64_t n,
-                                                        float* __restrict__ dpred) {
+                                                        act_t* __restrict__ dpred) {
   const float c = stats[1];
   const float g = (gscale ? gscale[0] : 1.f) / (float)n;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float d = pred[i] - target[i];
+    const float d = lda1(pred + i) - lda1(target + i);
     const float ad = fabsf(d);
     const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    dpred[i] = g * ((ad <= c) ? sgn : d / c);
+    sta1(dpred + i, g * ((ad <= c) ? sgn : d / c));
   }
 }
 
@@ -177,11 +177,13 @@ inline int ce_grid(int64_t P) {
 
 extern "C" {
 
+#if NASSEG_FP32_ONLY
 int64_t nasseg_ce_workspace(void) { return 2 * 1024; }
+#endif
 
 // logits [P][C] dense NHWC, target [P] (elem_size 1 = uint8, 8 = int64).
 // out[0] = mean NLL over valid pixels, out[1] = valid count. ws: nasseg_ce_workspace() floats.
-int nasseg_ce_fwd(const float* logits, const void* target, int elem_size, int64_t P, int C,
+int NASSEG_FN(ce_fwd)(const act_t* logits, const void* target, int elem_size, int64_t P, int C,
                   int ignore, float* out, float* ws, void* stream) {
   NASSEG_REQUIRE(P > 0 && C > 0, "ce_fwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
@@ -201,8 +203,8 @@ int nasseg_ce_fwd(const float* logits, const void* target, int elem_size, int64_
 }
 
 // stats = out of nasseg_ce_fwd; gscale = device scalar upstream gradient (null = 1)
-int nasseg_ce_bwd(const float* logits, const void* target, int elem_size, const float* stats,
-                  const float* gscale, int64_t P, int C, int ignore, float* dlogits, void* stream) {
+int NASSEG_FN(ce_bwd)(const act_t* logits, const void* target, int elem_size, const float* stats,
+                  const float* gscale, int64_t P, int C, int ignore, act_t* dlogits, void* stream) {
   NASSEG_REQUIRE(P > 0 && C > 0, "ce_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const int grid = ce_grid(P) * 2;
@@ -220,7 +222,7 @@ int nasseg_ce_bwd(const float* logits, const void* target, int elem_size, const 
 
 // berHu loss (depth head): out[0] = mean loss, out[1] = c = 0.2 * max|pred - target|.
 // pred / target: n fp32 elements, any layout (elementwise).  ws: nasseg_ce_workspace() floats.
-int nasseg_berhu_fwd(const float* pred, const float* target, int64_t n, float* out, float* ws,
+int NASSEG_FN(berhu_fwd)(const act_t* pred, const act_t* target, int64_t n, float* out, float* ws,
                      void* stream) {
   NASSEG_REQUIRE(n > 0, "berhu_fwd: empty input");
   hipStream_t s = (hipStream_t)stream;
@@ -235,8 +237,8 @@ int nasseg_berhu_fwd(const float* pred, const float* target, int64_t n, float* o
   return NASSEG_OK;
 }
 
-int nasseg_berhu_bwd(const float* pred, const float* target, const float* stats,
-                     const float* gscale, int64_t n, float* dpred, void* stream) {
+int NASSEG_FN(berhu_bwd)(const act_t* pred, const act_t* target, const float* stats,
+                     const float* gscale, int64_t n, act_t* dpred, void* stream) {
   NASSEG_REQUIRE(n > 0, "berhu_bwd: empty input");
   hipLaunchKernelGGL(berhu_bwd_kernel, dim3(ce_grid(n) * 2), dim3(256), 0, (hipStream_t)stream, pred,
                      target, stats, gscale, n, dpred);

@@ -20,8 +20,8 @@ inline int pool_grid(int64_t n) {
   return (int)b;
 }
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x,
-                                                          float* __restrict__ y,
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const act_t* __restrict__ x,
+                                                          act_t* __restrict__ y,
                                                           uint8_t* __restrict__ idx, int B, int H,
                                                           int W, int C4, int Ho, int Wo, int K,
                                                           int stride, int pad) {
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    const float* xb = x + (int64_t)b * H * W * C + c4 * 4;
+    const act_t* xb = x + (int64_t)b * H * W * C + c4 * 4;
     float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     uchar4 mi = make_uchar4(0, 0, 0, 0);
     bool first = true;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
       for (int tx = 0; tx < K; ++tx) {
         const int ix = ox * stride - pad + tx;
         if (ix < 0 || ix >= W) continue;
-        const float4 v = ld4(xb + ((int64_t)iy * W + ix) * C);
+        const float4 v = lda4(xb + ((int64_t)iy * W + ix) * C);
         const uint8_t t = (uint8_t)(ty * K + tx);
         // torch: take v when (v > max) or isnan(v); the first in-bounds tap seeds the index
         if (first || v.x > m.x || v.x != v.x) { m.x = v.x; mi.x = t; }
@@ -54,15 +54,15 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
         first = false;
       }
     }
-    st4(y + i * 4, m);
+    sta4(y + i * 4, m);
     if (idx) *reinterpret_cast<uchar4*>(idx + i * 4) = mi;
   }
 }
 
 // dx[iy,ix] = sum over windows (oy,ox) that contain (iy,ix) as tap t and whose idx == t
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const act_t* __restrict__ dy,
                                                           const uint8_t* __restrict__ idx,
-                                                          float* __restrict__ dx, int B, int H,
+                                                          act_t* __restrict__ dx, int B, int H,
                                                           int W, int C4, int Ho, int Wo, int K,
                                                           int stride, int pad) {
   const int C = C4 * 4;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         if (ox >= Wo) continue;
         const int64_t o = ((((int64_t)b * Ho + oy) * Wo + ox) * C4 + c4) * 4;
         const uchar4 w = *reinterpret_cast<const uchar4*>(idx + o);
-        const float4 d = ld4(dy + o);
+        const float4 d = lda4(dy + o);
         const uint8_t t = (uint8_t)(ty * K + tx);
         if (w.x == t) g.x += d.x;
         if (w.y == t) g.y += d.y;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
         if (w.w == t) g.w += d.w;
       }
     }
-    st4(dx + i * 4, g);
+    sta4(dx + i * 4, g);
   }
 }
 
@@ -106,8 +106,8 @@ __device__ __forceinline__ int valid_count(int o, int stride, int pad, int K, in
   return hi - lo;
 }
 
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x,
-                                                          float* __restrict__ y, int B, int H,
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const act_t* __restrict__ x,
+                                                          act_t* __restrict__ y, int B, int H,
                                                           int W, int C4, int Ho, int Wo, int K,
                                                           int stride, int pad) {
   const int C = C4 * 4;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
     p /= Wo;
     const int oy = (int)(p % Ho);
     const int b = (int)(p / Ho);
-    const float* xb = x + (int64_t)b * H * W * C + c4 * 4;
+    const act_t* xb = x + (int64_t)b * H * W * C + c4 * 4;
     float4 s = f4zero();
     for (int ty = 0; ty < K; ++ty) {
       const int iy = oy * stride - pad + ty;
@@ -127,16 +127,16 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restric
       for (int tx = 0; tx < K; ++tx) {
         const int ix = ox * stride - pad + tx;
         if (ix < 0 || ix >= W) continue;
-        s = add4(s, ld4(xb + ((int64_t)iy * W + ix) * C));
+        s = add4(s, lda4(xb + ((int64_t)iy * W + ix) * C));
       }
     }
     const float n = (float)(valid_count(oy, stride, pad, K, H) * valid_count(ox, stride, pad, K, W));
-    st4(y + i * 4, make_float4(s.x / n, s.y / n, s.z / n, s.w / n));
+    sta4(y + i * 4, make_float4(s.x / n, s.y / n, s.z / n, s.w / n));
   }
 }
 
-__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy,
-                                                          float* __restrict__ dx, int B, int H,
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const act_t* __restrict__ dy,
+                                                          act_t* __restrict__ dx, int B, int H,
                                                           int W, int C4, int Ho, int Wo, int K,
                                                           int stride, int pad) {
   const int64_t total = (int64_t)B * H * W * C4;
@@ -160,14 +160,14 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
         const int ox = nx / stride;
         if (ox >= Wo) continue;
         const float n = (float)(cy * valid_count(ox, stride, pad, K, W));
-        const float4 d = ld4(dy + ((((int64_t)b * Ho + oy) * Wo + ox) * C4 + c4) * 4);
+        const float4 d = lda4(dy + ((((int64_t)b * Ho + oy) * Wo + ox) * C4 + c4) * 4);
         g.x += d.x / n;
         g.y += d.y / n;
         g.z += d.z / n;
         g.w += d.w / n;
       }
     }
-    st4(dx + i * 4, g);
+    sta4(dx + i * 4, g);
   }
 }
 
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 extern "C" {
 
 // mode 0 = max (idx: uint8 [B][Ho][Wo][C] winner tap, may be null), 1 = avg
-int nasseg_pool_fwd(int mode, const float* x, float* y, uint8_t* idx, int B, int H, int W, int C,
+int NASSEG_FN(pool_fwd)(int mode, const act_t* x, act_t* y, uint8_t* idx, int B, int H, int W, int C,
                     int Ho, int Wo, int K, int stride, int pad, void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0, "pool_fwd: C=%d must be a multiple of 4", C);
   NASSEG_REQUIRE(K > 0 && K * K <= 255 && stride > 0, "pool_fwd: bad window");
@@ -192,7 +192,7 @@ int nasseg_pool_fwd(int mode, const float* x, float* y, uint8_t* idx, int B, int
   return NASSEG_OK;
 }
 
-int nasseg_pool_bwd(int mode, const float* dy, const uint8_t* idx, float* dx, int B, int H, int W,
+int NASSEG_FN(pool_bwd)(int mode, const act_t* dy, const uint8_t* idx, act_t* dx, int B, int H, int W,
                     int C, int Ho, int Wo, int K, int stride, int pad, void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0, "pool_bwd: C=%d must be a multiple of 4", C);
   NASSEG_REQUIRE(mode != 0 || idx, "pool_bwd: max pooling needs the index tensor");

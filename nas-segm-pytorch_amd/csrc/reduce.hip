@@ -19,11 +19,11 @@ namespace {
 enum { RED_SUM = 0, RED_SUMSQ = 1, RED_BN_BWD = 2, RED_DOT2 = 3, RED_DOT1 = 4 };
 
 struct RedArgs {
-  const float* a;
+  const act_t* a;  // (activations: fp32 or bf16 storage)
   int64_t lda;
-  const float* b;
+  const act_t* b;
   int64_t ldb;
-  const float* c;
+  const act_t* c;
   int64_t ldc;
   const float* scale;
   const float* shift;
@@ -44,8 +44,9 @@ template <>
 struct Vt<4> {
   typedef float4 T;
   static __device__ __forceinline__ T zero() { return f4zero(); }
-  static __device__ __forceinline__ T ld(const float* p) { return ld4(p); }
-  static __device__ __forceinline__ void st(float* p, T v) { st4(p, v); }
+  static __device__ __forceinline__ T ld(const float* p) { return lda4(p); }
+  static __device__ __forceinline__ T ld(const bf16_t* p) { return lda4(p); }
+  static __device__ __forceinline__ void st(float* p, T v) { sta4(p, v); }
   static __device__ __forceinline__ T add(T a, T b) { return add4(a, b); }
   static __device__ __forceinline__ T mul(T a, T b) { return mul4(a, b); }
   static __device__ __forceinline__ T sub(T a, T b) {
@@ -62,6 +63,7 @@ struct Vt<1> {
   typedef float T;
   static __device__ __forceinline__ T zero() { return 0.f; }
   static __device__ __forceinline__ T ld(const float* p) { return *p; }
+  static __device__ __forceinline__ T ld(const bf16_t* p) { return lda1(p); }
   static __device__ __forceinline__ void st(float* p, T v) { *p = v; }
   static __device__ __forceinline__ T add(T a, T b) { return a + b; }
   static __device__ __forceinline__ T mul(T a, T b) { return a * b; }
@@ -97,9 +99,9 @@ __global__ __launch_bounds__(256) void colred_kernel(RedArgs q) {
     is = V::ld(q.invstd + cv * VEC);
   }
   if (live) {
-    const float* pa = q.a + (int64_t)seg * q.R * q.lda + cv * VEC;
-    const float* pb = q.b ? q.b + (int64_t)seg * q.R * q.ldb + cv * VEC : nullptr;
-    const float* pc = q.c ? q.c + (int64_t)seg * q.R * q.ldc + cv * VEC : nullptr;
+    const act_t* pa = q.a + (int64_t)seg * q.R * q.lda + cv * VEC;
+    const act_t* pb = q.b ? q.b + (int64_t)seg * q.R * q.ldb + cv * VEC : nullptr;
+    const act_t* pc = q.c ? q.c + (int64_t)seg * q.R * q.ldc + cv * VEC : nullptr;
 #pragma unroll 8
     for (int64_t r = r0 + rr; r < r1; r += rpi) {
       T va = V::ld(pa + r * q.lda);
@@ -246,6 +248,7 @@ int launch_colred(RedArgs& q, hipStream_t s) {
 
 extern "C" {
 
+#if NASSEG_FP32_ONLY
 // floats of workspace for any nasseg_colred_* / nasseg_bn_* call on [S][R][C]
 int64_t nasseg_colred_workspace(int S, int64_t R, int C) {
   if (C <= 0 || S <= 0 || R <= 0) return 0;
@@ -255,10 +258,12 @@ int64_t nasseg_colred_workspace(int S, int64_t R, int C) {
   return (int64_t)S * cap * 2 * C + 16;
 }
 
+#endif  // NASSEG_FP32_ONLY (queries and fp32-vector entry points exist once)
+
 // mode: 0 sum(a), 1 {sum(a), sum(a^2)}, 3 {sum(a*b), sum(a*c)}, 4 sum(a*b)
 // out[seg][nacc][C] = mul * sums   (nacc = 2 for modes 1 and 3, else 1)
-int nasseg_colred(int mode, const float* a, int64_t lda, const float* b, int64_t ldb,
-                  const float* c, int64_t ldc, float* out, float* ws, int S, int64_t R, int C,
+int NASSEG_FN(colred)(int mode, const act_t* a, int64_t lda, const act_t* b, int64_t ldb,
+                  const act_t* c, int64_t ldc, float* out, float* ws, int S, int64_t R, int C,
                   float mul, void* stream) {
   NASSEG_REQUIRE(S > 0 && R > 0 && C > 0, "colred: bad shape");
   hipStream_t s = (hipStream_t)stream;
@@ -283,7 +288,7 @@ int nasseg_colred(int mode, const float* a, int64_t lda, const float* b, int64_t
 // training-mode BatchNorm statistics of x [M][C] (row stride ldx).
 // Writes mean, invstd, scale = gamma*invstd, shift = beta - mean*scale and
 // updates running stats / num_batches_tracked in place (any may be null).
-int nasseg_bn_stats(const float* x, int64_t ldx, int64_t M, int C, float eps, float momentum,
+int NASSEG_FN(bn_stats)(const act_t* x, int64_t ldx, int64_t M, int C, float eps, float momentum,
                     const float* gamma, const float* beta, float* mean, float* invstd,
                     float* scale, float* shift, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* ws, void* stream) {
@@ -300,6 +305,7 @@ int nasseg_bn_stats(const float* x, int64_t ldx, int64_t M, int C, float eps, fl
   return NASSEG_OK;
 }
 
+#if NASSEG_FP32_ONLY
 // sum groups of `rows_per_group` consecutive rows of partial[nblk][per] into out[g][per]
 // (fp32 out, fp64 accumulation, fixed order): first level of a two-level finalisation
 __global__ __launch_bounds__(256) void rows_group_sum(const float* __restrict__ partial,
@@ -381,9 +387,11 @@ int nasseg_bn_eval_params(int C, float eps, const float* gamma, const float* bet
   return NASSEG_OK;
 }
 
+#endif  // NASSEG_FP32_ONLY
+
 // BatchNorm backward sums: with g = dy * act'(x*scale+shift) and
 // xhat = (x-mean)*invstd:  sums[0][c] = sum g (= dbeta), sums[1][c] = sum g*xhat (= dgamma)
-int nasseg_bn_bwd_reduce(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t M,
+int NASSEG_FN(bn_bwd_reduce)(const act_t* dy, int64_t lddy, const act_t* x, int64_t ldx, int64_t M,
                          int C, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int act, float* sums, float* ws, void* stream) {
   NASSEG_REQUIRE(M > 0 && C > 0, "bn_bwd_reduce: bad shape");

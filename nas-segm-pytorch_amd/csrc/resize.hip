@@ -48,8 +48,8 @@ inline int rs_grid(int64_t n) {
   return (int)b;
 }
 
-__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restrict__ x,
-                                                           float* __restrict__ y, int64_t ldy,
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const act_t* __restrict__ x,
+                                                           act_t* __restrict__ y, int64_t ldy,
                                                            int yoff, int B, int Hi, int Wi, int C4,
                                                            int Ho, int Wo, float sh, float sw,
                                                            int act) {
@@ -64,23 +64,23 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const float* __restri
     const int b = (int)(prow / Ho);
     const Lin ly = lin_coeff(oy, sh, Hi, Ho);
     const Lin lx = lin_coeff(ox, sw, Wi, Wo);
-    const float* xb = x + (int64_t)b * Hi * Wi * C + c4 * 4;
-    const float4 v00 = ld4(xb + ((int64_t)ly.i0 * Wi + lx.i0) * C);
-    const float4 v01 = ld4(xb + ((int64_t)ly.i0 * Wi + lx.i1) * C);
-    const float4 v10 = ld4(xb + ((int64_t)ly.i1 * Wi + lx.i0) * C);
-    const float4 v11 = ld4(xb + ((int64_t)ly.i1 * Wi + lx.i1) * C);
+    const act_t* xb = x + (int64_t)b * Hi * Wi * C + c4 * 4;
+    const float4 v00 = lda4(xb + ((int64_t)ly.i0 * Wi + lx.i0) * C);
+    const float4 v01 = lda4(xb + ((int64_t)ly.i0 * Wi + lx.i1) * C);
+    const float4 v10 = lda4(xb + ((int64_t)ly.i1 * Wi + lx.i0) * C);
+    const float4 v11 = lda4(xb + ((int64_t)ly.i1 * Wi + lx.i1) * C);
     float4 o;
     o.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
     o.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
     o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
     o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
-    st4(y + p * ldy + yoff + c4 * 4, act_apply4(o, act));
+    sta4(y + p * ldy + yoff + c4 * 4, act_apply4(o, act));
   }
 }
 
 // scalar-channel variant (C not a multiple of 4: class logits)
-__global__ __launch_bounds__(256) void bilinear_fwd_scalar_kernel(const float* __restrict__ x,
-                                                                  float* __restrict__ y, int B,
+__global__ __launch_bounds__(256) void bilinear_fwd_scalar_kernel(const act_t* __restrict__ x,
+                                                                  act_t* __restrict__ y, int B,
                                                                   int Hi, int Wi, int C, int Ho,
                                                                   int Wo, float sh, float sw) {
   const int64_t total = (int64_t)B * Ho * Wo * C;
@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256) void bilinear_fwd_scalar_kernel(const float* _
     const int b = (int)(prow / Ho);
     const Lin ly = lin_coeff(oy, sh, Hi, Ho);
     const Lin lx = lin_coeff(ox, sw, Wi, Wo);
-    const float* xb = x + (int64_t)b * Hi * Wi * C + c;
-    const float v00 = xb[((int64_t)ly.i0 * Wi + lx.i0) * C];
-    const float v01 = xb[((int64_t)ly.i0 * Wi + lx.i1) * C];
-    const float v10 = xb[((int64_t)ly.i1 * Wi + lx.i0) * C];
-    const float v11 = xb[((int64_t)ly.i1 * Wi + lx.i1) * C];
-    y[i] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    const act_t* xb = x + (int64_t)b * Hi * Wi * C + c;
+    const float v00 = lda1(xb + ((int64_t)ly.i0 * Wi + lx.i0) * C);
+    const float v01 = lda1(xb + ((int64_t)ly.i0 * Wi + lx.i1) * C);
+    const float v10 = lda1(xb + ((int64_t)ly.i1 * Wi + lx.i0) * C);
+    const float v11 = lda1(xb + ((int64_t)ly.i1 * Wi + lx.i1) * C);
+    sta1(y + i, ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11));
   }
 }
 
@@ -129,9 +129,9 @@ __device__ __forceinline__ float lin_weight(int o, int i, float scale, int in_si
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restrict__ dy,
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const act_t* __restrict__ dy,
                                                            int64_t lddy, int dyoff,
-                                                           float* __restrict__ dx, int B, int Hi,
+                                                           act_t* __restrict__ dx, int B, int Hi,
                                                            int Wi, int CV, int Ho, int Wo, float sh,
                                                            float sw) {
   const int64_t total = (int64_t)B * Hi * Wi * CV;
@@ -149,26 +149,26 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     for (int oy = ylo; oy <= yhi; ++oy) {
       const float wy = lin_weight(oy, iy, sh, Hi, Ho);
       if (wy == 0.f) continue;
-      const float* drow = dy + (((int64_t)b * Ho + oy) * Wo) * lddy + dyoff + cv * VEC;
+      const act_t* drow = dy + (((int64_t)b * Ho + oy) * Wo) * lddy + dyoff + cv * VEC;
       for (int ox = xlo; ox <= xhi; ++ox) {
         const float wx = lin_weight(ox, ix, sw, Wi, Wo);
         if (wx == 0.f) continue;
         const float w = wy * wx;
         if (VEC == 4) {
-          const float4 d = ld4(drow + (int64_t)ox * lddy);
+          const float4 d = lda4(drow + (int64_t)ox * lddy);
           g.x = fmaf(w, d.x, g.x);
           g.y = fmaf(w, d.y, g.y);
           g.z = fmaf(w, d.z, g.z);
           g.w = fmaf(w, d.w, g.w);
         } else {
-          g.x = fmaf(w, drow[(int64_t)ox * lddy], g.x);
+          g.x = fmaf(w, lda1(drow + (int64_t)ox * lddy), g.x);
         }
       }
     }
     if (VEC == 4)
-      st4(dx + i * 4, g);
+      sta4(dx + i * 4, g);
     else
-      dx[i] = g.x;
+      sta1(dx + i, g.x);
   }
 }
 
@@ -178,15 +178,15 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
 //   pass 2  dx[b][iy][ix][c]  = sum_oy wy(oy, iy) * tmp[b][oy][ix][c]
 // One axis per kernel (AXIS 1 = x, 0 = y); the destination window is walked without branches
 // (clamped loads, zero weights drop out).
-template <int AXIS>
-__global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const float* __restrict__ src,
+// (TS / TD: element types of src / dst - the intermediate of the two passes stays fp32)
+template <int AXIS, typename TS, typename TD>
+__global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const TS* __restrict__ src,
                                                                 int64_t lds, int soff,
-                                                                float* __restrict__ dst, int B,
+                                                                TD* __restrict__ dst, int B,
                                                                 int H, int Wsrc, int Wdst, int C4,
                                                                 int Hdst, float scale) {
   // AXIS 1: src [B][H][Wsrc][lds], dst [B][H][Wdst][C] (reduce along x: Wsrc = Wo, Wdst = Wi)
   // AXIS 0: src [B][H][Wsrc][C] with H = Ho, dst [B][Hdst][Wsrc][C]   (reduce along y)
-  const int C = C4 * 4;
   const int rows_out = AXIS == 1 ? H : Hdst;
   const int cols_out = AXIS == 1 ? Wdst : Wsrc;
   const int64_t total = (int64_t)B * rows_out * cols_out * C4;
@@ -206,13 +206,13 @@ __global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const float* __r
     for (int o = lo; o <= hi; ++o) {
       const float w = lin_weight(o, idx, scale, n_in, n_out);
       const int64_t pix = AXIS == 1 ? ((int64_t)b * H + y) * Wsrc + o : ((int64_t)b * H + o) * Wsrc + x;
-      const float4 d = keep_if4(ld4(src + pix * lds + soff + c4 * 4), w != 0.f);
+      const float4 d = keep_if4(lda4(src + pix * lds + soff + c4 * 4), w != 0.f);
       g.x = fmaf(w, d.x, g.x);
       g.y = fmaf(w, d.y, g.y);
       g.z = fmaf(w, d.z, g.z);
       g.w = fmaf(w, d.w, g.w);
     }
-    st4(dst + i * 4, g);
+    sta4(dst + i * 4, g);
   }
 }
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void nearest_label_kernel(const TI* __restrict
 extern "C" {
 
 // y[b,oy,ox, yoff:yoff+C] = act(bilinear(x)[b,oy,ox,:]); x dense [B][Hi][Wi][C]
-int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
+int NASSEG_FN(bilinear_fwd)(const act_t* x, act_t* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream) {
   NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_fwd: bad shape");
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
@@ -259,25 +259,31 @@ int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, 
   return NASSEG_OK;
 }
 
-// floats of workspace nasseg_bilinear_bwd wants for this geometry (0: single-pass gather)
-int64_t nasseg_bilinear_bwd_workspace(int B, int Hi, int Wi, int C, int Ho, int Wo) {
+static int64_t bilinear_bwd_ws(int B, int Hi, int Wi, int C, int Ho, int Wo) {
   if (C % 4 != 0 || Ho < 3 * Hi || Wo < 3 * Wi) return 0;
   return (int64_t)B * Ho * Wi * C;
 }
 
+#if NASSEG_FP32_ONLY
+// floats of workspace nasseg_bilinear_bwd wants for this geometry (0: single-pass gather)
+int64_t nasseg_bilinear_bwd_workspace(int B, int Hi, int Wi, int C, int Ho, int Wo) {
+  return bilinear_bwd_ws(B, Hi, Wi, C, Ho, Wo);
+}
+#endif
+
 // dx [B][Hi][Wi][C] = transpose of the forward map applied to dy[..., dyoff:dyoff+C].
 // ws: nasseg_bilinear_bwd_workspace() floats, or null (then always the single-pass gather).
-int nasseg_bilinear_bwd(const float* dy, int64_t lddy, int dyoff, float* dx, int B, int Hi, int Wi,
+int NASSEG_FN(bilinear_bwd)(const act_t* dy, int64_t lddy, int dyoff, act_t* dx, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, float* ws, void* stream) {
   NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad shape");
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = C % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0;
-  if (ws && vec && nasseg_bilinear_bwd_workspace(B, Hi, Wi, C, Ho, Wo) > 0) {
+  if (ws && vec && bilinear_bwd_ws(B, Hi, Wi, C, Ho, Wo) > 0) {
     // up-sampling by >= 3 in both directions: separable two-pass form
-    hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1>), dim3(rs_grid((int64_t)B * Ho * Wi * (C / 4))),
+    hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1, act_t, float>), dim3(rs_grid((int64_t)B * Ho * Wi * (C / 4))),
                        dim3(256), 0, s, dy, lddy, dyoff, ws, B, Ho, Wo, Wi, C / 4, 0, sw);
-    hipLaunchKernelGGL((bilinear_bwd_axis_kernel<0>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
+    hipLaunchKernelGGL((bilinear_bwd_axis_kernel<0, float, act_t>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
                        dim3(256), 0, s, ws, (int64_t)C, 0, dx, B, Ho, Wi, Wi, C / 4, Hi, sh);
     NASSEG_LAUNCH_CHECK("bilinear_bwd_axis");
     return NASSEG_OK;
@@ -292,6 +298,7 @@ int nasseg_bilinear_bwd(const float* dy, int64_t lddy, int dyoff, float* dx, int
   return NASSEG_OK;
 }
 
+#if NASSEG_FP32_ONLY
 // labels: elem_size 1 (uint8) or 8 (int64) -> int64 [B][Ho][Wo]
 int nasseg_nearest_label(const void* x, int elem_size, int64_t* y, int B, int Hi, int Wi, int Ho,
                          int Wo, void* stream) {
@@ -310,5 +317,7 @@ int nasseg_nearest_label(const void* x, int elem_size, int64_t* y, int B, int Hi
   NASSEG_LAUNCH_CHECK("nearest_label");
   return NASSEG_OK;
 }
+
+#endif  // NASSEG_FP32_ONLY
 
 }  // extern "C"

@@ -18,18 +18,29 @@ RED_SUM, RED_SUMSQ, RED_DOT2, RED_DOT1 = 0, 1, 3, 4
 # ---------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------
+_BF16_PREFIX = "nasseg_bf16_"
+
+
+def _k(name, t):
+    """Entry point for activations stored like ``t``: nasseg_<op> (fp32) or its bfloat16 twin
+    nasseg_bf16_<op> (same arguments; include/nasseg.h)."""
+    if t.dtype == torch.float32:
+        return name
+    return _BF16_PREFIX + name[7:]
+
+
 def _cl(x):
-    """fp32 NHWC-contiguous view/copy of a 4-D NCHW-shaped tensor."""
+    """NHWC-contiguous view/copy of a 4-D NCHW-shaped activation (fp32 or bf16 storage)."""
     require_device(x)
-    if x.dtype != torch.float32:
-        raise NassegError("nasseg kernels are fp32 (got {})".format(x.dtype))
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise NassegError("nasseg activations are fp32 or bf16 (got {})".format(x.dtype))
     if x.dim() != 4:
         raise NassegError("expected a 4-D activation, got shape {}".format(tuple(x.shape)))
     return x.contiguous(memory_format=torch.channels_last)
 
 
 def _new(like, B, C, H, W):
-    return torch.empty((B, C, H, W), device=like.device, dtype=torch.float32,
+    return torch.empty((B, C, H, W), device=like.device, dtype=like.dtype,
                        memory_format=torch.channels_last)
 
 
@@ -50,7 +61,7 @@ def _colred(mode, a, lda, b, ldb, c, ldc, S, R, C, mul=1.0):
     nacc = 2 if mode in (RED_SUMSQ, RED_DOT2) else 1
     out = _vec(a, S * nacc * C)
     ws = _ws(a, lib.query("nasseg_colred_workspace", S, R, C))
-    lib.call("nasseg_colred", mode, ptr(a), lda, ptr(b), ldb, ptr(c), ldc, ptr(out), ptr(ws),
+    lib.call(_k("nasseg_colred", a), mode, ptr(a), lda, ptr(b), ldb, ptr(c), ldc, ptr(out), ptr(ws),
              S, R, C, float(mul), current_stream())
     return out
 
@@ -58,7 +69,7 @@ def _colred(mode, a, lda, b, ldb, c, ldc, S, R, C, mul=1.0):
 def _affine_act(x, scale, shift, res, act):
     B, C, H, W = x.shape
     y = _new(x, B, C, H, W)
-    lib.call("nasseg_affine_act", ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(y), x.numel(), C,
+    lib.call(_k("nasseg_affine_act", x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(y), x.numel(), C,
              act, current_stream())
     return y
 
@@ -66,14 +77,14 @@ def _affine_act(x, scale, shift, res, act):
 def _axpby(a, b, alpha, beta, act=ACT_NONE):
     B, C, H, W = a.shape
     y = _new(a, B, C, H, W)
-    lib.call("nasseg_axpby", ptr(a), ptr(b), ptr(alpha), ptr(beta), ptr(y), a.numel(), C, act,
+    lib.call(_k("nasseg_axpby", a), ptr(a), ptr(b), ptr(alpha), ptr(beta), ptr(y), a.numel(), C, act,
              current_stream())
     return y
 
 
 def _act_bwd(dy, ref, act):
     dx = torch.empty_like(dy)
-    lib.call("nasseg_act_bwd", ptr(dy), ptr(ref), ptr(dx), dy.numel(), act, current_stream())
+    lib.call(_k("nasseg_act_bwd", dy), ptr(dy), ptr(ref), ptr(dx), dy.numel(), act, current_stream())
     return dx
 
 
@@ -96,7 +107,7 @@ class _DepthwiseConv(torch.autograd.Function):
         wt = _vec(x, K * K * C)
         lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
         y = _new(x, B, C, Ho, Wo)
-        lib.call("nasseg_dwconv", ptr(x), ptr(wt), ptr(y), None, None, ACT_RELU if relu_in else ACT_NONE,
+        lib.call(_k("nasseg_dwconv", x), ptr(x), ptr(wt), ptr(y), None, None, ACT_RELU if relu_in else ACT_NONE,
                  None, None, ACT_NONE, B, H, W, C, Ho, Wo, K, stride, pad, dil, 0, None, s)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, pad, dil, bool(relu_in))
@@ -119,18 +130,18 @@ class _DepthwiseConv(torch.autograd.Function):
             if stride == 1 and padb >= 0:
                 # correlation with the 180-degree rotated kernel
                 lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 1, s)
-                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+                lib.call(_k("nasseg_dwconv", dy), ptr(dy), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
                          ACT_NONE, B, Ho, Wo, C, H, W, K, 1, padb, dil, 0, None, s)
             else:
                 lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, K, 0, s)
-                lib.call("nasseg_dwconv", ptr(dy), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+                lib.call(_k("nasseg_dwconv", dy), ptr(dy), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
                          ACT_NONE, B, Ho, Wo, C, H, W, K, stride, pad, dil, 1, None, s)
             if relu_in:
                 dx = _act_bwd(dx, x, ACT_RELU)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws = _ws(x, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, K))
-            lib.call("nasseg_dwconv_wgrad", ptr(x), ptr(dy), ptr(dw), ptr(ws), None, None,
+            lib.call(_k("nasseg_dwconv_wgrad", x), ptr(x), ptr(dy), ptr(dw), ptr(ws), None, None,
                      ACT_RELU if relu_in else ACT_NONE, B, H, W, C, Ho, Wo, K, stride, pad, dil, s)
         return dx, dw, None, None, None, None
 
@@ -225,11 +236,11 @@ def _dense_backward_data(dz, wb, form, x_shape, N, kh, kw, stride, pad, dil):
     Ho, Wo = dz.shape[2], dz.shape[3]
     dx = _new(dz, B, K, H, W)
     if form == 5:
-        lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
+        lib.call(_k("nasseg_conv_fwd", dz), ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
                  ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, 1, dil * (kh - 1) - pad, dil, 0,
                  None, current_stream())
     else:
-        lib.call("nasseg_conv_fwd", ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
+        lib.call(_k("nasseg_conv_fwd", dz), ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
                  ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None,
                  current_stream())
     return dx
@@ -249,7 +260,7 @@ class _Conv2d(torch.autograd.Function):
             raise NassegError("conv output would be empty")
         y = _new(x, B, N, Ho, Wo)
         wp = _pack_dense(w, "fwd")
-        lib.call("nasseg_conv_fwd", ptr(x), K, ptr(wp), ptr(y), N, None, None, 0, None, ptr(bias),
+        lib.call(_k("nasseg_conv_fwd", x), ptr(x), K, ptr(wp), ptr(y), N, None, None, 0, None, ptr(bias),
                  ACT_NONE, None, 0, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0, None,
                  current_stream())
         ctx.save_for_backward(x, w)
@@ -273,7 +284,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
-            lib.call("nasseg_conv_wgrad", ptr(x), K, ptr(dy), N, ptr(dw), ptr(ws), None, None, 0, B,
+            lib.call(_k("nasseg_conv_wgrad", x), ptr(x), K, ptr(dy), N, ptr(dw), ptr(ws), None, None, 0, B,
                      H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colred(RED_SUM, dy, N, None, 0, None, 0, 1, B * Ho * Wo, N)
@@ -299,7 +310,7 @@ def _conv_backward(x, w, dz, stride, pad, dil, need_dx, need_dw):
     if need_dw:
         dw = torch.empty_like(w)
         ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
-        lib.call("nasseg_conv_wgrad", ptr(x), K, ptr(dz), N, ptr(dw), ptr(ws), None, None, 0, B, H,
+        lib.call(_k("nasseg_conv_wgrad", x), ptr(x), K, ptr(dz), N, ptr(dw), ptr(ws), None, None, 0, B, H,
                  W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
     return dx, dw
 
@@ -335,7 +346,7 @@ class _ConvBNAct(torch.autograd.Function):
             lib.call("nasseg_bn_eval_params", N, float(eps), ptr(gamma), ptr(beta), ptr(running_mean),
                      ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
             y = _new(x, B, N, Ho, Wo)
-            lib.call("nasseg_conv_fwd", ptr(x), K, ptr(wp), ptr(y), N, None, None, 0, ptr(scale),
+            lib.call(_k("nasseg_conv_fwd", x), ptr(x), K, ptr(wp), ptr(y), N, None, None, 0, ptr(scale),
                      ptr(shift), act, ptr(res), N, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0,
                      None, s)
             return y
@@ -347,13 +358,13 @@ class _ConvBNAct(torch.autograd.Function):
                         (B, N, Ho, Wo)))
             nblk = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N)
             part = _ws(x, (nblk + 64) * 2 * N)  # + scratch rows of the two-level finalize
-            lib.call("nasseg_conv_fwd", ptr(x), K, ptr(wp), ptr(z), N, None, None, 0, None, None,
+            lib.call(_k("nasseg_conv_fwd", x), ptr(x), K, ptr(wp), ptr(z), N, None, None, 0, None, None,
                      ACT_NONE, None, 0, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0, ptr(part), s)
             lib.call("nasseg_bn_finalize", ptr(part), nblk, M, N, float(eps), float(momentum),
                      ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                      ptr(running_mean), ptr(running_var), ptr(nbt), s)
         else:
-            lib.call("nasseg_conv_fwd", ptr(x), K, ptr(wp), ptr(z), N, None, None, 0, None, None,
+            lib.call(_k("nasseg_conv_fwd", x), ptr(x), K, ptr(wp), ptr(z), N, None, None, 0, None, None,
                      ACT_NONE, None, 0, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0, None, s)
             lib.call("nasseg_bn_eval_params", N, float(eps), ptr(gamma), ptr(beta), ptr(running_mean),
                      ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
@@ -373,12 +384,12 @@ class _ConvBNAct(torch.autograd.Function):
         s = current_stream()
         sums = _vec(z, 2 * N)
         ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
-        lib.call("nasseg_bn_bwd_reduce", ptr(dy), N, ptr(z), N, M, N, ptr(scale), ptr(shift),
+        lib.call(_k("nasseg_bn_bwd_reduce", dy), ptr(dy), N, ptr(z), N, M, N, ptr(scale), ptr(shift),
                  ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
         dx = dw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dz = torch.empty_like(z)
-            lib.call("nasseg_bn_bwd_apply", ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean),
+            lib.call(_k("nasseg_bn_bwd_apply", dy), ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean),
                      ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
             dx, dw = _conv_backward(x, w, dz, stride, pad, dil, ctx.needs_input_grad[0],
                                     ctx.needs_input_grad[1])
@@ -419,10 +430,10 @@ def _dw_backward_data(dz, wt, K, x_shape, stride, pad, dil, bn=None):
         if nb > 0:
             z, scale, shift, mean, invstd, act = bn
             part = _ws(dz, (nb + 64) * 2 * C)
-            lib.call("nasseg_dwconv_bwd_data_bn", ptr(dz), ptr(wt), ptr(dx), ptr(z), ptr(scale),
+            lib.call(_k("nasseg_dwconv_bwd_data_bn", dz), ptr(dz), ptr(wt), ptr(dx), ptr(z), ptr(scale),
                      ptr(shift), ptr(mean), ptr(invstd), act, *geom, ptr(part), s)
             return dx, (part, nb)
-    lib.call("nasseg_dwconv", ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
+    lib.call(_k("nasseg_dwconv", dz), ptr(dz), ptr(wt), ptr(dx), None, None, ACT_NONE, None, None,
              ACT_NONE, *geom, None, s)
     return dx, None
 
@@ -545,10 +556,10 @@ class _ConvChain(torch.autograd.Function):
                     o_res = res
             wp = packed[i]
             if kind == "dw":
-                lib.call("nasseg_dwconv", ptr(cur), ptr(wp), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
+                lib.call(_k("nasseg_dwconv", cur), ptr(cur), ptr(wp), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
                          ptr(o_sh), o_act, B, H, W, K, Ho, Wo, kh, stride, pad, dil, 0, ptr(part), s)
             else:
-                lib.call("nasseg_conv_fwd", ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh), pact,
+                lib.call(_k("nasseg_conv_fwd", cur), ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh), pact,
                          ptr(o_sc), ptr(o_sh), o_act, ptr(o_res), N, B, H, W, K, Ho, Wo, N, kh, kw,
                          stride, pad, dil, 0, ptr(part), s)
             if needs_grad:
@@ -568,7 +579,7 @@ class _ConvChain(torch.autograd.Function):
                                  ptr(rm), ptr(rv), ptr(nbt), s)
                     else:
                         ws = _ws(cur, lib.query("nasseg_colred_workspace", 1, M, N))
-                        lib.call("nasseg_bn_stats", ptr(z), N, M, N, float(eps), float(momentum),
+                        lib.call(_k("nasseg_bn_stats", z), ptr(z), N, M, N, float(eps), float(momentum),
                                  ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                  ptr(rm), ptr(rv), ptr(nbt), ptr(ws), s)
                 cur, pend = z, (scale, shift, act)
@@ -613,7 +624,7 @@ class _ConvChain(torch.autograd.Function):
                     lib.call("nasseg_rows_sum", ptr(pre[0]), pre[1], 2 * N, ptr(sums), s)
                 else:
                     ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
-                    lib.call("nasseg_bn_bwd_reduce", ptr(g), N, ptr(z), N, M, N, ptr(scale),
+                    lib.call(_k("nasseg_bn_bwd_reduce", g), ptr(g), N, ptr(z), N, M, N, ptr(scale),
                              ptr(shift), ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
                 if ctx.needs_input_grad[3 + 6 * i + 1]:
                     grads[6 * i + 1] = sums[N:2 * N]
@@ -623,7 +634,7 @@ class _ConvChain(torch.autograd.Function):
                     g = None
                     break
                 dz = torch.empty_like(z)
-                lib.call("nasseg_bn_bwd_apply", ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean),
+                lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean),
                          ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
             else:
                 dz = g
@@ -652,7 +663,7 @@ class _ConvChain(torch.autograd.Function):
                 if need_dw:
                     dwt = torch.empty_like(w)
                     ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", Bc, K, Ho, Wo, k))
-                    lib.call("nasseg_dwconv_wgrad", ptr(cur), ptr(dz), ptr(dwt), ptr(ws), ptr(psc),
+                    lib.call(_k("nasseg_dwconv_wgrad", cur), ptr(cur), ptr(dz), ptr(dwt), ptr(ws), ptr(psc),
                              ptr(psh), pact, Bc, H, W, K, Ho, Wo, k, stride, pad, dil, s)
                     grads[6 * i] = dwt
                 g = None
@@ -663,7 +674,7 @@ class _ConvChain(torch.autograd.Function):
                 if need_dw:
                     dwt = torch.empty_like(w)
                     ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", Bc, Ho, Wo, N, K, kh, kw))
-                    lib.call("nasseg_conv_wgrad", ptr(cur), K, ptr(dz), N, ptr(dwt), ptr(ws), ptr(psc),
+                    lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N, ptr(dwt), ptr(ws), ptr(psc),
                              ptr(psh), pact, Bc, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
                     grads[6 * i] = dwt
                 g = None
@@ -673,7 +684,7 @@ class _ConvChain(torch.autograd.Function):
                         zp, psc_, psh_, pmu_, pis_, pact_ = bn_prev
                         nb = lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K) if pmu_ is not None else 0
                         part = _ws(cur, (nb + 64) * 2 * K) if nb else None
-                        lib.call("nasseg_conv_bwd_data_bn", ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
+                        lib.call(_k("nasseg_conv_bwd_data_bn", dz), ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
                                  ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
                                  K, kh, kw, stride, pad, dil, ptr(part), s)
                         pre = (part, nb)
@@ -727,7 +738,7 @@ class _BatchNormAct(torch.autograd.Function):
                     "Expected more than 1 value per channel when training, got input size {}".format(
                         tuple(x.shape)))
             ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
-            lib.call("nasseg_bn_stats", ptr(x), C, M, C, float(eps), float(momentum), ptr(gamma),
+            lib.call(_k("nasseg_bn_stats", x), ptr(x), C, M, C, float(eps), float(momentum), ptr(gamma),
                      ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(running_mean),
                      ptr(running_var), ptr(nbt), ptr(ws), s)
         else:
@@ -751,12 +762,12 @@ class _BatchNormAct(torch.autograd.Function):
         s = current_stream()
         sums = _vec(x, 2 * C)
         ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
-        lib.call("nasseg_bn_bwd_reduce", ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift),
+        lib.call(_k("nasseg_bn_bwd_reduce", dy), ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift),
                  ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            lib.call("nasseg_bn_bwd_apply", ptr(dy), ptr(x), ptr(scale), ptr(shift), ptr(mean),
+            lib.call(_k("nasseg_bn_bwd_apply", dy), ptr(dy), ptr(x), ptr(scale), ptr(shift), ptr(mean),
                      ptr(invstd), ptr(sums), M, C, int(training), act, ptr(dx), s)
         dgamma = sums[C:2 * C] if (affine and ctx.needs_input_grad[1]) else None
         dbeta = sums[0:C] if (affine and ctx.needs_input_grad[2]) else None
@@ -784,7 +795,7 @@ class _Pool(torch.autograd.Function):
         idx = None
         if mode == 0:
             idx = torch.empty((B, Ho, Wo, C), device=x.device, dtype=torch.uint8)
-        lib.call("nasseg_pool_fwd", mode, ptr(x), ptr(y), ptr(idx), B, H, W, C, Ho, Wo, k, stride,
+        lib.call(_k("nasseg_pool_fwd", x), mode, ptr(x), ptr(y), ptr(idx), B, H, W, C, Ho, Wo, k, stride,
                  pad, current_stream())
         ctx.cfg = (mode, k, stride, pad, (B, C, H, W))
         ctx.idx = idx
@@ -795,7 +806,7 @@ class _Pool(torch.autograd.Function):
         mode, k, stride, pad, (B, C, H, W) = ctx.cfg
         dy = _cl(dy)
         dx = _new(dy, B, C, H, W)
-        lib.call("nasseg_pool_bwd", mode, ptr(dy), ptr(ctx.idx), ptr(dx), B, H, W, C, dy.shape[2],
+        lib.call(_k("nasseg_pool_bwd", dy), mode, ptr(dy), ptr(ctx.idx), ptr(dx), B, H, W, C, dy.shape[2],
                  dy.shape[3], k, stride, pad, current_stream())
         return dx, None, None, None, None
 
@@ -818,7 +829,7 @@ class _Bilinear(torch.autograd.Function):
         x = _cl(x)
         B, C, H, W = x.shape
         y = _new(x, B, C, Ho, Wo)
-        lib.call("nasseg_bilinear_fwd", ptr(x), ptr(y), C, 0, B, H, W, C, Ho, Wo, ACT_NONE,
+        lib.call(_k("nasseg_bilinear_fwd", x), ptr(x), ptr(y), C, 0, B, H, W, C, Ho, Wo, ACT_NONE,
                  current_stream())
         ctx.shape = (B, C, H, W)
         return y
@@ -829,7 +840,7 @@ class _Bilinear(torch.autograd.Function):
         dy = _cl(dy)
         dx = _new(dy, B, C, H, W)
         nws = lib.query("nasseg_bilinear_bwd_workspace", B, H, W, C, dy.shape[2], dy.shape[3])
-        lib.call("nasseg_bilinear_bwd", ptr(dy), C, 0, ptr(dx), B, H, W, C, dy.shape[2],
+        lib.call(_k("nasseg_bilinear_bwd", dy), ptr(dy), C, 0, ptr(dx), B, H, W, C, dy.shape[2],
                  dy.shape[3], ptr(_ws(dy, nws)) if nws else None, current_stream())
         return dx, None, None
 
@@ -860,10 +871,10 @@ class _ConcatResize(torch.autograd.Function):
             if x.shape[0] != B:
                 raise NassegError("concat: batch sizes differ")
             if (H, W) == (Ho, Wo):
-                lib.call("nasseg_chan_copy", ptr(x), C, 0, ptr(y), Ct, off, None, 0, 0, B * Ho * Wo,
+                lib.call(_k("nasseg_chan_copy", x), ptr(x), C, 0, ptr(y), Ct, off, None, 0, 0, B * Ho * Wo,
                          C, act, ACT_NONE, s)
             else:
-                lib.call("nasseg_bilinear_fwd", ptr(x), ptr(y), Ct, off, B, H, W, C, Ho, Wo, act, s)
+                lib.call(_k("nasseg_bilinear_fwd", x), ptr(x), ptr(y), Ct, off, B, H, W, C, Ho, Wo, act, s)
             shapes.append((C, H, W))
             off += C
         ctx.shapes = shapes
@@ -889,11 +900,11 @@ class _ConcatResize(torch.autograd.Function):
                 continue
             dx = _new(dy, B, C, H, W)
             if (H, W) == (Ho, Wo):
-                lib.call("nasseg_chan_copy", ptr(dy), Ct, off, ptr(dx), C, 0, None, 0, 0,
+                lib.call(_k("nasseg_chan_copy", dy), ptr(dy), Ct, off, ptr(dx), C, 0, None, 0, 0,
                          B * Ho * Wo, C, ACT_NONE, ACT_NONE, s)
             else:
                 nws = lib.query("nasseg_bilinear_bwd_workspace", B, H, W, C, Ho, Wo)
-                lib.call("nasseg_bilinear_bwd", ptr(dy), Ct, off, ptr(dx), B, H, W, C, Ho, Wo,
+                lib.call(_k("nasseg_bilinear_bwd", dy), ptr(dy), Ct, off, ptr(dx), B, H, W, C, Ho, Wo,
                          ptr(_ws(dy, nws)) if nws else None, s)
             grads.append(dx)
             off += C
@@ -939,7 +950,7 @@ class _CatBNReluConv(torch.autograd.Function):
             ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
             for h, t in enumerate((x, y)):
                 lo, hi = h * C, (h + 1) * C
-                lib.call("nasseg_bn_stats", ptr(t), C, M, C, float(eps), float(momentum), ptr(gamma[lo:hi]),
+                lib.call(_k("nasseg_bn_stats", t), ptr(t), C, M, C, float(eps), float(momentum), ptr(gamma[lo:hi]),
                          ptr(beta[lo:hi]), ptr(mean[lo:hi]), ptr(invstd[lo:hi]), ptr(scale[lo:hi]),
                          ptr(shift[lo:hi]), ptr(rm[lo:hi]) if rm is not None else None,
                          ptr(rv[lo:hi]) if rv is not None else None,
@@ -952,10 +963,10 @@ class _CatBNReluConv(torch.autograd.Function):
             items += [(w, 1, 0, C), (w, 1, C, C)]
         packed = _pack_many(x, items)
         y1 = _new(x, B, N, H, W)
-        lib.call("nasseg_conv_fwd", ptr(x), C, ptr(packed[0]), ptr(y1), N, ptr(scale[0:C]), ptr(shift[0:C]),
+        lib.call(_k("nasseg_conv_fwd", x), ptr(x), C, ptr(packed[0]), ptr(y1), N, ptr(scale[0:C]), ptr(shift[0:C]),
                  ACT_RELU, None, None, ACT_NONE, None, 0, B, H, W, C, H, W, N, 1, 1, 1, 0, 1, 0, None, s)
         out = _new(x, B, N, H, W)
-        lib.call("nasseg_conv_fwd", ptr(y), C, ptr(packed[1]), ptr(out), N, ptr(scale[C:]), ptr(shift[C:]),
+        lib.call(_k("nasseg_conv_fwd", y), ptr(y), C, ptr(packed[1]), ptr(out), N, ptr(scale[C:]), ptr(shift[C:]),
                  ACT_RELU, None, None, ACT_NONE, ptr(y1), N, B, H, W, C, H, W, N, 1, 1, 1, 0, 1, 0, None, s)
         if needs_grad:
             ctx.save_for_backward(x, y, stats, packed[2], packed[3])
@@ -985,25 +996,25 @@ class _CatBNReluConv(torch.autograd.Function):
             if need_dx or need_bn:
                 g = _new(x, B, C, H, W)
                 part = _ws(x, (nb + 64) * 2 * C)
-                lib.call("nasseg_conv_bwd_data_bn", ptr(dout), N, ptr(wb), ptr(g), C, ptr(t), C, ptr(sc),
+                lib.call(_k("nasseg_conv_bwd_data_bn", dout), ptr(dout), N, ptr(wb), ptr(g), C, ptr(t), C, ptr(sc),
                          ptr(sh), ptr(mu), ptr(isd), ACT_RELU, B, H, W, N, H, W, C, 1, 1, 1, 0, 1,
                          ptr(part), s)
                 sums = _vec(x, 2 * C)
                 lib.call("nasseg_rows_sum", ptr(part), nb, 2 * C, ptr(sums), s)
                 if need_bn:  # sums = [sum g | sum g*xhat] -> rows (dbeta, dgamma) of dbn at columns lo..hi
-                    lib.call("nasseg_chan_copy", ptr(sums), C, 0, ptr(dbn), 2 * C, lo, None, 0, 0, 2, C,
+                    lib.call(_k("nasseg_chan_copy", sums), ptr(sums), C, 0, ptr(dbn), 2 * C, lo, None, 0, 0, 2, C,
                              ACT_NONE, ACT_NONE, s)
                 if need_dx:
                     dz = torch.empty_like(t)
-                    lib.call("nasseg_bn_bwd_apply", ptr(g), ptr(t), ptr(sc), ptr(sh), ptr(mu), ptr(isd),
+                    lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(t), ptr(sc), ptr(sh), ptr(mu), ptr(isd),
                              ptr(sums), M, C, int(training), ACT_RELU, ptr(dz), s)
                     grads_in[h] = dz
             if need_w:
                 dwh = _vec(x, N * C)
                 ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, H, W, N, C, 1, 1))
-                lib.call("nasseg_conv_wgrad", ptr(t), C, ptr(dout), N, ptr(dwh), ptr(ws), ptr(sc), ptr(sh),
+                lib.call(_k("nasseg_conv_wgrad", t), ptr(t), C, ptr(dout), N, ptr(dwh), ptr(ws), ptr(sc), ptr(sh),
                          ACT_RELU, B, H, W, C, H, W, N, 1, 1, 1, 0, 1, s)
-                lib.call("nasseg_chan_copy", ptr(dwh), C, 0, ptr(dw), 2 * C, lo, None, 0, 0, N, C, ACT_NONE,
+                lib.call(_k("nasseg_chan_copy", dwh), ptr(dwh), C, 0, ptr(dw), 2 * C, lo, None, 0, 0, N, C, ACT_NONE,
                          ACT_NONE, s)
         dgamma = dbn[2 * C:4 * C] if ctx.needs_input_grad[2] else None
         dbeta = dbn[0:2 * C] if ctx.needs_input_grad[3] else None
@@ -1096,7 +1107,7 @@ class _ChannelRepeat(torch.autograd.Function):
         y = _new(x, B, C * rep, H, W)
         s = current_stream()
         for r in range(rep):
-            lib.call("nasseg_chan_copy", ptr(x), C, 0, ptr(y), C * rep, r * C, None, 0, 0, B * H * W,
+            lib.call(_k("nasseg_chan_copy", x), ptr(x), C, 0, ptr(y), C * rep, r * C, None, 0, 0, B * H * W,
                      C, ACT_NONE, ACT_NONE, s)
         ctx.cfg = (rep, (B, C, H, W))
         return y
@@ -1106,7 +1117,7 @@ class _ChannelRepeat(torch.autograd.Function):
         rep, (B, C, H, W) = ctx.cfg
         dy = _cl(dy)
         dx = _new(dy, B, C, H, W)
-        lib.call("nasseg_chan_fold", ptr(dy), ptr(dx), B * H * W, C, rep, current_stream())
+        lib.call(_k("nasseg_chan_fold", dy), ptr(dy), ptr(dx), B * H * W, C, rep, current_stream())
         return dx, None
 
 
@@ -1121,7 +1132,7 @@ def zeros(like, B, C, H, W):
     """A zero activation that is not connected to the autograd graph (Zero op)."""
     require_device(like)
     y = _new(like, B, C, H, W)
-    lib.call("nasseg_fill", ptr(y), y.numel(), 0.0, current_stream())
+    lib.call(_k("nasseg_fill", y), ptr(y), y.numel(), 0.0, current_stream())
     return y
 
 
@@ -1135,7 +1146,7 @@ class _GlobalAvgPool(torch.autograd.Function):
         B, C, H, W = x.shape
         out = _colred(RED_SUM, x, C, None, 0, None, 0, B, H * W, C, 1.0 / (H * W))
         ctx.shape = (B, C, H, W)
-        return out.view(B, C, 1, 1)
+        return out.view(B, C, 1, 1).to(x.dtype)  # (the reduction is fp32; B*C values)
 
     @staticmethod
     def backward(ctx, dy):
@@ -1143,9 +1154,9 @@ class _GlobalAvgPool(torch.autograd.Function):
         dy = dy.contiguous().view(B, C, 1, 1)
         # every pixel receives dy / (H*W): a broadcast with a scale
         scale = _vec(dy, C)
-        lib.call("nasseg_fill", ptr(scale), C, 1.0 / (H * W), current_stream())
+        lib.call(_k("nasseg_fill", scale), ptr(scale), C, 1.0 / (H * W), current_stream())
         dx = _new(dy, B, C, H, W)
-        lib.call("nasseg_bilinear_fwd", ptr(dy), ptr(dx), C, 0, B, 1, 1, C, H, W, ACT_NONE,
+        lib.call(_k("nasseg_bilinear_fwd", dy), ptr(dy), ptr(dx), C, 0, B, 1, 1, C, H, W, ACT_NONE,
                  current_stream())
         return _axpby(dx, None, scale, None)
 
@@ -1164,7 +1175,7 @@ class _Broadcast(torch.autograd.Function):
         B, C = v.shape[0], v.shape[1]
         v = v.contiguous().view(B, C, 1, 1)
         y = _new(v, B, C, H, W)
-        lib.call("nasseg_bilinear_fwd", ptr(v), ptr(y), C, 0, B, 1, 1, C, H, W, ACT_NONE,
+        lib.call(_k("nasseg_bilinear_fwd", v), ptr(v), ptr(y), C, 0, B, 1, 1, C, H, W, ACT_NONE,
                  current_stream())
         ctx.shape = (B, C, H, W)
         return y
@@ -1174,7 +1185,7 @@ class _Broadcast(torch.autograd.Function):
         B, C, H, W = ctx.shape
         dy = _cl(dy)
         dv = _colred(RED_SUM, dy, C, None, 0, None, 0, B, H * W, C)
-        return dv.view(B, C, 1, 1), None, None
+        return dv.view(B, C, 1, 1).to(dy.dtype), None, None
 
 
 def broadcast_to(v, size):
@@ -1204,7 +1215,7 @@ class _LogSoftmaxNLL(torch.autograd.Function):
                 tuple(target.shape), tuple(logits.shape)))
         out = _vec(logits, 2)
         ws = _ws(logits, lib.query("nasseg_ce_workspace"))
-        lib.call("nasseg_ce_fwd", ptr(logits), ptr(target), esz, B * H * W, C, int(ignore_index),
+        lib.call(_k("nasseg_ce_fwd", logits), ptr(logits), ptr(target), esz, B * H * W, C, int(ignore_index),
                  ptr(out), ptr(ws), current_stream())
         ctx.save_for_backward(logits, target, out)
         ctx.cfg = (esz, int(ignore_index))
@@ -1217,7 +1228,7 @@ class _LogSoftmaxNLL(torch.autograd.Function):
         B, C, H, W = logits.shape
         g = g.to(torch.float32).contiguous().view(1)
         d = torch.empty_like(logits)
-        lib.call("nasseg_ce_bwd", ptr(logits), ptr(target), esz, ptr(out), ptr(g), B * H * W, C,
+        lib.call(_k("nasseg_ce_bwd", logits), ptr(logits), ptr(target), esz, ptr(out), ptr(g), B * H * W, C,
                  ignore, ptr(d), current_stream())
         return d, None, None
 
@@ -1231,14 +1242,14 @@ class _BerHu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
         require_device(pred, target)
-        if pred.dtype != torch.float32 or target.dtype != torch.float32:
-            raise NassegError("berhu: fp32 tensors expected")
+        if pred.dtype not in (torch.float32, torch.bfloat16) or target.dtype != pred.dtype:
+            raise NassegError("berhu: fp32 or bf16 tensors of one dtype expected")
         if pred.shape != target.shape:
             raise NassegError("berhu: shapes differ")
         p, t = pred.contiguous(), target.contiguous()
         out = _vec(p, 2)
         ws = _ws(p, lib.query("nasseg_ce_workspace"))
-        lib.call("nasseg_berhu_fwd", ptr(p), ptr(t), p.numel(), ptr(out), ptr(ws), current_stream())
+        lib.call(_k("nasseg_berhu_fwd", p), ptr(p), ptr(t), p.numel(), ptr(out), ptr(ws), current_stream())
         ctx.save_for_backward(p, t, out)
         return out[0].clone()
 
@@ -1247,7 +1258,7 @@ class _BerHu(torch.autograd.Function):
         p, t, out = ctx.saved_tensors
         g = g.to(torch.float32).contiguous().view(1)
         d = torch.empty_like(p)
-        lib.call("nasseg_berhu_bwd", ptr(p), ptr(t), ptr(out), ptr(g), p.numel(), ptr(d),
+        lib.call(_k("nasseg_berhu_bwd", p), ptr(p), ptr(t), ptr(out), ptr(g), p.numel(), ptr(d),
                  current_stream())
         return d, None
 
@@ -1274,6 +1285,8 @@ def argmax_confusion(logits, gt, n_classes, cm=None, out_size=None, return_preds
     int64 (n,n) device tensor that is accumulated into (created when None).
     """
     logits = _cl(logits.detach())
+    if logits.dtype != torch.float32:
+        logits = logits.float()  # the reward path interpolates and compares in fp32
     B, C, h, w = logits.shape
     preds = None
     if gt is not None:

@@ -11,7 +11,7 @@ WHAT="${1:-all}"
 python -c "import torch; print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))" > $OUT/env.log 2>&1
 nproc >> $OUT/env.log; grep -m1 "model name" /proc/cpuinfo >> $OUT/env.log
 if [[ "$WHAT" == "all" || "$WHAT" == "tests" ]]; then
-  for f in tests/test_hip_kernels.py tests/test_hip_golden.py tests/test_hip_engine.py; do
+  for f in tests/test_hip_kernels.py tests/test_hip_golden.py tests/test_hip_engine.py tests/test_hip_bf16.py; do
     n=$(basename $f .py)
     timeout 900 python -m pytest $f -m gpu -q --tb=short --timeout 300 -p no:cacheprovider > $OUT/$n.log 2>&1
     echo "$n exit $?" >> $OUT/summary.log
