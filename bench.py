@@ -48,9 +48,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 
 
 def algorithmic_bytes(name, a):
-    """ALGORITHMIC bytes of one launch of a C-ABI entry point (fp32; inputs read
-    once + outputs written once, SURVEY.md section 8(d) per-primitive formulas).
-    `a` is the positional argument tuple of the call (include/nasseg.h order)."""
+    """ALGORITHMIC bytes of one launch of a C-ABI entry point (inputs read once + outputs
+    written once, SURVEY.md section 8(d) per-primitive formulas).  `a` is the positional
+    argument tuple of the call (include/nasseg.h order).  The bfloat16 twins move half the
+    bytes (weights and per-channel vectors, which stay fp32, are negligible)."""
+    if name.startswith("nasseg_bf16_"):
+        return algorithmic_bytes("nasseg_" + name[len("nasseg_bf16_"):], a) // 2
     if name == "nasseg_dwconv":
         B, H, W, C, Ho, Wo, K = a[9], a[10], a[11], a[12], a[13], a[14], a[15]
         return 4 * (B * C * H * W + B * C * Ho * Wo + C * K * K)
@@ -248,6 +251,9 @@ def main():
     ap.add_argument("--graph", type=int, default=0, choices=(0, 1, 2),
                     help="0 = launch every kernel from the host; 1 = replay forward+loss+backward from a "
                          "hipGraph (all-reduce, clip, optimisers outside); 2 = whole step in the graph (1 GPU)")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="storage type of activations and their gradients (arithmetic, statistics, "
+                         "parameters and parameter gradients are fp32 either way); the BASELINE metric is f32")
     ap.add_argument("--fused-optim", type=int, default=0, choices=(0, 1),
                     help="torch.optim fused=True implementations of SGD / Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -288,6 +294,8 @@ def main():
     optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5,
                                  capturable=args.graph == 2, **fused)
     image, mask = synthetic_batch(args.batch, args.height, args.width, rank, device, wl[2])
+    if args.dtype == "bf16":
+        image = image.to(torch.bfloat16)
 
     def eager_step():
         return segmenter_step(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1)
@@ -299,7 +307,8 @@ def main():
         with torch.no_grad():
             probe = segmenter(image)
             probe = probe[0] if isinstance(probe, tuple) else probe
-        depth = torch.rand(probe.shape, device=device).contiguous(memory_format=torch.channels_last) * 10.0
+        depth = (torch.rand(probe.shape, device=device).contiguous(memory_format=torch.channels_last)
+                 * 10.0).to(image.dtype)
         del probe
 
         def eager_step():  # noqa: F811 - regression head: berHu instead of softmax/NLL
@@ -367,7 +376,8 @@ def main():
             top = rows[0]
             total_ms = sum(r["ms"] for r in rows)
             # depthwise forward + backward-data launches (plain and with the fused BN-backward sums)
-            dwr = [r for r in rows if r["kernel"] in ("nasseg_dwconv", "nasseg_dwconv_bwd_data_bn")]
+            dwr = [r for r in rows if r["kernel"].replace("nasseg_bf16_", "nasseg_")
+                   in ("nasseg_dwconv", "nasseg_dwconv_bwd_data_bn")]
             dw = ([{"gbs": sum(r["bytes"] for r in dwr) / 1e9 / (sum(r["ms"] for r in dwr) / 1e3)}]
                   if dwr and sum(r["ms"] for r in dwr) > 0 else [])
             fam = {"nasseg_conv_fwd": "conv_fwd_kernel", "nasseg_conv_wgrad": "conv_wgrad_kernel(+finalize)",
@@ -377,14 +387,16 @@ def main():
                    "nasseg_bn_bwd_apply": "bn_bwd_apply_kernel", "nasseg_affine_act": "affine_act_kernel",
                    "nasseg_bn_stats": "colred_kernel<1>(+bn_stats_finalize)",
                    "nasseg_bn_bwd_reduce": "colred_kernel<2>(+colred_finalize)"}
+            base = top["kernel"].replace("nasseg_bf16_", "nasseg_")
             roof = {"bound": "hbm", "kernel": top["kernel"],
-                    "rocprof_kernel_family": fam.get(top["kernel"], top["kernel"]),
+                    "rocprof_kernel_family": fam.get(base, base),
                     "top5": [{"kernel": r["kernel"], "gbs": round(r["gbs"], 1),
                               "frac": round(r["gbs"] / HBM_PEAK_GBS, 3),
                               "share": round(r["ms"] / total_ms, 3)} for r in rows[:5]],
                     "achieved": top["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": top["gbs"] / HBM_PEAK_GBS,
-                    "traffic": pmc_traffic(fam.get(top["kernel"], "").split("(")[0].split(" ")[0]),
+                    "traffic": (pmc_traffic(fam.get(base, "").split("(")[0].split(" ")[0])
+                                if args.dtype == "f32" else None),
                     "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                     "avg_launch_ms": top["ms"] / top["launches"], "launches_per_step": top["launches"] / 2,
                     "share_of_kernel_time": top["ms"] / total_ms,
@@ -421,7 +433,8 @@ def main():
                 args.batch),
             "value": imgs / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "f32" else "bf16 storage / f32 arithmetic",
             "data": "synthetic (randn images, randint labels with a 255 band; random-init weights)",
             "config": {"workload": "{}: {} - MobileNetV2 encoder + searched decoder, "
                                    "{}x3x{}x{} per GPU, train_segmenter step".format(

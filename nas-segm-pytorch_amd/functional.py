@@ -986,7 +986,7 @@ class _CatBNReluConv(torch.autograd.Function):
         need_w = ctx.needs_input_grad[7]
         need_bn = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         dbn = _vec(x, 4 * C) if need_bn else None  # [dbeta(2C) | dgamma(2C)]
-        dw = torch.empty((N, 2 * C, 1, 1), device=x.device, dtype=x.dtype) if need_w else None
+        dw = torch.empty((N, 2 * C, 1, 1), device=x.device, dtype=torch.float32) if need_w else None
         nb = lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, C)
         grads_in = [None, None]
         for h, (t, wb) in enumerate(((x, wb_lo), (y, wb_hi))):

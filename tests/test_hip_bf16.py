@@ -154,3 +154,17 @@ def test_network_step_bf16_tracks_fp32(name, training):
         assert cos_out > 0.9 and (cos_g > 0.8 or rec["kind"] != "template"), (rel, cos_out, cos_g)
     else:
         assert rel < 0.05 and cos_out > 0.999 and cos_g > 0.99, (rel, cos_out, cos_g)
+
+
+def test_concat_reduce_split_path_bf16():
+    """ConcatReduce without the concatenation (the path large maps take) in bf16"""
+    C, N = 32, 32
+    w = (rnd(N, 2 * C, 1, 1, seed=2) * 0.1).to(DEV)
+    gamma, beta = (rnd(2 * C, seed=3) * 0.3 + 1).to(DEV), rnd(2 * C, seed=4).to(DEV)
+
+    def fn(x, y, w, g, b):
+        rm, rv = torch.zeros(2 * C, device=DEV), torch.ones(2 * C, device=DEV)
+        nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+        return F().cat_bn_relu_conv(x, y, g, b, rm, rv, nbt, w, True, 0.1, 1e-5)
+
+    both(fn, [act(rnd(2, C, 16, 24, seed=1)), act(rnd(2, C, 16, 24, seed=5))], [w, gamma, beta])

@@ -36,6 +36,10 @@ if [[ "$WHAT" == "all" || "$WHAT" == "graph" ]]; then
     timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_${wl}_g0.json 2> $OUT/bench_${wl}_g0.err
     echo "bench $wl exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_g0.json >> $OUT/summary.log
   done
+  for wl in headline depth480; do
+    timeout 300 python bench.py --workload $wl --dtype bf16 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_${wl}_bf16.json 2> $OUT/bench_${wl}_bf16.err
+    echo "bench $wl bf16 exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_bf16.json >> $OUT/summary.log
+  done
   for wl in arch1 cvpr321; do
     for g in 0 2; do
       timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --graph $g --no-cpu-baseline > $OUT/bench_${wl}_g$g.json 2> $OUT/bench_${wl}_g$g.err
