@@ -50,7 +50,10 @@ def _ignore_index(segm_crit):
 
 
 def _to_device_image(image, device):
-    return image.to(device=device, dtype=torch.float32, non_blocking=True).contiguous(
+    # fp32 like the reference; a loader that already yields bfloat16 images selects the bf16
+    # activation-storage twins of every kernel (include/nasseg.h)
+    dtype = torch.bfloat16 if image.dtype == torch.bfloat16 else torch.float32
+    return image.to(device=device, dtype=dtype, non_blocking=True).contiguous(
         memory_format=torch.channels_last)
 
 
