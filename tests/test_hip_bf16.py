@@ -168,3 +168,37 @@ def test_concat_reduce_split_path_bf16():
         return F().cat_bn_relu_conv(x, y, g, b, rm, rv, nbt, w, True, 0.1, 1e-5)
 
     both(fn, [act(rnd(2, C, 16, 24, seed=1)), act(rnd(2, C, 16, 24, seed=5))], [w, gamma, beta])
+
+
+def test_training_steps_bf16_eager_and_graphed():
+    """segmenter_step on bf16 images: finite losses/parameters over a few optimiser steps, and the
+    hipGraph replay of the same steps is bit-identical to launching them from the host"""
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    rec = load_json("nets_meta.json")["wacv_arch0"]
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randn(2, 3, 97, 129, generator=g).to(DEV).to(BF).contiguous(memory_format=torch.channels_last),
+                torch.randint(0, 19, (2, 97, 129), generator=g).to(DEV)) for _ in range(3)]
+
+    def run(graphed):
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+        oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        losses = []
+        if graphed:
+            stepper = GraphedSegmenterStep(net, batches[0][0], batches[0][1], oe, od, 255, 3.0, 3.0, -1)
+            for x, t in batches:
+                losses.append(float(stepper.step(x, t)))
+        else:
+            for x, t in batches:
+                losses.append(float(segmenter_step(net, x, t, oe, od, 255, 3.0, 3.0, -1).detach()))
+        return losses, {k: v.detach().cpu() for k, v in net.state_dict().items()}
+
+    l0, sd0 = run(False)
+    assert all(v == v and abs(v) < 50 for v in l0), l0
+    assert all(bool(torch.isfinite(v.float()).all()) for v in sd0.values())
+    l1, sd1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
