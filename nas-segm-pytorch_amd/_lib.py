@@ -155,9 +155,15 @@ def ptr(t):
 
 
 def current_stream():
+    """Raw handle of torch's current HIP stream on the current device (the C-level accessors:
+    torch.cuda.current_stream() builds a Stream object per call, ~9 us of the ~17 us the host
+    spends per launch)."""
     import torch
 
-    return torch.cuda.current_stream().cuda_stream
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:  # private accessors moved: the public, slower way
+        return torch.cuda.current_stream().cuda_stream
 
 
 def require_device(*tensors):

@@ -38,6 +38,7 @@ class RankParallel(nn.Module):
         self._flat = None
         self._views = None
         self._used = None
+        self._plist = None
         if broadcast:
             self.broadcast_parameters()
 
@@ -57,6 +58,12 @@ class RankParallel(nn.Module):
             for t in list(self.module.parameters()) + list(self.module.buffers()):
                 dist.broadcast(t.data, src, group=self.process_group)
 
+    def _parameters_once(self):
+        # a candidate's module tree is fixed: walk it once, not twice per step
+        if self._plist is None:
+            self._plist = list(self.module.parameters())
+        return self._plist
+
     def _build_bucket(self, used):
         total = sum(p.numel() for p in used)
         ref = used[0]
@@ -74,7 +81,7 @@ class RankParallel(nn.Module):
         small add kernel per parameter and step).  Which parameters the loss reaches is read off
         those fresh gradients in ``sync_gradients``: parameters autograd never touches keep
         ``grad is None`` - the optimisers skip those, as under the reference's nn.DataParallel."""
-        for p in self.module.parameters():
+        for p in self._parameters_once():
             p.grad = None
         return None
 
@@ -88,7 +95,7 @@ class RankParallel(nn.Module):
         # the parameters this backward reached: static per architecture and training stage
         # (decoder only on cached features, everything end to end), hence identical on every
         # rank; the bucket is rebuilt when the stage changes
-        have = [p for p in self.module.parameters() if p.requires_grad and p.grad is not None]
+        have = [p for p in self._parameters_once() if p.requires_grad and p.grad is not None]
         if (self._flat is None or len(have) != len(self._used)
                 or any(a is not b for a, b in zip(have, self._used))):
             if not have:

@@ -201,10 +201,11 @@ def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=
     loss.backward()
     if hasattr(segmenter, "sync_gradients"):
         segmenter.sync_gradients()
-    _clip_and_step([
-        (list(model.encoder.parameters()), enc_grad_clip, optim_enc),
-        (list(model.decoder.parameters()), dec_grad_clip, optim_dec),
-    ])
+    groups = getattr(model, "_nasseg_step_params", None)
+    if groups is None:  # (a candidate's module tree is fixed: walk it once, not every step)
+        groups = (list(model.encoder.parameters()), list(model.decoder.parameters()))
+        model._nasseg_step_params = groups
+    _clip_and_step([(groups[0], enc_grad_clip, optim_enc), (groups[1], dec_grad_clip, optim_dec)])
     return loss
 
 
