@@ -94,6 +94,7 @@ class _Library(object):
     def __init__(self):
         self._dll = None
         self._fn = {}
+        self._memo = {}
         self.profiler = None
 
     def load(self):
@@ -138,12 +139,21 @@ class _Library(object):
         return rc
 
     def query(self, name, *args):
-        """Call a value-returning entry point (workspace sizes, versions)."""
+        """Call a value-returning entry point (workspace sizes, plan queries, versions).  These
+        are pure functions of their integer arguments, so results are memoised: a training step
+        asks the same few hundred questions every time."""
+        key = (name,) + args
+        hit = self._memo.get(key)
+        if hit is not None:
+            return hit
         fn = self._fn.get(name)
         if fn is None:
             self.load()
             fn = self._fn[name]
-        return fn(*args)
+        value = fn(*args)
+        if len(self._memo) < 65536:
+            self._memo[key] = value
+        return value
 
 
 lib = _Library()

@@ -166,48 +166,63 @@ def _pack_dense(w, mode):
     return wp
 
 
+_PACK_PLANS = {}
+
+
 def _pack_many(like, items):
     """Re-pack several weights with ONE launch.  items: [(weight, kind)] or, for a slice of the
     input channels of a dense weight, [(weight, kind, koff, K)]; kind 'fwd' | 0 | 1 | 2 for dense
     weights (as _pack_dense; 5 = mode 1 with flipped taps, see _dense_backward_data), 'dw' |
     'dwflip' for depthwise ones.  Returns the packed tensors in order (the weight itself where
-    its layout already is the packed one)."""
+    its layout already is the packed one).
+
+    The launch descriptor (pointer / shape tables) and the destination buffer of a given set of
+    weights are built once and kept: a chain packs the same parameters every step, and building
+    the ctypes tables cost more host time than the launch.  The buffer is rewritten by every
+    call; a forward's packed weights stay valid until the parameters change, i.e. for its own
+    backward."""
     import ctypes
 
-    out, descs, off = [], [], 0
-    for item in items:
-        w, kind = item[0], item[1]
-        if kind in ("dw", "dwflip"):
-            C, _, k, _ = w.shape
-            d = (C, 1, k, k, 3 if kind == "dw" else 4, 0, 0)
-            numel = w.numel()
-        else:
-            N, Ksrc, kh, kw = w.shape
-            koff, K = (item[2], item[3]) if len(item) > 2 else (0, Ksrc)
-            mode = lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) if kind == "fwd" else int(kind)
-            if kh == 1 and kw == 1 and mode == 5:
-                mode = 1
-            if kh == 1 and kw == 1 and mode == 0 and K == Ksrc:
-                out.append(w)
-                continue
-            d = (N, K, kh, kw, mode, Ksrc if K != Ksrc else 0, koff)
-            numel = N * K * kh * kw
-        out.append(None)
-        descs.append((len(out) - 1, w, d, off, numel))
-        off += (numel + 3) // 4 * 4  # keep every packed tensor 16-byte aligned
-    if descs:
-        buf = _vec(like, off)
+    key = (like.device,) + tuple((it[0].data_ptr(), tuple(it[0].shape)) + tuple(it[1:]) for it in items)
+    plan = _PACK_PLANS.get(key)
+    if plan is None:
+        slots, descs, off = [], [], 0
+        for item in items:
+            w, kind = item[0], item[1]
+            if kind in ("dw", "dwflip"):
+                C, _, k, _ = w.shape
+                d = (C, 1, k, k, 3 if kind == "dw" else 4, 0, 0)
+                numel = w.numel()
+            else:
+                N, Ksrc, kh, kw = w.shape
+                koff, K = (item[2], item[3]) if len(item) > 2 else (0, Ksrc)
+                mode = lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) if kind == "fwd" else int(kind)
+                if kh == 1 and kw == 1 and mode == 5:
+                    mode = 1
+                if kh == 1 and kw == 1 and mode == 0 and K == Ksrc:
+                    slots.append(None)  # the weight itself
+                    continue
+                d = (N, K, kh, kw, mode, Ksrc if K != Ksrc else 0, koff)
+                numel = N * K * kh * kw
+            slots.append((off, numel))
+            descs.append((w, d, off, numel))
+            off += (numel + 3) // 4 * 4  # keep every packed tensor 16-byte aligned
         n = len(descs)
-        src = (ctypes.c_void_p * n)(*[ptr(w) for _, w, _, _, _ in descs])
-        dst = (ctypes.c_void_p * n)()
-        dims = (ctypes.c_int * (7 * n))()
-        for j, (pos, w, d, o, numel) in enumerate(descs):
-            t = buf[o:o + numel]
-            out[pos] = t
-            dst[j] = ptr(t)
+        buf = _vec(like, off) if n else None
+        src = (ctypes.c_void_p * max(n, 1))(*[ptr(w) for w, _, _, _ in descs])
+        dst = (ctypes.c_void_p * max(n, 1))()
+        dims = (ctypes.c_int * (7 * max(n, 1)))()
+        for j, (w, d, o, numel) in enumerate(descs):
+            dst[j] = ptr(buf[o:o + numel])
             dims[7 * j:7 * j + 7] = d
+        views = [None if sl is None else buf[sl[0]:sl[0] + sl[1]] for sl in slots]
+        if len(_PACK_PLANS) > 4096:  # (parameters of discarded candidates)
+            _PACK_PLANS.clear()
+        plan = _PACK_PLANS[key] = (n, src, dst, dims, views, buf)
+    n, src, dst, dims, views, _ = plan
+    if n:
         lib.call("nasseg_pack_weights", n, src, dst, dims, current_stream())
-    return out
+    return [item[0] if v is None else v for item, v in zip(items, views)]
 
 
 def _dgrad_form(kh, kw, stride, pad, dil):
