@@ -189,6 +189,29 @@ def test_full_size_headline_shape_properties():
     assert int(same.diagonal().sum()) == valid and int(same.sum()) == valid
 
 
+def test_full_size_headline_logits_match_the_oracle():
+    """the BASELINE headline network at its full input size, 1x3x1024x2048, inference mode: HIP
+    logits against the CPU oracle (the restatement pinned to the reference by the golden vectors)
+    - the north-star bound of 1e-4, and identical arg-max labels away from near-ties"""
+    from _util import oracle_forward
+
+    rec = load_json("nets_meta.json")["wacv_arch0"]
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).eval()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 3, 1024, 2048, generator=g)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        want = oracle_forward(sd, x, rec, training=False)
+        got = net.to(DEV)(x.to(DEV).contiguous(memory_format=torch.channels_last)).cpu()
+    assert tuple(got.shape) == tuple(want.shape) == (1, 19, 256, 512)
+    err = float((got - want).abs().max())
+    assert err <= 1e-4, err
+    top2 = want.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3
+    assert bool((got.argmax(1) == want.argmax(1))[clear].all())
+
+
 def test_linearity_of_dense_and_depthwise_conv_at_size():
     """conv(a*x + y) == a*conv(x) + conv(y) at a BASELINE-sized activation"""
     from nas_segm_amd import functional as F
