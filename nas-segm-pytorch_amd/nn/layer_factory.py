@@ -203,6 +203,28 @@ class Zero(nn.Module):
         return F.zeros(x, B, C * self.repeats[1], (H + s - 1) // s, (W + s - 1) // s)
 
 
+class FactorizedReduce(nn.Module):
+    """ReLU -> two stride-2 1x1 convs (the second on the map shifted by one pixel) -> cat -> BN
+    (layer_factory.py:300-313; no caller in the reference - kept so that the module namespace is
+    complete).  An odd spatial size makes the two halves differ by one pixel: RuntimeError, as
+    torch.cat would raise."""
+
+    def __init__(self, C_in, C_out, affine=True):
+        super(FactorizedReduce, self).__init__()
+        assert C_out % 2 == 0
+        self.relu = ReLU(inplace=False)
+        self.conv_1 = Conv2d(C_in, C_out // 2, 1, stride=2, padding=0, bias=False)
+        self.conv_2 = Conv2d(C_in, C_out // 2, 1, stride=2, padding=0, bias=False)
+        self.bn = BatchNorm2d(C_out, affine=affine)
+
+    def forward(self, x):
+        x = self.relu(x)
+        a, b = self.conv_1(x), self.conv_2(x[:, :, 1:, 1:])
+        if tuple(a.shape[2:]) != tuple(b.shape[2:]):
+            raise RuntimeError("Sizes of tensors must match except in dimension 1")
+        return self.bn(F.concat_resize([a, b], a.shape[2:]))
+
+
 def resize(x1, x2, largest=True):
     """Bilinearly bring the two maps to a common size: the larger one if
     ``largest`` else the smaller.  Sizes are compared as (H, W) tuples, i.e.

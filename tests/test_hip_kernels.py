@@ -538,3 +538,41 @@ def test_dense_backward_data_mask_only(N, act):
                None, None, act, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, None, s)
     mask = ((x > 0) if act == 1 else ((x > 0) & (x < 6))).float()
     assert torch.equal(g, g_ref * mask)
+
+
+def test_factorized_reduce_matches_torch():
+    """FactorizedReduce (no caller in the reference, kept for namespace completeness) against the
+    same module assembled from torch.nn on the CPU"""
+    from nas_segm_amd.nn.layer_factory import FactorizedReduce
+
+    torch.manual_seed(0)
+    mod = FactorizedReduce(16, 24)
+
+    class Ref(torch.nn.Module):  # the composition the reference class describes
+        def __init__(self):
+            super().__init__()
+            self.relu = torch.nn.ReLU(inplace=False)
+            self.conv_1 = torch.nn.Conv2d(16, 12, 1, stride=2, padding=0, bias=False)
+            self.conv_2 = torch.nn.Conv2d(16, 12, 1, stride=2, padding=0, bias=False)
+            self.bn = torch.nn.BatchNorm2d(24)
+
+        def forward(self, x):
+            x = self.relu(x)
+            return self.bn(torch.cat([self.conv_1(x), self.conv_2(x[:, :, 1:, 1:])], dim=1))
+
+    ref = Ref()
+    assert set(ref.state_dict()) == set(mod.state_dict())
+    ref.load_state_dict(mod.state_dict())
+    x = rnd(2, 16, 12, 16, seed=5)
+    xr = x.clone().requires_grad_(True)
+    want = ref(xr)
+    xg = dev(x.clone()).requires_grad_(True)
+    got = mod.to(DEV)(xg)
+    assert_close(got, want, 3e-5, 3e-5, "forward")
+    cot = rnd(*want.shape, seed=6)
+    want.backward(cot)
+    got.backward(dev(cot))
+    assert_close(xg.grad, xr.grad, 1e-4, 2e-3, "dx")
+    assert_close(mod.conv_2.weight.grad, ref.conv_2.weight.grad, 2e-4, 2e-3, "dw2")
+    with pytest.raises(RuntimeError):
+        mod(dev(rnd(1, 16, 13, 16, seed=7)))
