@@ -13,6 +13,7 @@ import torch.distributed as dist
 from ..helpers.utils import compute_params
 from ..nn.encoders import create_encoder
 from ..nn.micro_decoders import MicroDecoder, TemplateDecoder
+from .graphed import GraphedSegmenterStep
 from .inference import validate
 from .segmenter import RankParallel, Segmenter
 from .trainer import train_segmenter
@@ -35,7 +36,7 @@ def build_candidate(config, ctrl_version="wacv", num_classes=19, agg_size=48, au
 
 def evaluate_candidate(config, train_batches, val_batches, ctrl_version="wacv", num_classes=19,
                        agg_size=48, aux_cell=True, repeats=1, epochs=1, aux_weight=0.15,
-                       omit_classes=(0,), device="cuda", stats=None):
+                       omit_classes=(0,), device="cuda", stats=None, graphed=False):
     """Train the candidate on ``train_batches`` (lists of {"image", "mask"}) for ``epochs``
     passes and return its validation reward; failures score 0 like in the reference."""
     try:
@@ -46,12 +47,28 @@ def evaluate_candidate(config, train_batches, val_batches, ctrl_version="wacv", 
     model = segmenter.module
     optim_enc = torch.optim.SGD(model.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
     optim_dec = torch.optim.Adam(model.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
-    for epoch in range(epochs):
-        ret = train_segmenter(segmenter, train_batches, optim_enc, optim_dec, epoch, _Crit(), False,
-                              3.0, 3.0, False, print_every=10 ** 9,
-                              aux_weight=aux_weight if ctrl_version == "cvpr" else -1)
-        if ret == 0:  # try_except: RuntimeError inside the step
+    aux = aux_weight if ctrl_version == "cvpr" else -1
+    if graphed:
+        # one capture per candidate, one replay per step (engine/graphed.py): same results, no host
+        # launch cost - what bounds a candidate at 321x321 ... 713x713
+        try:
+            first = train_batches[0]
+            image = first["image"].to(device=device, dtype=torch.float32).contiguous(
+                memory_format=torch.channels_last)
+            stepper = GraphedSegmenterStep(segmenter, image, first["mask"].to(device).long(), optim_enc,
+                                           optim_dec, 255, 3.0, 3.0, aux)
+            for epoch in range(epochs):
+                for sample in train_batches:
+                    stepper.step(sample["image"].to(device=device, dtype=torch.float32).contiguous(
+                        memory_format=torch.channels_last), sample["mask"].to(device).long())
+        except RuntimeError:  # scored 0, as the reference's try_except does
             return 0.0
+    else:
+        for epoch in range(epochs):
+            ret = train_segmenter(segmenter, train_batches, optim_enc, optim_dec, epoch, _Crit(), False,
+                                  3.0, 3.0, False, print_every=10 ** 9, aux_weight=aux)
+            if ret == 0:  # try_except: RuntimeError inside the step
+                return 0.0
     reward = validate(segmenter, val_batches, 0, 0, num_classes=num_classes, print_every=10 ** 9,
                       omit_classes=list(omit_classes))
     if stats is not None:

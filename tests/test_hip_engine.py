@@ -244,9 +244,16 @@ def test_candidate_evaluation_with_controller_samples():
         return [batch(19) for _ in range(2)], [batch(19)]
 
     configs = [s["config"] for s in ctrl["wacv"]["samples"][:2]]
+    torch.manual_seed(21)  # (candidate weights are drawn from the global generator)
     rewards = evaluate_candidates(configs, make_batches, ctrl_version="wacv", num_classes=19,
                                   agg_size=48, aux_cell=False, repeats=1, omit_classes=())
     assert len(rewards) == 2 and all(np.isfinite(r) and 0.0 <= r <= 1.0 for r in rewards)
+    # the same candidates trained through a hipGraph replay: identical rewards
+    g.manual_seed(3)
+    torch.manual_seed(21)
+    replayed = evaluate_candidates(configs, make_batches, ctrl_version="wacv", num_classes=19,
+                                   agg_size=48, aux_cell=False, repeats=1, omit_classes=(), graphed=True)
+    assert replayed == rewards, (replayed, rewards)
     cv = [s["config"] for s in ctrl["cvpr"]["samples"][:1]]
     r2 = evaluate_candidates(cv, make_batches, ctrl_version="cvpr", num_classes=19, agg_size=48,
                              aux_cell=True, repeats=1, omit_classes=())
