@@ -311,118 +311,6 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, dilation=1):
     return _Conv2d.apply(x, weight, bias, int(stride), int(padding), int(dilation))
 
 
-def _conv_backward(x, w, dz, stride, pad, dil, need_dx, need_dw):
-    """(dx, dw) of a bias-free dense conv given the gradient dz of its output."""
-    B, K, H, W = x.shape
-    N, _, kh, kw = w.shape
-    Ho, Wo = dz.shape[2], dz.shape[3]
-    s = current_stream()
-    dx = dw = None
-    if need_dx:
-        form = _dense_dgrad_form(w, stride, pad, dil)
-        (wp,) = _pack_many(dz, [(w, form)])
-        dx = _dense_backward_data(dz, wp, form, (B, K, H, W), N, kh, kw, stride, pad, dil)
-    if need_dw:
-        dw = torch.empty_like(w)
-        ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
-        lib.call(_k("nasseg_conv_wgrad", x), ptr(x), K, ptr(dz), N, ptr(dw), ptr(ws), None, None, 0, B, H,
-                 W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
-    return dx, dw
-
-
-class _ConvBNAct(torch.autograd.Function):
-    """conv (no bias) -> BatchNorm -> activation (+ residual) as ONE autograd node.
-
-    Training: the conv kernel's epilogue emits the per-workgroup sums of y and y^2, so the
-    batch statistics cost no extra pass over the conv output; then one elementwise pass
-    normalises.  Inference (no grad): scale/shift/activation/residual are folded into the
-    conv epilogue - a single kernel, the conv output is never written un-normalised."""
-
-    @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, nbt, training, momentum, eps,
-                act, residual, stride, pad, dil):
-        x = _cl(x)
-        w = weight.contiguous()
-        B, K, H, W = x.shape
-        N, Kw, kh, kw = w.shape
-        if Kw != K:
-            raise NassegError("conv weight {} does not match C_in={}".format(tuple(w.shape), K))
-        Ho, Wo = conv_out_size(H, kh, stride, pad, dil), conv_out_size(W, kw, stride, pad, dil)
-        if Ho <= 0 or Wo <= 0:
-            raise NassegError("conv output would be empty")
-        M = B * Ho * Wo
-        s = current_stream()
-        stats = _vec(x, 4 * N)  # mean | invstd | scale | shift
-        mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
-        res = _cl(residual) if residual is not None else None
-        wp = _pack_dense(w, "fwd")
-        needs_grad = any(ctx.needs_input_grad)
-        if not training and not needs_grad:
-            lib.call("nasseg_bn_eval_params", N, float(eps), ptr(gamma), ptr(beta), ptr(running_mean),
-                     ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
-            y = _new(x, B, N, Ho, Wo)
-            lib.call(_k("nasseg_conv_fwd", x), ptr(x), K, ptr(wp), ptr(y), N, None, None, 0, ptr(scale),
-                     ptr(shift), act, ptr(res), N, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0,
-                     None, s)
-            return y
-        z = _new(x, B, N, Ho, Wo)
-        if training:
-            if M <= 1:
-                raise ValueError(
-                    "Expected more than 1 value per channel when training, got input size {}".format(
-                        (B, N, Ho, Wo)))
-            nblk = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N)
-            part = _ws(x, (nblk + 64) * 2 * N)  # + scratch rows of the two-level finalize
-            lib.call(_k("nasseg_conv_fwd", x), ptr(x), K, ptr(wp), ptr(z), N, None, None, 0, None, None,
-                     ACT_NONE, None, 0, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0, ptr(part), s)
-            lib.call("nasseg_bn_finalize", ptr(part), nblk, M, N, float(eps), float(momentum),
-                     ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                     ptr(running_mean), ptr(running_var), ptr(nbt), s)
-        else:
-            lib.call(_k("nasseg_conv_fwd", x), ptr(x), K, ptr(wp), ptr(z), N, None, None, 0, None, None,
-                     ACT_NONE, None, 0, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, 0, None, s)
-            lib.call("nasseg_bn_eval_params", N, float(eps), ptr(gamma), ptr(beta), ptr(running_mean),
-                     ptr(running_var), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
-        y = _affine_act(z, scale, shift, res, act)
-        ctx.save_for_backward(x, w, z, stats)
-        ctx.cfg = (bool(training), act, residual is not None, gamma is not None, stride, pad, dil)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w, z, stats = ctx.saved_tensors
-        training, act, has_res, affine, stride, pad, dil = ctx.cfg
-        dy = _cl(dy)
-        B, N, Ho, Wo = z.shape
-        M = B * Ho * Wo
-        mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
-        s = current_stream()
-        sums = _vec(z, 2 * N)
-        ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
-        lib.call(_k("nasseg_bn_bwd_reduce", dy), ptr(dy), N, ptr(z), N, M, N, ptr(scale), ptr(shift),
-                 ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
-        dx = dw = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dz = torch.empty_like(z)
-            lib.call(_k("nasseg_bn_bwd_apply", dy), ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean),
-                     ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
-            dx, dw = _conv_backward(x, w, dz, stride, pad, dil, ctx.needs_input_grad[0],
-                                    ctx.needs_input_grad[1])
-        dgamma = sums[N:2 * N] if (affine and ctx.needs_input_grad[2]) else None
-        dbeta = sums[0:N] if (affine and ctx.needs_input_grad[3]) else None
-        dres = dy if (has_res and ctx.needs_input_grad[11]) else None
-        return (dx, dw, dgamma, dbeta, None, None, None, None, None, None, None, dres, None, None,
-                None)
-
-
-def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, training,
-                momentum=0.1, eps=1e-5, act=ACT_NONE, residual=None, stride=1, padding=0, dilation=1):
-    """act(BN(conv(x))) (+ residual) with the BN statistics fused into the conv kernel."""
-    return _ConvBNAct.apply(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked,
-                            bool(training), momentum, eps, int(act), residual, int(stride),
-                            int(padding), int(dilation))
-
-
 # ---------------------------------------------------------------------------
 # conv -> BN -> act chains with "normalise on read"
 # ---------------------------------------------------------------------------
@@ -731,6 +619,14 @@ def conv_chain(x, ops, in_act0=ACT_NONE, residual=None):
                             True, int(act), bool(training), float(momentum), float(eps)))
             tensors.extend([weight, gamma, beta, rm, rv, nbt if training else None])
     return _ConvChain.apply((int(in_act0), tuple(cfg_ops)), x, residual, *tensors)
+
+
+def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, training,
+                momentum=0.1, eps=1e-5, act=ACT_NONE, residual=None, stride=1, padding=0, dilation=1):
+    """act(BN(conv(x))) (+ residual): a conv chain of one link (statistics in the conv epilogue;
+    in inference without grad the BatchNorm is folded into the conv's epilogue - one kernel)."""
+    bn = (gamma, beta, running_mean, running_var, num_batches_tracked, bool(training), momentum, eps)
+    return conv_chain(x, [(weight, stride, padding, dilation, False, bn, int(act))], ACT_NONE, residual)
 
 
 # ---------------------------------------------------------------------------
