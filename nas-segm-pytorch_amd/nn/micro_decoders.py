@@ -72,6 +72,19 @@ def _sum_to_larger(x1, x2):
     return F.add(x1, x2)
 
 
+def _param_header(n_params):
+    """first block of the genotype description both decoders print (millions of parameters)"""
+    return "#PARAMS\n\n {:3.2f}M".format(n_params / 1e6)
+
+
+def _attach_heads(decoder, collected_width, agg_size, num_classes):
+    """The tail both decoders share: ``pre_clf`` (1x1 + BN + ReLU over the concatenated collected
+    maps) and ``conv_clf`` (3x3 with bias, one channel per class); sets ``num_classes``."""
+    decoder.pre_clf = conv_bn_relu(collected_width, agg_size, 1, 1, 0)
+    decoder.conv_clf = conv3x3(agg_size, num_classes, stride=1, bias=True)
+    decoder.num_classes = num_classes
+
+
 class AggregateCell(nn.Module):
     """Optional 1x1 conv+BN+ReLU per branch, up-sample the smaller, add
     (micro_decoders.py:28-51)."""
@@ -79,14 +92,13 @@ class AggregateCell(nn.Module):
     def __init__(self, size_1, size_2, agg_size, pre_transform=True):
         super(AggregateCell, self).__init__()
         self.pre_transform = pre_transform
-        if pre_transform:
-            self.branch_1 = conv_bn_relu(size_1, agg_size, 1, 1, 0)
-            self.branch_2 = conv_bn_relu(size_2, agg_size, 1, 1, 0)
+        if pre_transform:  # one 1x1 projection per input, registered as branch_1 / branch_2
+            for slot, width in enumerate((size_1, size_2), start=1):
+                self.add_module("branch_{}".format(slot), conv_bn_relu(width, agg_size, 1, 1, 0))
 
     def forward(self, x1, x2):
         if self.pre_transform:
-            x1 = self.branch_1(x1)
-            x2 = self.branch_2(x2)
+            x1, x2 = self.branch_1(x1), self.branch_2(x2)
         return _sum_to_larger(x1, x2)
 
 
@@ -152,10 +164,10 @@ class MergeCell(nn.Module):
     def __init__(self, ctx_config, conn, inps, agg_size, ctx_cell, repeats=1):
         super(MergeCell, self).__init__()
         self.index_1, self.index_2 = conn
-        inp_1, inp_2 = inps
-        self.op_1 = ctx_cell(ctx_config, inp_1, repeats=repeats)
-        self.op_2 = ctx_cell(ctx_config, inp_2, repeats=repeats)
-        self.agg = AggregateCell(inp_1, inp_2, agg_size)
+        # same genotype, separate weights, one cell per incoming map
+        for slot, width in enumerate(inps, start=1):
+            self.add_module("op_{}".format(slot), ctx_cell(ctx_config, width, repeats=repeats))
+        self.agg = AggregateCell(inps[0], inps[1], agg_size)
 
     def forward(self, x1, x2):
         return self.agg(self.op_1(x1), self.op_2(x2))
@@ -205,16 +217,12 @@ class MicroDecoder(nn.Module):
             self.pool.append("({} + {})".format(self.pool[ind_1], self.pool[ind_2]))
         self.cells = nn.ModuleList(cells)
         self.aux_clfs = nn.ModuleList(heads)
-        self.pre_clf = conv_bn_relu(agg_size * len(self.collect_inds), agg_size, 1, 1, 0)
-        self.conv_clf = conv3x3(agg_size, num_classes, stride=1, bias=True)
+        _attach_heads(self, agg_size * len(self.collect_inds), agg_size, num_classes)
         self.info = " + ".join(self.pool[i] for i in self.collect_inds)
-        self.num_classes = num_classes
 
     def prettify(self, n_params):
-        header = "#PARAMS\n\n {:3.2f}M".format(n_params / 1e6)
-        ctx_desc = "#Contextual:\n" + self.cells[0].prettify()
-        conn_desc = "#Connections:\n" + self.info
-        return header + "\n\n" + ctx_desc + "\n\n" + conn_desc
+        return "\n\n".join((_param_header(n_params), "#Contextual:\n" + self.cells[0].prettify(),
+                            "#Connections:\n" + self.info))
 
     def forward(self, x):
         maps = [getattr(self, "adapt{}".format(n + 1))(t) for n, t in enumerate(x)]
@@ -290,11 +298,8 @@ class TemplateDecoder(nn.Module):
             self._collect_inds.append(node)
             self._pools.append("{}({},{})".format(agg_name, self._pools[n_scales + block - 2],
                                                   self._pools[n_scales + block - 1]))
-        c_pre_clf = sum(c for idx, c in enumerate(widths) if idx in self._collect_inds)
-        self.pre_clf = conv_bn_relu(c_pre_clf, agg_size, 1, 1, 0)
-        self.conv_clf = conv3x3(agg_size, num_classes, stride=1, bias=True)
+        _attach_heads(self, sum(widths[idx] for idx in self._collect_inds), agg_size, num_classes)
         self.info = " + ".join(self._pools[i] for i in self._collect_inds)
-        self.num_classes = num_classes
 
     def _reset_clf(self, num_classes):
         """Swap the classifier for a different label set (micro_decoders.py:367-373).
@@ -307,8 +312,7 @@ class TemplateDecoder(nn.Module):
             self.num_classes = num_classes
 
     def prettify(self, n_params):
-        header = "#PARAMS\n\n {:3.2f}M".format(n_params / 1e6)
-        return header + "\n\n" + "#Connections:\n" + self.info
+        return _param_header(n_params) + "\n\n#Connections:\n" + self.info
 
     def forward(self, x):
         maps = list(x)
