@@ -7,6 +7,8 @@ no ATen compute op runs on the hot path.  Tensors keep the reference's NCHW
 *shape* but live in ``torch.channels_last`` memory, which is the NHWC layout the
 kernels address directly.
 """
+import ctypes
+
 import torch
 
 from ._lib import NassegError, current_stream, lib, ptr, require_device
@@ -181,8 +183,6 @@ def _pack_many(like, items):
     the ctypes tables cost more host time than the launch.  The buffer is rewritten by every
     call; a forward's packed weights stay valid until the parameters change, i.e. for its own
     backward."""
-    import ctypes
-
     key = (like.device,) + tuple((it[0].data_ptr(), tuple(it[0].shape)) + tuple(it[1:]) for it in items)
     plan = _PACK_PLANS.get(key)
     if plan is None:
