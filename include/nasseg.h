@@ -93,6 +93,11 @@ int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g
                             int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
                             int dil, float* stats, void* stream);
 int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw);
+/* weight gradients are read by the optimiser only: nasseg_conv_wgrad / nasseg_dwconv_wgrad called
+ * with dw == NULL leave their per-slab partial sums in ws, and this call finalises many layers
+ * with one launch per 16: dims[5*i..] = partial rows, taps, N, K, flat (depthwise: N = C, K = 1) */
+int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* const* dw,
+                               const int* dims, void* stream);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,

@@ -227,6 +227,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_finalize(const float* __restri
   }
 }
 
+// The second stage of MANY backward-weight reductions in one launch (dense and depthwise: a
+// depthwise weight is the case N = C, K = 1).  Weight gradients are consumed by the optimiser
+// only, so their finalisation can leave the backward chain and be batched: ~100 launches of a
+// few microseconds each become a handful.
+struct FinDesc {
+  const float* partial;
+  float* dw;
+  int nslab, ntaps, N, K, flat;
+};
+constexpr int kFinMax = 16;
+struct FinTable {
+  FinDesc d[kFinMax];
+};
+__global__ __launch_bounds__(256) void wgrad_finalize_many(FinTable t) {
+  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  const FinDesc d = t.d[blockIdx.y];
+  const int64_t per = (int64_t)d.ntaps * d.N * d.K;
+  if ((int64_t)blockIdx.x * NASSEG_RP_ELEMS >= per) return;  // (uniform over the workgroup)
+  const int64_t i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
+  const bool valid = i < per;
+  const double s = reduce_partials16(d.partial, d.nslab, per, i, valid, red);
+  if (valid && rp_slice() == 0) {
+    int n, k, tap;
+    if (!d.flat) {
+      k = (int)(i % d.K);
+      const int64_t q = i / d.K;
+      n = (int)(q % d.N);
+      tap = (int)(q / d.N);
+    } else {
+      const int Kq = d.ntaps * d.K;
+      n = (int)(i / Kq);
+      const int kq = (int)(i - (int64_t)n * Kq);
+      tap = kq / d.K;
+      k = kq - tap * d.K;
+    }
+    d.dw[((int64_t)n * d.K + k) * d.ntaps + tap] = (float)s;
+  }
+}
+
 struct WgMode {
   bool aln, alk, gather, flat, pro;
 };
@@ -300,6 +339,8 @@ int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh,
 #endif  // NASSEG_FP32_ONLY
 
 // dw (N,K,kh,kw) = sum_pixels dy[pixel][n] * in_act(in_scale*x[src(pixel,tap)][k]+in_shift)
+// dw == null: only the per-slab partial sums are produced (ws); nasseg_wgrad_finalize_many turns
+// the partials of many layers into their gradients with one launch.
 // (the input prologue is available for pointwise convs with K % 4 == 0 and N % 4 == 0)
 int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
@@ -339,11 +380,47 @@ int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, fl
   rc = nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_wgrad: no kernel for vn=%d vk=%d", p.vn, p.vk);
 #undef WG_CASE
   if (rc) return rc;
+  if (!dw) return NASSEG_OK;  // partial sums stay in ws for nasseg_wgrad_finalize_many
   const int64_t per = (int64_t)taps * N * K;
   hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64(per, NASSEG_RP_ELEMS)), dim3(256), 0,
                      s, ws, dw, p.nslab, taps, N, K, p.flat);
   NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
   return NASSEG_OK;
 }
+
+#if NASSEG_FP32_ONLY
+// count reductions finalised by one launch per 16: partial[i] = the workspace a
+// nasseg_conv_wgrad / nasseg_dwconv_wgrad call (either dtype) left behind when its dw argument
+// was null, dw[i] = that layer's gradient tensor, dims[5*i..] = number of partial rows
+// (workspace floats / (taps*N*K)), taps, N, K, flat (1 when nasseg_conv_fwd_pack_mode(K,kh,kw)
+// == 2, else 0); a depthwise weight (C,1,k,k) is passed as taps = k*k, N = C, K = 1.
+int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* const* dw,
+                               const int* dims, void* stream) {
+  NASSEG_REQUIRE(count >= 0 && (count == 0 || (partial && dw && dims)), "wgrad_finalize_many: bad arguments");
+  for (int base = 0; base < count; base += kFinMax) {
+    const int n = count - base < kFinMax ? count - base : kFinMax;
+    FinTable t;
+    int64_t most = 0;
+    for (int i = 0; i < n; ++i) {
+      const int* d = dims + 5 * (base + i);
+      NASSEG_REQUIRE(partial[base + i] && dw[base + i] && d[0] > 0 && d[1] > 0 && d[2] > 0 && d[3] > 0,
+                     "wgrad_finalize_many: bad descriptor %d", base + i);
+      t.d[i].partial = partial[base + i];
+      t.d[i].dw = dw[base + i];
+      t.d[i].nslab = d[0];
+      t.d[i].ntaps = d[1];
+      t.d[i].N = d[2];
+      t.d[i].K = d[3];
+      t.d[i].flat = d[4];
+      const int64_t per = (int64_t)d[1] * d[2] * d[3];
+      if (per > most) most = per;
+    }
+    hipLaunchKernelGGL(wgrad_finalize_many, dim3((unsigned)cdiv64(most, NASSEG_RP_ELEMS), n), dim3(256),
+                       0, (hipStream_t)stream, t);
+    NASSEG_LAUNCH_CHECK("wgrad_finalize_many");
+  }
+  return NASSEG_OK;
+}
+#endif  // NASSEG_FP32_ONLY
 
 }  // extern "C"

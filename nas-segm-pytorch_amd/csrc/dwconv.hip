@@ -813,7 +813,8 @@ int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K) {
 #endif  // NASSEG_FP32_ONLY
 
 // dw (C,1,K,K) = sum over pixels of dy * in_act(in_scale*x_tap + in_shift); ws must hold
-// nasseg_dwconv_wgrad_workspace() floats.
+// nasseg_dwconv_wgrad_workspace() floats.  dw == null: only the partial rows [rows][K*K][C] are
+// produced (rows = workspace floats / (K*K*C)) for nasseg_wgrad_finalize_many.
 int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* ws,
                         const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
                         int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream) {
@@ -852,6 +853,7 @@ int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* w
                        Ho, Wo, K, stride, pad, dil, in_act);
     NASSEG_LAUNCH_CHECK("dw_wgrad_generic");
   }
+  if (!dw) return NASSEG_OK;  // partial sums stay in ws for nasseg_wgrad_finalize_many
   hipLaunchKernelGGL(dw_wgrad_finalize, dim3(cdiv(K * K * C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws,
                      dw, gx * gy, K * K, C);
   NASSEG_LAUNCH_CHECK("dw_wgrad_finalize");

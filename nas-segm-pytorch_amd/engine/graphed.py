@@ -62,11 +62,12 @@ class GraphedSegmenterStep(object):
         self.image = image.detach().clone(memory_format=torch.channels_last)
         self.target = target.detach().clone()
         self.flat = self._views = self._used = None
+        self._params = list(self.model.parameters())
         self._capture(warmup)
 
     # -- the captured region ---------------------------------------------------------
     def _fwd_bwd(self, with_optimisers):
-        for p in self.model.parameters():
+        for p in self._params:
             p.grad = None
         output = self.segmenter(self.image)
         aux_outs = []
@@ -78,7 +79,8 @@ class GraphedSegmenterStep(object):
             for aux_out in aux_outs:
                 aux_out = F.bilinear_resize(aux_out, target.size()[1:])
                 loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
-        loss.backward()
+        with F.deferred_wgrad(params=self._params):  # (gradients were cleared above)
+            loss.backward()
         if with_optimisers:
             _clip_and_step(self.groups)
         return loss.detach()

@@ -143,6 +143,7 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
         _freeze_bn(decoder)
     ignore = _ignore_index(segm_crit)
     np.random.shuffle(indices)
+    dec_params = list(decoder.parameters())
     feat_keys = [k for k in Xy_train.keys() if k not in ("y", "kd_y", "out_size")]
     out_size = tuple(Xy_train["out_size"])
     for i in range(n_passes):
@@ -164,7 +165,8 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
                 aux_out = F.bilinear_resize(aux_out, out_size)
                 loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
         optim_dec.zero_grad()
-        loss.backward()
+        with F.deferred_wgrad(params=dec_params):
+            loss.backward()
         if getattr(segmenter, "world_size", 1) > 1:
             # the feature cache is sharded: every rank steps on its own cached samples and the
             # decoder gradients are averaged (the reference runs this stage on one GPU)
@@ -197,14 +199,17 @@ def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=
         for aux_out in aux_outs:
             aux_out = F.bilinear_resize(aux_out, target.size()[1:])
             loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
-    _zero_grads(segmenter, (optim_enc, optim_dec))
-    loss.backward()
-    if hasattr(segmenter, "sync_gradients"):
-        segmenter.sync_gradients()
     groups = getattr(model, "_nasseg_step_params", None)
     if groups is None:  # (a candidate's module tree is fixed: walk it once, not every step)
         groups = (list(model.encoder.parameters()), list(model.decoder.parameters()))
         model._nasseg_step_params = groups
+    _zero_grads(segmenter, (optim_enc, optim_dec))
+    # gradients were just cleared: the second stages of all weight-gradient reductions run
+    # batched when backward is through
+    with F.deferred_wgrad(params=groups[0] + groups[1]):
+        loss.backward()
+    if hasattr(segmenter, "sync_gradients"):
+        segmenter.sync_gradients()
     _clip_and_step([(groups[0], enc_grad_clip, optim_enc), (groups[1], dec_grad_clip, optim_dec)])
     return loss
 

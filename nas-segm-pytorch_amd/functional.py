@@ -54,6 +54,66 @@ def _vec(like, n):
     return torch.empty((int(n),), device=like.device, dtype=torch.float32)
 
 
+# ---------------------------------------------------------------------------
+# deferred finalisation of weight gradients
+# ---------------------------------------------------------------------------
+class deferred_wgrad(object):
+    """``with F.deferred_wgrad(): loss.backward()``
+
+    A weight gradient is a two-stage reduction (per-slab partial sums, then their sum) and only
+    the optimiser reads it.  Inside this context the backward-weight calls stop after stage one
+    and the second stages of ALL layers run when the context exits - one launch per 16 layers
+    (nasseg_wgrad_finalize_many) instead of one small launch per layer on the backward chain.
+    Opt-in, because between backward and the exit the gradient tensors are allocated but not yet
+    written: the caller must have cleared the gradients and every weight must be used once in
+    the graph (autograd then just adopts the new tensor; an accumulation - or the copy it makes
+    of a tensor somebody else still references, which is why only the ADDRESS is queued here -
+    would read it too early), and must not touch ``param.grad`` before the exit.
+    Same arithmetic in the same order: results are bit-identical."""
+
+    active = False
+    pending = []
+
+    def __init__(self, enabled=True, params=None):
+        """params: the parameters being trained; when given, the exit verifies that every
+        deferred gradient is the tensor autograd adopted as some ``param.grad`` (it would be a
+        copy - of unwritten memory - had a condition above been violated) and fails loudly."""
+        self.enabled = bool(enabled)
+        self.params = params
+
+    def __enter__(self):
+        self.prev = deferred_wgrad.active
+        deferred_wgrad.active = self.enabled
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        deferred_wgrad.active = self.prev
+        todo, deferred_wgrad.pending = deferred_wgrad.pending, []
+        if todo and exc_type is None:
+            n = len(todo)
+            parts = (ctypes.c_void_p * n)(*[ptr(ws) for ws, _, _ in todo])
+            outs = (ctypes.c_void_p * n)(*[addr for _, addr, _ in todo])
+            dims = (ctypes.c_int * (5 * n))()
+            for j, (_, _, d) in enumerate(todo):
+                dims[5 * j:5 * j + 5] = d
+            lib.call("nasseg_wgrad_finalize_many", n, parts, outs, dims, current_stream())
+            if self.params is not None:
+                adopted = set(p.grad.data_ptr() for p in self.params if p.grad is not None)
+                if any(addr not in adopted for _, addr, _ in todo):
+                    raise NassegError("deferred_wgrad: autograd copied a weight gradient before it was "
+                                      "finalised (gradients not cleared, or a weight used twice?)")
+        return False
+
+
+def _finish_wgrad(ws, dw, taps, N, K, flat):
+    """Returns the pointer to pass as ``dw`` to a backward-weight entry point: the tensor itself,
+    or NULL with the second stage queued when finalisation is deferred."""
+    if not deferred_wgrad.active:
+        return ptr(dw)
+    deferred_wgrad.pending.append((ws, dw.data_ptr(), (ws.numel() // (taps * N * K), taps, N, K, flat)))
+    return None
+
+
 def conv_out_size(size, k, stride, pad, dil):
     return (size + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -143,7 +203,8 @@ class _DepthwiseConv(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws = _ws(x, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, K))
-            lib.call(_k("nasseg_dwconv_wgrad", x), ptr(x), ptr(dy), ptr(dw), ptr(ws), None, None,
+            lib.call(_k("nasseg_dwconv_wgrad", x), ptr(x), ptr(dy), _finish_wgrad(ws, dw, K * K, C, 1, 0),
+                     ptr(ws), None, None,
                      ACT_RELU if relu_in else ACT_NONE, B, H, W, C, Ho, Wo, K, stride, pad, dil, s)
         return dx, dw, None, None, None, None
 
@@ -299,7 +360,9 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
-            lib.call(_k("nasseg_conv_wgrad", x), ptr(x), K, ptr(dy), N, ptr(dw), ptr(ws), None, None, 0, B,
+            flat = int(lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) == 2)
+            lib.call(_k("nasseg_conv_wgrad", x), ptr(x), K, ptr(dy), N,
+                     _finish_wgrad(ws, dw, kh * kw, N, K, flat), ptr(ws), None, None, 0, B,
                      H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colred(RED_SUM, dy, N, None, 0, None, 0, 1, B * Ho * Wo, N)
@@ -566,7 +629,8 @@ class _ConvChain(torch.autograd.Function):
                 if need_dw:
                     dwt = torch.empty_like(w)
                     ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", Bc, K, Ho, Wo, k))
-                    lib.call(_k("nasseg_dwconv_wgrad", cur), ptr(cur), ptr(dz), ptr(dwt), ptr(ws), ptr(psc),
+                    lib.call(_k("nasseg_dwconv_wgrad", cur), ptr(cur), ptr(dz),
+                             _finish_wgrad(ws, dwt, k * k, K, 1, 0), ptr(ws), ptr(psc),
                              ptr(psh), pact, Bc, H, W, K, Ho, Wo, k, stride, pad, dil, s)
                     grads[6 * i] = dwt
                 g = None
@@ -577,7 +641,9 @@ class _ConvChain(torch.autograd.Function):
                 if need_dw:
                     dwt = torch.empty_like(w)
                     ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", Bc, Ho, Wo, N, K, kh, kw))
-                    lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N, ptr(dwt), ptr(ws), ptr(psc),
+                    flat = int(lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) == 2)
+                    lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N,
+                             _finish_wgrad(ws, dwt, kh * kw, N, K, flat), ptr(ws), ptr(psc),
                              ptr(psh), pact, Bc, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
                     grads[6 * i] = dwt
                 g = None

@@ -329,3 +329,36 @@ def test_search_loop_with_real_candidates(tmp_path):
     lines = open(path).read().strip().split("\n")
     assert len(lines) == 3 and all(l.startswith("reward: ") and ", genotype: [[" in l for l in lines)
     assert all(int(l.split("params: ")[1].split(",")[0]) > 50000 for l in lines)
+
+
+def test_segmenter_step_equals_a_plain_backward_step():
+    """segmenter_step defers the second stage of the weight-gradient reductions to one batched
+    launch after backward; parameters after two steps equal, bit for bit, those of the same steps
+    written out with an ordinary loss.backward()"""
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.engine.trainer import _clip_and_step, segmenter_step
+
+    rec = load_json("nets_meta.json")["wacv_arch0"]
+    g = torch.Generator().manual_seed(9)
+    batches = [(torch.randn(2, 3, 97, 129, generator=g).to(DEV).contiguous(memory_format=torch.channels_last),
+                torch.randint(0, 19, (2, 97, 129), generator=g).to(DEV)) for _ in range(2)]
+
+    def run(plain):
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+        oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        for x, t in batches:
+            if plain:
+                out = net(x)
+                loss = F.log_softmax_nll(out, F.nearest_label_resize(t, out.shape[2:]), 255)
+                oe.zero_grad()
+                od.zero_grad()
+                loss.backward()
+                _clip_and_step([(list(net.encoder.parameters()), 3.0, oe), (list(net.decoder.parameters()), 3.0, od)])
+            else:
+                segmenter_step(net, x, t, oe, od, 255, 3.0, 3.0, -1)
+        return _cpu_sd(net)
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -576,3 +576,60 @@ def test_factorized_reduce_matches_torch():
     assert_close(mod.conv_2.weight.grad, ref.conv_2.weight.grad, 2e-4, 2e-3, "dw2")
     with pytest.raises(RuntimeError):
         mod(dev(rnd(1, 16, 13, 16, seed=7)))
+
+
+def test_deferred_weight_gradient_finalisation_is_bit_identical():
+    """with F.deferred_wgrad(): the second stage of every backward-weight reduction runs batched at
+    the exit (nasseg_wgrad_finalize_many, > 16 layers => several launches); gradients equal the
+    immediate path bit for bit - dense 1x1 / 3x3 / flat stem, depthwise.  The deferred run comes
+    FIRST and on poisoned memory, so a gradient read before its finalisation cannot pass."""
+    f = F()
+    torch.manual_seed(0)
+    convs = [(3, 32, 3, 2, 1), (32, 16, 1, 1, 0), (16, 96, 1, 1, 0), (96, 24, 1, 1, 0), (24, 19, 3, 1, 1)]
+    dwk = [3, 5, 3, 7]
+    nets = []
+    for rep_ in range(3):  # three independent stacks: 27 weights, each used once
+        dense = [(torch.randn(n, k, ks, ks) / (k * ks * ks) ** 0.5).to(DEV) for k, n, ks, _, _ in convs]
+        dws = [(torch.randn(convs[i][1], 1, kk, kk) * 0.2).to(DEV) for i, kk in enumerate(dwk)]
+        nets.append((dense, dws))
+    x0 = dev(rnd(2, 3, 40, 48, seed=1))
+
+    def run(deferred):
+        leaves, loss = [], 0.0
+        for dense, dws in nets:
+            d = [w.clone().requires_grad_(True) for w in dense]
+            p = [w.clone().requires_grad_(True) for w in dws]
+            leaves += d + p
+            x = x0
+            for i, (k, n, ks, st, pd) in enumerate(convs):
+                x = f.conv2d(x, d[i], None, st, pd, 1)
+                if i < 4:
+                    x = f.depthwise_conv2d(x, p[i], 1, dwk[i] // 2, 1)
+            loss = loss + (x * x).mean()
+        poison = torch.full((64 << 20,), float("nan"), device=DEV)  # recycled by the allocations below
+        del poison
+        if deferred:
+            with f.deferred_wgrad():
+                loss.backward()
+            assert not f.deferred_wgrad.pending and not f.deferred_wgrad.active
+        else:
+            loss.backward()
+        return [t.grad.clone() for t in leaves]
+
+    g1, g0 = run(True), run(False)
+    for a, b in zip(g0, g1):
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
+
+
+def test_deferred_weight_gradient_detects_an_early_copy():
+    """a weight used twice makes autograd add its two gradients during backward, i.e. before the
+    deferred finalisation: with ``params`` given the context fails loudly instead of training on
+    unwritten memory"""
+    f = F()
+    w = (rnd(16, 16, 1, 1, seed=1) * 0.2).to(DEV).requires_grad_(True)
+    x = dev(rnd(2, 16, 8, 8, seed=2))
+    y = f.conv2d(f.conv2d(x, w), w)
+    with pytest.raises(RuntimeError):
+        with f.deferred_wgrad(params=[w]):
+            (y * y).mean().backward()
+    assert not f.deferred_wgrad.pending and not f.deferred_wgrad.active
