@@ -98,6 +98,10 @@ int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh,
  * with one launch per 16: dims[5*i..] = partial rows, taps, N, K, flat (depthwise: N = C, K = 1) */
 int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* const* dw,
                                const int* dims, void* stream);
+/* first stage of `count` small layers in launches of up to 8 layers of one kernel specialisation
+ * running side by side: desc[20*i..] = the arguments of nasseg_conv_wgrad from x to dil (without
+ * dw), pointers as integers; equals nasseg_conv_wgrad(..., dw = NULL, ...) per layer */
+int nasseg_conv_wgrad_many(int count, const int64_t* desc, void* stream);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
@@ -256,6 +260,7 @@ int nasseg_bf16_conv_bwd_data_bn(const nasseg_bf16_t* dy, int lddy, const float*
                             const float* mean, const float* invstd, int act, int B, int Hs, int Ws,
                             int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
                             int dil, float* stats, void* stream);
+int nasseg_bf16_conv_wgrad_many(int count, const int64_t* desc, void* stream);
 int nasseg_bf16_conv_wgrad(const nasseg_bf16_t* x, int ldx, const nasseg_bf16_t* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,

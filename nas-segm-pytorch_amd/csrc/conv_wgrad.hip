@@ -11,6 +11,8 @@
 // Per-wave accumulators are combined through LDS in a fixed order, per-workgroup partials
 // [slab][tap][N][K] by a second deterministic pass (reduce_partials16).
 // "Flat" mode gathers (tap, k) of a small-K conv (the 3-channel stem) as one axis.
+#include <vector>
+
 #include "conv_common.h"
 
 namespace {
@@ -64,8 +66,10 @@ __device__ __forceinline__ void load_vec(const float* p, int i0, int len, float*
 // VN / VK: floats per lane along n / k (chunk = 16*V); ALN / ALK: aligned vector loads;
 // GATHER: per-tap source-pixel arithmetic; FLAT: (tap, k) is one gathered axis; PRO: the
 // forward had an input prologue (affine + activation on x), re-applied on load.
+// (bx, by, bz): the workgroup's coordinates in the layer's own grid (slab, n/k chunk, tap) - the
+// grouped launch below runs several layers' grids side by side in one kernel
 template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+__device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const int by, const int bz) {
   constexpr int NACC = VN * VK * 4;
   __shared__ float red[3][NACC][65];  // waves 1..3 park their accumulators here
   const int lane = threadIdx.x & 63;
@@ -73,15 +77,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   const int li = lane & 15;  // row/col index inside a 16-wide MFMA tile
   const int pk = lane >> 4;  // pixel slot 0..3
   const int ntaps = a.g.kh * a.g.kw;
-  const int tap = FLAT ? 0 : blockIdx.z;
+  const int tap = FLAT ? 0 : bz;
   const int ty = tap / a.g.kw, tx = tap - ty * a.g.kw;
-  const int nchunk = blockIdx.y / a.kchunks;
-  const int kchunk = blockIdx.y - nchunk * a.kchunks;
+  const int nchunk = by / a.kchunks;
+  const int kchunk = by - nchunk * a.kchunks;
   const int n0 = nchunk * 16 * VN + li * VN;
   const int k0 = kchunk * 16 * VK + li * VK;
   const int Kq = FLAT ? ntaps * a.K : a.K;
   const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
-  const int p_begin = blockIdx.x * a.pix_per_block + wave * (a.pix_per_block >> 2);
+  const int p_begin = bx * a.pix_per_block + wave * (a.pix_per_block >> 2);
   int p_end = p_begin + (a.pix_per_block >> 2);
   if (p_end > Mtot) p_end = Mtot;
 
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   }
   __syncthreads();
   if (wave == 0) {
-    float* pout = a.partial + (((int64_t)blockIdx.x * (FLAT ? 1 : ntaps) + tap) * a.N) * Kq;
+    float* pout = a.partial + (((int64_t)bx * (FLAT ? 1 : ntaps) + tap) * a.N) * Kq;
 #pragma unroll
     for (int ca = 0; ca < VN; ++ca)
 #pragma unroll
@@ -197,6 +201,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
           if (n < a.N && k < Kq) pout[(int64_t)n * Kq + k] = v;
         }
   }
+}
+
+template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+  wgrad_tile<VN, VK, ALN, ALK, GATHER, FLAT, PRO>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several layers of ONE specialisation in one launch: weight gradients of small maps are
+// latency-bound launches that use a fraction of the GPU each and that nothing but the optimiser
+// waits for - deferred to the end of backward and grouped they run concurrently.
+constexpr int kWgGroup = 8;
+struct WgGroup {
+  int n;
+  int start[kWgGroup + 1];  // first flattened workgroup of each layer
+  int nslab[kWgGroup];
+  int gy[kWgGroup];
+  WgArgs a[kWgGroup];
+};
+template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
+__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(WgGroup g) {
+  int d = 0;
+  while (d + 1 < g.n && (int)blockIdx.x >= g.start[d + 1]) ++d;
+  const int local = blockIdx.x - g.start[d];
+  const int bx = local % g.nslab[d];
+  const int t = local / g.nslab[d];
+  wgrad_tile<VN, VK, ALN, ALK, GATHER, FLAT, PRO>(g.a[d], bx, t % g.gy[d], t / g.gy[d]);
 }
 
 // dw (N,K,kh,kw) = sum over slabs of partial.  flat == 0: partial[slab][tap][N][K];
@@ -295,6 +325,31 @@ int launch_wgrad(const WgArgs& a, dim3 grid, const WgMode& m, hipStream_t s) {
   return NASSEG_OK;
 }
 
+template <int VN, int VK>
+int launch_wgrad_group(const WgGroup& g, const WgMode& m, hipStream_t s) {
+  const dim3 grid(g.start[g.n]);
+#define GO(ALN_, ALK_, G_, F_, P_)                                                                \
+  hipLaunchKernelGGL((conv_wgrad_group_kernel<VN, VK, ALN_, ALK_, G_, F_, P_>), grid, dim3(256), 0, s, g)
+  if (m.flat) {
+    if (m.aln) GO(true, false, true, true, false);
+    else GO(false, false, true, true, false);
+  } else if (m.pro) {
+    GO(true, true, false, false, true);
+  } else if (m.aln && m.alk) {
+    if (m.gather) GO(true, true, true, false, false);
+    else GO(true, true, false, false, false);
+  } else if (m.aln) {
+    GO(true, false, true, false, false);
+  } else if (m.alk) {
+    GO(false, true, true, false, false);
+  } else {
+    GO(false, false, true, false, false);
+  }
+#undef GO
+  NASSEG_LAUNCH_CHECK("conv_wgrad_group_kernel");
+  return NASSEG_OK;
+}
+
 inline int pick_v(int len) { return len > 32 ? 4 : (len > 16 ? 2 : 1); }
 
 struct WgPlan {
@@ -342,19 +397,26 @@ int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh,
 // dw == null: only the per-slab partial sums are produced (ws); nasseg_wgrad_finalize_many turns
 // the partials of many layers into their gradients with one launch.
 // (the input prologue is available for pointwise convs with K % 4 == 0 and N % 4 == 0)
-int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, float* dw, float* ws,
-                      const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
-                      int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
-                      int dil, void* stream) {
+// everything a launch of one layer needs: kernel arguments, specialisation, grid
+struct WgSetup {
+  WgArgs a;
+  WgMode m;
+  WgPlan p;
+  dim3 grid;
+};
+static int wgrad_setup(WgSetup& u, const act_t* x, int ldx, const act_t* dy, int lddy, float* ws,
+                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
+                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                       int dil) {
   NASSEG_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "conv_wgrad: bad geometry");
   NASSEG_REQUIRE(K > 0 && N > 0 && ldx >= K && lddy >= N, "conv_wgrad: bad channels");
   NASSEG_REQUIRE((int64_t)B * Hs * Ws < 2147483647LL && (int64_t)B * Ho * Wo < 2147483647LL,
                  "conv_wgrad: too many pixels");
-  hipStream_t s = (hipStream_t)stream;
   const int64_t Mtot = (int64_t)B * Ho * Wo;
   const int taps = kh * kw;
-  WgPlan p = wgrad_plan(Mtot, N, K, taps);
-  WgMode m;
+  u.p = wgrad_plan(Mtot, N, K, taps);
+  const WgPlan& p = u.p;
+  WgMode& m = u.m;
   m.flat = p.flat != 0;
   m.pro = in_scale || in_shift || in_act;
   m.gather = !(kh == 1 && kw == 1 && stride == 1 && pad == 0 && Hs == Ho && Ws == Wo);
@@ -362,7 +424,7 @@ int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, fl
   m.alk = !m.flat && (K % p.vk == 0) && (ldx % p.vk == 0);
   NASSEG_REQUIRE(!m.pro || (!m.flat && !m.gather && m.aln && m.alk),
                  "conv_wgrad: the input prologue needs a pointwise conv with aligned channels");
-  WgArgs a;
+  WgArgs& a = u.a;
   a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.partial = ws;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   a.K = K; a.N = N;
@@ -371,20 +433,87 @@ int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, fl
   a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
   a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
   a.g.transposed = 0;
-  dim3 grid(p.nslab, p.nchunks * p.kchunks, p.flat ? 1 : taps);
-  int rc;
+  u.grid = dim3(p.nslab, p.nchunks * p.kchunks, p.flat ? 1 : taps);
+  return NASSEG_OK;
+}
+
+int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, float* dw, float* ws,
+                      const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
+                      int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                      int dil, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  WgSetup u;
+  int rc = wgrad_setup(u, x, ldx, dy, lddy, ws, in_scale, in_shift, in_act, B, Hs, Ws, K, Ho, Wo, N,
+                       kh, kw, stride, pad, dil);
+  if (rc) return rc;
+  const WgPlan& p = u.p;
 #define WG_CASE(VN_, VK_) \
-  if (p.vn == VN_ && p.vk == VK_) rc = launch_wgrad<VN_, VK_>(a, grid, m, s); else
+  if (p.vn == VN_ && p.vk == VK_) rc = launch_wgrad<VN_, VK_>(u.a, u.grid, u.m, s); else
   WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1)
   WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
   rc = nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_wgrad: no kernel for vn=%d vk=%d", p.vn, p.vk);
 #undef WG_CASE
   if (rc) return rc;
   if (!dw) return NASSEG_OK;  // partial sums stay in ws for nasseg_wgrad_finalize_many
+  const int taps = kh * kw;
   const int64_t per = (int64_t)taps * N * K;
   hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64(per, NASSEG_RP_ELEMS)), dim3(256), 0,
                      s, ws, dw, p.nslab, taps, N, K, p.flat);
   NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
+  return NASSEG_OK;
+}
+
+// The first stage (per-slab partial sums into each layer's ws) of `count` layers, grouped by
+// kernel specialisation into launches of up to 8 layers that run side by side - for layers whose
+// maps are too small to fill the GPU.  desc[20*i..] = x, ldx, dy, lddy, ws, in_scale, in_shift,
+// in_act, B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil: the arguments of nasseg_conv_wgrad
+// (pointers as integers), which this call equals with dw == NULL for every layer; finish with
+// nasseg_wgrad_finalize_many.
+int NASSEG_FN(conv_wgrad_many)(int count, const int64_t* desc, void* stream) {
+  NASSEG_REQUIRE(count >= 0 && (count == 0 || desc), "conv_wgrad_many: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (count == 0) return NASSEG_OK;
+  std::vector<WgSetup> u((size_t)count);
+  std::vector<int> key((size_t)count);
+  std::vector<char> done((size_t)count, 0);
+  for (int i = 0; i < count; ++i) {
+    const int64_t* d = desc + 20 * (size_t)i;
+    int rc = wgrad_setup(u[i], (const act_t*)d[0], (int)d[1], (const act_t*)d[2], (int)d[3], (float*)d[4],
+                         (const float*)d[5], (const float*)d[6], (int)d[7], (int)d[8], (int)d[9],
+                         (int)d[10], (int)d[11], (int)d[12], (int)d[13], (int)d[14], (int)d[15],
+                         (int)d[16], (int)d[17], (int)d[18], (int)d[19]);
+    if (rc) return rc;
+    const WgMode& m = u[i].m;
+    key[i] = u[i].p.vn * 1000 + u[i].p.vk * 100 + (m.flat ? 16 : 0) + (m.pro ? 8 : 0) + (m.aln ? 4 : 0) +
+             (m.alk ? 2 : 0) + (m.gather ? 1 : 0);
+  }
+  for (int i = 0; i < count; ++i) {
+    if (done[i]) continue;
+    WgGroup g;
+    g.n = 0;
+    g.start[0] = 0;
+    for (int j = i; j < count && g.n < kWgGroup; ++j) {
+      if (done[j] || key[j] != key[i]) continue;
+      const dim3& gr = u[j].grid;
+      const int64_t blocks = (int64_t)gr.x * gr.y * gr.z;
+      if (g.n > 0 && g.start[g.n] + blocks > (1 << 20)) continue;
+      g.a[g.n] = u[j].a;
+      g.nslab[g.n] = (int)gr.x;
+      g.gy[g.n] = (int)gr.y;
+      g.start[g.n + 1] = g.start[g.n] + (int)blocks;
+      ++g.n;
+      done[j] = 1;
+    }
+    const WgPlan& p = u[i].p;
+    int rc;
+#define WG_CASE(VN_, VK_) \
+  if (p.vn == VN_ && p.vk == VK_) rc = launch_wgrad_group<VN_, VK_>(g, u[i].m, s); else
+    WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1)
+    WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
+    rc = nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_wgrad_many: no kernel for vn=%d vk=%d", p.vn, p.vk);
+#undef WG_CASE
+    if (rc) return rc;
+  }
   return NASSEG_OK;
 }
 

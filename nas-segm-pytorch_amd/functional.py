@@ -72,7 +72,9 @@ class deferred_wgrad(object):
     Same arithmetic in the same order: results are bit-identical."""
 
     active = False
-    pending = []
+    pending = []   # (partials, address of the gradient tensor, finalisation dims)
+    grouped = {}   # dtype -> [(tensors the kernels read, 20 launch arguments)]: first stages of
+    #                small dense layers, launched side by side at the exit (nasseg_conv_wgrad_many)
 
     def __init__(self, enabled=True, params=None):
         """params: the parameters being trained; when given, the exit verifies that every
@@ -89,6 +91,13 @@ class deferred_wgrad(object):
     def __exit__(self, exc_type, exc, tb):
         deferred_wgrad.active = self.prev
         todo, deferred_wgrad.pending = deferred_wgrad.pending, []
+        groups, deferred_wgrad.grouped = deferred_wgrad.grouped, {}
+        if exc_type is None:
+            for dtype, calls in groups.items():
+                flat = [v for _, desc in calls for v in desc]
+                table = (ctypes.c_int64 * len(flat))(*flat)
+                name = "nasseg_conv_wgrad_many" if dtype == torch.float32 else "nasseg_bf16_conv_wgrad_many"
+                lib.call(name, len(calls), table, current_stream())
         if todo and exc_type is None:
             n = len(todo)
             parts = (ctypes.c_void_p * n)(*[ptr(ws) for ws, _, _ in todo])
@@ -103,6 +112,28 @@ class deferred_wgrad(object):
                     raise NassegError("deferred_wgrad: autograd copied a weight gradient before it was "
                                       "finalised (gradients not cleared, or a weight used twice?)")
         return False
+
+
+# largest x + dy footprint (bytes) of a dense layer whose backward-weight launch is grouped
+_GROUP_WGRAD_BYTES = 48 << 20
+
+
+def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
+    """Weight gradient of a dense conv (geom = B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil),
+    ``cur`` read through the prologue (psc, psh, pact).  Immediate, or - inside deferred_wgrad -
+    with its second stage deferred and, for small maps, its first stage grouped as well."""
+    B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil = geom
+    dwt = torch.empty_like(w)
+    ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
+    flat = int(lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) == 2)
+    if deferred_wgrad.active and (B * Hs * Ws * K + B * Ho * Wo * N) * cur.element_size() <= _GROUP_WGRAD_BYTES:
+        desc = (ptr(cur), K, ptr(dz), N, ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
+        deferred_wgrad.grouped.setdefault(cur.dtype, []).append(((cur, dz, psc, psh), desc))
+        _finish_wgrad(ws, dwt, kh * kw, N, K, flat)
+        return dwt
+    lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N, _finish_wgrad(ws, dwt, kh * kw, N, K, flat),
+             ptr(ws), ptr(psc), ptr(psh), pact, *geom, current_stream())
+    return dwt
 
 
 def _finish_wgrad(ws, dw, taps, N, K, flat):
@@ -358,12 +389,7 @@ class _Conv2d(torch.autograd.Function):
             (wp,) = _pack_many(dy, [(w, form)])
             dx = _dense_backward_data(dy, wp, form, (B, K, H, W), N, kh, kw, stride, pad, dil)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            ws = _ws(x, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
-            flat = int(lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) == 2)
-            lib.call(_k("nasseg_conv_wgrad", x), ptr(x), K, ptr(dy), N,
-                     _finish_wgrad(ws, dw, kh * kw, N, K, flat), ptr(ws), None, None, 0, B,
-                     H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
+            dw = _dense_wgrad(x, dy, w, None, None, ACT_NONE, (B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil))
         if has_bias and ctx.needs_input_grad[2]:
             db = _colred(RED_SUM, dy, N, None, 0, None, 0, 1, B * Ho * Wo, N)
         return dx, dw, db, None, None, None
@@ -639,13 +665,8 @@ class _ConvChain(torch.autograd.Function):
             else:
                 _, _, kh, kw = w.shape
                 if need_dw:
-                    dwt = torch.empty_like(w)
-                    ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", Bc, Ho, Wo, N, K, kh, kw))
-                    flat = int(lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) == 2)
-                    lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N,
-                             _finish_wgrad(ws, dwt, kh * kw, N, K, flat), ptr(ws), ptr(psc),
-                             ptr(psh), pact, Bc, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, s)
-                    grads[6 * i] = dwt
+                    grads[6 * i] = _dense_wgrad(cur, dz, w, psc, psh, pact,
+                                                (Bc, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil))
                 g = None
                 if need_dx:
                     if bn_prev is not None:
