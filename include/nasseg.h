@@ -102,6 +102,8 @@ int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* co
  * running side by side: desc[20*i..] = the arguments of nasseg_conv_wgrad from x to dil (without
  * dw), pointers as integers; equals nasseg_conv_wgrad(..., dw = NULL, ...) per layer */
 int nasseg_conv_wgrad_many(int count, const int64_t* desc, void* stream);
+/* the depthwise twin: desc[16*i..] = the arguments of nasseg_dwconv_wgrad from x to dil, without dw */
+int nasseg_dwconv_wgrad_many(int count, const int64_t* desc, void* stream);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
@@ -261,6 +263,7 @@ int nasseg_bf16_conv_bwd_data_bn(const nasseg_bf16_t* dy, int lddy, const float*
                             int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
                             int dil, float* stats, void* stream);
 int nasseg_bf16_conv_wgrad_many(int count, const int64_t* desc, void* stream);
+int nasseg_bf16_dwconv_wgrad_many(int count, const int64_t* desc, void* stream);
 int nasseg_bf16_conv_wgrad(const nasseg_bf16_t* x, int ldx, const nasseg_bf16_t* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,

@@ -21,6 +21,8 @@
 // of squares per channel of y), i.e. the batch statistics of a following BatchNorm.
 #include <math.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -463,14 +465,28 @@ __global__ __launch_bounds__(256) void dw_generic(
 // of row chunks, then a per-block reduction over lanes that share a channel
 // group.  partial layout: [block][tap][C].  Deterministic (no atomics).
 // ---------------------------------------------------------------------------
+struct DwWgArgs {
+  const act_t* x;
+  const act_t* dy;
+  float* partial;
+  const float* in_scale;
+  const float* in_shift;
+  int in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, g, nchunk;
+};
+
+// (bx, by) of (gdx, gdy): the workgroup's coordinates in the layer's own grid - the grouped
+// launch below runs several layers' grids side by side in one kernel
 template <int K, int P, int E, bool PRO>
-__global__ __launch_bounds__(256) void dw_wgrad_strip(
-    const act_t* __restrict__ x, const act_t* __restrict__ dy, float* __restrict__ partial,
-    const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act, int B,
-    int H, int W, int C4, int Ho, int Wo, int stride, int pad, int dil, int g, int nchunk) {
+__device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, const int by,
+                                              const int gdx, const int gdy) {
+  const act_t* __restrict__ x = q.x;
+  const act_t* __restrict__ dy = q.dy;
+  float* __restrict__ partial = q.partial;
+  const int B = q.B, H = q.H, W = q.W, C4 = q.C4, Ho = q.Ho, Wo = q.Wo, stride = q.stride, pad = q.pad,
+            dil = q.dil, g = q.g, nchunk = q.nchunk;
   __shared__ float4 red[K][4][64];
   const int tid = threadIdx.x;
-  const int base = blockIdx.x * 256;
+  const int base = bx * 256;
   const int idx = base + tid;
   const bool live = idx < Wo * C4;
   const int ox = live ? idx / C4 : 0;
@@ -481,7 +497,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = f4zero();
   Prologue pro;
-  if (PRO) pro = make_prologue(in_scale, in_shift, in_act, c4);
+  if (PRO) pro = make_prologue(q.in_scale, q.in_shift, q.in_act, c4);
 
   int xoff[K];
   bool xok[K];
@@ -493,7 +509,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
   }
   constexpr int Q = (P - 1) * E + K;
   const int nwork = B * nchunk * g;
-  for (int wk = blockIdx.y; wk < nwork; wk += gridDim.y) {
+  for (int wk = by; wk < nwork; wk += gdy) {
     const int r = wk % g;
     int t2 = wk / g;
     const int chunk = t2 % nchunk;
@@ -543,8 +559,29 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(
   // four waves then meet in a small LDS buffer indexed by channel group, K taps at a
   // time.  (C4 > 64: every lane of a wave owns a different group, the shuffle step is
   // the identity and a wave only covers 64 of the groups - see block_reduce_taps.)
-  float* pout = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)(K * K) * C;
+  float* pout = partial + ((size_t)by * gdx + bx) * (size_t)(K * K) * C;
   block_reduce_groups<K * K, K>(acc, red, pout, base, C4);
+}
+
+template <int K, int P, int E, bool PRO>
+__global__ __launch_bounds__(256) void dw_wgrad_strip(DwWgArgs q) {
+  dw_wgrad_tile<K, P, E, PRO>(q, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+}
+
+// several depthwise layers of one specialisation in one launch (see conv_wgrad_group_kernel)
+constexpr int kDwGroup = 8;
+struct DwWgGroup {
+  int n;
+  int start[kDwGroup + 1];
+  int gx[kDwGroup], gy[kDwGroup];
+  DwWgArgs a[kDwGroup];
+};
+template <int K, int P, int E, bool PRO>
+__global__ __launch_bounds__(256) void dw_wgrad_group_kernel(DwWgGroup t) {
+  int d = 0;
+  while (d + 1 < t.n && (int)blockIdx.x >= t.start[d + 1]) ++d;
+  const int local = blockIdx.x - t.start[d];
+  dw_wgrad_tile<K, P, E, PRO>(t.a[d], local % t.gx[d], local / t.gx[d], t.gx[d], t.gy[d]);
 }
 
 // generic backward-weight (any K): same block reduction, one tap at a time.
@@ -834,9 +871,9 @@ int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* w
     constexpr int P = 4;
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(gx, gy, 1);
-#define LAUNCH_WG2(KK, EE, PR)                                                                    \
-  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE, PR>), grid, dim3(256), 0, s, x, dy, ws, in_scale, \
-                     in_shift, in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk)
+    DwWgArgs q = {x, dy, ws, in_scale, in_shift, in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk};
+#define LAUNCH_WG2(KK, EE, PR) \
+  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE, PR>), grid, dim3(256), 0, s, q)
 #define LAUNCH_WG(KK, EE) \
   do { if (pro) LAUNCH_WG2(KK, EE, true); else LAUNCH_WG2(KK, EE, false); } while (0)
     if (K == 3 && sc.e == 1) LAUNCH_WG(3, 1);
@@ -857,6 +894,79 @@ int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* w
   hipLaunchKernelGGL(dw_wgrad_finalize, dim3(cdiv(K * K * C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws,
                      dw, gx * gy, K * K, C);
   NASSEG_LAUNCH_CHECK("dw_wgrad_finalize");
+  return NASSEG_OK;
+}
+
+// First stage of `count` small depthwise layers, strip geometries of one specialisation grouped
+// into launches of up to 8 layers running side by side (others are launched one by one):
+// desc[16*i..] = x, dy, ws, in_scale, in_shift, in_act, B, H, W, C, Ho, Wo, K, stride, pad, dil -
+// the arguments of nasseg_dwconv_wgrad without dw (pointers as integers), which this call
+// equals with dw == NULL per layer; finish with nasseg_wgrad_finalize_many.
+int NASSEG_FN(dwconv_wgrad_many)(int count, const int64_t* desc, void* stream) {
+  NASSEG_REQUIRE(count >= 0 && (count == 0 || desc), "dwconv_wgrad_many: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int P = 4;
+  std::vector<char> done((size_t)(count > 0 ? count : 1), 0);
+  auto key_of = [&](const int64_t* d, StripCfg& sc) {
+    const int C = (int)d[9], K = (int)d[12];
+    sc = strip_cfg((int)d[13], (int)d[15]);
+    const bool strip_ok = (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2) && C % 4 == 0 && C / 4 <= 256;
+    if (!strip_ok) return -1;
+    const bool pro = d[3] || d[4] || d[5];
+    return K * 100 + sc.e * 10 + (pro ? 1 : 0);
+  };
+  for (int i = 0; i < count; ++i) {
+    if (done[i]) continue;
+    const int64_t* di = desc + 16 * (size_t)i;
+    StripCfg sci;
+    const int key = key_of(di, sci);
+    if (key < 0) {  // generic geometry: the ordinary entry point, first stage only
+      int rc = NASSEG_FN(dwconv_wgrad)((const act_t*)di[0], (const act_t*)di[1], nullptr, (float*)di[2],
+                                       (const float*)di[3], (const float*)di[4], (int)di[5], (int)di[6],
+                                       (int)di[7], (int)di[8], (int)di[9], (int)di[10], (int)di[11],
+                                       (int)di[12], (int)di[13], (int)di[14], (int)di[15], stream);
+      if (rc) return rc;
+      done[i] = 1;
+      continue;
+    }
+    DwWgGroup t;
+    t.n = 0;
+    t.start[0] = 0;
+    for (int j = i; j < count && t.n < kDwGroup; ++j) {
+      if (done[j]) continue;
+      const int64_t* d = desc + 16 * (size_t)j;
+      StripCfg sc;
+      if (key_of(d, sc) != key) continue;
+      const int B = (int)d[6], H = (int)d[7], W = (int)d[8], C = (int)d[9], Ho = (int)d[10], Wo = (int)d[11];
+      NASSEG_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "dwconv_wgrad_many: bad geometry");
+      const int C4 = C / 4;
+      const int gx = cdiv(Wo * C4, 256);
+      const int gy = (int)wgrad_rows(B, C, Ho, Wo);
+      DwWgArgs q = {(const act_t*)d[0], (const act_t*)d[1], (float*)d[2], (const float*)d[3],
+                    (const float*)d[4], (int)d[5], B, H, W, C4, Ho, Wo, (int)d[13], (int)d[14], (int)d[15],
+                    sc.g, cdiv(Ho, P * sc.g)};
+      t.a[t.n] = q;
+      t.gx[t.n] = gx;
+      t.gy[t.n] = gy;
+      t.start[t.n + 1] = t.start[t.n] + gx * gy;
+      ++t.n;
+      done[j] = 1;
+    }
+    const dim3 grid(t.start[t.n]);
+    const int K = key / 100, e = (key / 10) % 10;
+    const bool pro = key % 10;
+#define GO_DW(KK, EE)                                                                              \
+  do {                                                                                             \
+    if (pro) hipLaunchKernelGGL((dw_wgrad_group_kernel<KK, P, EE, true>), grid, dim3(256), 0, s, t); \
+    else hipLaunchKernelGGL((dw_wgrad_group_kernel<KK, P, EE, false>), grid, dim3(256), 0, s, t);   \
+  } while (0)
+    if (K == 3 && e == 1) GO_DW(3, 1);
+    else if (K == 3 && e == 2) GO_DW(3, 2);
+    else if (K == 5 && e == 1) GO_DW(5, 1);
+    else GO_DW(5, 2);
+#undef GO_DW
+    NASSEG_LAUNCH_CHECK("dw_wgrad_group_kernel");
+  }
   return NASSEG_OK;
 }
 

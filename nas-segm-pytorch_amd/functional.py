@@ -73,8 +73,9 @@ class deferred_wgrad(object):
 
     active = False
     pending = []   # (partials, address of the gradient tensor, finalisation dims)
-    grouped = {}   # dtype -> [(tensors the kernels read, 20 launch arguments)]: first stages of
-    #                small dense layers, launched side by side at the exit (nasseg_conv_wgrad_many)
+    grouped = {}   # (entry point, dtype) -> [(tensors the kernels read, launch arguments)]: first
+    #                stages of small layers, launched side by side at the exit
+    #                (nasseg_conv_wgrad_many / nasseg_dwconv_wgrad_many)
 
     def __init__(self, enabled=True, params=None):
         """params: the parameters being trained; when given, the exit verifies that every
@@ -93,10 +94,10 @@ class deferred_wgrad(object):
         todo, deferred_wgrad.pending = deferred_wgrad.pending, []
         groups, deferred_wgrad.grouped = deferred_wgrad.grouped, {}
         if exc_type is None:
-            for dtype, calls in groups.items():
+            for (entry, dtype), calls in groups.items():
                 flat = [v for _, desc in calls for v in desc]
                 table = (ctypes.c_int64 * len(flat))(*flat)
-                name = "nasseg_conv_wgrad_many" if dtype == torch.float32 else "nasseg_bf16_conv_wgrad_many"
+                name = entry if dtype == torch.float32 else entry.replace("nasseg_", "nasseg_bf16_", 1)
                 lib.call(name, len(calls), table, current_stream())
         if todo and exc_type is None:
             n = len(todo)
@@ -114,8 +115,25 @@ class deferred_wgrad(object):
         return False
 
 
-# largest x + dy footprint (bytes) of a dense layer whose backward-weight launch is grouped
+# largest x + dy footprint (bytes) of a layer whose backward-weight launch is grouped
 _GROUP_WGRAD_BYTES = 48 << 20
+
+
+def _dw_wgrad(cur, dz, w, psc, psh, pact, geom):
+    """Weight gradient of a depthwise conv (geom = B, H, W, C, Ho, Wo, k, stride, pad, dil); see
+    _dense_wgrad."""
+    B, H, W, C, Ho, Wo, k, stride, pad, dil = geom
+    dwt = torch.empty_like(w)
+    ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, k))
+    if deferred_wgrad.active and (B * H * W * C + B * Ho * Wo * C) * cur.element_size() <= _GROUP_WGRAD_BYTES:
+        desc = (ptr(cur), ptr(dz), ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
+        deferred_wgrad.grouped.setdefault(("nasseg_dwconv_wgrad_many", cur.dtype), []).append(
+            ((cur, dz, psc, psh), desc))
+        _finish_wgrad(ws, dwt, k * k, C, 1, 0)
+        return dwt
+    lib.call(_k("nasseg_dwconv_wgrad", cur), ptr(cur), ptr(dz), _finish_wgrad(ws, dwt, k * k, C, 1, 0), ptr(ws),
+             ptr(psc), ptr(psh), pact, *geom, current_stream())
+    return dwt
 
 
 def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
@@ -128,7 +146,8 @@ def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
     flat = int(lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) == 2)
     if deferred_wgrad.active and (B * Hs * Ws * K + B * Ho * Wo * N) * cur.element_size() <= _GROUP_WGRAD_BYTES:
         desc = (ptr(cur), K, ptr(dz), N, ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
-        deferred_wgrad.grouped.setdefault(cur.dtype, []).append(((cur, dz, psc, psh), desc))
+        deferred_wgrad.grouped.setdefault(("nasseg_conv_wgrad_many", cur.dtype), []).append(
+            ((cur, dz, psc, psh), desc))
         _finish_wgrad(ws, dwt, kh * kw, N, K, flat)
         return dwt
     lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N, _finish_wgrad(ws, dwt, kh * kw, N, K, flat),
@@ -232,11 +251,8 @@ class _DepthwiseConv(torch.autograd.Function):
             if relu_in:
                 dx = _act_bwd(dx, x, ACT_RELU)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            ws = _ws(x, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, K))
-            lib.call(_k("nasseg_dwconv_wgrad", x), ptr(x), ptr(dy), _finish_wgrad(ws, dw, K * K, C, 1, 0),
-                     ptr(ws), None, None,
-                     ACT_RELU if relu_in else ACT_NONE, B, H, W, C, Ho, Wo, K, stride, pad, dil, s)
+            dw = _dw_wgrad(x, dy, w, None, None, ACT_RELU if relu_in else ACT_NONE,
+                           (B, H, W, C, Ho, Wo, K, stride, pad, dil))
         return dx, dw, None, None, None, None
 
 
@@ -653,12 +669,8 @@ class _ConvChain(torch.autograd.Function):
             if kind == "dw":
                 k = w.shape[-1]
                 if need_dw:
-                    dwt = torch.empty_like(w)
-                    ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", Bc, K, Ho, Wo, k))
-                    lib.call(_k("nasseg_dwconv_wgrad", cur), ptr(cur), ptr(dz),
-                             _finish_wgrad(ws, dwt, k * k, K, 1, 0), ptr(ws), ptr(psc),
-                             ptr(psh), pact, Bc, H, W, K, Ho, Wo, k, stride, pad, dil, s)
-                    grads[6 * i] = dwt
+                    grads[6 * i] = _dw_wgrad(cur, dz, w, psc, psh, pact,
+                                             (Bc, H, W, K, Ho, Wo, k, stride, pad, dil))
                 g = None
                 if need_dx:
                     g, pre = _dw_backward_data(dz, wb, k, (Bc, K, H, W), stride, pad, dil, bn_prev)

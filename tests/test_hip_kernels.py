@@ -621,6 +621,42 @@ def test_deferred_weight_gradient_finalisation_is_bit_identical():
         assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
 
 
+def test_grouped_depthwise_weight_gradients_are_bit_identical():
+    """inside deferred_wgrad the first stages of small depthwise layers run side by side
+    (nasseg_dwconv_wgrad_many: grouped by kernel size / stride class / prologue, > 8 of a kind =>
+    several launches, 7x7 and C > 1024 through the one-by-one path); same bits as immediate"""
+    f = F()
+    torch.manual_seed(3)
+    # (C, k, stride, dil, relu_in)
+    cfgs = [(16, 3, 1, 1, False)] * 10 + [(16, 3, 2, 1, False), (24, 5, 1, 1, True), (24, 5, 2, 1, False),
+            (24, 3, 1, 2, True), (24, 5, 1, 2, False), (24, 7, 1, 1, False), (1028, 3, 1, 1, False)]
+    ws = [(torch.randn(c, 1, k, k) * 0.2).to(DEV) for c, k, _, _, _ in cfgs]
+    xs = [dev(rnd(2, c, 21, 34, seed=10 + i)) for i, (c, _, _, _, _) in enumerate(cfgs)]
+
+    def run(deferred):
+        leaves = [w.clone().requires_grad_(True) for w in ws]
+        loss = 0.0
+        for x, w, (c, k, st, dil, relu_in) in zip(xs, leaves, cfgs):
+            y = f.depthwise_conv2d(x, w, st, dil * (k // 2), dil, relu_in)
+            loss = loss + (y * y).mean()
+        poison = torch.full((16 << 20,), float("nan"), device=DEV)
+        del poison
+        with f.deferred_wgrad(deferred):
+            loss.backward()
+        assert not f.deferred_wgrad.pending and not f.deferred_wgrad.grouped
+        return [t.grad.clone() for t in leaves]
+
+    g1, g0 = run(True), run(False)
+    for a, b, cfg in zip(g0, g1, cfgs):
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b), cfg
+    for (c, k, st, dil, relu_in), x, w, g in list(zip(cfgs, xs, ws, g1))[9:]:
+        wr = w.clone().requires_grad_(True)
+        xin = torch.relu(x) if relu_in else x
+        y = torch.nn.functional.conv2d(xin.contiguous(), wr, None, st, dil * (k // 2), dil, c)
+        (y * y).mean().backward()
+        assert_close(g, wr.grad, 1e-5, 1e-3, "dw %r" % ((c, k, st, dil, relu_in),))
+
+
 def test_deferred_weight_gradient_detects_an_early_copy():
     """a weight used twice makes autograd add its two gradients during backward, i.e. before the
     deferred finalisation: with ``params`` given the context fails loudly instead of training on
