@@ -589,7 +589,7 @@ struct PackDesc {
   int N, K, ntaps, kind;
   int Ksrc, koff;  // the K channels packed are [koff, koff+K) of a source with Ksrc input channels
 };
-constexpr int kPackMax = 16;
+constexpr int kPackMax = 96;  // (3.8 KB of kernel arguments)
 struct PackTable {
   PackDesc d[kPackMax];
 };

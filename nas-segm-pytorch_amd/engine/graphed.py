@@ -63,24 +63,26 @@ class GraphedSegmenterStep(object):
         self.target = target.detach().clone()
         self.flat = self._views = self._used = None
         self._params = list(self.model.parameters())
+        self._pack_memo = []
         self._capture(warmup)
 
     # -- the captured region ---------------------------------------------------------
     def _fwd_bwd(self, with_optimisers):
         for p in self._params:
             p.grad = None
-        output = self.segmenter(self.image)
-        aux_outs = []
-        if isinstance(output, tuple):
-            output, aux_outs = output
-        target = F.nearest_label_resize(self.target, output.size()[2:])
-        loss = F.log_softmax_nll(output, target, self.ignore_index)
-        if self.aux_weight > 0:
-            for aux_out in aux_outs:
-                aux_out = F.bilinear_resize(aux_out, target.size()[1:])
-                loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
-        with F.deferred_wgrad(params=self._params):  # (gradients were cleared above)
-            loss.backward()
+        with F.packed_once(self._pack_memo):  # (one re-pack launch for all chains, recorded too)
+            output = self.segmenter(self.image)
+            aux_outs = []
+            if isinstance(output, tuple):
+                output, aux_outs = output
+            target = F.nearest_label_resize(self.target, output.size()[2:])
+            loss = F.log_softmax_nll(output, target, self.ignore_index)
+            if self.aux_weight > 0:
+                for aux_out in aux_outs:
+                    aux_out = F.bilinear_resize(aux_out, target.size()[1:])
+                    loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
+            with F.deferred_wgrad(params=self._params):  # (gradients were cleared above)
+                loss.backward()
         if with_optimisers:
             _clip_and_step(self.groups)
         return loss.detach()

@@ -144,6 +144,7 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
     ignore = _ignore_index(segm_crit)
     np.random.shuffle(indices)
     dec_params = list(decoder.parameters())
+    pack_memo = []
     feat_keys = [k for k in Xy_train.keys() if k not in ("y", "kd_y", "out_size")]
     out_size = tuple(Xy_train["out_size"])
     for i in range(n_passes):
@@ -152,21 +153,22 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
                               device=Xy_train["y"].device)
         feats = [Xy_train[k][idx] for k in feat_keys]
         target = Xy_train["y"][idx]
-        output = decoder(feats)
-        aux_outs = []
-        if isinstance(output, tuple):
-            output, aux_outs = output
-        output = F.bilinear_resize(output, out_size)
-        loss = F.log_softmax_nll(output, target, ignore)
-        if do_kd:
-            loss = loss + kd_coeff * kd_crit(output, Xy_train["kd_y"][idx])
-        if aux_weight > 0:
-            for aux_out in aux_outs:
-                aux_out = F.bilinear_resize(aux_out, out_size)
-                loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
-        optim_dec.zero_grad()
-        with F.deferred_wgrad(params=dec_params):
-            loss.backward()
+        with F.packed_once(pack_memo):  # (one weight re-pack launch per step)
+            output = decoder(feats)
+            aux_outs = []
+            if isinstance(output, tuple):
+                output, aux_outs = output
+            output = F.bilinear_resize(output, out_size)
+            loss = F.log_softmax_nll(output, target, ignore)
+            if do_kd:
+                loss = loss + kd_coeff * kd_crit(output, Xy_train["kd_y"][idx])
+            if aux_weight > 0:
+                for aux_out in aux_outs:
+                    aux_out = F.bilinear_resize(aux_out, out_size)
+                    loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
+            optim_dec.zero_grad()
+            with F.deferred_wgrad(params=dec_params):
+                loss.backward()
         if getattr(segmenter, "world_size", 1) > 1:
             # the feature cache is sharded: every rank steps on its own cached samples and the
             # decoder gradients are averaged (the reference runs this stage on one GPU)
@@ -189,25 +191,29 @@ def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=
     -> per-sub-module norm clipping -> optimiser steps.
     """
     model = _inner(segmenter)
-    output = segmenter(image)
-    aux_outs = []
-    if isinstance(output, tuple):
-        output, aux_outs = output
-    target = F.nearest_label_resize(target, output.size()[2:])
-    loss = F.log_softmax_nll(output, target, ignore_index)
-    if aux_weight > 0:
-        for aux_out in aux_outs:
-            aux_out = F.bilinear_resize(aux_out, target.size()[1:])
-            loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
     groups = getattr(model, "_nasseg_step_params", None)
     if groups is None:  # (a candidate's module tree is fixed: walk it once, not every step)
         groups = (list(model.encoder.parameters()), list(model.decoder.parameters()))
         model._nasseg_step_params = groups
-    _zero_grads(segmenter, (optim_enc, optim_dec))
-    # gradients were just cleared: the second stages of all weight-gradient reductions run
-    # batched when backward is through
-    with F.deferred_wgrad(params=groups[0] + groups[1]):
-        loss.backward()
+        model._nasseg_pack_memo = []
+    # the parameters are constant until the optimiser steps below: all chains' weights are
+    # re-packed by one launch at the start of the step
+    with F.packed_once(model._nasseg_pack_memo):
+        output = segmenter(image)
+        aux_outs = []
+        if isinstance(output, tuple):
+            output, aux_outs = output
+        target = F.nearest_label_resize(target, output.size()[2:])
+        loss = F.log_softmax_nll(output, target, ignore_index)
+        if aux_weight > 0:
+            for aux_out in aux_outs:
+                aux_out = F.bilinear_resize(aux_out, target.size()[1:])
+                loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
+        _zero_grads(segmenter, (optim_enc, optim_dec))
+        # gradients were just cleared: the second stages of all weight-gradient reductions run
+        # batched when backward is through
+        with F.deferred_wgrad(params=groups[0] + groups[1]):
+            loss.backward()
     if hasattr(segmenter, "sync_gradients"):
         segmenter.sync_gradients()
     _clip_and_step([(groups[0], enc_grad_clip, optim_enc), (groups[1], dec_grad_clip, optim_dec)])

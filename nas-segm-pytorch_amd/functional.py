@@ -277,6 +277,57 @@ def _pack_dense(w, mode):
 
 
 _PACK_PLANS = {}
+_PACK_MERGED = {}
+
+
+class packed_once(object):
+    """``with F.packed_once(memo): forward (+ backward) of one training step``
+
+    Every conv chain re-packs its weights into the kernels' layouts with one small launch per
+    chain and step (~50 launches on the headline network, each on the dependency path).  Within
+    ONE step the parameters do not change, so inside this context the packs of all chains seen
+    the last time ``memo`` (a list the caller keeps with the model) went through it are issued
+    together at entry - nasseg_pack_weights takes any number of tensors - and the chains find
+    their packed weights ready.  Chains met for the first time pack themselves as usual and
+    are remembered in ``memo`` for the next entry.  Same kernel, same bytes: identical results.
+    The context must not span a parameter update."""
+
+    scope = None
+
+    def __init__(self, memo):
+        self.memo = memo
+
+    def __enter__(self):
+        self.prev, packed_once.scope = packed_once.scope, self
+        self.done, self.seen, self.noted = set(), [], set()
+        keys = tuple(k for k in self.memo if k in _PACK_PLANS)
+        if keys:
+            merged = _PACK_MERGED.get(keys)
+            if merged is None:
+                plans = [_PACK_PLANS[k] for k in keys]
+                n = sum(pl[0] for pl in plans)
+                src = (ctypes.c_void_p * max(n, 1))()
+                dst = (ctypes.c_void_p * max(n, 1))()
+                dims = (ctypes.c_int * (7 * max(n, 1)))()
+                j = 0
+                for cnt, psrc, pdst, pdims, _, _ in plans:
+                    for i in range(cnt):
+                        src[j], dst[j] = psrc[i], pdst[i]
+                        dims[7 * j:7 * j + 7] = pdims[7 * i:7 * i + 7]
+                        j += 1
+                if len(_PACK_MERGED) > 64:
+                    _PACK_MERGED.clear()
+                merged = _PACK_MERGED[keys] = (n, src, dst, dims, plans)  # (plans: keeps the buffers alive)
+            if merged[0]:
+                lib.call("nasseg_pack_weights", merged[0], merged[1], merged[2], merged[3], current_stream())
+            self.done.update(keys)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        packed_once.scope = self.prev
+        if exc_type is None:
+            self.memo[:] = self.seen
+        return False
 
 
 def _pack_many(like, items):
@@ -328,8 +379,14 @@ def _pack_many(like, items):
             _PACK_PLANS.clear()
         plan = _PACK_PLANS[key] = (n, src, dst, dims, views, buf)
     n, src, dst, dims, views, _ = plan
-    if n:
+    scope = packed_once.scope
+    if scope is not None and key not in scope.noted:
+        scope.noted.add(key)
+        scope.seen.append(key)
+    if n and (scope is None or key not in scope.done):
         lib.call("nasseg_pack_weights", n, src, dst, dims, current_stream())
+        if scope is not None:
+            scope.done.add(key)  # (a weight used twice in the step is packed once)
     return [item[0] if v is None else v for item, v in zip(items, views)]
 
 

@@ -359,6 +359,30 @@ def test_segmenter_step_equals_a_plain_backward_step():
                 segmenter_step(net, x, t, oe, od, 255, 3.0, 3.0, -1)
         return _cpu_sd(net)
 
-    a, b = run(False), run(True)
+    # ... and, from the second step on, re-packs the weights of all conv chains with one launch
+    # at the start of the step (F.packed_once) instead of one per chain
+    packs, call = [0], F.lib.call
+
+    def counting(name, *args):
+        packs[-1] += name == "nasseg_pack_weights"
+        return call(name, *args)
+
+    F.lib.call = counting
+    try:
+        batches.append(batches[0])
+        a = run(False)
+        packs.append(0)
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+        oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3)
+        od = torch.optim.SGD(net.decoder.parameters(), lr=1e-3)
+        per_step = []
+        for x, t in batches:
+            packs.append(0)
+            segmenter_step(net, x, t, oe, od, 255, 0.0, 0.0, -1)
+            per_step.append(packs[-1])
+    finally:
+        F.lib.call = call
+    assert per_step[0] > 10 and per_step[1] == 1 and per_step[2] == 1, per_step
+    b = run(True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
