@@ -73,6 +73,12 @@ def algorithmic_bytes(name, a):
     if name == "nasseg_conv_wgrad":
         B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17]
         return 4 * (B * Hs * Ws * K + B * Ho * Wo * N + N * K * kh * kw)
+    if name == "nasseg_conv_wgrad_bn":  # x, g, z read, dz written (BatchNorm backward applied on load)
+        B, H, W, K, N = a[20], a[21], a[22], a[23], a[24]
+        return 4 * (B * H * W * (K + 3 * N) + N * K)
+    if name == "nasseg_dwconv_wgrad_bn":
+        B, H, W, C, Ho, Wo, K = a[16], a[17], a[18], a[19], a[20], a[21], a[22]
+        return 4 * (B * C * H * W + 3 * B * C * Ho * Wo + C * K * K)
     if name == "nasseg_bn_stats":
         return 4 * a[2] * a[3]
     if name == "nasseg_bn_bwd_reduce":
@@ -384,6 +390,7 @@ def main():
                    "nasseg_dwconv": "dw_fwd_strip / dw_bwd_data_s2 / dw_generic",
                    "nasseg_conv_bwd_data_bn": "conv_fwd_kernel", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
                    "nasseg_dwconv_wgrad": "dw_wgrad_strip(+finalize)",
+                   "nasseg_conv_wgrad_bn": "conv_wgrad_bn_kernel", "nasseg_dwconv_wgrad_bn": "dw_wgrad_strip",
                    "nasseg_bn_bwd_apply": "bn_bwd_apply_kernel", "nasseg_affine_act": "affine_act_kernel",
                    "nasseg_bn_stats": "colred_kernel<1>(+bn_stats_finalize)",
                    "nasseg_bn_bwd_reduce": "colred_kernel<2>(+colred_finalize)"}

@@ -104,6 +104,27 @@ int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* co
 int nasseg_conv_wgrad_many(int count, const int64_t* desc, void* stream);
 /* the depthwise twin: desc[16*i..] = the arguments of nasseg_dwconv_wgrad from x to dil, without dw */
 int nasseg_dwconv_wgrad_many(int count, const int64_t* desc, void* stream);
+
+/* Weight gradient fused with the second half of a BatchNorm backward (replaces one nasseg_bn_bwd_apply pass
+ * per layer; autograd of BatchNorm2d + Conv2d at src/nn/layer_factory.py:96-98,117-122,125-158,243-255).
+ * The conv's output z went through BatchNorm (+ activation); g is the gradient w.r.t. that output with the
+ * activation mask applied (bn_act == 0: as nasseg_conv_bwd_data_bn / nasseg_dwconv_bwd_data_bn leave it, or no
+ * activation) or still to be applied here (bn_act != 0: g' = g * act'(scale*z + shift), g' for g below);
+ * sums[2][N] = {sum g, sum g*xhat} over the M pixels (nasseg_bn_bwd_reduce / nasseg_rows_sum).  On load
+ *   dz = scale*(g - sums0/M - xhat*sums1/M)   (bn_train; else dz = scale*g),  xhat = (z - mean)*invstd,
+ * from which the weight gradient is computed AND which is written to dz for the backward-data call.
+ * nasseg_conv_wgrad_bn: pointwise convs (1x1, stride 1), K % 4 == 0, N % 4 == 0, workspace of
+ * nasseg_conv_wgrad_workspace(B,H,W,N,K,1,1).  nasseg_dwconv_wgrad_bn: nasseg_dwconv_strip_ok geometries.
+ * dw == NULL: first stage only (nasseg_wgrad_finalize_many). */
+int nasseg_conv_wgrad_bn(const float* x, int ldx, const float* g, int ldg, const float* z, int ldz, float* dz,
+                         int lddz, float* dw, float* ws, const float* in_scale, const float* in_shift, int in_act,
+                         const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                         const float* bn_sums, int bn_train, int bn_act, int B, int H, int W, int K, int N, void* stream);
+int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float* dz, float* dw, float* ws,
+                           const float* in_scale, const float* in_shift, int in_act, const float* bn_scale, const float* bn_shift,
+                           const float* bn_mean, const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act,
+                           int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
+                           void* stream);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
@@ -264,6 +285,16 @@ int nasseg_bf16_conv_bwd_data_bn(const nasseg_bf16_t* dy, int lddy, const float*
                             int dil, float* stats, void* stream);
 int nasseg_bf16_conv_wgrad_many(int count, const int64_t* desc, void* stream);
 int nasseg_bf16_dwconv_wgrad_many(int count, const int64_t* desc, void* stream);
+int nasseg_bf16_conv_wgrad_bn(const nasseg_bf16_t* x, int ldx, const nasseg_bf16_t* g, int ldg,
+                              const nasseg_bf16_t* z, int ldz, nasseg_bf16_t* dz, int lddz, float* dw, float* ws,
+                              const float* in_scale, const float* in_shift, int in_act, const float* bn_scale, const float* bn_shift,
+                              const float* bn_mean, const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act,
+                              int B, int H, int W, int K, int N, void* stream);
+int nasseg_bf16_dwconv_wgrad_bn(const nasseg_bf16_t* x, const nasseg_bf16_t* g, const nasseg_bf16_t* z,
+                                nasseg_bf16_t* dz, float* dw, float* ws, const float* in_scale,
+                                const float* in_shift, int in_act, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act, int B, int H, int W,
+                                int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream);
 int nasseg_bf16_conv_wgrad(const nasseg_bf16_t* x, int ldx, const nasseg_bf16_t* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,

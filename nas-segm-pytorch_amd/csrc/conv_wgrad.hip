@@ -30,7 +30,30 @@ struct WgArgs {
   int kchunks;     // number of k chunks (16*VK wide)
   int pix_per_block;  // multiple of 64
   ConvGeom g;      // non-transposed forward geometry
+  // BN variant (nasseg_conv_wgrad_bn): dy is the gradient w.r.t. the BatchNorm output (activation
+  // mask applied), z the conv's own raw output; the second half of the BatchNorm backward runs on
+  // load and its result is also written to dz for the backward-data kernel that follows
+  const act_t* z;
+  act_t* dz;
+  int ldz, lddz, bn_train, bn_act;
+  float invM;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  const float* bn_sums;  // [2][N]: sum g, sum g*xhat
 };
+
+template <int V, bool AL>
+__device__ __forceinline__ void store_vec(act_t* p, int i0, int len, const float* v) {
+  if (AL && V == 4) {
+    if (i0 < len) sta4(p + i0, make_float4(v[0], v[1], v[2], v[3]));
+  } else {
+#pragma unroll
+    for (int c = 0; c < V; ++c)
+      if (i0 + c < len) sta1(p + i0 + c, v[c]);
+  }
+}
 
 // out[0..V) = p[i0..i0+V) from a clamped address; caller masks.  AL: V-aligned vector load.
 #ifdef NASSEG_BF16
@@ -68,7 +91,7 @@ __device__ __forceinline__ void load_vec(const float* p, int i0, int len, float*
 // forward had an input prologue (affine + activation on x), re-applied on load.
 // (bx, by, bz): the workgroup's coordinates in the layer's own grid (slab, n/k chunk, tap) - the
 // grouped launch below runs several layers' grids side by side in one kernel
-template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
+template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO, bool BN = false>
 __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const int by, const int bz) {
   constexpr int NACC = VN * VK * 4;
   __shared__ float red[3][NACC][65];  // waves 1..3 park their accumulators here
@@ -123,6 +146,28 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const 
     }
   }
 
+  // dz = ca*g' + cb*z + cd  ==  scale*(g' - sum(g')/M - xhat*sum(g'*xhat)/M), xhat = (z - mean)*invstd,
+  // g' = g * act'(scale*z + shift) (bn_act != 0: g arrives without its activation mask)
+  float ca[VN], cb[VN], cd[VN], cs[VN];
+  const bool wr = BN && kchunk == 0 && tap == 0;  // every dz element is written by exactly one lane
+  if (BN) {
+#pragma unroll
+    for (int c = 0; c < VN; ++c) {
+      const int nc = nok[c] ? n0 + c : 0;
+      const float sc = a.bn_scale[nc];
+      ca[c] = sc;
+      cb[c] = 0.f;
+      cd[c] = 0.f;
+      cs[c] = a.bn_act ? a.bn_shift[nc] : 0.f;
+      if (a.bn_train) {
+        const float is = a.bn_invstd[nc], mu = a.bn_mean[nc];
+        const float s0 = a.bn_sums[nc] * a.invM, s1 = a.bn_sums[a.N + nc] * a.invM;
+        cb[c] = -sc * is * s1;
+        cd[c] = sc * (mu * is * s1 - s0);
+      }
+    }
+  }
+
   // Loop bounds are wave-uniform; loads are unconditional from clamped addresses and
   // masked afterwards, so the 2*U vector loads of an iteration are issued back to back.
   constexpr int U = 4;
@@ -134,6 +179,21 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const 
       const bool pok = p < p_end;
       const int pc = pok ? p : p_end - 1;
       load_vec<VN, ALN>(a.dy + (int64_t)pc * a.lddy, n0, a.N, dv[u]);
+      if (BN) {
+        float zv[VN];
+        load_vec<VN, ALN>(a.z + (int64_t)pc * a.ldz, n0, a.N, zv);
+#pragma unroll
+        for (int c = 0; c < VN; ++c) {
+          float gm = dv[u][c];
+          if (a.bn_act) gm *= act_mask(fmaf(zv[c], ca[c], cs[c]), a.bn_act);
+          float v = fmaf(gm, ca[c], fmaf(zv[c], cb[c], cd[c]));
+#ifdef NASSEG_BF16
+          v = bf16_to_f32(f32_to_bf16(v));  // (the value the backward-data kernel will read)
+#endif
+          dv[u][c] = v;
+        }
+        if (wr && pok) store_vec<VN, ALN>(a.dz + (int64_t)pc * a.lddz, n0, a.N, dv[u]);
+      }
       if (FLAT) {
         const int ox = pc % a.g.Wo;
         const int t = pc / a.g.Wo;
@@ -206,6 +266,11 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const 
 template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   wgrad_tile<VN, VK, ALN, ALK, GATHER, FLAT, PRO>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// pointwise conv followed by a BatchNorm: the BatchNorm's backward is applied to dy on load
+template <int VN, int VK, bool PRO>
+__global__ __launch_bounds__(256) void conv_wgrad_bn_kernel(WgArgs a) {
+  wgrad_tile<VN, VK, true, true, false, false, PRO, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several layers of ONE specialisation in one launch: weight gradients of small maps are
@@ -428,6 +493,8 @@ static int wgrad_setup(WgSetup& u, const act_t* x, int ldx, const act_t* dy, int
   a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.partial = ws;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   a.K = K; a.N = N;
+  a.z = nullptr; a.dz = nullptr; a.ldz = a.lddz = 0; a.bn_train = a.bn_act = 0; a.invM = 0.f;
+  a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = a.bn_sums = nullptr;
   a.kchunks = p.kchunks;
   a.pix_per_block = p.pix_per_block;
   a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
@@ -459,6 +526,53 @@ int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, fl
   const int64_t per = (int64_t)taps * N * K;
   hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64(per, NASSEG_RP_ELEMS)), dim3(256), 0,
                      s, ws, dw, p.nslab, taps, N, K, p.flat);
+  NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
+  return NASSEG_OK;
+}
+
+// nasseg_conv_wgrad of a POINTWISE conv whose output z went through a BatchNorm (+ activation),
+// fused with the second half of that BatchNorm's backward: g is the gradient w.r.t. the BatchNorm
+// output - bn_act == 0: with the activation mask already applied (nasseg_conv_bwd_data_bn's output,
+// or no activation at all); bn_act != 0: the mask act'(scale*z + shift) is applied here, on load -,
+// sums = {sum g', sum g'*xhat} of the masked gradient per channel over the M = B*H*W pixels.  On load  dz = scale*(g - sums0/M - xhat*sums1/M)  (train; eval: dz = scale*g), which is
+// what the weight gradient is computed from AND is written to dz for the backward-data call -
+// nasseg_bn_bwd_apply without its own pass over g and z.  K % 4 == 0, N % 4 == 0.
+int NASSEG_FN(conv_wgrad_bn)(const act_t* x, int ldx, const act_t* g, int ldg, const act_t* z, int ldz,
+                             act_t* dz, int lddz, float* dw, float* ws, const float* in_scale,
+                             const float* in_shift, int in_act, const float* bn_scale,
+                             const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                             const float* bn_sums, int bn_train, int bn_act, int B, int H, int W, int K,
+                             int N, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  NASSEG_REQUIRE(z && dz && bn_scale && (!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
+                 "conv_wgrad_bn: missing BatchNorm tensors");
+  NASSEG_REQUIRE(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldg % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 &&
+                     ldz >= N && lddz >= N,
+                 "conv_wgrad_bn: channels must be multiples of 4");
+  WgSetup u;
+  int rc = wgrad_setup(u, x, ldx, g, ldg, ws, in_scale, in_shift, in_act, B, H, W, K, H, W, N, 1, 1, 1, 0, 1);
+  if (rc) return rc;
+  NASSEG_REQUIRE(u.m.aln && u.m.alk && !u.m.flat && !u.m.gather, "conv_wgrad_bn: unsupported geometry");
+  u.a.z = z; u.a.ldz = ldz; u.a.dz = dz; u.a.lddz = lddz;
+  u.a.bn_scale = bn_scale; u.a.bn_shift = bn_shift; u.a.bn_mean = bn_mean; u.a.bn_invstd = bn_invstd;
+  u.a.bn_sums = bn_sums;
+  u.a.bn_train = bn_train; u.a.bn_act = bn_act;
+  u.a.invM = (float)(1.0 / ((double)B * H * W));
+  const WgPlan& p = u.p;
+#define WG_CASE(VN_, VK_)                                                                          \
+  if (p.vn == VN_ && p.vk == VK_) {                                                                \
+    if (u.m.pro) hipLaunchKernelGGL((conv_wgrad_bn_kernel<VN_, VK_, true>), u.grid, dim3(256), 0, s, u.a); \
+    else hipLaunchKernelGGL((conv_wgrad_bn_kernel<VN_, VK_, false>), u.grid, dim3(256), 0, s, u.a); \
+  } else
+  WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1)
+  WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
+  rc = nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_wgrad_bn: no kernel for vn=%d vk=%d", p.vn, p.vk);
+#undef WG_CASE
+  if (rc) return rc;
+  NASSEG_LAUNCH_CHECK("conv_wgrad_bn_kernel");
+  if (!dw) return NASSEG_OK;
+  hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64((int64_t)N * K, NASSEG_RP_ELEMS)), dim3(256), 0,
+                     s, ws, dw, p.nslab, 1, N, K, 0);
   NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
   return NASSEG_OK;
 }

@@ -472,11 +472,22 @@ struct DwWgArgs {
   const float* in_scale;
   const float* in_shift;
   int in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, g, nchunk;
+  // BN variant (nasseg_dwconv_wgrad_bn): dy is the masked gradient w.r.t. the BatchNorm output, z
+  // the conv's raw output; dz = second half of the BatchNorm backward, computed on load and stored
+  const act_t* z;
+  act_t* dz;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  const float* bn_sums;
+  float invM;
+  int bn_train, bn_act;
 };
 
 // (bx, by) of (gdx, gdy): the workgroup's coordinates in the layer's own grid - the grouped
 // launch below runs several layers' grids side by side in one kernel
-template <int K, int P, int E, bool PRO>
+template <int K, int P, int E, bool PRO, bool BN = false>
 __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, const int by,
                                               const int gdx, const int gdy) {
   const act_t* __restrict__ x = q.x;
@@ -498,6 +509,21 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
   for (int t = 0; t < K * K; ++t) acc[t] = f4zero();
   Prologue pro;
   if (PRO) pro = make_prologue(q.in_scale, q.in_shift, q.in_act, c4);
+  // dz = ca*g + cb*z + cd  ==  scale*(g - sum(g)/M - xhat*sum(g*xhat)/M)
+  float4 ca = f4zero(), cb = f4zero(), cd = f4zero(), cs = f4zero();
+  if (BN) {
+    ca = lda4(q.bn_scale + c4 * 4);
+    if (q.bn_act) cs = lda4(q.bn_shift + c4 * 4);  // g arrives without its activation mask
+    if (q.bn_train) {
+      const float4 is = lda4(q.bn_invstd + c4 * 4), mu = lda4(q.bn_mean + c4 * 4);
+      const float4 s0 = lda4(q.bn_sums + c4 * 4), s1 = lda4(q.bn_sums + C + c4 * 4);
+      const float m = q.invM;
+      cb = make_float4(-ca.x * is.x * (s1.x * m), -ca.y * is.y * (s1.y * m), -ca.z * is.z * (s1.z * m),
+                       -ca.w * is.w * (s1.w * m));
+      cd = make_float4(ca.x * (mu.x * is.x * (s1.x * m) - s0.x * m), ca.y * (mu.y * is.y * (s1.y * m) - s0.y * m),
+                       ca.z * (mu.z * is.z * (s1.z * m) - s0.z * m), ca.w * (mu.w * is.w * (s1.w * m) - s0.w * m));
+    }
+  }
 
   int xoff[K];
   bool xok[K];
@@ -520,8 +546,23 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int oy = oy0 + j * g;
-      d[j] = keep_if(lda4(dy + (((size_t)b * Ho + (oy < Ho ? oy : Ho - 1)) * Wo + ox) * C + c4 * 4),
-                     oy < Ho);
+      const size_t off = (((size_t)b * Ho + (oy < Ho ? oy : Ho - 1)) * Wo + ox) * C + c4 * 4;
+      float4 gv = lda4(dy + off);
+      if (BN) {
+        const float4 zv = lda4(q.z + off);
+        if (q.bn_act) {
+          const float4 y = fma4(zv, ca, cs);
+          gv = make_float4(gv.x * act_mask(y.x, q.bn_act), gv.y * act_mask(y.y, q.bn_act),
+                           gv.z * act_mask(y.z, q.bn_act), gv.w * act_mask(y.w, q.bn_act));
+        }
+        gv = fma4(gv, ca, fma4(zv, cb, cd));
+#ifdef NASSEG_BF16
+        gv = make_float4(bf16_to_f32(f32_to_bf16(gv.x)), bf16_to_f32(f32_to_bf16(gv.y)),
+                         bf16_to_f32(f32_to_bf16(gv.z)), bf16_to_f32(f32_to_bf16(gv.w)));
+#endif
+        if (oy < Ho) sta4(q.dz + off, gv);  // (every dy element is loaded by exactly one lane)
+      }
+      d[j] = keep_if(gv, oy < Ho);
     }
     const act_t* xb = x + (size_t)b * H * W * C + c4 * 4;
     const int iy0 = oy0 * stride - pad;
@@ -563,9 +604,9 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
   block_reduce_groups<K * K, K>(acc, red, pout, base, C4);
 }
 
-template <int K, int P, int E, bool PRO>
+template <int K, int P, int E, bool PRO, bool BN = false>
 __global__ __launch_bounds__(256) void dw_wgrad_strip(DwWgArgs q) {
-  dw_wgrad_tile<K, P, E, PRO>(q, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
+  dw_wgrad_tile<K, P, E, PRO, BN>(q, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
 // several depthwise layers of one specialisation in one launch (see conv_wgrad_group_kernel)
@@ -852,9 +893,9 @@ int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K) {
 // dw (C,1,K,K) = sum over pixels of dy * in_act(in_scale*x_tap + in_shift); ws must hold
 // nasseg_dwconv_wgrad_workspace() floats.  dw == null: only the partial rows [rows][K*K][C] are
 // produced (rows = workspace floats / (K*K*C)) for nasseg_wgrad_finalize_many.
-int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* ws,
-                        const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
-                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream) {
+static int dw_wgrad_impl(const act_t* x, const act_t* dy, float* dw, float* ws, const float* in_scale,
+                         const float* in_shift, int in_act, int B, int H, int W, int C, int Ho, int Wo,
+                         int K, int stride, int pad, int dil, const DwWgArgs* bn, void* stream) {
   NASSEG_REQUIRE(C % 4 == 0, "dwconv_wgrad: C=%d must be a multiple of 4", C);
   hipStream_t s = (hipStream_t)stream;
   const int C4 = C / 4;
@@ -867,15 +908,26 @@ int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* w
   }
   const bool pro = in_scale || in_shift || in_act;
   const bool strip_ok = (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2);
+  NASSEG_REQUIRE(!bn || strip_ok, "dwconv_wgrad_bn: needs a strip geometry (nasseg_dwconv_strip_ok)");
   if (strip_ok) {
     constexpr int P = 4;
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(gx, gy, 1);
     DwWgArgs q = {x, dy, ws, in_scale, in_shift, in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk};
-#define LAUNCH_WG2(KK, EE, PR) \
-  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE, PR>), grid, dim3(256), 0, s, q)
-#define LAUNCH_WG(KK, EE) \
-  do { if (pro) LAUNCH_WG2(KK, EE, true); else LAUNCH_WG2(KK, EE, false); } while (0)
+    if (bn) {
+      q.z = bn->z; q.dz = bn->dz; q.bn_scale = bn->bn_scale; q.bn_shift = bn->bn_shift; q.bn_mean = bn->bn_mean;
+      q.bn_invstd = bn->bn_invstd; q.bn_sums = bn->bn_sums; q.invM = bn->invM; q.bn_train = bn->bn_train;
+      q.bn_act = bn->bn_act;
+    }
+#define LAUNCH_WG2(KK, EE, PR, BB) \
+  hipLaunchKernelGGL((dw_wgrad_strip<KK, P, EE, PR, BB>), grid, dim3(256), 0, s, q)
+#define LAUNCH_WG(KK, EE)                                   \
+  do {                                                      \
+    if (bn && pro) LAUNCH_WG2(KK, EE, true, true);          \
+    else if (bn) LAUNCH_WG2(KK, EE, false, true);           \
+    else if (pro) LAUNCH_WG2(KK, EE, true, false);          \
+    else LAUNCH_WG2(KK, EE, false, false);                  \
+  } while (0)
     if (K == 3 && sc.e == 1) LAUNCH_WG(3, 1);
     else if (K == 3 && sc.e == 2) LAUNCH_WG(3, 2);
     else if (K == 5 && sc.e == 1) LAUNCH_WG(5, 1);
@@ -895,6 +947,35 @@ int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* w
                      dw, gx * gy, K * K, C);
   NASSEG_LAUNCH_CHECK("dw_wgrad_finalize");
   return NASSEG_OK;
+}
+
+int NASSEG_FN(dwconv_wgrad)(const act_t* x, const act_t* dy, float* dw, float* ws,
+                        const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
+                        int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream) {
+  return dw_wgrad_impl(x, dy, dw, ws, in_scale, in_shift, in_act, B, H, W, C, Ho, Wo, K, stride, pad, dil,
+                       nullptr, stream);
+}
+
+// nasseg_dwconv_wgrad of a depthwise conv whose output z went through a BatchNorm (+ activation),
+// fused with the second half of that BatchNorm's backward (see nasseg_conv_wgrad_bn): g = masked
+// gradient w.r.t. the BatchNorm output, sums = {sum g, sum g*xhat}; dz (written) = the gradient
+// w.r.t. z, which the weight gradient is computed from.  Strip geometries only
+// (nasseg_dwconv_strip_ok).
+int NASSEG_FN(dwconv_wgrad_bn)(const act_t* x, const act_t* g, const act_t* z, act_t* dz, float* dw, float* ws,
+                               const float* in_scale, const float* in_shift, int in_act,
+                               const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                               const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act, int B,
+                               int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil,
+                               void* stream) {
+  NASSEG_REQUIRE(z && dz && bn_scale && (!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
+                 "dwconv_wgrad_bn: missing BatchNorm tensors");
+  NASSEG_REQUIRE(B > 0 && Ho > 0 && Wo > 0, "dwconv_wgrad_bn: bad geometry");
+  DwWgArgs bn = {};
+  bn.z = z; bn.dz = dz; bn.bn_scale = bn_scale; bn.bn_shift = bn_shift; bn.bn_mean = bn_mean;
+  bn.bn_invstd = bn_invstd; bn.bn_sums = bn_sums; bn.bn_train = bn_train; bn.bn_act = bn_act;
+  bn.invM = (float)(1.0 / ((double)B * Ho * Wo));
+  return dw_wgrad_impl(x, g, dw, ws, in_scale, in_shift, in_act, B, H, W, C, Ho, Wo, K, stride, pad, dil,
+                       &bn, stream);
 }
 
 // First stage of `count` small depthwise layers, strip geometries of one specialisation grouped

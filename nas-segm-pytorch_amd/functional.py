@@ -155,6 +155,41 @@ def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
     return dwt
 
 
+def _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
+    """Can this layer's weight-gradient kernel apply the BatchNorm backward on load
+    (nasseg_conv_wgrad_bn / nasseg_dwconv_wgrad_bn)?  Large maps only: the launches of small ones
+    are grouped at the end of backward, after the backward-data kernels that need dz.  (The rule
+    must not depend on whether finalisation is deferred: both ways give the same bits.)"""
+    if (cur.numel() + z.numel()) * cur.element_size() <= _GROUP_WGRAD_BYTES:
+        return False
+    K, N = cur.shape[1], z.shape[1]
+    if kind == "dw":
+        return K % 4 == 0 and bool(lib.query("nasseg_dwconv_strip_ok", w.shape[-1], stride, dil))
+    return (w.shape[2] == 1 and w.shape[3] == 1 and stride == 1 and pad == 0 and K % 4 == 0 and N % 4 == 0)
+
+
+def _wgrad_bn(kind, cur, g, z, w, psc, psh, pact, bn, geom):
+    """Weight gradient of a conv followed by BatchNorm, from the masked gradient ``g`` w.r.t. the
+    BatchNorm output: returns (dw, dz); bn = (scale, shift, mean, invstd, sums, training, act) with
+    act = the activation whose mask g still lacks (ACT_NONE: g arrived masked, or no activation)."""
+    scale, shift, mean, invstd, sums, training, act = bn
+    dz = torch.empty_like(z)
+    dwt = torch.empty_like(w)
+    if kind == "dw":
+        B, H, W, C, Ho, Wo, k, stride, pad, dil = geom
+        ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, k))
+        lib.call(_k("nasseg_dwconv_wgrad_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(dz),
+                 _finish_wgrad(ws, dwt, k * k, C, 1, 0), ptr(ws), ptr(psc), ptr(psh), pact, ptr(scale), ptr(shift),
+                 ptr(mean), ptr(invstd), ptr(sums), int(training), act, *geom, current_stream())
+    else:
+        B, H, W, K, N = geom
+        ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", B, H, W, N, K, 1, 1))
+        lib.call(_k("nasseg_conv_wgrad_bn", cur), ptr(cur), K, ptr(g), N, ptr(z), N, ptr(dz), N,
+                 _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, ptr(scale), ptr(shift),
+                 ptr(mean), ptr(invstd), ptr(sums), int(training), act, B, H, W, K, N, current_stream())
+    return dwt, dz
+
+
 def _finish_wgrad(ws, dw, taps, N, K, flat):
     """Returns the pointer to pass as ``dw`` to a backward-weight entry point: the tensor itself,
     or NULL with the second stage queued when finalisation is deferred."""
@@ -681,6 +716,7 @@ class _ConvChain(torch.autograd.Function):
             M = B * Ho * Wo
             need_dw = ctx.needs_input_grad[3 + 6 * i]
             need_dx = i > 0 or ctx.needs_input_grad[1]
+            fused_bn = None  # BatchNorm backward applied by the weight-gradient kernel on load
             if has_bn:
                 mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
                 sums = _vec(z, 2 * N)
@@ -698,9 +734,16 @@ class _ConvChain(torch.autograd.Function):
                 if not (need_dw or need_dx):
                     g = None
                     break
-                dz = torch.empty_like(z)
-                lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean),
-                         ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
+                if need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
+                    # the weight-gradient kernel below computes dz while it loads g and z (masking
+                    # g first if it did not arrive masked) and leaves it behind for the
+                    # backward-data kernel
+                    fused_bn = (scale, shift, mean, invstd, sums, training, ACT_NONE if pre is not None else act)
+                    dz = None
+                else:
+                    dz = torch.empty_like(z)
+                    lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean),
+                             ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
             else:
                 dz = g
                 if not (need_dw or need_dx):
@@ -725,7 +768,10 @@ class _ConvChain(torch.autograd.Function):
                     bn_prev = (cur, None, None, None, None, in_act0)  # mask-only epilogue
             if kind == "dw":
                 k = w.shape[-1]
-                if need_dw:
+                if fused_bn is not None:
+                    grads[6 * i], dz = _wgrad_bn("dw", cur, g, z, w, psc, psh, pact, fused_bn,
+                                                 (Bc, H, W, K, Ho, Wo, k, stride, pad, dil))
+                elif need_dw:
                     grads[6 * i] = _dw_wgrad(cur, dz, w, psc, psh, pact,
                                              (Bc, H, W, K, Ho, Wo, k, stride, pad, dil))
                 g = None
@@ -733,7 +779,10 @@ class _ConvChain(torch.autograd.Function):
                     g, pre = _dw_backward_data(dz, wb, k, (Bc, K, H, W), stride, pad, dil, bn_prev)
             else:
                 _, _, kh, kw = w.shape
-                if need_dw:
+                if fused_bn is not None:
+                    grads[6 * i], dz = _wgrad_bn("dense", cur, g, z, w, psc, psh, pact, fused_bn,
+                                                 (Bc, H, W, K, N))
+                elif need_dw:
                     grads[6 * i] = _dense_wgrad(cur, dz, w, psc, psh, pact,
                                                 (Bc, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil))
                 g = None

@@ -519,6 +519,127 @@ def test_depthwise_backward_data_with_bn_backward_statistics(case, act):
     assert_close(sums, sums_ref, tol, 1e-4, "bn backward sums")
 
 
+def _bn_bwd_reference(f, g, z, vecs, train, act=0):
+    """sums {sum g', sum g'*xhat} and dz of nasseg_bn_bwd_reduce / nasseg_bn_bwd_apply"""
+    scale, shift, mean, invstd = vecs
+    B, C, H, W = z.shape
+    M = B * H * W
+    s = f.current_stream()
+    sums = torch.empty(2 * C, device=DEV)
+    ws = torch.empty(f.lib.query("nasseg_colred_workspace", 1, M, C), device=DEV)
+    f.lib.call(f._k("nasseg_bn_bwd_reduce", g), f.ptr(g), C, f.ptr(z), C, M, C, f.ptr(scale), f.ptr(shift),
+               f.ptr(mean), f.ptr(invstd), act, f.ptr(sums), f.ptr(ws), s)
+    dz = torch.empty_like(z)
+    f.lib.call(f._k("nasseg_bn_bwd_apply", g), f.ptr(g), f.ptr(z), f.ptr(scale), f.ptr(shift), f.ptr(mean),
+               f.ptr(invstd), f.ptr(sums), M, C, int(train), act, f.ptr(dz), s)
+    return sums, dz
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, K (input channels), N (output channels), input prologue, BatchNorm in training mode
+    (2, 16, 24, 16, 96, False, True), (2, 9, 11, 96, 16, True, True), (2, 16, 20, 24, 144, True, True),
+    (1, 13, 17, 144, 24, False, True), (2, 8, 8, 64, 64, True, False), (3, 33, 31, 32, 32, False, True),
+    (1, 40, 64, 224, 64, True, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_dense_weight_gradient_with_fused_bn_backward(case, dtype, act):
+    """nasseg_conv_wgrad_bn == nasseg_bn_bwd_apply followed by nasseg_conv_wgrad: same dz (also where N
+    or K is split over several workgroups: written once), same weight gradient"""
+    f = F()
+    B, H, W, K, N, pro, train = case
+    x = dev(rnd(B, K, H, W, seed=1)).to(dtype)
+    g = dev(rnd(B, N, H, W, seed=2)).to(dtype)
+    z = dev(rnd(B, N, H, W, seed=3)).to(dtype)
+    vecs = _bn_vectors(N, 4)
+    psc, psh = (_bn_vectors(K, 5)[:2] if pro else (None, None))
+    pact = 2 if pro else 0
+    sums, dz_ref = _bn_bwd_reference(f, g, z, vecs, train, act)
+    s = f.current_stream()
+    wsn = f.lib.query("nasseg_conv_wgrad_workspace", B, H, W, N, K, 1, 1)
+    dw_ref = torch.empty(N, K, 1, 1, device=DEV)
+    f.lib.call(f._k("nasseg_conv_wgrad", x), f.ptr(x), K, f.ptr(dz_ref), N, f.ptr(dw_ref),
+               f.ptr(torch.empty(wsn, device=DEV)), f.ptr(psc), f.ptr(psh), pact, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, s)
+    dz = torch.full_like(z, float("nan"))
+    dw = torch.empty(N, K, 1, 1, device=DEV)
+    f.lib.call(f._k("nasseg_conv_wgrad_bn", x), f.ptr(x), K, f.ptr(g), N, f.ptr(z), N, f.ptr(dz), N, f.ptr(dw),
+               f.ptr(torch.empty(wsn, device=DEV)), f.ptr(psc), f.ptr(psh), pact, f.ptr(vecs[0]), f.ptr(vecs[1]),
+               f.ptr(vecs[2]), f.ptr(vecs[3]), f.ptr(sums), int(train), act, B, H, W, K, N, s)
+    lo = dtype == torch.bfloat16
+    assert_close(dz.float(), dz_ref.float(), 2e-2 if lo else 2e-5, 1e-2 if lo else 1e-5, "dz")
+    scale = float(dw_ref.abs().max())
+    assert_close(dw, dw_ref, (2e-2 if lo else 1e-5) * scale, 2e-2 if lo else 1e-4, "dw")
+
+
+@pytest.mark.parametrize("case", [
+    # B, C, H, W, k, stride, pad, dil, input prologue, training
+    (2, 24, 13, 17, 3, 1, 1, 1, True, True), (2, 32, 16, 20, 5, 1, 2, 1, False, True),
+    (2, 96, 18, 22, 3, 2, 1, 1, True, True), (2, 16, 21, 19, 3, 1, 3, 3, True, True),
+    (1, 32, 30, 33, 5, 1, 12, 6, False, False), (2, 16, 18, 22, 5, 2, 2, 1, True, True),
+    (1, 960, 6, 7, 3, 1, 1, 1, True, True)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 2])
+def test_depthwise_weight_gradient_with_fused_bn_backward(case, dtype, act):
+    """nasseg_dwconv_wgrad_bn == nasseg_bn_bwd_apply followed by nasseg_dwconv_wgrad"""
+    f = F()
+    B, C, H, W, k, stride, pad, dil, pro, train = case
+    Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    x = dev(rnd(B, C, H, W, seed=1)).to(dtype)
+    g = dev(rnd(B, C, Ho, Wo, seed=2)).to(dtype)
+    z = dev(rnd(B, C, Ho, Wo, seed=3)).to(dtype)
+    vecs = _bn_vectors(C, 4)
+    psc, psh = (_bn_vectors(C, 5)[:2] if pro else (None, None))
+    pact = 2 if pro else 0
+    sums, dz_ref = _bn_bwd_reference(f, g, z, vecs, train, act)
+    s = f.current_stream()
+    wsn = f.lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, k)
+    dw_ref = torch.empty(C, 1, k, k, device=DEV)
+    f.lib.call(f._k("nasseg_dwconv_wgrad", x), f.ptr(x), f.ptr(dz_ref), f.ptr(dw_ref), f.ptr(torch.empty(wsn, device=DEV)),
+               f.ptr(psc), f.ptr(psh), pact, B, H, W, C, Ho, Wo, k, stride, pad, dil, s)
+    dz = torch.full_like(z, float("nan"))
+    dw = torch.empty(C, 1, k, k, device=DEV)
+    f.lib.call(f._k("nasseg_dwconv_wgrad_bn", x), f.ptr(x), f.ptr(g), f.ptr(z), f.ptr(dz), f.ptr(dw),
+               f.ptr(torch.empty(wsn, device=DEV)), f.ptr(psc), f.ptr(psh), pact, f.ptr(vecs[0]), f.ptr(vecs[1]),
+               f.ptr(vecs[2]), f.ptr(vecs[3]), f.ptr(sums), int(train), act, B, H, W, C, Ho, Wo, k, stride, pad, dil, s)
+    lo = dtype == torch.bfloat16
+    assert_close(dz.float(), dz_ref.float(), 2e-2 if lo else 2e-5, 1e-2 if lo else 1e-5, "dz")
+    scale = float(dw_ref.abs().max())
+    assert_close(dw, dw_ref, (2e-2 if lo else 1e-5) * scale, 2e-2 if lo else 1e-4, "dw")
+
+
+def test_chain_backward_is_the_same_with_and_without_the_fused_bn_weight_gradient(monkeypatch):
+    """an inverted-residual chain (pw+BN+ReLU6, dw+BN+ReLU6, pw+BN, + residual) and a separable chain:
+    gradients with the BatchNorm backward applied inside the weight-gradient kernels (the path of
+    large maps) against the separate nasseg_bn_bwd_apply pass (small maps)"""
+    from nas_segm_amd.nn.layer_factory import InvertedResidual, SepConv
+
+    f = F()
+    torch.manual_seed(2)
+    mods = [InvertedResidual(24, 24, 1, 6).to(DEV).train(), InvertedResidual(16, 24, 2, 6).to(DEV).train(),
+            SepConv(24, 32, 5, 1, 2, dilation=1, affine=True, repeats=2).to(DEV).train()]
+    xs = [dev(rnd(2, 24, 20, 28, seed=3)), dev(rnd(2, 16, 21, 27, seed=4)), dev(rnd(2, 24, 20, 28, seed=5))]
+
+    def run(threshold):
+        monkeypatch.setattr(f, "_GROUP_WGRAD_BYTES", threshold)
+        out = []
+        for m, x in zip(mods, xs):
+            m.zero_grad()
+            xg = x.clone().requires_grad_(True)
+            y = m(xg)
+            (y * dev(rnd(*y.shape, seed=6))).sum().backward()
+            out.append([xg.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+        return out
+
+    fused, plain = run(-1), run(1 << 40)
+    calls = []
+    orig = f.lib.call
+    monkeypatch.setattr(f.lib, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
+    run(-1)
+    assert any(n.endswith("conv_wgrad_bn") for n in calls) and any(n.endswith("dwconv_wgrad_bn") for n in calls)
+    for a, b in zip(fused, plain):
+        for u, v in zip(a, b):
+            assert_close(u, v, 5e-5 * max(1.0, float(v.abs().max())), 5e-4, "gradient")
+
+
 @pytest.mark.parametrize("N,act", [(64, 1), (224, 1), (24, 2)])
 def test_dense_backward_data_mask_only(N, act):
     """nasseg_conv_bwd_data_bn without a statistics buffer: only the act' mask (identity scale/shift) -
