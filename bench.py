@@ -40,8 +40,8 @@ WORKLOADS = {
     # one genotype sampled by the reference controller per rank (tests/golden/controller.json), search
     # defaults (agg 48, sep repeats 1); the reward of one batch is computed with the HIP mIoU kernels
     "search713": ("sampled", None, 19, 8, 713, 713, "sampled WACV cell per GPU, 713x713 bs8 (BASELINE config 4)"),
-    # 1-channel depth head, berHu loss (fp32 - the bf16 variant of BASELINE config 5 does not exist yet)
-    "depth480": ("micro", CVPR_ARCH2_DEPTH, 1, 8, 480, 640, "CVPR depth arch, berHu, 480x640 bs8 (BASELINE config 5, fp32)"),
+    # 1-channel depth head, berHu loss (BASELINE config 5 is bf16: run with --dtype bf16)
+    "depth480": ("micro", CVPR_ARCH2_DEPTH, 1, 8, 480, 640, "CVPR depth arch, berHu, 480x640 bs8 (BASELINE config 5)"),
 }
 NUM_CLASSES = 19
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -403,7 +403,7 @@ def main():
                     "achieved": top["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": top["gbs"] / HBM_PEAK_GBS,
                     "traffic": (pmc_traffic(fam.get(base, "").split("(")[0].split(" ")[0])
-                                if args.dtype == "f32" else None),
+                                if args.dtype == "f32" and args.workload == "headline" else None),
                     "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                     "avg_launch_ms": top["ms"] / top["launches"], "launches_per_step": top["launches"] / 2,
                     "share_of_kernel_time": top["ms"] / total_ms,

@@ -9,7 +9,7 @@ OUT=gpurun_out
 mkdir -p $OUT
 WHAT="${1:-all}"
 python -c "import torch; print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))" > $OUT/env.log 2>&1
-nproc >> $OUT/env.log; grep -m1 "model name" /proc/cpuinfo >> $OUT/env.log
+(rocm-smi --showuniqueid --showpower 2>/dev/null | grep -i "unique\|power" | head -4) >> $OUT/env.log; nproc >> $OUT/env.log; grep -m1 "model name" /proc/cpuinfo >> $OUT/env.log
 if [[ "$WHAT" == "all" || "$WHAT" == "tests" ]]; then
   for f in tests/test_hip_kernels.py tests/test_hip_golden.py tests/test_hip_engine.py tests/test_hip_bf16.py; do
     n=$(basename $f .py)
@@ -32,7 +32,7 @@ if [[ "$WHAT" == "all" || "$WHAT" == "graph" ]]; then
     timeout 300 python bench.py --steps 8 --warmup 2 --graph $g --no-cpu-baseline --no-roofline > $OUT/bench_graph$g.json 2> $OUT/bench_graph$g.err
     echo "bench --graph $g exit $?" >> $OUT/summary.log; cat $OUT/bench_graph$g.json >> $OUT/summary.log
   done
-  for wl in search713 depth480; do
+  for wl in depth480; do
     timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_${wl}_g0.json 2> $OUT/bench_${wl}_g0.err
     echo "bench $wl exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_g0.json >> $OUT/summary.log
   done
@@ -40,7 +40,7 @@ if [[ "$WHAT" == "all" || "$WHAT" == "graph" ]]; then
     timeout 300 python bench.py --workload $wl --dtype bf16 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_${wl}_bf16.json 2> $OUT/bench_${wl}_bf16.err
     echo "bench $wl bf16 exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_bf16.json >> $OUT/summary.log
   done
-  for wl in arch1 cvpr321; do
+  for wl in arch1 cvpr321 search713; do
     for g in 0 2; do
       timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --graph $g --no-cpu-baseline > $OUT/bench_${wl}_g$g.json 2> $OUT/bench_${wl}_g$g.err
       echo "bench $wl --graph $g exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_g$g.json >> $OUT/summary.log
