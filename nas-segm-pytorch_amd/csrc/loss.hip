@@ -49,18 +49,146 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const act_t* __restrict__ l
   }
 }
 
-// out[0] = loss (mean), out[1] = number of valid pixels
-__global__ void ce_finalize_kernel(const float* __restrict__ partial, int nblk,
-                                   float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// out[0] = loss (mean), out[1] = number of valid pixels.  One workgroup of 256 threads: thread t
+// adds the partials of blocks t, t+256, ... in fp64, then a fixed-order tree through LDS.
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                          float* __restrict__ out) {
+  __shared__ double red_l[256];
+  __shared__ double red_n[256];
   double l = 0.0, n = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = threadIdx.x; b < nblk; b += 256) {
     l += (double)partial[b * 2];
     n += (double)partial[b * 2 + 1];
   }
-  out[0] = (float)(l / n);
-  out[1] = (float)n;
+  red_l[threadIdx.x] = l;
+  red_n[threadIdx.x] = n;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      red_l[threadIdx.x] += red_l[threadIdx.x + s];
+      red_n[threadIdx.x] += red_n[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = (float)(red_l[0] / red_n[0]);
+    out[1] = (float)red_n[0];
+  }
 }
+
+// The same two computations for C <= 63 with the scores staged through LDS: a workgroup's 256
+// pixels are 256*C CONTIGUOUS floats, loaded (and, backward, stored) with fully coalesced
+// accesses; each lane then works on its pixel's row in LDS (row stride C|1 is odd: no bank
+// conflicts).  One lane per pixel straight from HBM touches 64 rows 4*C bytes apart per load.
+// Pixel -> (workgroup, thread) assignment, per-pixel arithmetic and reduction order are those
+// of ce_fwd_kernel / ce_bwd_kernel: bit-identical results.
+template <typename TL, bool BWD>
+__global__ __launch_bounds__(256) void ce_tile_kernel(const act_t* __restrict__ logits,
+                                                      const TL* __restrict__ target, int64_t P, int C,
+                                                      int ignore, float* __restrict__ partial,
+                                                      const float* __restrict__ stats,
+                                                      const float* __restrict__ gscale,
+                                                      act_t* __restrict__ dlogits) {
+  extern __shared__ float tile[];  // [256][C | 1]
+  __shared__ float red_l[256];
+  __shared__ float red_n[256];
+  const int CS = C | 1;
+  const int tid = threadIdx.x;
+  const int64_t ntiles = (P + 255) / 256;
+  float loss = 0.f, cnt = 0.f;
+  float g = 0.f;
+  if (BWD) g = (gscale ? gscale[0] : 1.f) / stats[1];
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int64_t p0 = t * 256;
+    const int np = (int)((P - p0) < 256 ? (P - p0) : 256);
+    const int nel = np * C;
+    const act_t* src = logits + p0 * C;
+    const int nel4 = nel >> 2;  // (p0*C is a multiple of 4: vector accesses are aligned)
+    for (int i = tid; i < nel4; i += 256) {
+      const float4 v = lda4(src + 4 * i);
+      int pix = (4 * i) / C;
+      int c = 4 * i - pix * C;
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        tile[pix * CS + c] = e[r];
+        if (++c == C) {
+          c = 0;
+          ++pix;
+        }
+      }
+    }
+    for (int i = 4 * nel4 + tid; i < nel; i += 256) {
+      const int pix = i / C;
+      tile[pix * CS + (i - pix * C)] = lda1(src + i);
+    }
+    __syncthreads();
+    if (tid < np) {
+      float* row = tile + tid * CS;
+      const int64_t tg = (int64_t)target[p0 + tid];
+      const bool skip = tg == ignore || tg < 0 || tg >= C;
+      if (BWD && skip) {
+        for (int c = 0; c < C; ++c) row[c] = 0.f;
+      } else if (!skip) {
+        float m = row[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) {
+          const float e = expf(row[c] - m);
+          if (BWD) row[c] = e;  // (kept: the softmax needs it again)
+          sum += e;
+        }
+        if (BWD) {
+          const float inv = 1.f / sum;
+          for (int c = 0; c < C; ++c) row[c] = g * (row[c] * inv - ((int64_t)c == tg ? 1.f : 0.f));
+        } else {
+          loss += (m + logf(sum)) - row[tg];
+          cnt += 1.f;
+        }
+      }
+    }
+    __syncthreads();
+    if (BWD) {
+      act_t* dst = dlogits + p0 * C;
+      for (int i = tid; i < nel4; i += 256) {
+        int pix = (4 * i) / C;
+        int c = 4 * i - pix * C;
+        float e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e[r] = tile[pix * CS + c];
+          if (++c == C) {
+            c = 0;
+            ++pix;
+          }
+        }
+        sta4(dst + 4 * i, make_float4(e[0], e[1], e[2], e[3]));
+      }
+      for (int i = 4 * nel4 + tid; i < nel; i += 256) {
+        const int pix = i / C;
+        sta1(dst + i, tile[pix * CS + (i - pix * C)]);
+      }
+      __syncthreads();
+    }
+  }
+  if (!BWD) {
+    red_l[tid] = loss;
+    red_n[tid] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        red_l[tid] += red_l[tid + s];
+        red_n[tid] += red_n[tid + s];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      partial[blockIdx.x * 2] = red_l[0];
+      partial[blockIdx.x * 2 + 1] = red_n[0];
+    }
+  }
+}
+constexpr int kCeTileMaxC = 63;
 
 // dlogits[p][c] = gscale[0] * (softmax(p)[c] - [c == target]) / nvalid   (0 for ignored pixels)
 template <typename TL>
@@ -188,16 +316,23 @@ int NASSEG_FN(ce_fwd)(const act_t* logits, const void* target, int elem_size, in
   NASSEG_REQUIRE(P > 0 && C > 0, "ce_fwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const int grid = ce_grid(P);
-  if (elem_size == 8)
+  NASSEG_REQUIRE(elem_size == 8 || elem_size == 1, "ce_fwd: elem_size %d not supported", elem_size);
+  const size_t lds = (size_t)256 * (C | 1) * sizeof(float);
+  const bool tiled = C <= kCeTileMaxC && ((uintptr_t)logits & 15) == 0;  // (vector staging loads)
+  if (tiled && elem_size == 8)
+    hipLaunchKernelGGL((ce_tile_kernel<int64_t, false>), dim3(grid), dim3(256), lds, s, logits,
+                       (const int64_t*)target, P, C, ignore, ws, nullptr, nullptr, nullptr);
+  else if (tiled)
+    hipLaunchKernelGGL((ce_tile_kernel<uint8_t, false>), dim3(grid), dim3(256), lds, s, logits,
+                       (const uint8_t*)target, P, C, ignore, ws, nullptr, nullptr, nullptr);
+  else if (elem_size == 8)
     hipLaunchKernelGGL((ce_fwd_kernel<int64_t>), dim3(grid), dim3(256), 0, s, logits,
                        (const int64_t*)target, P, C, ignore, ws);
-  else if (elem_size == 1)
+  else
     hipLaunchKernelGGL((ce_fwd_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, logits,
                        (const uint8_t*)target, P, C, ignore, ws);
-  else
-    return nasseg_fail(NASSEG_ERR_ARG, "ce_fwd: elem_size %d not supported", elem_size);
   NASSEG_LAUNCH_CHECK("ce_fwd");
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, s, ws, grid, out);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, ws, grid, out);
   NASSEG_LAUNCH_CHECK("ce_finalize");
   return NASSEG_OK;
 }
@@ -208,14 +343,23 @@ int NASSEG_FN(ce_bwd)(const act_t* logits, const void* target, int elem_size, co
   NASSEG_REQUIRE(P > 0 && C > 0, "ce_bwd: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const int grid = ce_grid(P) * 2;
-  if (elem_size == 8)
+  NASSEG_REQUIRE(elem_size == 8 || elem_size == 1, "ce_bwd: elem_size %d not supported", elem_size);
+  const size_t lds = (size_t)256 * (C | 1) * sizeof(float);
+  int64_t tiles = (P + 255) / 256;
+  if (tiles > 4096) tiles = 4096;
+  const bool tiled = C <= kCeTileMaxC && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0;
+  if (tiled && elem_size == 8)
+    hipLaunchKernelGGL((ce_tile_kernel<int64_t, true>), dim3((unsigned)tiles), dim3(256), lds, s, logits,
+                       (const int64_t*)target, P, C, ignore, nullptr, stats, gscale, dlogits);
+  else if (tiled)
+    hipLaunchKernelGGL((ce_tile_kernel<uint8_t, true>), dim3((unsigned)tiles), dim3(256), lds, s, logits,
+                       (const uint8_t*)target, P, C, ignore, nullptr, stats, gscale, dlogits);
+  else if (elem_size == 8)
     hipLaunchKernelGGL((ce_bwd_kernel<int64_t>), dim3(grid), dim3(256), 0, s, logits,
                        (const int64_t*)target, stats, gscale, P, C, ignore, dlogits);
-  else if (elem_size == 1)
+  else
     hipLaunchKernelGGL((ce_bwd_kernel<uint8_t>), dim3(grid), dim3(256), 0, s, logits,
                        (const uint8_t*)target, stats, gscale, P, C, ignore, dlogits);
-  else
-    return nasseg_fail(NASSEG_ERR_ARG, "ce_bwd: elem_size %d not supported", elem_size);
   NASSEG_LAUNCH_CHECK("ce_bwd");
   return NASSEG_OK;
 }

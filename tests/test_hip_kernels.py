@@ -295,7 +295,7 @@ def test_global_avg_pool_and_broadcast(shape):
              fwd_tol=1e-6, grad_rtol=2e-3)
 
 
-@pytest.mark.parametrize("C", [19, 21, 2, 1])
+@pytest.mark.parametrize("C", [19, 21, 2, 1, 63, 70])  # (C > 63: the kernel without LDS staging)
 @pytest.mark.parametrize("all_ignored", [False, True])
 def test_log_softmax_nll(C, all_ignored):
     B, H, W = 2, 17, 23
