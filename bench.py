@@ -20,6 +20,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver supports dmabuf IPC only: without this RCCL's buffer exchange between the ranks of a
+# node fails (hipIpcGetMemHandle: invalid argument); the image exports it, keep it if launched bare
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -279,7 +282,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(args.backend, rank=rank, world_size=world)  # nccl = RCCL over xGMI
+        # nccl = RCCL over xGMI; binding the group to its device creates the communicator here,
+        # not lazily inside the first collective
+        extra = dict(device_id=device) if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **extra)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     import nas_segm_amd  # noqa: F401
