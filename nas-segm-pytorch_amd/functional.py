@@ -338,6 +338,8 @@ class packed_once(object):
         keys = tuple(k for k in self.memo if k in _PACK_PLANS)
         if keys:
             merged = _PACK_MERGED.get(keys)
+            if merged is not None and any(_PACK_PLANS[k] is not pl for k, pl in zip(keys, merged[4])):
+                merged = None  # (a plan was rebuilt since: its buffer is a new one)
             if merged is None:
                 plans = [_PACK_PLANS[k] for k in keys]
                 n = sum(pl[0] for pl in plans)
@@ -412,7 +414,10 @@ def _pack_many(like, items):
         views = [None if sl is None else buf[sl[0]:sl[0] + sl[1]] for sl in slots]
         if len(_PACK_PLANS) > 4096:  # (parameters of discarded candidates)
             _PACK_PLANS.clear()
+            _PACK_MERGED.clear()
         plan = _PACK_PLANS[key] = (n, src, dst, dims, views, buf)
+        if packed_once.scope is not None:
+            packed_once.scope.done.discard(key)  # (a new buffer: whatever was packed for this key is gone)
     n, src, dst, dims, views, _ = plan
     scope = packed_once.scope
     if scope is not None and key not in scope.noted:

@@ -383,6 +383,25 @@ def test_segmenter_step_equals_a_plain_backward_step():
     finally:
         F.lib.call = call
     assert per_step[0] > 10 and per_step[1] == 1 and per_step[2] == 1, per_step
+    # the plan cache being emptied (it is, when it outgrows 4096 entries) must not leave a step with
+    # weights packed into buffers nobody reads any more
+    ref_net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+    ref_net.load_state_dict(net.state_dict())
+    oe2 = torch.optim.SGD(ref_net.encoder.parameters(), lr=1e-3)
+    od2 = torch.optim.SGD(ref_net.decoder.parameters(), lr=1e-3)
+    F._PACK_PLANS.clear()
+    for x, t in batches:
+        segmenter_step(net, x, t, oe, od, 255, 0.0, 0.0, -1)
+        out = ref_net(x)
+        loss = F.log_softmax_nll(out, F.nearest_label_resize(t, out.shape[2:]), 255)
+        oe2.zero_grad()
+        od2.zero_grad()
+        loss.backward()
+        oe2.step()
+        od2.step()
+    sd_a, sd_b = _cpu_sd(net), _cpu_sd(ref_net)
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
     b = run(True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
