@@ -335,12 +335,15 @@ def main():
             return loss
 
     step = eager_step
-    if args.graph and args.workload == "depth480":
-        raise SystemExit("--graph replays the softmax/NLL step; depth480 runs from the host")
     if args.graph:
         from nas_segm_amd.engine.graphed import GraphedSegmenterStep
-        graphed = GraphedSegmenterStep(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
-                                       capture_optimisers=args.graph == 2)
+        if args.workload == "depth480":
+            graphed = GraphedSegmenterStep(segmenter, image, depth, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
+                                           capture_optimisers=args.graph == 2, loss_fn=NF.berhu_loss)
+            mask = depth
+        else:
+            graphed = GraphedSegmenterStep(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
+                                           capture_optimisers=args.graph == 2)
 
         def step():
             return graphed.step(image, mask)

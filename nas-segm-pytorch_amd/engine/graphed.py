@@ -46,12 +46,16 @@ class GraphedSegmenterStep(object):
 
     def __init__(self, segmenter, image, target, optim_enc, optim_dec, ignore_index=255,
                  enc_grad_clip=0.0, dec_grad_clip=0.0, aux_weight=-1, capture_optimisers=False,
-                 warmup=2):
+                 warmup=2, loss_fn=None):
+        """loss_fn(output, target) -> scalar replaces the softmax/NLL (+ aux heads) of the
+        segmentation step, e.g. ``F.berhu_loss`` for a depth head; it must be capturable (device
+        tensors in, device scalar out, no host synchronisation)."""
         self.segmenter = segmenter
         self.model = _inner(segmenter)
         self.optim_enc, self.optim_dec = optim_enc, optim_dec
         self.ignore_index = ignore_index
         self.aux_weight = aux_weight
+        self.loss_fn = loss_fn
         self.world = int(getattr(segmenter, "world_size", 1))
         self.groups = [
             (list(self.model.encoder.parameters()), enc_grad_clip, optim_enc),
@@ -75,12 +79,15 @@ class GraphedSegmenterStep(object):
             aux_outs = []
             if isinstance(output, tuple):
                 output, aux_outs = output
-            target = F.nearest_label_resize(self.target, output.size()[2:])
-            loss = F.log_softmax_nll(output, target, self.ignore_index)
-            if self.aux_weight > 0:
-                for aux_out in aux_outs:
-                    aux_out = F.bilinear_resize(aux_out, target.size()[1:])
-                    loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
+            if self.loss_fn is not None:
+                loss = self.loss_fn(output, self.target)
+            else:
+                target = F.nearest_label_resize(self.target, output.size()[2:])
+                loss = F.log_softmax_nll(output, target, self.ignore_index)
+                if self.aux_weight > 0:
+                    for aux_out in aux_outs:
+                        aux_out = F.bilinear_resize(aux_out, target.size()[1:])
+                        loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
             with F.deferred_wgrad(params=self._params):  # (gradients were cleared above)
                 loss.backward()
         if with_optimisers:

@@ -298,6 +298,50 @@ def test_graphed_step_equals_eager_step(net_name, capture_opt):
         assert torch.equal(sd0[k], sd1[k]), k
 
 
+def test_graphed_step_with_a_custom_loss_equals_eager():
+    """GraphedSegmenterStep(loss_fn=F.berhu_loss): the depth-head step (BASELINE config 5) replayed from
+    a hipGraph leaves the parameters of the same steps written out eagerly"""
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import _clip_and_step
+
+    rec = load_json("nets_meta.json")["wacv_arch0"]
+    g = torch.Generator().manual_seed(12)
+    xs = [torch.randn(2, 3, 65, 97, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+          for _ in range(3)]
+
+    def run(graphed):
+        net = build_product_net(rec["kind"], rec["genotype"], 1, rec["dec_kwargs"], 0).to(DEV).train()
+        oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9)
+        od = torch.optim.SGD(net.decoder.parameters(), lr=1e-3)
+        with torch.no_grad():
+            shape = net(xs[0]).shape
+        ts = [(torch.rand(shape, generator=g) * 10).to(DEV).contiguous(memory_format=torch.channels_last)
+              for _ in xs]
+        losses = []
+        if graphed:
+            stepper = GraphedSegmenterStep(net, xs[0], ts[0], oe, od, 255, 3.0, 3.0, -1, loss_fn=F.berhu_loss)
+            for x, t in zip(xs, ts):
+                losses.append(float(stepper.step(x, t)))
+        else:
+            for x, t in zip(xs, ts):
+                loss = F.berhu_loss(net(x), t)
+                oe.zero_grad()
+                od.zero_grad()
+                loss.backward()
+                _clip_and_step([(list(net.encoder.parameters()), 3.0, oe), (list(net.decoder.parameters()), 3.0, od)])
+                losses.append(float(loss))
+        return losses, _cpu_sd(net)
+
+    g = torch.Generator().manual_seed(12)
+    l0, sd0 = run(False)
+    g = torch.Generator().manual_seed(12)
+    l1, sd1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+
+
 def test_search_loop_with_real_candidates(tmp_path):
     """outer loop (config 4) on one GPU: genotypes + entropy/log-prob recorded from the reference
     controller feed search_loop; every candidate is built, trained and validated by

@@ -36,6 +36,8 @@ if [[ "$WHAT" == "all" || "$WHAT" == "graph" ]]; then
     timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_${wl}_g0.json 2> $OUT/bench_${wl}_g0.err
     echo "bench $wl exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_g0.json >> $OUT/summary.log
   done
+  timeout 300 python bench.py --workload depth480 --dtype bf16 --graph 2 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_depth480_bf16_g2.json 2> $OUT/bench_depth480_bf16_g2.err
+  echo "bench depth480 bf16 --graph 2 exit $?" >> $OUT/summary.log; cat $OUT/bench_depth480_bf16_g2.json >> $OUT/summary.log
   for wl in headline depth480; do
     timeout 300 python bench.py --workload $wl --dtype bf16 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_${wl}_bf16.json 2> $OUT/bench_${wl}_bf16.err
     echo "bench $wl bf16 exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_bf16.json >> $OUT/summary.log
