@@ -335,15 +335,33 @@ constexpr int kFinMax = 16;
 struct FinTable {
   FinDesc d[kFinMax];
 };
+// elements of a layer one workgroup finalises: with at most 32 slabs (large weights: few, long
+// rows) one thread adds the slabs of one element in order - coalesced rows, and exactly the sum
+// reduce_partials16 forms when every slice holds at most one row; otherwise 8 elements x 32 slices
+__host__ __device__ inline int fin_elems_per_block(int nslab) {
+  return nslab <= NASSEG_RP_SLICES ? 256 : NASSEG_RP_ELEMS;
+}
 __global__ __launch_bounds__(256) void wgrad_finalize_many(FinTable t) {
   __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
   const FinDesc d = t.d[blockIdx.y];
   const int64_t per = (int64_t)d.ntaps * d.N * d.K;
-  if ((int64_t)blockIdx.x * NASSEG_RP_ELEMS >= per) return;  // (uniform over the workgroup)
-  const int64_t i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
-  const bool valid = i < per;
-  const double s = reduce_partials16(d.partial, d.nslab, per, i, valid, red);
-  if (valid && rp_slice() == 0) {
+  const bool direct = d.nslab <= NASSEG_RP_SLICES;
+  if ((int64_t)blockIdx.x * fin_elems_per_block(d.nslab) >= per) return;  // (uniform over the workgroup)
+  int64_t i;
+  bool valid;
+  double s = 0.0;
+  if (direct) {
+    i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    valid = i < per;
+    if (valid)
+      for (int b = 0; b < d.nslab; ++b) s += (double)d.partial[(int64_t)b * per + i];
+  } else {
+    i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
+    valid = i < per;
+    s = reduce_partials16(d.partial, d.nslab, per, i, valid, red);
+    valid = valid && rp_slice() == 0;
+  }
+  if (valid) {
     int n, k, tap;
     if (!d.flat) {
       k = (int)(i % d.K);
@@ -655,11 +673,10 @@ int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* co
       t.d[i].N = d[2];
       t.d[i].K = d[3];
       t.d[i].flat = d[4];
-      const int64_t per = (int64_t)d[1] * d[2] * d[3];
-      if (per > most) most = per;
+      const int64_t blocks = cdiv64((int64_t)d[1] * d[2] * d[3], fin_elems_per_block(d[0]));
+      if (blocks > most) most = blocks;
     }
-    hipLaunchKernelGGL(wgrad_finalize_many, dim3((unsigned)cdiv64(most, NASSEG_RP_ELEMS), n), dim3(256),
-                       0, (hipStream_t)stream, t);
+    hipLaunchKernelGGL(wgrad_finalize_many, dim3((unsigned)most, n), dim3(256), 0, (hipStream_t)stream, t);
     NASSEG_LAUNCH_CHECK("wgrad_finalize_many");
   }
   return NASSEG_OK;
