@@ -449,3 +449,37 @@ def test_segmenter_step_equals_a_plain_backward_step():
     b = run(True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_bench_prints_the_contract_line():
+    """bench.py at a reduced size: ONE JSON line with the driver's fields, the roofline of a kernel
+    family measured live and the CPU baseline beside it"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--batch", "2", "--height", "128", "--width", "256"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["unit"] == "images/sec"
+    assert rec["value"] > 0 and abs(rec["value"] * rec["ms_per_step"] / 1e3 - 2.0) < 1e-6  # batch 2 per step
+    assert rec["higher_is_better"] is True and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+    roof = rec["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["achieved"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cpu = rec["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
