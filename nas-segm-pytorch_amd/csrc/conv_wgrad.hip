@@ -338,15 +338,92 @@ struct FinTable {
 // elements of a layer one workgroup finalises: with at most 32 slabs (large weights: few, long
 // rows) one thread adds the slabs of one element in order - coalesced rows, and exactly the sum
 // reduce_partials16 forms when every slice holds at most one row; otherwise 8 elements x 32 slices
-__host__ __device__ inline int fin_elems_per_block(int nslab) {
-  return nslab <= NASSEG_RP_SLICES ? 256 : NASSEG_RP_ELEMS;
+// ... otherwise 8 threads x 32 slices, a thread taking 4 consecutive elements (one 16-byte load
+// per row; per % 4 == 0) or one.  Every element is summed in the order of reduce_partials16 in
+// all three shapes.
+__host__ __device__ inline int fin_elems_per_block(int nslab, int64_t per) {
+  if (nslab <= NASSEG_RP_SLICES) return 256;
+  return (per & 3) == 0 ? 4 * NASSEG_RP_ELEMS : NASSEG_RP_ELEMS;
+}
+// reduce_partials16 for the 4 consecutive elements e4 .. e4+3 (16-byte aligned rows)
+__device__ __forceinline__ void reduce_partials16x4(const float* __restrict__ partial, int nblk, int64_t per,
+                                                    int64_t e4, bool valid, double (*red)[NASSEG_RP_ELEMS + 1][4],
+                                                    double* tot) {
+  const int slice = rp_slice();
+  const int el = rp_elem();
+  double s[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s[i][r] = 0.0;
+  if (valid) {
+    int b = slice;
+    for (; b + 7 * NASSEG_RP_SLICES < nblk; b += 8 * NASSEG_RP_SLICES) {
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = ld4(partial + (int64_t)(b + i * NASSEG_RP_SLICES) * per + e4);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s[i][0] += (double)v[i].x;
+        s[i][1] += (double)v[i].y;
+        s[i][2] += (double)v[i].z;
+        s[i][3] += (double)v[i].w;
+      }
+    }
+    for (; b < nblk; b += NASSEG_RP_SLICES) {
+      const float4 v = ld4(partial + (int64_t)b * per + e4);
+      s[0][0] += (double)v.x;
+      s[0][1] += (double)v.y;
+      s[0][2] += (double)v.z;
+      s[0][3] += (double)v.w;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    red[slice][el][r] = ((s[0][r] + s[1][r]) + (s[2][r] + s[3][r])) + ((s[4][r] + s[5][r]) + (s[6][r] + s[7][r]));
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tot[r] = 0.0;
+  if (slice == 0) {
+#pragma unroll
+    for (int i = 0; i < NASSEG_RP_SLICES; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[r] += red[i][el][r];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void fin_store(const FinDesc& d, int64_t i, double s) {
+  int n, k, tap;
+  if (!d.flat) {
+    k = (int)(i % d.K);
+    const int64_t q = i / d.K;
+    n = (int)(q % d.N);
+    tap = (int)(q / d.N);
+  } else {
+    const int Kq = d.ntaps * d.K;
+    n = (int)(i / Kq);
+    const int kq = (int)(i - (int64_t)n * Kq);
+    tap = kq / d.K;
+    k = kq - tap * d.K;
+  }
+  d.dw[((int64_t)n * d.K + k) * d.ntaps + tap] = (float)s;
 }
 __global__ __launch_bounds__(256) void wgrad_finalize_many(FinTable t) {
-  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  __shared__ double red4[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1][4];
   const FinDesc d = t.d[blockIdx.y];
   const int64_t per = (int64_t)d.ntaps * d.N * d.K;
   const bool direct = d.nslab <= NASSEG_RP_SLICES;
-  if ((int64_t)blockIdx.x * fin_elems_per_block(d.nslab) >= per) return;  // (uniform over the workgroup)
+  if ((int64_t)blockIdx.x * fin_elems_per_block(d.nslab, per) >= per) return;  // (uniform over the workgroup)
+  if (!direct && (per & 3) == 0) {
+    const int64_t e4 = ((int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem()) * 4;
+    double tot[4];
+    reduce_partials16x4(d.partial, d.nslab, per, e4, e4 < per, red4, tot);
+    if (e4 < per && rp_slice() == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fin_store(d, e4 + r, tot[r]);
+    }
+    return;
+  }
   int64_t i;
   bool valid;
   double s = 0.0;
@@ -356,29 +433,14 @@ __global__ __launch_bounds__(256) void wgrad_finalize_many(FinTable t) {
     if (valid)
       for (int b = 0; b < d.nslab; ++b) s += (double)d.partial[(int64_t)b * per + i];
   } else {
+    double(*red)[NASSEG_RP_ELEMS + 1] = reinterpret_cast<double(*)[NASSEG_RP_ELEMS + 1]>(&red4[0][0][0]);
     i = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
     valid = i < per;
     s = reduce_partials16(d.partial, d.nslab, per, i, valid, red);
     valid = valid && rp_slice() == 0;
   }
-  if (valid) {
-    int n, k, tap;
-    if (!d.flat) {
-      k = (int)(i % d.K);
-      const int64_t q = i / d.K;
-      n = (int)(q % d.N);
-      tap = (int)(q / d.N);
-    } else {
-      const int Kq = d.ntaps * d.K;
-      n = (int)(i / Kq);
-      const int kq = (int)(i - (int64_t)n * Kq);
-      tap = kq / d.K;
-      k = kq - tap * d.K;
-    }
-    d.dw[((int64_t)n * d.K + k) * d.ntaps + tap] = (float)s;
-  }
+  if (valid) fin_store(d, i, s);
 }
-
 struct WgMode {
   bool aln, alk, gather, flat, pro;
 };
@@ -673,7 +735,8 @@ int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* co
       t.d[i].N = d[2];
       t.d[i].K = d[3];
       t.d[i].flat = d[4];
-      const int64_t blocks = cdiv64((int64_t)d[1] * d[2] * d[3], fin_elems_per_block(d[0]));
+      const int64_t per = (int64_t)d[1] * d[2] * d[3];
+      const int64_t blocks = cdiv64(per, fin_elems_per_block(d[0], per));
       if (blocks > most) most = blocks;
     }
     hipLaunchKernelGGL(wgrad_finalize_many, dim3((unsigned)most, n), dim3(256), 0, (hipStream_t)stream, t);

@@ -742,6 +742,39 @@ def test_deferred_weight_gradient_finalisation_is_bit_identical():
         assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
 
 
+@pytest.mark.parametrize("case", [
+    # B, H, W, K, N, k: many slabs with rows of 4-element groups / odd rows / a 3x3; few slabs (large weight)
+    (2, 128, 128, 8, 12, 1), (2, 128, 128, 7, 9, 1), (1, 96, 96, 16, 8, 3), (1, 24, 24, 256, 320, 1)])
+def test_batched_weight_gradient_finalisation_matches_the_immediate_one(case):
+    """nasseg_wgrad_finalize_many sums the slabs in three shapes (one element per thread for <= 32 slabs,
+    32 slices x 4-element groups, 32 slices x single elements): each gives the bits of the immediate
+    finalisation inside nasseg_conv_wgrad"""
+    import ctypes
+
+    f = F()
+    B, H, W, K, N, k = case
+    x = dev(rnd(B, K, H, W, seed=1))
+    dy = dev(rnd(B, N, H, W, seed=2))
+    s = f.current_stream()
+    wsn = f.lib.query("nasseg_conv_wgrad_workspace", B, H, W, N, K, k, k)
+    geom = (B, H, W, K, H, W, N, k, k, 1, k // 2, 1)
+    want = torch.empty(N, K, k, k, device=DEV)
+    f.lib.call("nasseg_conv_wgrad", f.ptr(x), K, f.ptr(dy), N, f.ptr(want), f.ptr(torch.empty(wsn, device=DEV)),
+               None, None, 0, *geom, s)
+    ws = torch.empty(wsn, device=DEV)
+    f.lib.call("nasseg_conv_wgrad", f.ptr(x), K, f.ptr(dy), N, None, f.ptr(ws), None, None, 0, *geom, s)
+    got = torch.full((N, K, k, k), float("nan"), device=DEV)
+    nslab = wsn // (k * k * N * K)
+    flat = int(f.lib.query("nasseg_conv_fwd_pack_mode", K, k, k) == 2)
+    parts = (ctypes.c_void_p * 1)(f.ptr(ws))
+    outs = (ctypes.c_void_p * 1)(f.ptr(got))
+    dims = (ctypes.c_int * 5)(nslab, k * k, N, K, flat)
+    f.lib.call("nasseg_wgrad_finalize_many", 1, parts, outs, dims, s)
+    assert torch.equal(got, want), (nslab, float((got - want).abs().max()))
+    ref = torch.nn.grad.conv2d_weight(x.cpu().contiguous(), (N, K, k, k), dy.cpu().contiguous(), padding=k // 2)
+    assert_close(got, ref, 2e-4 * float(ref.abs().max()), 1e-4, "dw")
+
+
 def test_grouped_depthwise_weight_gradients_are_bit_identical():
     """inside deferred_wgrad the first stages of small depthwise layers run side by side
     (nasseg_dwconv_wgrad_many: grouped by kernel size / stride class / prologue, > 8 of a kind =>
