@@ -1,2 +1,2 @@
 """NAS inner loop: candidate training steps and validation (mirrors src/engine)."""
-from .segmenter import RankParallel, Segmenter  # noqa: F401
+from .segmenter import PeerFailure, RankParallel, Segmenter  # noqa: F401

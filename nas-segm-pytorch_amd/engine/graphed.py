@@ -67,8 +67,21 @@ class GraphedSegmenterStep(object):
         self.target = target.detach().clone()
         self.flat = self._views = self._used = None
         self._params = list(self.model.parameters())
-        self._pack_memo = []
-        self._capture(warmup)
+        self._pack_memo = F.PackMemo()  # (owns the packed-weight buffers the graph reads)
+        # A capture that fails on ONE rank (HIP out of memory, say) must fail on all of them: the
+        # others would otherwise wait for it in the first gradient all-reduce.
+        error = None
+        try:
+            self._capture(warmup)
+        except RuntimeError as e:
+            error = e
+        if self.world > 1:
+            flag = torch.tensor([1.0 if error is not None else 0.0], device=self.image.device)
+            dist.all_reduce(flag, group=getattr(segmenter, "process_group", None))
+            if error is None and float(flag) > 0:
+                error = RuntimeError("GraphedSegmenterStep: the capture failed on a peer rank")
+        if error is not None:
+            raise error
 
     # -- the captured region ---------------------------------------------------------
     def _fwd_bwd(self, with_optimisers):

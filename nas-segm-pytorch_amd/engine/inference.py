@@ -50,19 +50,26 @@ def validate(segmenter, val_loader, epoch, epoch2, num_classes=-1, print_every=1
     model = segmenter.module if hasattr(segmenter, "module") else segmenter
     device = next(model.parameters()).device
     cm = torch.zeros((num_classes, num_classes), device=device, dtype=torch.int64)
-    with torch.no_grad():
-        for i, sample in enumerate(val_loader):
-            image = sample["image"].to(device=device, dtype=torch.float32).contiguous(
-                memory_format=torch.channels_last)
-            gt = sample["mask"].to(device).to(torch.uint8)  # astype(np.uint8) in the reference
-            output = segmenter(image)
-            if isinstance(output, tuple):
-                output, _ = output
-            F.argmax_confusion(output, gt, num_classes, cm=cm)
-            if i % print_every == 0:
-                logger.info(" Val epoch: {} [{}/{}]\tMean IoU: {:.3f}".format(
-                    epoch, i, len(val_loader),
-                    np.mean([iu for iu in compute_iu(cm) if iu <= 1.0])))
+    try:
+        with torch.no_grad():
+            for i, sample in enumerate(val_loader):
+                image = sample["image"].to(device=device, dtype=torch.float32).contiguous(
+                    memory_format=torch.channels_last)
+                gt = sample["mask"].to(device).to(torch.uint8)  # astype(np.uint8) in the reference
+                output = segmenter(image)
+                if isinstance(output, tuple):
+                    output, _ = output
+                F.argmax_confusion(output, gt, num_classes, cm=cm)
+                if i % print_every == 0:
+                    logger.info(" Val epoch: {} [{}/{}]\tMean IoU: {:.3f}".format(
+                        epoch, i, len(val_loader),
+                        np.mean([iu for iu in compute_iu(cm) if iu <= 1.0])))
+    except RuntimeError:
+        # data parallel: the peers will wait in the confusion-matrix all-reduce - take part in
+        # it with the failure flag set so that every rank scores this candidate 0
+        if hasattr(segmenter, "reduce_confusion"):
+            segmenter.reduce_confusion(cm, failed=True)
+        raise
     if hasattr(segmenter, "reduce_confusion"):
         segmenter.reduce_confusion(cm)
     cm_host = cm.cpu().numpy()

@@ -17,6 +17,13 @@ class Segmenter(nn.Module):
         return self.decoder(self.encoder(x))
 
 
+class PeerFailure(RuntimeError):
+    """A data-parallel peer reported a failure in the step just synchronised (see
+    RankParallel.sync_gradients): every rank raises this at the same point of its own step
+    sequence, so that the engine's ``try_except`` convention - a RuntimeError scores the candidate
+    0 - abandons the candidate on ALL ranks together and the collectives stay paired."""
+
+
 class RankParallel(nn.Module):
     """Data parallelism with one process per GPU over RCCL.
 
@@ -29,6 +36,17 @@ class RankParallel(nn.Module):
     BatchNorm statistics stay per rank, as under nn.DataParallel; parameters and
     buffers are broadcast from rank 0 when a candidate is (re)built.
     Works un-initialised too (world size 1): every collective becomes a no-op.
+
+    Failure protocol.  The reference runs in ONE process, where "RuntimeError => candidate
+    scored 0" (helpers/utils.py:172-187) needs no coordination.  With one process per GPU a
+    rank that leaves its step loop alone would leave its peers blocked in the next all-reduce.
+    The bucket therefore has a fixed layout (every trainable parameter, whether or not the
+    loss of the current stage reaches it - so a rank can take part in the collective without
+    having run backward) plus ONE status element: a rank whose forward/backward raised calls
+    ``sync_gradients(failed=True)`` - zeros and status 1 - and re-raises; its peers find a
+    non-zero status next to their loss value (``check_peers``, no extra collective and no
+    extra host synchronisation) and raise ``PeerFailure``.  The same slot rides on the
+    confusion-matrix all-reduce of validation.
     """
 
     def __init__(self, module, process_group=None, broadcast=True):
@@ -37,8 +55,8 @@ class RankParallel(nn.Module):
         self.process_group = process_group
         self._flat = None
         self._views = None
-        self._used = None
         self._plist = None
+        self._status = None
         if broadcast:
             self.broadcast_parameters()
 
@@ -59,21 +77,26 @@ class RankParallel(nn.Module):
                 dist.broadcast(t.data, src, group=self.process_group)
 
     def _parameters_once(self):
-        # a candidate's module tree is fixed: walk it once, not twice per step
-        if self._plist is None:
-            self._plist = list(self.module.parameters())
-        return self._plist
+        # a candidate's module tree is fixed: walk it once, not twice per step (the version
+        # counter is bumped by the one API that swaps modules, TemplateDecoder._reset_clf)
+        from ..nn.modules import TREE_VERSION
 
-    def _build_bucket(self, used):
-        total = sum(p.numel() for p in used)
-        ref = used[0]
-        self._flat = torch.zeros(total, device=ref.device, dtype=ref.dtype)
-        self._used = used
+        if self._plist is None or self._plist[0] != TREE_VERSION[0]:
+            self._plist = (TREE_VERSION[0], [p for p in self.module.parameters() if p.requires_grad])
+            self._flat = None
+        return self._plist[1]
+
+    def _build_bucket(self):
+        params = self._parameters_once()
+        total = sum(p.numel() for p in params)
+        ref = params[0]
+        self._flat = torch.zeros(total + 1, device=ref.device, dtype=torch.float32)
         self._views = []
         off = 0
-        for p in used:
+        for p in params:
             self._views.append(self._flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._status = self._flat[total:total + 1]
 
     def attach_flat_grads(self):
         """Call instead of ``optimizer.zero_grad()``: clears every gradient so that autograd
@@ -85,36 +108,68 @@ class RankParallel(nn.Module):
             p.grad = None
         return None
 
-    def sync_gradients(self):
+    def sync_gradients(self, failed=False):
         """Average the gradients over the ranks with ONE collective: the fresh gradients are
-        packed into a flat fp32 bucket by one multi-tensor copy, the bucket is all-reduced and
-        every reached ``param.grad`` is re-pointed at its slice of it."""
+        packed into the flat fp32 bucket by one multi-tensor copy, the bucket is all-reduced and
+        every reached ``param.grad`` is re-pointed at its slice of it.  ``failed``: this rank's
+        forward/backward raised - it contributes zeros and sets the status element, so that the
+        peers' collective completes and they learn about it (``check_peers``)."""
         ws = self.world_size
         if ws == 1:
             return
-        # the parameters this backward reached: static per architecture and training stage
-        # (decoder only on cached features, everything end to end), hence identical on every
-        # rank; the bucket is rebuilt when the stage changes
-        have = [p for p in self._parameters_once() if p.requires_grad and p.grad is not None]
-        if (self._flat is None or len(have) != len(self._used)
-                or any(a is not b for a, b in zip(have, self._used))):
-            if not have:
-                return
-            self._build_bucket(have)
-        src, dst = [], []
-        for p, v in zip(self._used, self._views):
+        params = self._parameters_once()
+        if self._flat is None:
+            self._build_bucket()
+        if failed:
+            self._flat.zero_()
+            self._status.fill_(1.0)
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.process_group)
+            return
+        src, dst, reached = [], [], []
+        for p, v in zip(params, self._views):
+            if p.grad is None:
+                continue  # (its slice is never written: stays zero on every rank)
+            reached.append((p, v))
             if p.grad.data_ptr() != v.data_ptr():
                 src.append(p.grad)
                 dst.append(v)
         if dst:
             torch._foreach_copy_(dst, src)
+        self._status.zero_()
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.process_group)
         self._flat.div_(ws)
-        for p, v in zip(self._used, self._views):
+        for p, v in reached:
             p.grad = v
 
-    def reduce_confusion(self, cm):
-        """Sum the int64 confusion matrix over ranks at the end of validation."""
+    def step_values(self, loss):
+        """(loss value, peers ok) with ONE device-to-host copy - the host synchronisation the
+        reference's ``loss.item()`` makes every step anyway."""
+        if self.world_size == 1 or self._status is None:
+            return float(loss), True
+        both = torch.stack([loss.detach().reshape(()).float(), self._status[0]]).tolist()
+        return both[0], both[1] == 0.0
+
+    def check_peers(self, loss):
+        """float(loss); raises PeerFailure (on every healthy rank alike) when a peer failed in
+        the step whose gradients were just synchronised"""
+        value, ok = self.step_values(loss)
+        if not ok:
+            raise PeerFailure("a data-parallel peer failed in this step: candidate abandoned on all ranks")
+        return value
+
+    def reduce_confusion(self, cm, failed=False):
+        """Sum the int64 confusion matrix over ranks at the end of validation; one extra element
+        carries the failure status (see the class docstring)."""
         if self.world_size > 1:
-            dist.all_reduce(cm, op=dist.ReduceOp.SUM, group=self.process_group)
+            buf = torch.zeros(cm.numel() + 1, device=cm.device, dtype=torch.int64)
+            if failed:
+                buf[-1] = 1
+            else:
+                buf[:-1].copy_(cm.reshape(-1))
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.process_group)
+            if failed:
+                return cm
+            if int(buf[-1]) != 0:
+                raise PeerFailure("a data-parallel peer failed during validation: candidate abandoned")
+            cm.copy_(buf[:-1].view_as(cm))
         return cm

@@ -19,6 +19,7 @@ from torch import nn
 
 from .. import functional as F
 from ..helpers.utils import AverageMeter, try_except
+from ..nn.modules import TREE_VERSION
 
 logger = logging.getLogger(__name__)
 
@@ -84,12 +85,26 @@ def _clip_and_step(groups):
 
 
 def _zero_grads(segmenter, optimisers):
+    """every ``param.grad`` back to None (not zeros): deferred_wgrad relies on autograd ADOPTING
+    the fresh gradient tensors of backward"""
     if hasattr(segmenter, "attach_flat_grads") and getattr(segmenter, "world_size", 1) > 1:
         segmenter.attach_flat_grads()
     else:
         for o in optimisers:
             if o is not None:
-                o.zero_grad()
+                o.zero_grad(set_to_none=True)
+
+
+def _distributed(segmenter):
+    return getattr(segmenter, "world_size", 1) > 1
+
+
+def _loss_value(segmenter, loss):
+    """the per-step host synchronisation (``loss.item()`` in the reference); data parallel, the
+    same copy brings the peers' status: PeerFailure if one of them failed in this step"""
+    if _distributed(segmenter):
+        return segmenter.check_peers(loss)
+    return loss.item()
 
 
 @try_except
@@ -144,7 +159,7 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
     ignore = _ignore_index(segm_crit)
     np.random.shuffle(indices)
     dec_params = list(decoder.parameters())
-    pack_memo = []
+    pack_memo = F.PackMemo()
     feat_keys = [k for k in Xy_train.keys() if k not in ("y", "kd_y", "out_size")]
     out_size = tuple(Xy_train["out_size"])
     for i in range(n_passes):
@@ -153,28 +168,33 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
                               device=Xy_train["y"].device)
         feats = [Xy_train[k][idx] for k in feat_keys]
         target = Xy_train["y"][idx]
-        with F.packed_once(pack_memo):  # (one weight re-pack launch per step)
-            output = decoder(feats)
-            aux_outs = []
-            if isinstance(output, tuple):
-                output, aux_outs = output
-            output = F.bilinear_resize(output, out_size)
-            loss = F.log_softmax_nll(output, target, ignore)
-            if do_kd:
-                loss = loss + kd_coeff * kd_crit(output, Xy_train["kd_y"][idx])
-            if aux_weight > 0:
-                for aux_out in aux_outs:
-                    aux_out = F.bilinear_resize(aux_out, out_size)
-                    loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
-            optim_dec.zero_grad()
-            with F.deferred_wgrad(params=dec_params):
-                loss.backward()
-        if getattr(segmenter, "world_size", 1) > 1:
+        try:
+            with F.packed_once(pack_memo):  # (one weight re-pack launch per step)
+                output = decoder(feats)
+                aux_outs = []
+                if isinstance(output, tuple):
+                    output, aux_outs = output
+                output = F.bilinear_resize(output, out_size)
+                loss = F.log_softmax_nll(output, target, ignore)
+                if do_kd:
+                    loss = loss + kd_coeff * kd_crit(output, Xy_train["kd_y"][idx])
+                if aux_weight > 0:
+                    for aux_out in aux_outs:
+                        aux_out = F.bilinear_resize(aux_out, out_size)
+                        loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
+                _zero_grads(segmenter, (optim_dec,))
+                with F.deferred_wgrad(params=dec_params):
+                    loss.backward()
+        except RuntimeError:
+            if _distributed(segmenter):
+                segmenter.sync_gradients(failed=True)  # (the peers are waiting in this collective)
+            raise
+        if _distributed(segmenter):
             # the feature cache is sharded: every rank steps on its own cached samples and the
             # decoder gradients are averaged (the reference runs this stage on one GPU)
             segmenter.sync_gradients()
-        _clip_and_step([(list(decoder.parameters()), dec_grad_clip, optim_dec)])
-        losses.update(loss.item())
+        _clip_and_step([(dec_params, dec_grad_clip, optim_dec)])
+        losses.update(_loss_value(segmenter, loss))
         batch_time.update(time.time() - start)
         if do_polyak:
             _polyak_update(decoder.parameters(), avg_param, polyak_decay)
@@ -191,33 +211,49 @@ def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=
     -> per-sub-module norm clipping -> optimiser steps.
     """
     model = _inner(segmenter)
-    groups = getattr(model, "_nasseg_step_params", None)
-    if groups is None:  # (a candidate's module tree is fixed: walk it once, not every step)
-        groups = (list(model.encoder.parameters()), list(model.decoder.parameters()))
-        model._nasseg_step_params = groups
-        model._nasseg_pack_memo = []
+    cached = getattr(model, "_nasseg_step_params", None)
+    if cached is None or cached[0] != TREE_VERSION[0]:
+        # a candidate's module tree is fixed: walk it once, not every step (and again when a
+        # sub-module was swapped - TemplateDecoder._reset_clf bumps the version)
+        cached = (TREE_VERSION[0], (list(model.encoder.parameters()), list(model.decoder.parameters())))
+        model._nasseg_step_params = cached
+        model._nasseg_pack_memo = F.PackMemo()
+    groups = cached[1]
     # the parameters are constant until the optimiser steps below: all chains' weights are
     # re-packed by one launch at the start of the step
-    with F.packed_once(model._nasseg_pack_memo):
-        output = segmenter(image)
-        aux_outs = []
-        if isinstance(output, tuple):
-            output, aux_outs = output
-        target = F.nearest_label_resize(target, output.size()[2:])
-        loss = F.log_softmax_nll(output, target, ignore_index)
-        if aux_weight > 0:
-            for aux_out in aux_outs:
-                aux_out = F.bilinear_resize(aux_out, target.size()[1:])
-                loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
-        _zero_grads(segmenter, (optim_enc, optim_dec))
-        # gradients were just cleared: the second stages of all weight-gradient reductions run
-        # batched when backward is through
-        with F.deferred_wgrad(params=groups[0] + groups[1]):
-            loss.backward()
+    try:
+        with F.packed_once(model._nasseg_pack_memo):
+            output = segmenter(image)
+            aux_outs = []
+            if isinstance(output, tuple):
+                output, aux_outs = output
+            target = F.nearest_label_resize(target, output.size()[2:])
+            loss = F.log_softmax_nll(output, target, ignore_index)
+            if aux_weight > 0:
+                for aux_out in aux_outs:
+                    aux_out = F.bilinear_resize(aux_out, target.size()[1:])
+                    loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
+            _zero_grads(segmenter, (optim_enc, optim_dec))
+            # gradients were just cleared: the second stages of all weight-gradient reductions run
+            # batched when backward is through
+            with F.deferred_wgrad(params=groups[0] + groups[1]):
+                loss.backward()
+    except RuntimeError:
+        if _distributed(segmenter):
+            segmenter.sync_gradients(failed=True)  # (the peers are waiting in this collective)
+        raise
+    finish_step(segmenter, groups, optim_enc, optim_dec, enc_grad_clip, dec_grad_clip)
+    return loss
+
+
+def finish_step(segmenter, groups, optim_enc, optim_dec, enc_grad_clip, dec_grad_clip):
+    """What follows backward in a training step (src/engine/trainer.py:255-268): average the
+    gradients over the data-parallel ranks (one RCCL all-reduce; the reference's DataParallel
+    sums replica gradients on GPU 0), clip the encoder's and the decoder's gradient norms
+    separately, step both optimisers.  groups = (encoder parameters, decoder parameters)."""
     if hasattr(segmenter, "sync_gradients"):
         segmenter.sync_gradients()
     _clip_and_step([(groups[0], enc_grad_clip, optim_enc), (groups[1], dec_grad_clip, optim_dec)])
-    return loss
 
 
 @try_except
@@ -240,7 +276,7 @@ def train_segmenter(segmenter, train_loader, optim_enc, optim_dec, epoch, segm_c
                               enc_grad_clip, dec_grad_clip, aux_weight)
         if do_polyak:
             _polyak_update(segmenter.parameters(), avg_param, polyak_decay)
-        losses.update(loss.item())
+        losses.update(_loss_value(segmenter, loss))
         batch_time.update(time.time() - start)
         if i % print_every == 0:
             logger.info(" Train epoch: {} [{}/{}]\tAvg. Loss: {:.3f}\tAvg. Time: {:.3f}".format(

@@ -8,6 +8,7 @@ no ATen compute op runs on the hot path.  Tensors keep the reference's NCHW
 kernels address directly.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -312,7 +313,33 @@ def _pack_dense(w, mode):
 
 
 _PACK_PLANS = {}
-_PACK_MERGED = {}
+_PACK_SWEEP_AT = 1024  # plans; above it the entries of dead parameters are dropped
+
+
+class _PackPlan(object):
+    """Launch descriptor + destination buffer of one set of weights (see _pack_many).  `refs` are
+    weak references to the source tensors: a plan whose parameters are gone is never served again
+    (a new tensor may live at the same address) and is dropped at the next sweep."""
+    __slots__ = ("n", "src", "dst", "dims", "views", "buf", "refs")
+
+    def alive(self):
+        return all(r() is not None for r in self.refs)
+
+
+class PackMemo(list):
+    """What ``packed_once`` remembers between the steps of ONE model / graphed stepper: the
+    (key, plan) pairs of the chains seen last time - strong references, so the packed-weight
+    buffers a captured hipGraph has baked in stay allocated for as long as their owner lives,
+    whatever happens to the global cache - and the merged launch table built from them."""
+
+    def __init__(self, *a):
+        super(PackMemo, self).__init__(*a)
+        self.merged = None
+
+
+def _sweep_pack_plans():
+    for k in [k for k, pl in _PACK_PLANS.items() if not pl.alive()]:
+        del _PACK_PLANS[k]
 
 
 class packed_once(object):
@@ -321,9 +348,9 @@ class packed_once(object):
     Every conv chain re-packs its weights into the kernels' layouts with one small launch per
     chain and step (~50 launches on the headline network, each on the dependency path).  Within
     ONE step the parameters do not change, so inside this context the packs of all chains seen
-    the last time ``memo`` (a list the caller keeps with the model) went through it are issued
-    together at entry - nasseg_pack_weights takes any number of tensors - and the chains find
-    their packed weights ready.  Chains met for the first time pack themselves as usual and
+    the last time ``memo`` (a ``PackMemo`` the caller keeps with the model) went through it are
+    issued together at entry - nasseg_pack_weights takes any number of tensors - and the chains
+    find their packed weights ready.  Chains met for the first time pack themselves as usual and
     are remembered in ``memo`` for the next entry.  Same kernel, same bytes: identical results.
     The context must not span a parameter update."""
 
@@ -335,29 +362,32 @@ class packed_once(object):
     def __enter__(self):
         self.prev, packed_once.scope = packed_once.scope, self
         self.done, self.seen, self.noted = set(), [], set()
-        keys = tuple(k for k in self.memo if k in _PACK_PLANS)
-        if keys:
-            merged = _PACK_MERGED.get(keys)
-            if merged is not None and any(_PACK_PLANS[k] is not pl for k, pl in zip(keys, merged[4])):
-                merged = None  # (a plan was rebuilt since: its buffer is a new one)
+        # only plans that still are the current ones of their keys (a plan rebuilt since has a
+        # new buffer: whoever asks for that key will read the new one)
+        entries = [(k, pl) for k, pl in self.memo if _PACK_PLANS.get(k) is pl]
+        if entries:
+            merged = getattr(self.memo, "merged", None)
+            if merged is not None and (len(merged[4]) != len(entries)
+                                       or any(a is not b[1] for a, b in zip(merged[4], entries))):
+                merged = None
             if merged is None:
-                plans = [_PACK_PLANS[k] for k in keys]
-                n = sum(pl[0] for pl in plans)
+                plans = [pl for _, pl in entries]
+                n = sum(pl.n for pl in plans)
                 src = (ctypes.c_void_p * max(n, 1))()
                 dst = (ctypes.c_void_p * max(n, 1))()
                 dims = (ctypes.c_int * (7 * max(n, 1)))()
                 j = 0
-                for cnt, psrc, pdst, pdims, _, _ in plans:
-                    for i in range(cnt):
-                        src[j], dst[j] = psrc[i], pdst[i]
-                        dims[7 * j:7 * j + 7] = pdims[7 * i:7 * i + 7]
+                for pl in plans:
+                    for i in range(pl.n):
+                        src[j], dst[j] = pl.src[i], pl.dst[i]
+                        dims[7 * j:7 * j + 7] = pl.dims[7 * i:7 * i + 7]
                         j += 1
-                if len(_PACK_MERGED) > 64:
-                    _PACK_MERGED.clear()
-                merged = _PACK_MERGED[keys] = (n, src, dst, dims, plans)  # (plans: keeps the buffers alive)
+                merged = (n, src, dst, dims, plans)
+                if isinstance(self.memo, PackMemo):
+                    self.memo.merged = merged
             if merged[0]:
                 lib.call("nasseg_pack_weights", merged[0], merged[1], merged[2], merged[3], current_stream())
-            self.done.update(keys)
+            self.done.update(k for k, _ in entries)
         return self
 
     def __exit__(self, exc_type, exc, tb):
@@ -375,12 +405,15 @@ def _pack_many(like, items):
     its layout already is the packed one).
 
     The launch descriptor (pointer / shape tables) and the destination buffer of a given set of
-    weights are built once and kept: a chain packs the same parameters every step, and building
-    the ctypes tables cost more host time than the launch.  The buffer is rewritten by every
-    call; a forward's packed weights stay valid until the parameters change, i.e. for its own
-    backward."""
+    weights are built once and kept (_PackPlan): a chain packs the same parameters every step,
+    and building the ctypes tables cost more host time than the launch.  The buffer is rewritten
+    by every call; a forward's packed weights stay valid until the parameters change, i.e. for
+    its own backward.  Plans are dropped only when their parameters are gone (never wholesale: a
+    captured hipGraph holds their buffers' addresses - and, through its PackMemo, the plans)."""
     key = (like.device,) + tuple((it[0].data_ptr(), tuple(it[0].shape)) + tuple(it[1:]) for it in items)
     plan = _PACK_PLANS.get(key)
+    if plan is not None and not plan.alive():
+        plan = None  # (same addresses, other tensors: the old owner may still replay the old buffer)
     if plan is None:
         slots, descs, off = [], [], 0
         for item in items:
@@ -404,30 +437,31 @@ def _pack_many(like, items):
             descs.append((w, d, off, numel))
             off += (numel + 3) // 4 * 4  # keep every packed tensor 16-byte aligned
         n = len(descs)
-        buf = _vec(like, off) if n else None
-        src = (ctypes.c_void_p * max(n, 1))(*[ptr(w) for w, _, _, _ in descs])
-        dst = (ctypes.c_void_p * max(n, 1))()
-        dims = (ctypes.c_int * (7 * max(n, 1)))()
+        plan = _PackPlan()
+        plan.n = n
+        plan.buf = _vec(like, off) if n else None
+        plan.src = (ctypes.c_void_p * max(n, 1))(*[ptr(w) for w, _, _, _ in descs])
+        plan.dst = (ctypes.c_void_p * max(n, 1))()
+        plan.dims = (ctypes.c_int * (7 * max(n, 1)))()
         for j, (w, d, o, numel) in enumerate(descs):
-            dst[j] = ptr(buf[o:o + numel])
-            dims[7 * j:7 * j + 7] = d
-        views = [None if sl is None else buf[sl[0]:sl[0] + sl[1]] for sl in slots]
-        if len(_PACK_PLANS) > 4096:  # (parameters of discarded candidates)
-            _PACK_PLANS.clear()
-            _PACK_MERGED.clear()
-        plan = _PACK_PLANS[key] = (n, src, dst, dims, views, buf)
+            plan.dst[j] = ptr(plan.buf[o:o + numel])
+            plan.dims[7 * j:7 * j + 7] = d
+        plan.views = [None if sl is None else plan.buf[sl[0]:sl[0] + sl[1]] for sl in slots]
+        plan.refs = [weakref.ref(it[0]) for it in items]
+        if len(_PACK_PLANS) >= _PACK_SWEEP_AT:  # (parameters of discarded candidates)
+            _sweep_pack_plans()
+        _PACK_PLANS[key] = plan
         if packed_once.scope is not None:
             packed_once.scope.done.discard(key)  # (a new buffer: whatever was packed for this key is gone)
-    n, src, dst, dims, views, _ = plan
     scope = packed_once.scope
     if scope is not None and key not in scope.noted:
         scope.noted.add(key)
-        scope.seen.append(key)
-    if n and (scope is None or key not in scope.done):
-        lib.call("nasseg_pack_weights", n, src, dst, dims, current_stream())
+        scope.seen.append((key, plan))
+    if plan.n and (scope is None or key not in scope.done):
+        lib.call("nasseg_pack_weights", plan.n, plan.src, plan.dst, plan.dims, current_stream())
         if scope is not None:
             scope.done.add(key)  # (a weight used twice in the step is packed once)
-    return [item[0] if v is None else v for item, v in zip(items, views)]
+    return [item[0] if v is None else v for item, v in zip(items, plan.views)]
 
 
 def _dgrad_form(kh, kw, stride, pad, dil):
@@ -1250,11 +1284,33 @@ def channel_repeat(x, rep):
 
 
 def zeros(like, B, C, H, W):
-    """A zero activation that is not connected to the autograd graph (Zero op)."""
+    """A zero activation that is not connected to the autograd graph."""
     require_device(like)
     y = _new(like, B, C, H, W)
     lib.call(_k("nasseg_fill", y), ptr(y), y.numel(), 0.0, current_stream())
     return y
+
+
+class _ZeroOf(torch.autograd.Function):
+    """The reference's Zero op multiplies a view of x by 0.0 (src/nn/layer_factory.py:286-297):
+    its output is zeros but stays CONNECTED to x, so everything upstream receives a zero
+    gradient (not None: weight decay and momentum still act on those parameters, and a cell of
+    'none' ops only still back-propagates)."""
+
+    @staticmethod
+    def forward(ctx, x, C, H, W):
+        ctx.shape = tuple(x.shape)
+        return zeros(x, x.shape[0], C, H, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        return zeros(dy, B, C, H, W), None, None, None
+
+
+def zero_of(x, C, H, W):
+    """zeros of shape (B, C, H, W) that depend on x with a zero gradient (Zero op)."""
+    return _ZeroOf.apply(_cl(x), int(C), int(H), int(W))
 
 
 # ---------------------------------------------------------------------------

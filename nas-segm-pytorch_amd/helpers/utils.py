@@ -1,4 +1,7 @@
 """The error convention of the engine entry points (src/helpers/utils.py:172-187)."""
+import logging
+
+logger = logging.getLogger(__name__)
 
 
 def try_except(func):
@@ -9,7 +12,10 @@ def try_except(func):
     def wrapper_func(*args, **kwargs):
         try:
             return func(*args, **kwargs)
-        except RuntimeError:
+        except RuntimeError as e:
+            # (the reference swallows it silently; a candidate that scores 0 because of a bug on
+            #  this side of the boundary should at least leave a trace)
+            logger.warning(" %s failed, candidate scored 0: %s", getattr(func, "__name__", "call"), e)
             return 0
 
     wrapper_func.__wrapped__ = func

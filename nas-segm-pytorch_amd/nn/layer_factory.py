@@ -200,7 +200,7 @@ class Zero(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         s = self.stride
-        return F.zeros(x, B, C * self.repeats[1], (H + s - 1) // s, (W + s - 1) // s)
+        return F.zero_of(x, C * self.repeats[1], (H + s - 1) // s, (W + s - 1) // s)
 
 
 class FactorizedReduce(nn.Module):

@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import functional as F
 from ..rl.genotypes import AGG_OP_NAMES, OP_NAMES, OP_NAMES_WACV
 from .layer_factory import AGG_OPS, OPS, conv3x3, conv_bn_relu
-from .modules import FusedSequential
+from .modules import TREE_VERSION, FusedSequential
 
 
 def _hw(t):
@@ -310,6 +310,7 @@ class TemplateDecoder(nn.Module):
             del self.conv_clf
             self.conv_clf = conv3x3(self.agg_size, num_classes, stride=1, bias=True).to(device)
             self.num_classes = num_classes
+            TREE_VERSION[0] += 1  # (cached parameter lists of the engine are stale now)
 
     def prettify(self, n_params):
         return _param_header(n_params) + "\n\n#Connections:\n" + self.info

@@ -12,9 +12,28 @@ import torch.nn as nn
 from .. import functional as F
 from .._lib import NassegError
 
+# bumped by whatever swaps sub-modules of a built network (TemplateDecoder._reset_clf): the
+# engine caches a candidate's parameter lists and re-walks the tree when this changes
+TREE_VERSION = [0]
+
+
+def _require_width(channels, what):
+    """The kernels move four channels (one float4) per lane: every feature-map width on the path
+    must be a multiple of 4 (the image's 3 and the class logits are the exceptions the dense conv
+    handles).  The reference accepts any width; refusing at CONSTRUCTION with a ValueError - which
+    the engine's try_except does not swallow - beats every candidate silently scoring 0."""
+    if channels % 4 != 0:
+        raise ValueError("nasseg: {} = {} is not a multiple of 4 (choose agg_size / width_mult "
+                         "accordingly; see INTEGRATION.md)".format(what, channels))
+
 
 class Conv2d(nn.Conv2d):
     """nn.Conv2d: dense (groups=1) on the fp32 MFMA path, or depthwise (groups=C)."""
+
+    def __init__(self, *args, **kwargs):
+        super(Conv2d, self).__init__(*args, **kwargs)
+        if self.groups > 1 and self.groups == self.in_channels == self.out_channels:
+            _require_width(self.in_channels, "depthwise conv channels")
 
     def _check(self):
         k, s, p, d = self.kernel_size, self.stride, self.padding, self.dilation
@@ -43,6 +62,10 @@ class Conv2d(nn.Conv2d):
 
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d with an optional fused activation / residual add."""
+
+    def __init__(self, num_features, *args, **kwargs):
+        super(BatchNorm2d, self).__init__(num_features, *args, **kwargs)
+        _require_width(num_features, "BatchNorm2d features")
 
     def forward(self, x, act=F.ACT_NONE, residual=None):
         if self.momentum is None:

@@ -203,14 +203,15 @@ def build_ref_net(kind, genotype, classes, dec_kwargs, seed):
     from nn.micro_decoders import MicroDecoder, TemplateDecoder
 
     torch.manual_seed(seed)
+    config = GENOTYPES[genotype] if isinstance(genotype, str) else genotype
     if kind == "template":
         enc = mbv2(pretrained=False, return_layers=[1, 2])
-        dec = TemplateDecoder(inp_sizes=enc.out_sizes, num_classes=classes, config=GENOTYPES[genotype],
+        dec = TemplateDecoder(inp_sizes=enc.out_sizes, num_classes=classes, config=config,
                               **dec_kwargs)
     else:
         enc = mbv2(pretrained=False)
         dec = MicroDecoder(inp_sizes=list(enc.out_sizes), num_classes=classes,
-                           config=GENOTYPES[genotype], **dec_kwargs)
+                           config=config, **dec_kwargs)
 
     class EncoderDecoder(nn.Module):
         def __init__(self, encoder, decoder):
@@ -231,9 +232,41 @@ def make_labels(gen, B, H, W, classes):
 
 
 def gen_nets():
+    _gen_nets(NETS, "nets.npz", "nets_meta.json")
+
+
+def sampled_nets():
+    """BASELINE config 4: genotypes the reference controller sampled (controller.json, written by
+    gen_controller under torch.manual_seed(9314)) built with the search-time defaults
+    (src/utils/default_args.py:77-79: agg_size 48, sep_repeats 1, aux_cell) - plus the training
+    record of the depth network (config 5; one output channel, so no segmentation loss: the
+    gradients are taken under a fixed seeded cotangent instead)."""
+    ctrl = json.load(open(os.path.join(OUT, "controller.json")))
+    wacv = [s["config"] for s in ctrl["wacv"]["samples"]]
+    cvpr = [s["config"] for s in ctrl["cvpr"]["samples"]]
+    return [
+        ("wacv_sampled0", "template", wacv[0], 19, dict(agg_size=48, repeats=1), (2, 3, 65, 97), 5, False),
+        ("wacv_sampled1", "template", wacv[1], 19, dict(agg_size=48, repeats=1), (2, 3, 65, 97), 6, False),
+        ("wacv_sampled3", "template", wacv[3], 19, dict(agg_size=48, repeats=1), (2, 3, 65, 97), 7, False),
+        ("cvpr_sampled0", "micro", cvpr[0], 21, dict(agg_size=48, repeats=1, aux_cell=True),
+         (2, 3, 97, 129), 8, False),
+        ("cvpr_sampled3", "micro", cvpr[3], 21, dict(agg_size=48, repeats=1, aux_cell=True),
+         (2, 3, 97, 129), 9, False),
+        # (4 images: the cell's global-average-pool branch normalises a B x C x 1 x 1 map over B
+        #  samples - with B = 2 its output is +-1 whatever the input)
+        ("cvpr_arch2_depth_train", "micro", "cvpr_arch2", 1, dict(agg_size=64, repeats=2),
+         (4, 3, 97, 129), 4, False),
+    ]
+
+
+def gen_nets_sampled():
+    _gen_nets(sampled_nets(), "nets_sampled.npz", "nets_sampled_meta.json")
+
+
+def _gen_nets(nets, npz_name, meta_name):
     st = Store()
     meta = {}
-    for name, kind, geno, classes, kw, shape, seed, full in NETS:
+    for name, kind, geno, classes, kw, shape, seed, full in nets:
         net = build_ref_net(kind, geno, classes, kw, seed)
         gen = torch.Generator().manual_seed(9000 + seed)
         x = torch.randn(*shape, generator=gen)
@@ -250,7 +283,8 @@ def gen_nets():
         st.put(name + "/logits_eval", out)
         for i, a in enumerate(aux):
             st.put(name + "/aux_eval/{}".format(i), a)
-        rec = {"kind": kind, "genotype": GENOTYPES[geno], "classes": classes, "dec_kwargs": kw,
+        rec = {"kind": kind, "genotype": GENOTYPES[geno] if isinstance(geno, str) else geno,
+               "classes": classes, "dec_kwargs": kw,
                "shape": list(shape), "seed": seed, "full_sd": full, "checksums": checksums(sd0),
                "n_params": sum(p.numel() for p in net.parameters()), "n_aux": len(aux)}
         if classes > 1:
@@ -290,6 +324,7 @@ def gen_nets():
             # itself, how far every stored gradient moves under two such perturbations;
             # parity tests use it as the tolerance floor.
             sens = {k: 0.0 for k in pick}
+            mass_sens = {k: 0.0 for k in grads}
             logit_sens = 0.0
             for ps in (1, 2):
                 net.load_state_dict(sd0)
@@ -311,11 +346,53 @@ def gen_nets():
                 named = dict(net.named_parameters())
                 for k in pick:
                     sens[k] = max(sens[k], float((named[k].grad - grads[k]).abs().max()))
+                for k in grads:
+                    mass_sens[k] = max(mass_sens[k], abs(float(named[k].grad.double().abs().sum())
+                                                         - float(grads[k].double().abs().sum())))
             rec["grad_sensitivity"] = sens
+            # ... and how far the abs-sum ("mass") of EVERY gradient tensor moves: the tolerance
+            # floor of the checksum comparison over all parameters
+            rec["grad_mass_sensitivity"] = mass_sens
+            rec["train_logits_sensitivity"] = logit_sens
+        elif name.endswith("_train"):
+            # one output channel (depth): train-mode forward and the gradients of
+            # sum(output * g) for a fixed cotangent g
+            net.train()
+            output = net(x)
+            if isinstance(output, tuple):
+                output = output[0]
+            g = torch.randn(output.shape, generator=gen)
+            net.zero_grad()
+            output.backward(g)
+            st.put(name + "/logits_train", output)
+            st.put(name + "/g", g)
+            grads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+            rec["grad_checksums"] = checksums(grads)
+            keys = sorted(grads.keys())
+            pick = [keys[i] for i in np.linspace(0, len(keys) - 1, 14).astype(int)]
+            for k in pick:
+                st.put(name + "/grad/" + k, grads[k])
+            sens = {k: 0.0 for k in grads}
+            logit_sens = 0.0
+            for ps in (1, 2):
+                net.load_state_dict(sd0)
+                net.train()
+                pg = torch.Generator().manual_seed(ps)
+                outp = net(x + 1e-6 * torch.randn(x.shape, generator=pg))
+                if isinstance(outp, tuple):
+                    outp = outp[0]
+                logit_sens = max(logit_sens, float((outp - output).abs().max()))
+                net.zero_grad()
+                outp.backward(g)
+                named = dict(net.named_parameters())
+                for k in grads:
+                    sens[k] = max(sens[k], float((named[k].grad - grads[k]).abs().max()))
+            rec["grad_sensitivity"] = {k: sens[k] for k in pick}
+            rec["grad_mass_sensitivity"] = {k: float(v) * grads[k].numel() for k, v in sens.items()}
             rec["train_logits_sensitivity"] = logit_sens
         meta[name] = rec
-    st.save("nets.npz")
-    json.dump(meta, open(os.path.join(OUT, "nets_meta.json"), "w"))
+    st.save(npz_name)
+    json.dump(meta, open(os.path.join(OUT, meta_name), "w"))
 
 
 # ---------------------------------------------------------------------------
@@ -408,100 +485,205 @@ def gen_miou():
 # ---------------------------------------------------------------------------
 # D. engine: reference train_segmenter / populate_task0 / train_task0 / validate
 # ---------------------------------------------------------------------------
+class _Seg(nn.Module):  # src/main_search.py:411-420
+    def __init__(self, encoder, decoder):
+        super(_Seg, self).__init__()
+        self.encoder, self.decoder = encoder, decoder
+
+    def forward(self, x):
+        return self.decoder(self.encoder(x))
+
+
+ENGINE_NETS = [
+    ("wacv_arch0", "template", "wacv_arch0", 19, dict(agg_size=64, repeats=2), -1),
+    ("cvpr_arch1_search", "micro", "cvpr_arch1", 21, dict(agg_size=48, repeats=1, aux_cell=True), 0.15),
+]
+
+
+def _perturbed(batches, noise_seed):
+    if not noise_seed:
+        return batches
+    pg = torch.Generator().manual_seed(noise_seed)
+    return [{"image": b["image"] + 1e-6 * torch.randn(b["image"].shape, generator=pg), "mask": b["mask"]}
+            for b in batches]
+
+
 def gen_engine():
+    """train_segmenter / validate / populate_task0 / train_task0 of the reference on seeded
+    batches; run three times - as is (the record) and with the images perturbed by 1e-6 (twice):
+    how far the REFERENCE's own losses, parameters and reward move is stored next to every value
+    (``*_sensitivity``) and is the floor of the parity tolerances (whole-network training through
+    ~100 train-mode BatchNorms, ReLUs and max-pools is ill-conditioned: gradients move by ~1 %
+    at fp32 rounding level, whatever the crop size)."""
     import engine.inference as ref_inf
     import engine.trainer as ref_tr
     from utils.solvers import create_optimisers
 
     st = Store()
     meta = {}
-    for name, kind, geno, classes, kw, aux_weight in [
-        ("wacv_arch0", "template", "wacv_arch0", 19, dict(agg_size=64, repeats=2), -1),
-        ("cvpr_arch1_search", "micro", "cvpr_arch1", 21, dict(agg_size=48, repeats=1, aux_cell=True), 0.15),
-    ]:
-        net = build_ref_net(kind, geno, classes, kw, seed=11)
-
-        class Seg(nn.Module):  # src/main_search.py:411-420
-            def __init__(self, encoder, decoder):
-                super(Seg, self).__init__()
-                self.encoder, self.decoder = encoder, decoder
-
-            def forward(self, x):
-                return self.decoder(self.encoder(x))
-
-        segmenter = nn.DataParallel(Seg(net.encoder, net.decoder))
+    crit = nn.NLLLoss(ignore_index=255)
+    for name, kind, geno, classes, kw, aux_weight in ENGINE_NETS:
         gen = torch.Generator().manual_seed(4242)
         H, W = (65, 97) if kind == "template" else (97, 129)
-        batches = []
+        batches, vbatches = [], []
         for _ in range(2):
             img = torch.randn(2, 3, H, W, generator=gen)
             batches.append({"image": img, "mask": make_labels(gen, 2, H, W, classes).to(torch.uint8)})
-        for i, b in enumerate(batches):
-            st.put("{}/train/image/{}".format(name, i), b["image"])
-            st.put("{}/train/mask/{}".format(name, i), b["mask"])
-        meta[name] = {"kind": kind, "genotype": GENOTYPES[geno], "classes": classes, "dec_kwargs": kw,
-                      "seed": 11, "aux_weight": aux_weight,
-                      "init_checksums": checksums(segmenter.module.state_dict())}
-        # --- task1: end-to-end, SGD encoder / Adam decoder (default_args.py:57-66) ---
-        optim_enc, optim_dec = create_optimisers(
-            "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
-            segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
-        losses = []
-        crit = nn.NLLLoss(ignore_index=255)
-
-        def rec_crit(inp, tgt, _c=crit, _l=losses):
-            v = _c(inp, tgt)
-            _l.append(float(v))
-            return v
-
-        avg_param = [p.data.clone() for p in segmenter.parameters()]
-        ret = ref_tr.train_segmenter(segmenter, FakeLoader(batches), optim_enc, optim_dec, 0, rec_crit,
-                                     False, 3.0, 3.0, True, print_every=100, aux_weight=aux_weight,
-                                     avg_param=avg_param, polyak_decay=0.99)
-        assert ret is None, "reference train_segmenter failed"
-        sd1 = segmenter.module.state_dict()
-        meta[name]["task1_crit_values"] = losses[:]
-        meta[name]["task1_checksums"] = checksums(sd1)
-        meta[name]["task1_polyak_checksums"] = checksums({str(i): a for i, a in enumerate(avg_param)})
-        st.put(name + "/task1/conv_clf.weight", sd1["decoder.conv_clf.weight"])
-        st.put(name + "/task1/layer1.0.weight", sd1["encoder.layer1.0.weight"])
-        # --- validation reward of the trained candidate ---
-        vbatches = []
         for _ in range(2):
             img = torch.randn(2, 3, H, W, generator=gen)
             vbatches.append({"image": img, "mask": make_labels(gen, 2, H, W, classes - 3).to(torch.uint8)})
-        for i, b in enumerate(vbatches):
-            st.put("{}/val/image/{}".format(name, i), b["image"])
-            st.put("{}/val/mask/{}".format(name, i), b["mask"])
-        reward = ref_inf.validate(segmenter, FakeLoader(vbatches), 0, 0, num_classes=classes,
-                                  print_every=100, omit_classes=[0])
-        meta[name]["val_reward"] = float(reward)
-        # --- task0: cache encoder features, decoder-only epoch ---
-        loader1 = FakeLoader([{"image": b["image"][i:i + 1], "mask": b["mask"][i:i + 1]}
-                              for b in batches for i in range(2)])
-        Xy = ref_tr.populate_task0(segmenter, loader1, None, 4, do_kd=False)
-        assert not isinstance(Xy, int), "reference populate_task0 failed"
-        meta[name]["task0_cache_checksums"] = checksums(
-            {str(k): v for k, v in Xy.items() if k != "out_size"})
-        meta[name]["task0_out_size"] = [int(s) for s in Xy["out_size"]]
-        _, optim_dec0 = create_optimisers(
-            "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
-            segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
-        np.random.seed(123)
-        losses0 = []
+        for tag, bs in (("train", batches), ("val", vbatches)):
+            for i, b in enumerate(bs):
+                st.put("{}/{}/image/{}".format(name, tag, i), b["image"])
+                st.put("{}/{}/mask/{}".format(name, tag, i), b["mask"])
 
-        def rec_crit0(inp, tgt, _c=crit, _l=losses0):
-            v = _c(inp, tgt)
-            _l.append(float(v))
-            return v
+        def run(noise_seed):
+            out = {}
+            net = build_ref_net(kind, geno, classes, kw, seed=11)
+            segmenter = nn.DataParallel(_Seg(net.encoder, net.decoder))
+            out["init_checksums"] = checksums(segmenter.module.state_dict())
+            tb, vb = _perturbed(batches, noise_seed), _perturbed(vbatches, noise_seed)
+            # --- task1: end-to-end, SGD encoder / Adam decoder (default_args.py:57-66) ---
+            optim_enc, optim_dec = create_optimisers(
+                "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
+                segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
+            losses = []
 
-        ret = ref_tr.train_task0(Xy, segmenter, optim_dec0, 0, rec_crit0, None, 2, False, False, 0.0,
-                                 3.0, False, aux_weight=max(aux_weight, 0))
-        assert ret is None, "reference train_task0 failed"
-        meta[name]["task0_crit_values"] = losses0[:]
-        meta[name]["task0_checksums"] = checksums(segmenter.module.decoder.state_dict())
+            def rec_crit(inp, tgt, _l=losses):
+                v = crit(inp, tgt)
+                _l.append(float(v))
+                return v
+
+            avg_param = [p.data.clone() for p in segmenter.parameters()]
+            ret = ref_tr.train_segmenter(segmenter, FakeLoader(tb), optim_enc, optim_dec, 0, rec_crit,
+                                         False, 3.0, 3.0, True, print_every=100, aux_weight=aux_weight,
+                                         avg_param=avg_param, polyak_decay=0.99)
+            assert ret is None, "reference train_segmenter failed"
+            sd1 = {k: v.clone() for k, v in segmenter.module.state_dict().items()}
+            out["task1_crit_values"] = losses[:]
+            out["task1_checksums"] = checksums(sd1)
+            out["task1_polyak_checksums"] = checksums({str(i): a for i, a in enumerate(avg_param)})
+            out["sd1"] = sd1
+            # --- validation reward of the trained candidate ---
+            reward = ref_inf.validate(segmenter, FakeLoader(vb), 0, 0, num_classes=classes,
+                                      print_every=100, omit_classes=[0])
+            out["val_reward"] = float(reward)
+            # --- task0: cache encoder features, decoder-only epoch ---
+            loader1 = FakeLoader([{"image": b["image"][i:i + 1], "mask": b["mask"][i:i + 1]}
+                                  for b in tb for i in range(2)])
+            Xy = ref_tr.populate_task0(segmenter, loader1, None, 4, do_kd=False)
+            assert not isinstance(Xy, int), "reference populate_task0 failed"
+            out["task0_cache_checksums"] = checksums({str(k): v for k, v in Xy.items() if k != "out_size"})
+            out["task0_out_size"] = [int(s) for s in Xy["out_size"]]
+            _, optim_dec0 = create_optimisers(
+                "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
+                segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
+            np.random.seed(123)
+            losses0 = []
+
+            def rec_crit0(inp, tgt, _l=losses0):
+                v = crit(inp, tgt)
+                _l.append(float(v))
+                return v
+
+            ret = ref_tr.train_task0(Xy, segmenter, optim_dec0, 0, rec_crit0, None, 2, False, False, 0.0,
+                                     3.0, False, aux_weight=max(aux_weight, 0))
+            assert ret is None, "reference train_task0 failed"
+            out["task0_crit_values"] = losses0[:]
+            out["task0_checksums"] = checksums(segmenter.module.decoder.state_dict())
+            return out
+
+        base = run(0)
+        sd1 = base.pop("sd1")
+        rec = {"kind": kind, "genotype": GENOTYPES[geno], "classes": classes, "dec_kwargs": kw,
+               "seed": 11, "aux_weight": aux_weight}
+        rec.update(base)
+        st.put(name + "/task1/conv_clf.weight", sd1["decoder.conv_clf.weight"])
+        st.put(name + "/task1/layer1.0.weight", sd1["encoder.layer1.0.weight"])
+        sens = {"task1_crit": [0.0] * len(base["task1_crit_values"]),
+                "task0_crit": [0.0] * len(base["task0_crit_values"]), "val_reward": 0.0,
+                "task1_mass": {k: 0.0 for k in base["task1_checksums"]},
+                "task1_polyak_mass": {k: 0.0 for k in base["task1_polyak_checksums"]},
+                "task0_cache_mass": {k: 0.0 for k in base["task0_cache_checksums"]},
+                "task0_mass": {k: 0.0 for k in base["task0_checksums"]}}
+        for ns in (1, 2):
+            other = run(ns)
+            for key in ("task1_crit", "task0_crit"):
+                sens[key] = [max(s, abs(a - b)) for s, a, b in
+                             zip(sens[key], other[key + "_values"], base[key + "_values"])]
+            sens["val_reward"] = max(sens["val_reward"], abs(other["val_reward"] - base["val_reward"]))
+            for key, ck in (("task1_mass", "task1_checksums"), ("task1_polyak_mass", "task1_polyak_checksums"),
+                            ("task0_cache_mass", "task0_cache_checksums"), ("task0_mass", "task0_checksums")):
+                for k in sens[key]:
+                    sens[key][k] = max(sens[key][k], abs(other[ck][k][1] - base[ck][k][1]))
+        rec["sensitivity"] = sens
+        meta[name] = rec
     st.save("engine.npz")
     json.dump(meta, open(os.path.join(OUT, "engine_meta.json"), "w"))
+
+
+def gen_engine_optim():
+    """The optimiser side of train_segmenter in isolation: the gradients the reference's backward
+    left in ``param.grad`` at every step (before clipping) are recorded together with the
+    parameters / Polyak averages after the step.  Given the SAME gradients the rest of the step -
+    per-sub-module clip_grad_norm_, SGD(momentum, weight decay) on the encoder, Adam(weight decay)
+    on the decoder, Polyak averaging (src/engine/trainer.py:255-273) - is deterministic, so the
+    product's post-step parameters are held to fp32 rounding, not to the conditioning of the
+    network's backward."""
+    import engine.trainer as ref_tr
+    from utils.solvers import create_optimisers
+
+    st = Store()
+    meta = {}
+    crit = nn.NLLLoss(ignore_index=255)
+    name, kind, geno, classes, kw, aux_weight = ENGINE_NETS[0]
+    kw = dict(agg_size=48, repeats=1)  # (search-time decoder size: a third of the parameters)
+    gen = torch.Generator().manual_seed(555)
+    batches = []
+    for _ in range(2):
+        img = torch.randn(2, 3, 65, 97, generator=gen)
+        batches.append({"image": img, "mask": make_labels(gen, 2, 65, 97, classes).to(torch.uint8)})
+    net = build_ref_net(kind, geno, classes, kw, seed=17)
+    segmenter = nn.DataParallel(_Seg(net.encoder, net.decoder))
+    st.put_sd("init", segmenter.module.state_dict())
+    optim_enc, optim_dec = create_optimisers(
+        "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
+        segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
+    avg_param = [p.data.clone() for p in segmenter.parameters()]
+    names = [k for k, _ in segmenter.module.named_parameters()]
+    step = [0]
+    clip = nn.utils.clip_grad_norm_
+
+    def recording_clip(parameters, max_norm, *a, **k):
+        # called once per sub-module per step, encoder first (trainer.py:258-265): the
+        # gradients are still the raw ones when the encoder's call arrives
+        if step[0] % 2 == 0:
+            for kname, p in segmenter.module.named_parameters():
+                st.put("grad/{}/{}".format(step[0] // 2, kname), p.grad)
+        step[0] += 1
+        return clip(parameters, max_norm, *a, **k)
+
+    nn.utils.clip_grad_norm_ = recording_clip
+    try:
+        for i, b in enumerate(batches):
+            ret = ref_tr.train_segmenter(segmenter, FakeLoader([b]), optim_enc, optim_dec, 0, crit,
+                                         False, 3.0, 3.0, True, print_every=100, aux_weight=aux_weight,
+                                         avg_param=avg_param, polyak_decay=0.99)
+            assert ret is None, "reference train_segmenter failed"
+            if i + 1 < len(batches):
+                continue  # (the last step's result depends on every earlier one)
+            for kname, p in segmenter.module.named_parameters():
+                st.put("after/{}".format(kname), p.data)
+            for kname, a in zip(names, avg_param):
+                st.put("polyak/{}".format(kname), a)
+    finally:
+        nn.utils.clip_grad_norm_ = clip
+    assert step[0] == 2 * len(batches), step
+    meta = {"kind": kind, "genotype": GENOTYPES[geno], "classes": classes, "dec_kwargs": kw, "seed": 17,
+            "steps": len(batches), "enc": {"lr": 1e-3, "momentum": 0.9, "weight_decay": 1e-5},
+            "dec": {"lr": 3e-3, "weight_decay": 1e-5}, "clip": 3.0, "polyak_decay": 0.99}
+    st.save("engine_optim.npz")
+    json.dump(meta, open(os.path.join(OUT, "engine_optim_meta.json"), "w"))
 
 
 # ---------------------------------------------------------------------------
@@ -518,13 +700,30 @@ def gen_controller():
                              lstm_hidden_size=100, lstm_num_layers=2, dec_num_cells=3,
                              cell_max_repeat=4, cell_max_stride=2, ctrl_lr=1e-4,
                              ctrl_baseline_decay=0.95, ctrl_agent="ppo", ctrl_version=version, **kw)
-        samples = []
+        samples, raw = [], []
         for _ in range(6):
             config, entropy, log_prob = agent.controller.sample()
+            raw.append((config, entropy, log_prob))
             action = agent.controller.config2action(config)
             samples.append({"config": config, "action": [int(a) for a in action],
                             "entropy": float(entropy), "log_prob": float(log_prob)})
-        out[version] = {"action_size": int(agent.controller.action_size()), "samples": samples}
+        # the search loop's hand-over to the controller: the sampled records go through the
+        # reference's train_agent (src/rl/agent.py:73-77 -> PPO.update ->
+        # RolloutStorage.insert, helpers/storage.py:26-34) in sampling order with rewards
+        # 0.01, 0.02, ...; what the rollout buffer holds afterwards is the contract a driver
+        # that evaluates several candidates per iteration must reproduce
+        from rl.agent import train_agent
+
+        for k, (smp, (cfg, ent, lp)) in enumerate(zip(samples, raw)):
+            train_agent(agent, (cfg, 0.01 * (k + 1), ent, lp))
+        ro = agent.rollouts
+        n = len(samples)
+        out[version] = {"action_size": int(agent.controller.action_size()), "samples": samples,
+                        "ppo_rollout": {"num_steps": int(ro.num_steps), "step": int(ro.step),
+                                        "actions": ro.actions[:n].astype(int).tolist(),
+                                        "rewards": ro.rewards[:n, 0].tolist(),
+                                        "log_probs": ro.action_log_probs[:n, 0].tolist(),
+                                        "baseline": float(agent.baseline)}}
     json.dump(out, open(os.path.join(OUT, "controller.json"), "w"), indent=1)
     print("wrote controller.json")
 
@@ -537,6 +736,6 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     shutil.rmtree(TMP, ignore_errors=True)
     build_cython()
-    which = sys.argv[1:] or ["ops", "nets", "miou", "engine", "controller"]
+    which = sys.argv[1:] or ["ops", "nets", "miou", "engine", "controller", "nets_sampled", "engine_optim"]
     for w in which:
         globals()["gen_" + w]()

@@ -43,8 +43,13 @@ def _worker(rank, world, port, q):
         reached = [p for p in net.parameters() if p is not net.never_reached]
         local = [p.grad.clone() for p in reached]
         dp.sync_gradients()
-        assert dp._flat.numel() == sum(p.numel() for p in reached)
-        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(reached, dp._views))
+        # fixed layout: every trainable parameter (reached by this loss or not) + one status element
+        assert dp._flat.numel() == sum(p.numel() for p in net.parameters()) + 1
+        views = dict((id(p), v) for p, v in zip(dp._parameters_once(), dp._views))
+        assert all(p.grad.data_ptr() == views[id(p)].data_ptr() for p in reached)
+        assert float(views[id(net.never_reached)].abs().sum()) == 0.0
+        value, peers_ok = dp.step_values(torch.tensor(1.5))
+        assert value == 1.5 and peers_ok
         ok_alias = net.never_reached.grad is None
         for p, l in zip(reached, local):
             allg = [torch.zeros_like(l) for _ in range(world)]
@@ -164,3 +169,256 @@ def test_search_loop_single_process():
     seen = []
     hist = search_loop(lambda: ([[1]], 0.1, -0.2), seen.append, lambda cfg: 0.5, 3)
     assert hist == [([[1]], 0.5)] * 3 and seen == [([[1]], 0.5, 0.1, -0.2)] * 3
+
+
+# ---------------------------------------------------------------------------
+# the engine's entry points on two ranks.  The CPU has no product kernels, so the handful of
+# functional ops the engine itself calls are replaced by their torch equivalents inside the
+# worker and the "segmenter" is a two-layer torch net behind the product's Segmenter /
+# RankParallel - what is under test is the rank protocol, not the kernels.
+# ---------------------------------------------------------------------------
+def _torch_functional():
+    import torch.nn.functional as TF
+
+    from nas_segm_amd import functional as F
+
+    F.nearest_label_resize = lambda t, size: TF.interpolate(
+        t[:, None].float(), size=tuple(size), mode="nearest").long()[:, 0]
+    F.log_softmax_nll = lambda logits, target, ignore_index=255: TF.nll_loss(
+        TF.log_softmax(logits, 1), target, ignore_index=ignore_index)
+    F.bilinear_resize = lambda x, size: x if tuple(x.shape[2:]) == tuple(size) else TF.interpolate(
+        x, size=tuple(size), mode="bilinear", align_corners=False)
+
+    def argmax_confusion(logits, gt, n, cm=None, **kw):
+        pred = TF.interpolate(logits, size=tuple(gt.shape[1:]), mode="bilinear", align_corners=False).argmax(1)
+        keep = gt < n
+        if cm is None:
+            cm = torch.zeros((n, n), dtype=torch.int64)
+        cm += torch.bincount(gt[keep].long() * n + pred[keep], minlength=n * n).view(n, n)
+        return cm
+
+    F.argmax_confusion = argmax_confusion
+
+
+class _ToyEncoder(torch.nn.Module):
+    def __init__(self, fail_at=None):
+        super(_ToyEncoder, self).__init__()
+        self.conv = torch.nn.Conv2d(3, 4, 3, stride=2, padding=1)
+        self.bn = torch.nn.BatchNorm2d(4)
+        self.calls, self.fail_at = 0, fail_at
+
+    def forward(self, x):
+        self.calls += 1
+        if self.fail_at is not None and self.calls == self.fail_at:
+            raise RuntimeError("HIP out of memory (simulated)")
+        return [torch.relu(self.bn(self.conv(x)))]
+
+
+class _ToyDecoder(torch.nn.Module):
+    def __init__(self):
+        super(_ToyDecoder, self).__init__()
+        self.clf = torch.nn.Conv2d(4, 5, 1)
+
+    def forward(self, feats):
+        return self.clf(feats[0])
+
+
+class _Crit(object):
+    ignore_index = 255
+
+
+def _toy_batches(rank, n, seed=0):
+    g = torch.Generator().manual_seed(1000 * seed + rank)
+    return [{"image": torch.randn(2, 3, 8, 12, generator=g),
+             "mask": torch.randint(0, 5, (2, 8, 12), generator=g).to(torch.uint8)} for _ in range(n)]
+
+
+def _engine_worker(rank, world, port, q):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nas_segm_amd.engine import RankParallel, Segmenter
+        from nas_segm_amd.engine.inference import validate
+        from nas_segm_amd.engine.trainer import populate_task0, train_segmenter, train_task0
+
+        _torch_functional()
+        out = {}
+
+        def candidate(fail_at=None):
+            torch.manual_seed(7)
+            net = Segmenter(_ToyEncoder(fail_at), _ToyDecoder())
+            dp = RankParallel(net)
+            oe = torch.optim.SGD(net.encoder.parameters(), lr=0.1, momentum=0.9)
+            od = torch.optim.Adam(net.decoder.parameters(), lr=0.01)
+            return net, dp, oe, od
+
+        def same_on_all_ranks(module):
+            flat = torch.cat([p.detach().reshape(-1) for p in module.parameters()])
+            allv = [torch.zeros_like(flat) for _ in range(world)]
+            dist.all_gather(allv, flat)
+            return all(torch.equal(allv[0], v) for v in allv)
+
+        # (1) a healthy epoch: parameters stay identical on all ranks (averaged gradients)
+        net, dp, oe, od = candidate()
+        init = torch.cat([p.detach().reshape(-1).clone() for p in net.parameters()])
+        ret = train_segmenter(dp, _toy_batches(rank, 3), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+        out["healthy"] = (ret, same_on_all_ranks(net),
+                          bool((torch.cat([p.detach().reshape(-1) for p in net.parameters()]) != init).any()))
+        r = validate(dp, _toy_batches(rank, 2, seed=1), 0, 0, num_classes=5, omit_classes=[])
+        rs = [None] * world
+        dist.all_gather_object(rs, float(r))
+        out["reward_same"] = all(abs(v - rs[0]) < 1e-12 for v in rs) and 0.0 < rs[0] <= 1.0
+
+        # (2) rank 1 fails in its SECOND step: every rank must leave train_segmenter with 0 at that
+        # step (nobody left waiting in an all-reduce), and the collectives that follow still pair
+        net, dp, oe, od = candidate(fail_at=2 if rank == 1 else None)
+        ret = train_segmenter(dp, _toy_batches(rank, 4), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["train_failure"] = (ret, net.encoder.calls, float(probe))
+
+        # (3) rank 0 fails during validation
+        net, dp, oe, od = candidate(fail_at=2 if rank == 0 else None)
+        r = validate(dp, _toy_batches(rank, 3, seed=2), 0, 0, num_classes=5, omit_classes=[])
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["val_failure"] = (r, float(probe))
+
+        # (4) task0 on a SHARDED feature cache: every rank caches its own samples, steps on its
+        # own batches, the decoder gradients are averaged - decoders stay identical
+        net, dp, oe, od = candidate()
+        shard = [{"image": b["image"][i:i + 1], "mask": b["mask"][i:i + 1]}
+                 for b in _toy_batches(rank, 2, seed=3) for i in range(2)]
+        Xy = populate_task0(dp, shard, None, 4, do_kd=False)
+        before = torch.cat([p.detach().reshape(-1).clone() for p in net.decoder.parameters()])
+        ret = train_task0(Xy, dp, od, 0, _Crit(), None, 2, False, False, 0.0, 3.0, False)
+        after = torch.cat([p.detach().reshape(-1) for p in net.decoder.parameters()])
+        feats = [None] * world
+        dist.all_gather_object(feats, float(Xy[0].double().abs().sum()))
+        out["task0"] = (ret, int(Xy[0].shape[0]), tuple(Xy["y"].shape), same_on_all_ranks(net.decoder),
+                        bool((after != before).any()), feats[0] != feats[1])
+        # ... and a rank failing in its task0 step takes the others with it
+        net, dp, oe, od = candidate()
+        if rank == 1:
+            net.decoder.forward = lambda feats: (_ for _ in ()).throw(RuntimeError("simulated"))
+        ret = train_task0(Xy, dp, od, 0, _Crit(), None, 2, False, False, 0.0, 3.0, False)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["task0_failure"] = (ret, float(probe))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_entry_points_two_ranks_gloo():
+    """train_segmenter / validate / populate_task0 / train_task0 on two ranks: replicas stay in
+    step, the task0 cache is sharded, and a RuntimeError on ONE rank scores the candidate 0 on ALL
+    ranks at the same step instead of leaving the others in an all-reduce (the reference's
+    try_except convention carried over to one process per GPU)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        out = results[rank]
+        assert out["healthy"] == (None, True, True), out["healthy"]
+        assert out["reward_same"]
+        ret, calls, probe = out["train_failure"]
+        assert ret == 0 and calls == 2 and probe == 3.0, out["train_failure"]  # both stopped at step 2
+        assert out["val_failure"] == (0, 3.0), out["val_failure"]
+        ret, n, yshape, same, moved, shards_differ = out["task0"]
+        assert ret is None and n == 4 and yshape == (4, 4, 6) and same and moved and shards_differ, out["task0"]
+        assert out["task0_failure"] == (0, 3.0), out["task0_failure"]
+
+
+def _ctrl_search_worker(rank, world, port, q, log_path):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _util import load_json
+        from nas_segm_amd.engine.search import search_loop
+
+        samples = load_json("controller.json")["wacv"]["samples"]
+        it = iter(samples)
+        inserted = []
+
+        def sample_fn():
+            s = next(it)
+            return s["config"], s["entropy"], s["log_prob"]
+
+        def evaluate_fn(config):  # rewards 0.01, 0.02, ... in sampling order, whatever rank evaluates
+            k = [s["config"] for s in samples].index(config)
+            return 0.01 * (k + 1), 1000 + k
+
+        writer = open(log_path, "w") if rank == 0 else None
+        search_loop(sample_fn, inserted.append, evaluate_fn, len(samples) // world, arch_writer=writer)
+        if writer:
+            writer.close()
+        q.put((rank, inserted))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_search_loop_feeds_the_controller_like_the_reference_gloo(tmp_path):
+    """config-4 outer loop with the records the REFERENCE controller sampled (golden): two
+    candidates per iteration, one per rank; what reaches ``train_agent`` - and therefore PPO's
+    RolloutStorage.insert (src/helpers/storage.py:26-34) - is, in order, exactly what the
+    reference's own train_agent calls stored for the same samples and rewards
+    (controller.json: ppo_rollout, recorded by make_golden.py); the genotype log parses with the
+    expressions of src/helpers/num_uq.py:14-16."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _util import load_json
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    log_path = str(tmp_path / "genotypes.out")
+    procs = [ctx.Process(target=_ctrl_search_worker, args=(r, world, port, q, log_path)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ctrl = load_json("controller.json")["wacv"]
+    rollout, samples = ctrl["ppo_rollout"], ctrl["samples"]
+    inserted = results[0]
+    assert results[1] == [] and len(inserted) == len(samples) == rollout["step"]
+    by_config = {str(s["config"]): s for s in samples}
+    for k, (config, reward, entropy, log_prob) in enumerate(inserted):
+        # train_agent: action = controller.config2action(config); storage row k = (action, log_prob, reward)
+        assert by_config[str(config)]["action"] == rollout["actions"][k], k
+        assert abs(reward - rollout["rewards"][k]) < 1e-12
+        assert abs(log_prob - rollout["log_probs"][k]) < 1e-6
+        assert entropy == by_config[str(config)]["entropy"]
+    # the reference's exponential baseline over these rewards (gradient_estimators.py:150-154)
+    base = None
+    for _, reward, _, _ in inserted:
+        base = reward if base is None else 0.95 * base + 0.05 * reward
+    assert abs(base - rollout["baseline"]) < 1e-12
+    lines = open(log_path, "rb").readlines()
+    assert len(lines) == len(samples)
+    for k, l in enumerate(lines):
+        arch = l.decode("utf-8").strip("\n").split(":")[-1]              # num_uq.py:14
+        reward = float(l.decode("utf-8").strip("\n").split(",")[0][7:])  # num_uq.py:15
+        epoch = int(l.decode("utf-8").strip("\n").split(":")[2].split(",")[0])  # num_uq.py:16
+        assert arch.strip() == str(samples[k]["config"]) and epoch == k
+        assert abs(reward - 0.01 * (k + 1)) < 1e-4

@@ -1,0 +1,295 @@
+"""Parity at the sizes BASELINE.json quotes (where the kernels take the dispatch paths only large
+maps take): a training step at 2x3x1024x2048 against the CPU oracle with the thresholds as
+shipped, and - where the oracle is too slow - size-independent properties at the full shapes of
+config 4 (8x3x713x713, a controller-sampled genotype) and config 5 (8x3x480x640, depth head,
+bfloat16 storage): batch-split equality in inference, additivity of the parameter gradients
+over the batch with frozen BatchNorm, bit-identical hipGraph replay, reward conservation laws."""
+import numpy as np
+import pytest
+import torch
+
+from _util import build_product_net, load_json
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cl(t):
+    return t.to(DEV).contiguous(memory_format=torch.channels_last)
+
+
+def _labels(gen, B, H, W, classes):
+    t = torch.randint(0, classes, (B, H, W), generator=gen)
+    t[:, H // 3: H // 3 + 5, :] = 255
+    return t
+
+
+def test_train_step_at_size_matches_the_oracle(monkeypatch):
+    """WACV arch0 (the BASELINE headline network), train-mode forward + loss + backward of
+    engine.trainer.segmenter_step at 2x3x1024x2048 with NATURAL dispatch - nothing monkeypatched:
+    BatchNorm backward applied by the weight-gradient kernels (maps > 48 MB), ConcatReduce
+    without the concatenation (>= 2^24 elements per input), two-level bn_finalize (> 512 partial
+    rows), multi-slab and grouped weight gradients, deferred finalisation, one weight re-pack per
+    step - against the CPU oracle (which tests/test_oracle_golden.py pins to the reference).
+    Floor of every tolerance: how far the ORACLE's own result moves when its input moves by 1e-6
+    (whole-network training is that ill-conditioned; see test_hip_golden._check_gradients)."""
+    from _util import oracle_forward
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.engine.trainer import segmenter_step
+    from oracle import engine as oeng
+
+    rec = load_json("nets_meta.json")["wacv_arch0"]
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).train()
+    sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    pkeys = {k for k, _ in net.named_parameters()}
+    gen = torch.Generator().manual_seed(21)
+    B, H, W = 2, 1024, 2048
+    x = torch.randn(B, 3, H, W, generator=gen)
+    target = _labels(gen, B, H, W, 19)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+
+    def oracle_run(xin):
+        sd = {k: (v.clone().requires_grad_(True) if k in pkeys else v.clone()) for k, v in sd0.items()}
+        out = oracle_forward(sd, xin, rec, training=True)
+        loss = oeng.train_loss(out, target)
+        loss.backward()
+        return out.detach(), float(loss), {k: sd[k].grad for k in pkeys}
+
+    want_out, want_loss, want_g = oracle_run(x)
+    pert_out, pert_loss, pert_g = oracle_run(x + 1e-6 * torch.randn(x.shape, generator=gen))
+    floor_out = float((pert_out - want_out).abs().max())
+    del pert_out
+
+    seen, n_split = set(), [0]
+    call, split = F.lib.call, F.cat_bn_relu_conv
+
+    def recording(name, *args):
+        seen.add(name)
+        return call(name, *args)
+
+    def counting(*a, **k):
+        n_split[0] += 1
+        return split(*a, **k)
+
+    monkeypatch.setattr(F.lib, "call", recording)
+    monkeypatch.setattr(F, "cat_bn_relu_conv", counting)
+    net = net.to(DEV)
+    xd, td = _cl(x), target.to(DEV)
+    with torch.no_grad():
+        got_out = net(xd).cpu()
+    net.load_state_dict(sd0)  # (the extra forward moved the running statistics)
+    loss = segmenter_step(net, xd, td, None, None, 255, 0.0, 0.0, -1)
+    torch.cuda.synchronize()
+    # the paths this size is here for were taken
+    for name in ("nasseg_conv_wgrad_bn", "nasseg_dwconv_wgrad_bn", "nasseg_conv_bwd_data_bn",
+                 "nasseg_dwconv_bwd_data_bn", "nasseg_wgrad_finalize_many", "nasseg_conv_wgrad_many",
+                 "nasseg_dwconv_wgrad_many", "nasseg_pack_weights"):
+        assert name in seen, name
+    assert n_split[0] >= 1, "ConcatReduce never took its no-concatenation path"
+
+    err_out = float((got_out - want_out).abs().max())
+    assert err_out <= 1e-4 + 4.0 * floor_out, (err_out, floor_out)
+    assert abs(float(loss) - want_loss) <= 1e-4 + 4.0 * abs(pert_loss - want_loss), (float(loss), want_loss)
+    bad, worst = [], 0.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        ref = want_g[k]
+        floor = float((pert_g[k] - ref).abs().max())
+        tol = 2e-3 * float(ref.abs().max()) + 4.0 * floor + 1e-7
+        err = float((p.grad.cpu() - ref).abs().max())
+        worst = max(worst, err / (float(ref.abs().max()) + 1e-12))
+        if err > tol:
+            bad.append((k, err, tol, float(ref.abs().max())))
+    assert not bad, "{} of {} gradients off: {}".format(len(bad), len(want_g), bad[:8])
+    print("train step at size: logits err {:.2e} (floor {:.2e}), worst relative gradient error {:.2e}".format(
+        err_out, floor_out, worst))
+
+
+def _frozen_bn_gradients(net, x, backward):
+    """parameter gradients with every BatchNorm on its running statistics (the engine's freeze_bn
+    mode): per-sample computations are then independent of the rest of the batch"""
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.engine.trainer import _freeze_bn
+
+    net.train()
+    _freeze_bn(net)
+    params = [p for p in net.parameters()]
+    for p in params:
+        p.grad = None
+    with F.packed_once(F.PackMemo()):
+        out = net(x)
+        out = out[0] if isinstance(out, tuple) else out
+        with F.deferred_wgrad(params=params):
+            backward(out)
+    return {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+
+def _assert_additive(whole, parts, weights, what):
+    bad = []
+    for k, g in whole.items():
+        comb = sum(w * p[k] for w, p in zip(weights, parts))
+        scale = float(g.abs().max())
+        err = float((g - comb).abs().max())
+        if err > 3e-4 * scale + 1e-7:
+            bad.append((k, err, scale))
+    assert not bad, "{}: {} of {} gradients are not additive over the batch: {}".format(
+        what, len(bad), len(whole), bad[:6])
+
+
+def test_config4_shape_properties_at_full_size():
+    """BASELINE config 4 at its full shape: a genotype sampled by the reference controller
+    (search-time decoder, agg 48 / repeats 1), 8x3x713x713."""
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    rec = load_json("nets_sampled_meta.json")["wacv_sampled0"]
+    gen = torch.Generator().manual_seed(31)
+    B, H, W = 8, 713, 713
+    x = _cl(torch.randn(B, 3, H, W, generator=gen))
+    t = _labels(gen, B, H, W, 19).to(DEV)
+
+    def fresh():
+        return build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 3).to(DEV)
+
+    # (1) inference: a batch of 8 equals its two halves evaluated separately
+    net = fresh().eval()
+    with torch.no_grad():
+        whole = net(x)
+        halves = torch.cat([net(x[:4].contiguous(memory_format=torch.channels_last)),
+                            net(x[4:].contiguous(memory_format=torch.channels_last))], 0)
+    assert tuple(whole.shape) == (B, 19, 179, 179)
+    assert float((whole - halves).abs().max()) <= 1e-6
+    # reward path at label resolution: conservation laws, and the batch splits
+    gt8 = t.to(torch.uint8)
+    cm = F.argmax_confusion(whole, gt8, 19)
+    valid = int((gt8 < 19).sum())
+    assert int(cm.sum()) == valid
+    assert torch.equal(cm.sum(1), torch.bincount(gt8[gt8 < 19].reshape(-1).long(), minlength=19))
+    cm2 = F.argmax_confusion(halves[:4].contiguous(memory_format=torch.channels_last), gt8[:4], 19)
+    F.argmax_confusion(halves[4:].contiguous(memory_format=torch.channels_last), gt8[4:], 19, cm=cm2)
+    assert torch.equal(cm, cm2)
+
+    # (2) frozen BatchNorm: the loss is the valid-pixel-weighted mean of the halves' losses, and so
+    # are all parameter gradients (every backward kernel at full size, natural dispatch)
+    def grads_of(xs, ts):
+        losses = []
+
+        def backward(out):
+            loss = F.log_softmax_nll(out, F.nearest_label_resize(ts, out.shape[2:]), 255)
+            losses.append(loss.detach())
+            loss.backward()
+        g = _frozen_bn_gradients(net, xs, backward)
+        return g, float(losses[0]), int((F.nearest_label_resize(ts, (179, 179)) != 255).sum())
+
+    g8, l8, n8 = grads_of(x, t)
+    ga, la, na = grads_of(x[:4].contiguous(memory_format=torch.channels_last), t[:4].contiguous())
+    gb, lb, nb = grads_of(x[4:].contiguous(memory_format=torch.channels_last), t[4:].contiguous())
+    assert n8 == na + nb
+    assert abs(l8 - (na * la + nb * lb) / n8) < 1e-5
+    assert set(g8) == {k for k, _ in net.named_parameters()}
+    _assert_additive(g8, [ga, gb], [na / n8, nb / n8], "config 4")
+
+    # (3) training steps (batch statistics): launched from the host and replayed from a hipGraph,
+    # bit for bit the same losses and parameters
+    def run(graphed):
+        m = fresh().train()
+        oe = torch.optim.SGD(m.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(m.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        losses = []
+        if graphed:
+            stepper = GraphedSegmenterStep(m, x, t, oe, od, 255, 3.0, 3.0, -1)
+            for _ in range(2):
+                losses.append(float(stepper.step(x, t)))
+        else:
+            for _ in range(2):
+                losses.append(float(segmenter_step(m, x, t, oe, od, 255, 3.0, 3.0, -1)))
+        return losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+    l0, sd0 = run(False)
+    assert all(np.isfinite(v) for v in l0) and abs(l0[0] - np.log(19.0)) < 1.0 and l0[1] < l0[0] + 0.5
+    l1, sd1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+
+
+def test_config5_shape_properties_at_full_size_bf16():
+    """BASELINE config 5 at its full shape: the depth network (one output channel), 8x3x480x640,
+    bfloat16 activation storage, berHu loss."""
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import _clip_and_step
+    from oracle import losses as olosses
+
+    rec = load_json("nets_meta.json")["cvpr_arch2_depth"]
+    BF = torch.bfloat16
+    gen = torch.Generator().manual_seed(41)
+    B, H, W = 8, 480, 640
+    x = _cl(torch.randn(B, 3, H, W, generator=gen)).to(BF)
+
+    def fresh():
+        return build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 4).to(DEV)
+
+    def halves_of(t):
+        return (t[:4].contiguous(memory_format=torch.channels_last),
+                t[4:].contiguous(memory_format=torch.channels_last))
+
+    # (1) inference: batch-split equality (bf16 storage: identical roundings of identical values;
+    # one bf16 ulp is allowed for the global-average-pool branch, whose two-stage reduction is
+    # partitioned by the total row count)
+    net = fresh().eval()
+    with torch.no_grad():
+        whole = net(x)[0]
+        halves = torch.cat([net(h)[0] for h in halves_of(x)], 0)
+    assert whole.dtype == BF and tuple(whole.shape) == (B, 1, 120, 160)
+    ulp = 2.0 ** -7 * float(whole.float().abs().max())
+    assert float((whole.float() - halves.float()).abs().max()) <= ulp
+    assert bool(torch.isfinite(whole.float()).all())
+
+    # (2) frozen BatchNorm: parameter gradients (fp32) of sum(out * g) add up over the batch
+    cot = _cl(torch.randn(whole.shape, generator=gen)).to(BF)
+    g8 = _frozen_bn_gradients(net, x, lambda out: out.backward(cot))
+    parts = [_frozen_bn_gradients(net, xs, lambda out, c=cs: out.backward(c))
+             for xs, cs in zip(halves_of(x), halves_of(cot))]
+    assert all(v.dtype == torch.float32 for v in g8.values())
+    _assert_additive(g8, parts, [1.0, 1.0], "config 5")
+
+    # (3) berHu forward / backward at the full output size against the oracle's formula
+    pred = whole.detach().clone().requires_grad_(True)
+    depth = _cl((torch.rand(whole.shape, generator=gen) * 10)).to(BF)
+    loss = F.berhu_loss(pred, depth)
+    loss.backward()
+    p_ref = pred.detach().float().cpu().requires_grad_(True)
+    l_ref = olosses.berhu(p_ref, depth.float().cpu())
+    l_ref.backward()
+    assert abs(float(loss) - float(l_ref)) < 1e-5 * max(1.0, abs(float(l_ref)))
+    tol = 2.0 ** -7 * float(p_ref.grad.abs().max())  # (the gradient is stored in bf16)
+    assert float((pred.grad.float().cpu() - p_ref.grad).abs().max()) <= tol
+
+    # (4) training steps with batch statistics: eager == hipGraph replay, bit for bit
+    def run(graphed):
+        m = fresh().train()
+        oe = torch.optim.SGD(m.encoder.parameters(), lr=1e-3, momentum=0.9)
+        od = torch.optim.SGD(m.decoder.parameters(), lr=1e-3)
+        losses = []
+        if graphed:
+            stepper = GraphedSegmenterStep(m, x, depth, oe, od, 255, 3.0, 3.0, -1, loss_fn=F.berhu_loss)
+            for _ in range(2):
+                losses.append(float(stepper.step(x, depth)))
+        else:
+            for _ in range(2):
+                lo = F.berhu_loss(m(x)[0], depth)
+                oe.zero_grad()
+                od.zero_grad()
+                lo.backward()
+                _clip_and_step([(list(m.encoder.parameters()), 3.0, oe), (list(m.decoder.parameters()), 3.0, od)])
+                losses.append(float(lo))
+        return losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+    l0, sd0 = run(False)
+    assert all(np.isfinite(v) for v in l0)
+    l1, sd1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
