@@ -1317,21 +1317,27 @@ def zero_of(x, C, H, W):
 # global average pooling and its broadcast
 # ---------------------------------------------------------------------------
 class _GlobalAvgPool(torch.autograd.Function):
+    """The pooled (B, C, 1, 1) map is ALWAYS fp32, also when the activations are stored in
+    bfloat16: what follows it in the reference's op (layer_factory.py:181-195) is a BatchNorm over
+    those B values per channel, which amplifies the small differences between the samples' means
+    - 8 bits of mantissa would leave nothing of them.  B*C values: storage cost nil."""
+
     @staticmethod
     def forward(ctx, x):
         x = _cl(x)
         B, C, H, W = x.shape
         out = _colred(RED_SUM, x, C, None, 0, None, 0, B, H * W, C, 1.0 / (H * W))
         ctx.shape = (B, C, H, W)
-        return out.view(B, C, 1, 1).to(x.dtype)  # (the reduction is fp32; B*C values)
+        ctx.dtype = x.dtype
+        return out.view(B, C, 1, 1)  # (the reduction is fp32)
 
     @staticmethod
     def backward(ctx, dy):
         B, C, H, W = ctx.shape
-        dy = dy.contiguous().view(B, C, 1, 1)
+        dy = dy.contiguous().view(B, C, 1, 1).to(ctx.dtype)
         # every pixel receives dy / (H*W): a broadcast with a scale
         scale = _vec(dy, C)
-        lib.call(_k("nasseg_fill", scale), ptr(scale), C, 1.0 / (H * W), current_stream())
+        lib.call("nasseg_fill", ptr(scale), C, 1.0 / (H * W), current_stream())
         dx = _new(dy, B, C, H, W)
         lib.call(_k("nasseg_bilinear_fwd", dy), ptr(dy), ptr(dx), C, 0, B, 1, 1, C, H, W, ACT_NONE,
                  current_stream())
@@ -1339,18 +1345,20 @@ class _GlobalAvgPool(torch.autograd.Function):
 
 
 def global_avg_pool(x):
-    """x.mean(2, keepdim=True).mean(3, keepdim=True) -> (B, C, 1, 1)."""
+    """x.mean(2, keepdim=True).mean(3, keepdim=True) -> (B, C, 1, 1), fp32 whatever x's storage."""
     return _GlobalAvgPool.apply(x)
 
 
 class _Broadcast(torch.autograd.Function):
-    """Bilinear interpolation from a 1x1 map = broadcast over (H, W)."""
+    """Bilinear interpolation from a 1x1 map = broadcast over (H, W); the output is stored as
+    ``dtype`` (the activation storage of the network), the gradient w.r.t. v keeps v's dtype."""
 
     @staticmethod
-    def forward(ctx, v, H, W):
+    def forward(ctx, v, H, W, dtype):
         require_device(v)
         B, C = v.shape[0], v.shape[1]
-        v = v.contiguous().view(B, C, 1, 1)
+        ctx.vdtype = v.dtype
+        v = v.contiguous().view(B, C, 1, 1).to(dtype)
         y = _new(v, B, C, H, W)
         lib.call(_k("nasseg_bilinear_fwd", v), ptr(v), ptr(y), C, 0, B, 1, 1, C, H, W, ACT_NONE,
                  current_stream())
@@ -1361,12 +1369,12 @@ class _Broadcast(torch.autograd.Function):
     def backward(ctx, dy):
         B, C, H, W = ctx.shape
         dy = _cl(dy)
-        dv = _colred(RED_SUM, dy, C, None, 0, None, 0, B, H * W, C)
-        return dv.view(B, C, 1, 1).to(dy.dtype), None, None
+        dv = _colred(RED_SUM, dy, C, None, 0, None, 0, B, H * W, C)  # (fp32 sums)
+        return dv.view(B, C, 1, 1).to(ctx.vdtype), None, None, None
 
 
-def broadcast_to(v, size):
-    return _Broadcast.apply(v, int(size[0]), int(size[1]))
+def broadcast_to(v, size, dtype=None):
+    return _Broadcast.apply(v, int(size[0]), int(size[1]), dtype if dtype is not None else v.dtype)
 
 
 # ---------------------------------------------------------------------------

@@ -123,8 +123,9 @@ class GAPConv1x1(nn.Module):
 
     def forward(self, x):
         size = x.size()[2:]
-        pooled = F.global_avg_pool(x)
-        return F.broadcast_to(self.conv1x1(pooled), size)
+        pooled = F.global_avg_pool(x)  # fp32 also under bf16 activation storage, and so is the
+        # 1x1 conv + BatchNorm over B values per channel that follows; back to x's storage below
+        return F.broadcast_to(self.conv1x1(pooled), size, x.dtype)
 
 
 class DilConv(nn.Module):

@@ -316,7 +316,7 @@ def _gen_nets(nets, npz_name, meta_name):
             pick = [keys[i] for i in np.linspace(0, len(keys) - 1, 14).astype(int)]
             for k in pick:
                 st.put(name + "/grad/" + k, grads[k])
-            bn_after = {k: v for k, v in net.state_dict().items() if "running_mean" in k}
+            bn_after = {k: v.clone() for k, v in net.state_dict().items() if "running_mean" in k}
             rec["bn_after_checksums"] = checksums(bn_after)
             # Conditioning of the whole-network gradients: tiny batches through ~100
             # train-mode BatchNorms and ReLUs make some of them change by percents when
@@ -325,8 +325,9 @@ def _gen_nets(nets, npz_name, meta_name):
             # parity tests use it as the tolerance floor.
             sens = {k: 0.0 for k in pick}
             mass_sens = {k: 0.0 for k in grads}
+            bn_sens = {k: 0.0 for k in bn_after}
             logit_sens = 0.0
-            for ps in (1, 2):
+            for ps in (1, 2, 3, 4):
                 net.load_state_dict(sd0)
                 net.train()
                 pg = torch.Generator().manual_seed(ps)
@@ -349,6 +350,11 @@ def _gen_nets(nets, npz_name, meta_name):
                 for k in grads:
                     mass_sens[k] = max(mass_sens[k], abs(float(named[k].grad.double().abs().sum())
                                                          - float(grads[k].double().abs().sum())))
+                for k, v in net.state_dict().items():
+                    if k in bn_sens:
+                        bn_sens[k] = max(bn_sens[k], abs(float(v.double().abs().sum())
+                                                         - float(bn_after[k].double().abs().sum())))
+            rec["bn_after_mass_sensitivity"] = bn_sens
             rec["grad_sensitivity"] = sens
             # ... and how far the abs-sum ("mass") of EVERY gradient tensor moves: the tolerance
             # floor of the checksum comparison over all parameters
@@ -374,7 +380,7 @@ def _gen_nets(nets, npz_name, meta_name):
                 st.put(name + "/grad/" + k, grads[k])
             sens = {k: 0.0 for k in grads}
             logit_sens = 0.0
-            for ps in (1, 2):
+            for ps in (1, 2, 3, 4):
                 net.load_state_dict(sd0)
                 net.train()
                 pg = torch.Generator().manual_seed(ps)
@@ -390,6 +396,42 @@ def _gen_nets(nets, npz_name, meta_name):
             rec["grad_sensitivity"] = {k: sens[k] for k in pick}
             rec["grad_mass_sensitivity"] = {k: float(v) * grads[k].numel() for k, v in sens.items()}
             rec["train_logits_sensitivity"] = logit_sens
+            # How the fp32 REFERENCE responds when nothing but its input image is rounded to
+            # bfloat16 (8 bits of mantissa): with batch statistics this randomly initialised
+            # network amplifies a relative perturbation ~200x, so a run that stores EVERY
+            # activation in bf16 cannot be expected closer to this record than that response.
+            net.load_state_dict(sd0)
+            net.train()
+            outp = net(x.to(torch.bfloat16).float())
+            outp = outp[0] if isinstance(outp, tuple) else outp
+            net.zero_grad()
+            outp.backward(g)
+            named = dict(net.named_parameters())
+
+            def _cos(a, b):
+                a, b = a.double().reshape(-1), b.double().reshape(-1)
+                return float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+
+            rec["bf16_input_response"] = {
+                "logits_rel_l2": float((outp - output).norm() / output.norm()),
+                "grad_cos": {k: _cos(named[k].grad, grads[k]) for k in pick}}
+            # The well-conditioned counterpart: the same gradients with every BatchNorm on its
+            # running statistics (the engine's freeze_bn mode, src/engine/trainer.py:124-127) -
+            # here a bf16 run must track the record closely.
+            net.load_state_dict(sd0)
+            net.train()
+            for m in net.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+            outf = net(x)
+            outf = outf[0] if isinstance(outf, tuple) else outf
+            net.zero_grad()
+            outf.backward(g)
+            fgrads = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+            st.put(name + "/logits_frozen", outf)
+            rec["frozen_grad_checksums"] = checksums(fgrads)
+            for k in pick:
+                st.put(name + "/frozen_grad/" + k, fgrads[k])
         meta[name] = rec
     st.save(npz_name)
     json.dump(meta, open(os.path.join(OUT, meta_name), "w"))
@@ -510,8 +552,8 @@ def _perturbed(batches, noise_seed):
 
 def gen_engine():
     """train_segmenter / validate / populate_task0 / train_task0 of the reference on seeded
-    batches; run three times - as is (the record) and with the images perturbed by 1e-6 (twice):
-    how far the REFERENCE's own losses, parameters and reward move is stored next to every value
+    batches; run nine times - as is (the record) and with the images perturbed by 1e-6 (eight
+    seeds): how far the REFERENCE's own losses, parameters and reward move is stored next to every value
     (``*_sensitivity``) and is the floor of the parity tolerances (whole-network training through
     ~100 train-mode BatchNorms, ReLUs and max-pools is ill-conditioned: gradients move by ~1 %
     at fp32 rounding level, whatever the crop size)."""
@@ -542,6 +584,7 @@ def gen_engine():
             net = build_ref_net(kind, geno, classes, kw, seed=11)
             segmenter = nn.DataParallel(_Seg(net.encoder, net.decoder))
             out["init_checksums"] = checksums(segmenter.module.state_dict())
+            sd_init = {k: v.clone() for k, v in segmenter.module.state_dict().items()}
             tb, vb = _perturbed(batches, noise_seed), _perturbed(vbatches, noise_seed)
             # --- task1: end-to-end, SGD encoder / Adam decoder (default_args.py:57-66) ---
             optim_enc, optim_dec = create_optimisers(
@@ -560,6 +603,9 @@ def gen_engine():
                                          avg_param=avg_param, polyak_decay=0.99)
             assert ret is None, "reference train_segmenter failed"
             sd1 = {k: v.clone() for k, v in segmenter.module.state_dict().items()}
+            out["task1_delta_mass"] = {k: float((sd1[k] - sd_init[k]).double().abs().sum())
+                                       for k, _ in segmenter.module.named_parameters()}
+            out["numel"] = {k: p.numel() for k, p in segmenter.module.named_parameters()}
             out["task1_crit_values"] = losses[:]
             out["task1_checksums"] = checksums(sd1)
             out["task1_polyak_checksums"] = checksums({str(i): a for i, a in enumerate(avg_param)})
@@ -606,7 +652,7 @@ def gen_engine():
                 "task1_polyak_mass": {k: 0.0 for k in base["task1_polyak_checksums"]},
                 "task0_cache_mass": {k: 0.0 for k in base["task0_cache_checksums"]},
                 "task0_mass": {k: 0.0 for k in base["task0_checksums"]}}
-        for ns in (1, 2):
+        for ns in range(1, 9):
             other = run(ns)
             for key in ("task1_crit", "task0_crit"):
                 sens[key] = [max(s, abs(a - b)) for s, a, b in

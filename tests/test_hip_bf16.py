@@ -97,7 +97,7 @@ def test_pool_resize_concat_add_bf16():
     both(lambda x: F().bilinear_resize(x, (104, 136)), [x])  # x8: separable backward
     both(lambda x, y: F().concat_resize([x, y], (13, 17), relu=True), [x, act(rnd(2, 8, 7, 9, seed=2))])
     both(lambda x, y: F().add(x, y), [x, act(rnd(2, 16, 13, 17, seed=3))])
-    both(lambda x: F().broadcast_to(F().global_avg_pool(x), (5, 7)), [x])
+    both(lambda x: F().broadcast_to(F().global_avg_pool(x), (5, 7), x.dtype), [x])
 
 
 def test_losses_bf16():

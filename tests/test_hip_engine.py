@@ -64,6 +64,7 @@ def test_engine_matches_reference_run(name, monkeypatch):
     rec = ENG_META[name]
     net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], rec["seed"])
     assert_checksums_close(checksums(net.state_dict()), rec["init_checksums"], what="init")
+    init = _cpu_sd(net)
     segmenter = RankParallel(net.to(DEV))
     batches = [{"image": torch.from_numpy(ENG_NPZ["{}/train/image/{}".format(name, i)]),
                 "mask": torch.from_numpy(ENG_NPZ["{}/train/mask/{}".format(name, i)])} for i in range(2)]
@@ -92,15 +93,33 @@ def test_engine_matches_reference_run(name, monkeypatch):
     assert len(values) == len(want)
     for i, (v, w, f) in enumerate(zip(values, want, sens["task1_crit"])):
         check("task1 loss {}".format(i), v, w, f, abs_=1e-4)
-    got = checksums(_cpu_sd(net))
+    after = _cpu_sd(net)
+    got = checksums(after)
+    # Parameters whose gradient is ANALYTICALLY zero - the BatchNorm bias of Pool's 1x1 conv: a
+    # per-channel shift that commutes with the max-pool and is removed by the BatchNorm that
+    # follows - receive pure rounding noise, which Adam normalises to steps of up to lr per
+    # element in a noise-dependent direction.  The reference's run identifies them (they moved by
+    # < 5 % of a full Adam step per element; every other decoder tensor moved by > 60 %): for those
+    # the only meaningful statement is that they stay at noise level here as well.
+    full_step = {k: rec["numel"][k] * 3e-3 * len(batches) for k in rec["numel"]}
+    noise = {k for k, m in rec["task1_delta_mass"].items()
+             if k.startswith("decoder.") and m < 0.05 * full_step[k]}
+    assert len(noise) <= 0.1 * len(rec["numel"]), len(noise)
+    names = [k for k, _ in net.named_parameters()]
     for k, (s, sa) in rec["task1_checksums"].items():
         if "num_batches_tracked" in k:
             assert got[k][0] == s, k
+        elif k in noise:
+            moved = float((after[k] - init[k]).double().abs().sum())
+            if not moved < 0.10 * full_step[k]:
+                bad.append("task1 {} (zero-gradient parameter) moved by {} of a full Adam step".format(
+                    k, moved / full_step[k]))
         else:
             check("task1 " + k, got[k][1], sa, sens["task1_mass"][k])
     pol = checksums({str(i): a.cpu() for i, a in enumerate(avg_param)})
     for k, (s, sa) in rec["task1_polyak_checksums"].items():
-        check("polyak " + k, pol[k][1], sa, sens["task1_polyak_mass"][k])
+        slack = 0.02 * 0.10 * full_step[names[int(k)]] if names[int(k)] in noise else 0.0
+        check("polyak " + k, pol[k][1], sa, sens["task1_polyak_mass"][k], abs_=1e-6 + slack)
 
     # validation reward of the trained candidate
     vb = [{"image": torch.from_numpy(ENG_NPZ["{}/val/image/{}".format(name, i)]),
@@ -132,7 +151,7 @@ def test_engine_matches_reference_run(name, monkeypatch):
     for k, (s, sa) in rec["task0_checksums"].items():
         if "num_batches_tracked" in k:
             assert got0[k][0] == s, k
-        else:
+        elif ("decoder." + k) not in noise:
             check("task0 " + k, got0[k][1], sa, sens["task0_mass"][k])
     assert not bad, "{} of the reference run's numbers missed:\n{}".format(len(bad), "\n".join(bad[:40]))
 
