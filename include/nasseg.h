@@ -66,6 +66,17 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
                         const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
                         int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream);
 
+/* ---- one SepConv stage in one kernel: depthwise k x k -> pointwise 1x1 (+ BN statistics) -----
+ * replaces the Conv2d(C, C, k, groups=C) -> Conv2d(C, N, 1) pair of SepConv / DilConv
+ * (layer_factory.py:207-218,241-262): the depthwise output tile stays in LDS and feeds the
+ * matrix cores directly; zdw (optional) receives the depthwise output for the backward pass. */
+int64_t nasseg_sepconv_blocks(int B, int C, int Ho, int Wo, int N, int K, int stride, int dil);
+int nasseg_sepconv_fwd(const float* x, const float* wdw, const float* wpw, float* zdw, float* y,
+                       const float* in_scale, const float* in_shift, int in_act,
+                       const float* out_scale, const float* out_shift, int out_act, int B, int H,
+                       int W, int C, int Ho, int Wo, int N, int K, int stride, int pad, int dil,
+                       float* stats, void* stream);
+
 /* ---- dense convolution on the fp32 matrix cores ----------------------------
  * replaces conv1x1 / conv3x3 / conv_bn / conv_bn_relu (layer_factory.py:7-24,
  * 94-122), every pointwise stage (:125-382) and the classifier heads
@@ -222,6 +233,10 @@ int nasseg_compute_ius_accs(const int64_t* cm, int n, double* iu, int64_t* n_pix
  * parameters, parameter gradients, workspaces and every per-channel vector stay fp32, and the
  * size / workspace queries are shared with the fp32 entry points. */
 typedef uint16_t nasseg_bf16_t;
+int nasseg_bf16_sepconv_fwd(const nasseg_bf16_t* x, const float* wdw, const float* wpw, nasseg_bf16_t* zdw,
+                            nasseg_bf16_t* y, const float* in_scale, const float* in_shift, int in_act,
+                            const float* out_scale, const float* out_shift, int out_act, int B, int H, int W, int C,
+                            int Ho, int Wo, int N, int K, int stride, int pad, int dil, float* stats, void* stream);
 int nasseg_bf16_affine_act(const nasseg_bf16_t* x, const float* scale, const float* shift, const nasseg_bf16_t* res,
                       nasseg_bf16_t* y, int64_t n, int C, int act, void* stream);
 int nasseg_bf16_bn_bwd_apply(const nasseg_bf16_t* dy, const nasseg_bf16_t* x, const float* scale, const float* shift,

@@ -41,7 +41,7 @@ def _compile(job):
     src, bf16 = job
     obj = os.path.join(OBJ_DIR, os.path.basename(src) + (".bf16.o" if bf16 else ".o"))
     deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
-            os.path.abspath(__file__)]
+            os.path.join(CSRC, "dw_common.h"), os.path.abspath(__file__)]
     if _stale(obj, deps):
         cmd = [HIPCC] + FLAGS + (["-DNASSEG_BF16"] if bf16 else []) + ["-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

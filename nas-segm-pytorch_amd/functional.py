@@ -8,6 +8,7 @@ no ATen compute op runs on the hot path.  Tensors keep the reference's NCHW
 kernels address directly.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -594,6 +595,39 @@ def _identity_vectors(like, n):
     return ent
 
 
+# depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
+FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
+
+
+# elements of the stage's depthwise output above which a 5x5 stage runs as two kernels when the
+# depthwise output has to be written anyway (training).  tools/kbench_sepconv.py on MI355X, fused
+# vs separate in us: 32ch 128x256 21 / 29, 64ch 64x128 15 / 20, 64ch 128x256 46 / 48 - but
+# 48ch 8x179x179 72 / 56, 24->64ch 256x512 93 / 79, 64ch dil-6 256x512 193 / 171: on large maps
+# both forms are bandwidth-bound and the separate kernels keep more waves resident (the fused one
+# holds the tile in LDS and its two phases do not overlap within a workgroup).  3x3 stages and
+# inference (no depthwise output written) win at every size measured.
+_SEPCONV_5X5_TRAIN_MAX = 10 << 20
+
+
+def _sepconv_ok(x, w_dw, w_pw, op_dw, op_pw, needs_grad):
+    """Does nasseg_sepconv_fwd serve this depthwise conv (no BatchNorm behind it) followed by
+    this pointwise conv - and is it the faster form here?"""
+    B, C, H, W = x.shape
+    k = w_dw.shape[-1]
+    _, stride, pad, dil = op_dw[:4]
+    N = w_pw.shape[0]
+    if tuple(w_dw.shape) != (C, 1, k, k) or tuple(w_pw.shape) != (N, C, 1, 1):
+        return False
+    if op_pw[1:4] != (1, 0, 1):  # pointwise: stride 1, no padding
+        return False
+    Ho, Wo = conv_out_size(H, k, stride, pad, dil), conv_out_size(W, k, stride, pad, dil)
+    if Ho <= 0 or Wo <= 0:
+        return False
+    if k == 5 and B * Ho * Wo * C > _SEPCONV_5X5_TRAIN_MAX and (needs_grad or C % 16 != 0):
+        return False
+    return lib.query("nasseg_sepconv_blocks", B, C, Ho, Wo, N, k, stride, dil) > 0
+
+
 class _ConvChain(torch.autograd.Function):
     """A run of convolutions (dense on the MFMA path or depthwise), each optionally followed
     by BatchNorm (+ReLU/ReLU6), as ONE autograd node in which a normalised activation that
@@ -640,11 +674,26 @@ class _ConvChain(torch.autograd.Function):
                     bwd_slot[i] = len(items)
                     items.append((weights[i], 1 if fused else _dense_dgrad_form(weights[i], stride, pad, dil)))
         packed = _pack_many(x, items)
+        fused_dw = None  # (z_dw, ...) of a depthwise conv already computed together with the next op
         for i, (kind, stride, pad, dil, has_bn, act, training, momentum, eps) in enumerate(ops):
             w, gamma, beta, rm, rv, nbt = tensors[6 * i:6 * i + 6]
             w = weights[i]
             B, K, H, W = cur.shape
             last = i == n_ops - 1
+            if (kind == "dw" and not has_bn and not last and FUSE_SEPCONV and ops[i + 1][0] == "dense"
+                    and not (i + 2 == n_ops and res is not None and not needs_grad)
+                    and _sepconv_ok(cur, w, weights[i + 1], ops[i], ops[i + 1], needs_grad)):
+                # SepConv / DilConv stage: this depthwise conv and the pointwise conv that follows
+                # run as ONE kernel (csrc/sepconv.hip) when op i+1 comes up; nothing to do here but
+                # remember the stage's input and its prologue
+                fused_dw = (cur, pend, w, packed[i], i)
+                continue
+            if fused_dw is not None:
+                # the pointwise half of a fused stage: its input is the (virtual) depthwise output
+                dk = fused_dw[2].shape[-1]
+                _, ds_, dp_, dd_ = ops[fused_dw[4]][:4]
+                H, W = conv_out_size(H, dk, ds_, dp_, dd_), conv_out_size(W, dk, ds_, dp_, dd_)
+                pend = None  # (the prologue belongs to the depthwise half: kept in fused_dw)
             if kind == "dw":
                 k = w.shape[-1]
                 if w.shape[0] != K or w.shape[1] != 1:
@@ -684,8 +733,12 @@ class _ConvChain(torch.autograd.Function):
                     lib.call("nasseg_bn_eval_params", N, float(eps), ptr(gamma), ptr(beta), ptr(rm),
                              ptr(rv), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
                 elif stats_ok:
-                    nblk = (lib.query("nasseg_dwconv_stats_blocks", B, N, Ho, Wo, kh, stride, dil)
-                            if kind == "dw" else lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N))
+                    if fused_dw is not None:
+                        nblk = lib.query("nasseg_sepconv_blocks", B, K, Ho, Wo, N, dk, ds_, dd_)
+                    elif kind == "dw":
+                        nblk = lib.query("nasseg_dwconv_stats_blocks", B, N, Ho, Wo, kh, stride, dil)
+                    else:
+                        nblk = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N)
                     part = _ws(cur, (nblk + 64) * 2 * N)
             o_sc = o_sh = o_res = None
             o_act = ACT_NONE
@@ -694,7 +747,21 @@ class _ConvChain(torch.autograd.Function):
                 if last and res is not None:
                     o_res = res
             wp = packed[i]
-            if kind == "dw":
+            if fused_dw is not None:
+                # (cur is still the depthwise conv's input: geometry of the stage from op i-1)
+                xin, dpend, dww, dwp, di = fused_dw
+                fused_dw = None
+                zdw = _new(xin, B, K, Ho, Wo) if needs_grad else None
+                dsc, dsh, dact = dpend if dpend is not None else (None, None, ACT_NONE)
+                lib.call(_k("nasseg_sepconv_fwd", xin), ptr(xin), ptr(dwp), ptr(w), ptr(zdw), ptr(z), ptr(dsc),
+                         ptr(dsh), dact, ptr(o_sc), ptr(o_sh), o_act, B, xin.shape[2], xin.shape[3], K, Ho, Wo, N,
+                         dk, ds_, dp_, dd_, ptr(part), s)
+                if needs_grad:
+                    saved.extend([xin, dsc, dsh, zdw, None, dww,
+                                  packed[bwd_slot[di]] if bwd_slot[di] is not None else None])
+                    meta.append((dact,))
+                    cur = zdw
+            elif kind == "dw":
                 lib.call(_k("nasseg_dwconv", cur), ptr(cur), ptr(wp), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
                          ptr(o_sh), o_act, B, H, W, K, Ho, Wo, kh, stride, pad, dil, 0, ptr(part), s)
             else:

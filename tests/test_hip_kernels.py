@@ -823,3 +823,126 @@ def test_deferred_weight_gradient_detects_an_early_copy():
         with f.deferred_wgrad(params=[w]):
             (y * y).mean().backward()
     assert not f.deferred_wgrad.pending and not f.deferred_wgrad.active
+
+
+# ---------------------------------------------------------------------------
+# one SepConv stage in one kernel (csrc/sepconv.hip)
+SEP_CASES = [
+    # B, C, N, H, W, k, stride, pad, dil
+    (2, 32, 32, 13, 17, 3, 1, 1, 1),
+    (2, 24, 48, 16, 20, 5, 1, 2, 1),
+    (1, 64, 64, 33, 47, 5, 1, 2, 1),
+    (2, 48, 24, 21, 19, 3, 1, 3, 3),
+    (2, 32, 64, 30, 33, 5, 1, 12, 6),
+    (2, 24, 24, 17, 23, 3, 2, 1, 1),
+    (2, 16, 8, 18, 22, 5, 2, 2, 1),
+    (3, 8, 16, 9, 5, 3, 1, 2, 2),     # DilConv geometry, a map narrower than a tile
+    (1, 128, 32, 8, 9, 3, 1, 1, 1),   # 32 channel groups: 8 columns per tile
+    (2, 4, 4, 70, 64, 3, 1, 1, 1),    # 4 channels: tile width capped at 48 columns
+]
+
+
+@pytest.mark.parametrize("case", SEP_CASES, ids=lambda c: "B{}C{}N{}_{}x{}_k{}s{}p{}d{}".format(*c))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pro", [False, True])
+def test_sepconv_stage_equals_the_two_kernel_chain_bit_for_bit(case, dtype, pro):
+    """nasseg_sepconv_fwd against nasseg_dwconv + nasseg_conv_fwd on the same inputs: the
+    depthwise strip and the MFMA accumulation order are those of the separate kernels, so the
+    depthwise output AND the pointwise output must be identical bits (fp32 and bf16 storage);
+    the statistics rows, summed, equal the sums of the output."""
+    Fm = F()
+    lib, ptr, stream = Fm.lib, Fm.ptr, Fm.current_stream
+    B, C, N, H, W, k, stride, pad, dil = case
+    Ho, Wo = Fm.conv_out_size(H, k, stride, pad, dil), Fm.conv_out_size(W, k, stride, pad, dil)
+    nblk = lib.query("nasseg_sepconv_blocks", B, C, Ho, Wo, N, k, stride, dil)
+    assert nblk > 0
+    x = dev(rnd(B, C, H, W, seed=1)).to(dtype)
+    wdw = dev(rnd(C, 1, k, k, seed=2) * 0.3)
+    wpw = dev(rnd(N, C, 1, 1, seed=3) * 0.2).contiguous()
+    psc = (rnd(C, seed=4) * 0.2 + 1.0).to(DEV) if pro else None
+    psh = (rnd(C, seed=5) * 0.3).to(DEV) if pro else None
+    pact = 2 if pro else 0
+    wt = torch.empty(k * k * C, device=DEV)
+    lib.call("nasseg_dw_pack_weight", ptr(wdw), ptr(wt), C, k, 0, stream())
+    name = lambda op: Fm._k(op, x)  # noqa: E731
+    # separate kernels
+    z_ref = torch.empty((B, C, Ho, Wo), device=DEV, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    lib.call(name("nasseg_dwconv"), ptr(x), ptr(wt), ptr(z_ref), ptr(psc), ptr(psh), pact, None, None, 0,
+             B, H, W, C, Ho, Wo, k, stride, pad, dil, 0, None, stream())
+    y_ref = torch.empty((B, N, Ho, Wo), device=DEV, dtype=dtype).contiguous(memory_format=torch.channels_last)
+    lib.call(name("nasseg_conv_fwd"), ptr(z_ref), C, ptr(wpw), ptr(y_ref), N, None, None, 0, None, None, 0,
+             None, 0, B, Ho, Wo, C, Ho, Wo, N, 1, 1, 1, 0, 1, 0, None, stream())
+    # fused, with the depthwise output and the statistics rows
+    z = torch.full_like(z_ref, float("nan"))
+    y = torch.full_like(y_ref, float("nan"))
+    part = torch.full((nblk * 2 * N,), float("nan"), device=DEV)
+    lib.call(name("nasseg_sepconv_fwd"), ptr(x), ptr(wt), ptr(wpw), ptr(z), ptr(y), ptr(psc), ptr(psh), pact,
+             None, None, 0, B, H, W, C, Ho, Wo, N, k, stride, pad, dil, ptr(part), stream())
+    assert torch.equal(z, z_ref), float((z.float() - z_ref.float()).abs().max())
+    assert torch.equal(y, y_ref), float((y.float() - y_ref.float()).abs().max())
+    rows = part.view(nblk, 2, N).double().sum(0).cpu()
+    # (the rows hold the sums of the fp32 values before they are rounded to the storage type)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    yd = y_ref.double().permute(1, 0, 2, 3).reshape(N, -1).cpu()
+    assert_close(rows[0], yd.sum(1), tol * (float(yd.abs().sum(1).max()) + 1.0), 0.0, "sum")
+    assert_close(rows[1], (yd * yd).sum(1), tol * (float((yd * yd).sum(1).max()) + 1.0), 0.0, "sum of squares")
+    # inference form: no depthwise output, folded affine + activation epilogue
+    osc, osh = (rnd(N, seed=6) * 0.2 + 1.0).to(DEV), (rnd(N, seed=7) * 0.3).to(DEV)
+    y2 = torch.full_like(y_ref, float("nan"))
+    lib.call(name("nasseg_sepconv_fwd"), ptr(x), ptr(wt), ptr(wpw), None, ptr(y2), ptr(psc), ptr(psh), pact,
+             ptr(osc), ptr(osh), 1, B, H, W, C, Ho, Wo, N, k, stride, pad, dil, None, stream())
+    y2_ref = torch.empty_like(y_ref)
+    lib.call(name("nasseg_conv_fwd"), ptr(z_ref), C, ptr(wpw), ptr(y2_ref), N, None, None, 0, ptr(osc), ptr(osh), 1,
+             None, 0, B, Ho, Wo, C, Ho, Wo, N, 1, 1, 1, 0, 1, 0, None, stream())
+    assert_close(y2, y2_ref, 2e-6 if dtype == torch.float32 else 2e-2, 1e-6 if dtype == torch.float32 else 1e-2,
+                 "folded epilogue")
+
+
+@pytest.mark.parametrize("name,stride", [("sep_conv_3x3", 1), ("sep_conv_5x5", 1), ("sep_conv_5x5_dil6", 1),
+                                         ("sep_conv_3x3", 2), ("dil_conv_5x5", 1), ("sep_conv_3x3_dil3", 1)])
+@pytest.mark.parametrize("training", [True, False])
+def test_registry_ops_with_and_without_the_fused_stage(name, stride, training):
+    """SepConv / DilConv through the registry with the one-kernel stage on and off: same outputs,
+    same gradients, same running statistics (the chain's bookkeeping - saved tensors, prologues of
+    the second repeat, BatchNorm partial rows - must not notice which kernels ran)."""
+    from nas_segm_amd.nn.layer_factory import OPS
+
+    Fm = F()
+    torch.manual_seed(3)
+    mod = OPS[name](32, 32 if stride == 1 else 64, stride, True, 2).to(DEV).train(training)
+    sd = {k: v.clone() for k, v in mod.state_dict().items()}
+    x0 = dev(rnd(2, 32, 37, 41, seed=8))
+    cot = None
+    results = []
+    calls = []
+    orig = Fm.lib.call
+
+    def counting(fn, *a):
+        calls.append(fn)
+        return orig(fn, *a)
+
+    for fuse in (True, False):
+        mod.load_state_dict(sd)
+        mod.zero_grad()
+        Fm.FUSE_SEPCONV = fuse
+        Fm.lib.call = counting
+        del calls[:]
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = mod(x)
+            if cot is None:
+                cot = dev(rnd(*y.shape, seed=9))
+            y.backward(cot)
+        finally:
+            Fm.FUSE_SEPCONV = True
+            Fm.lib.call = orig
+        assert ("nasseg_sepconv_fwd" in calls) == fuse
+        results.append((y.detach(), x.grad, [p.grad.clone() for p in mod.parameters()],
+                        {k: v.clone() for k, v in mod.state_dict().items() if "running" in k}))
+    (y1, dx1, g1, b1), (y0, dx0, g0, b0) = results
+    assert_close(y1, y0, 2e-5, 2e-5, "output")
+    assert_close(dx1, dx0, 2e-4 * float(dx0.abs().max()), 1e-4, "dx")
+    for a, b in zip(g1, g0):
+        assert_close(a, b, 2e-4 * float(b.abs().max()) + 1e-7, 1e-4, "parameter gradient")
+    for k in b0:
+        assert_close(b1[k], b0[k], 1e-6, 1e-5, k)
