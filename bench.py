@@ -45,6 +45,11 @@ WORKLOADS = {
     "search713": ("sampled", None, 19, 8, 713, 713, "sampled WACV cell per GPU, 713x713 bs8 (BASELINE config 4)"),
     # 1-channel depth head, berHu loss (BASELINE config 5 is bf16: run with --dtype bf16)
     "depth480": ("micro", CVPR_ARCH2_DEPTH, 1, 8, 480, 640, "CVPR depth arch, berHu, 480x640 bs8 (BASELINE config 5)"),
+    # the decoder-only step on the device-resident encoder-feature cache (5 of the
+    # 6 inner epochs of a candidate, default_args.py:52): search-time decoder (agg 48, sep repeats 1, aux
+    # cells), 256x256 crops, batch 64 (default_args.py:5,24), cache of 1024 samples per GPU (sharded)
+    "task0": ("micro_search", CVPR_ARCH0, 21, 64, 256, 256, "train_task0 step on the cached encoder features, "
+              "CVPR search decoder, 256x256 crops bs64"),
 }
 NUM_CLASSES = 19
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -60,6 +65,9 @@ def algorithmic_bytes(name, a):
     if name == "nasseg_dwconv":
         B, H, W, C, Ho, Wo, K = a[9], a[10], a[11], a[12], a[13], a[14], a[15]
         return 4 * (B * C * H * W + B * C * Ho * Wo + C * K * K)
+    if name == "nasseg_sepconv_fwd":  # x read, pointwise output written (+ the depthwise output when stored)
+        B, H, W, C, Ho, Wo, N, K = a[11], a[12], a[13], a[14], a[15], a[16], a[17], a[18]
+        return 4 * (B * C * H * W + B * N * Ho * Wo + (B * C * Ho * Wo if a[3] else 0) + C * K * K + N * C)
     if name == "nasseg_dwconv_wgrad":
         B, H, W, C, Ho, Wo, K = a[7], a[8], a[9], a[10], a[11], a[12], a[13]
         return 4 * (B * C * H * W + B * C * Ho * Wo + C * K * K)
@@ -127,6 +135,9 @@ def build_model(device, workload="headline"):
         genotype = samples[int(os.environ.get("RANK", "0")) % len(samples)]["config"]
         enc = mbv2(pretrained=False, return_layers=[1, 2])
         dec = TemplateDecoder(enc.out_sizes, classes, genotype, agg_size=48, repeats=1)
+    elif kind == "micro_search":
+        enc = mbv2(pretrained=False)
+        dec = MicroDecoder(list(enc.out_sizes), classes, genotype, agg_size=48, repeats=1, aux_cell=True)
     elif kind == "template":
         enc = mbv2(pretrained=False, return_layers=[1, 2])
         dec = TemplateDecoder(enc.out_sizes, classes, genotype, agg_size=64, repeats=2)
@@ -150,8 +161,9 @@ def synthetic_batch(batch, height, width, rank, device, classes=NUM_CLASSES):
 
 def cpu_baseline(height, width):
     """The oracle (CPU restatement of the reference graph) on the host cores:
-    1 warm-up + 3 timed train-mode forward+backward passes of WACV arch0 at
-    1x3xHxW (the metric's unit), plus the eval forward of BASELINE.md section 4."""
+    1 warm-up + the median of 5 timed train-mode forward+backward passes of WACV arch0 at
+    1x3xHxW (the metric's unit; fewer if 30 s do not suffice), plus the eval forward of
+    BASELINE.md section 4."""
     from oracle import engine as oeng
     from oracle import nets as onets
 
@@ -184,7 +196,7 @@ def cpu_baseline(height, width):
         with torch.no_grad():
             onets.segmenter(sd, x, "template", WACV_ARCH0, [24, 32], (1, 2), False, repeats=2)
 
-    def timed(fn, budget_s, max_n=3):
+    def timed(fn, budget_s, max_n=5):
         """1 warm-up, then up to max_n timed passes within a wall-clock budget"""
         t_start = time.perf_counter()
         t0 = time.perf_counter()
@@ -200,7 +212,7 @@ def cpu_baseline(height, width):
         ts.sort()
         return ts[len(ts) // 2], len(ts)
 
-    med, n_fb = timed(fwd_bwd, 25.0)
+    med, n_fb = timed(fwd_bwd, 30.0)
     fmed, n_f = timed(fwd_eval, 10.0)
     cpu_name = "unknown"
     try:
@@ -217,31 +229,98 @@ def cpu_baseline(height, width):
             "fwd_only_images_per_sec": 1.0 / fmed, "cpu_model": cpu_name}
 
 
-def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary
-    (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes of this same command).
-    Units: KB; on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced reads
-    (MI355X_MICROARCH.md, HBM section) and is doubled here.  None if no summary is committed."""
+def lib_hash():
+    """first 16 hex digits of the SHA-256 of the kernel library in use"""
+    import hashlib
+
+    from nas_segm_amd._lib import LIB_PATH
+    with open(LIB_PATH, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
+
+def pmc_summary():
+    """The committed rocprofv3 --pmc summary of this command (tools/gpu_pmc.sh: FETCH_SIZE and
+    WRITE_SIZE in separate passes) - used ONLY if it was collected with the kernel library that is
+    running now (its header carries the library's hash): counters of other kernels would be stale
+    numbers.  Returns (None, None) otherwise, else ({family: HBM bytes per launch}, HBM bytes per
+    step).  Units in the file: KB; on gfx950 FETCH_SIZE counts half of the bytes of wide coalesced
+    reads (MI355X_MICROARCH.md, HBM section) and is doubled here."""
     path = os.path.join(ROOT, "profiles", "pmc_fetch_write_latest.txt")
+    fams, step_bytes = {}, None
     try:
-        for line in open(path):
-            parts = [p.strip() for p in line.split(",")]
-            if len(parts) == 4 and parts[0] == family:
-                return (2.0 * float(parts[2]) + float(parts[3])) * 1024.0
-    except (OSError, ValueError):
-        pass
-    return None
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None, None
+    head = lines[0].split() if lines else []
+    if len(head) < 3 or head[0] != "#" or head[1] != "lib" or head[2] != lib_hash():
+        return None, None
+    try:
+        if "step_bytes" in head:
+            step_bytes = float(head[head.index("step_bytes") + 1])
+        for line in lines[1:]:
+            parts = [q.strip() for q in line.split(",")]
+            if len(parts) == 4 and parts[0] != "kernel family":
+                fams[parts[0]] = (2.0 * float(parts[2]) + float(parts[3])) * 1024.0
+    except ValueError:
+        return None, None
+    return fams, step_bytes
 
 
-def roofline_from_profile(summary):
-    """Per entry point: launches, total ms, algorithmic GB/s; dominant = most time."""
-    rows = []
-    for name, (n, ms, recs) in summary.items():
-        nbytes = sum(algorithmic_bytes(name, args) for _, args in recs)
-        rows.append({"kernel": name, "launches": n, "ms": ms, "bytes": nbytes,
-                     "gbs": (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0})
-    rows.sort(key=lambda r: -r["ms"])
-    return rows
+def kernel_family(name, a):
+    """the __global__ function (rocprofv3's kernel name) an entry-point call dispatches to: the
+    roofline is quoted per kernel family so that it can be held against the rocprof summary and
+    the PMC traffic of the same name under profiles/"""
+    base = name.replace("nasseg_bf16_", "nasseg_")
+    if base == "nasseg_conv_fwd":
+        # (conv_fwd.hip:conv_dispatch) 3x3, stride 1, dilation <= 2, plain forward form, at least one
+        # 8x32 tile, N <= 64, not the flat small-K path: the LDS-tiled kernel
+        B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil, transposed = a[13:26]
+        pro = bool(a[5] or a[6] or a[7])
+        if (not transposed and kh == 3 and kw == 3 and stride == 1 and dil <= 2 and kh * kw * K > 64 and not pro
+                and not a[26] and N <= 64 and Wo >= 32 and Ho >= 8 and 0 <= pad <= 2 * dil):
+            return "conv3x3_lds_kernel"
+        return "conv_fwd_kernel"
+    fam = {"nasseg_conv_bwd_data_bn": "conv_fwd_kernel", "nasseg_sepconv_fwd": "sepconv_fwd_kernel",
+           "nasseg_conv_wgrad": "conv_wgrad_kernel", "nasseg_conv_wgrad_bn": "conv_wgrad_bn_kernel",
+           "nasseg_dwconv": "dw_fwd_strip", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
+           "nasseg_dwconv_wgrad": "dw_wgrad_strip", "nasseg_dwconv_wgrad_bn": "dw_wgrad_strip",
+           "nasseg_bn_bwd_apply": "bn_bwd_apply_kernel", "nasseg_affine_act": "affine_act_kernel",
+           "nasseg_bn_stats": "colred_kernel", "nasseg_bn_bwd_reduce": "colred_kernel"}
+    return fam.get(base, base)
+
+
+def roofline_from_profile(records, n_steps=2):
+    """records: LaunchProfiler.records of ``n_steps`` identical steps -> (per entry point rows,
+    per kernel family groups).  A launch's duration is the MINIMUM over the steps of the bracket
+    of HIP events around it: the bracket also contains whatever the stream waited for between the
+    two event records (a host that falls behind leaves the queue empty), which a second sample
+    of the same launch does not repeat."""
+    per = len(records) // n_steps
+    steps = [records[i * per:(i + 1) * per] for i in range(n_steps)]
+    aligned = len(records) == per * n_steps and all(
+        [r[0] for r in st] == [r[0] for r in steps[0]] for st in steps)
+    launches = []
+    if aligned:
+        for i in range(per):
+            name, args = steps[0][i][0], steps[0][i][1]
+            ms = min(st[i][2].elapsed_time(st[i][3]) for st in steps)
+            launches.extend([(name, args, ms)] * n_steps)
+    else:  # (the steps did not issue the same launches: keep every sample as it is)
+        launches = [(r[0], r[1], r[2].elapsed_time(r[3])) for r in records]
+    rows, groups = {}, {}
+    for name, args, ms in launches:
+        nbytes = algorithmic_bytes(name, args)
+        r = rows.setdefault(name, {"kernel": name, "launches": 0, "ms": 0.0, "bytes": 0})
+        g = groups.setdefault(kernel_family(name, args), {"ms": 0.0, "bytes": 0, "launches": 0, "entries": set()})
+        for ent in (r, g):
+            ent["launches"] += 1
+            ent["ms"] += ms
+            ent["bytes"] += nbytes
+        g["entries"].add(name)
+    rows = sorted(rows.values(), key=lambda r: -r["ms"])
+    for r in rows:
+        r["gbs"] = (r["bytes"] / 1e9) / (r["ms"] / 1e3) if r["ms"] > 0 else 0.0
+    return rows, groups, launches
 
 
 def main():
@@ -271,6 +350,7 @@ def main():
     ap.add_argument("--shapes", type=int, default=0,
                     help="with --breakdown: also print the N most expensive (entry point, shape) rows")
     args = ap.parse_args()
+    args.graph_flag_given = any(a == "--graph" or a.startswith("--graph=") for a in sys.argv[1:])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -334,8 +414,42 @@ def main():
                             (list(net.decoder.parameters()), 3.0, optim_dec)])
             return loss
 
+    if args.workload == "task0":
+        # populate the (per-rank shard of the) feature cache with the encoder, then time decoder-only
+        # steps on it: populate_task0 / make_task0_step of the engine, batches drawn like train_task0
+        import numpy as np
+
+        from nas_segm_amd.engine.trainer import make_task0_step, populate_task0
+
+        n_cache = 16 * args.batch
+        g = torch.Generator().manual_seed(100 + rank)
+        loader = [{"image": torch.randn(args.batch, 3, args.height, args.width, generator=g),
+                   "mask": torch.randint(0, wl[2], (args.batch, args.height, args.width), generator=g)}
+                  for _ in range(n_cache // args.batch)]
+        Xy = populate_task0(segmenter, loader, None, n_cache, do_kd=False)
+        assert not isinstance(Xy, int), "populate_task0 failed"
+        del loader
+        segmenter.train()
+        rng = np.random.RandomState(rank)
+        os.environ["NASSEG_GRAPH"] = {0: "0", 1: "1", 2: "1"}[args.graph] if args.graph_flag_given else \
+            os.environ.get("NASSEG_GRAPH", "auto")
+        task0_step = make_task0_step(Xy, segmenter, optim_dec, args.batch, 255, 3.0, 0.15)
+        task0_eager = task0_step
+        if getattr(task0_step, "__self__", None) is not None:  # (a stepper's bound method: replayed)
+            os.environ["NASSEG_GRAPH"] = "0"
+            task0_eager = make_task0_step(Xy, segmenter, optim_dec, args.batch, 255, 3.0, 0.15)
+            os.environ["NASSEG_GRAPH"] = "auto"
+
+        def eager_step():  # noqa: F811
+            return task0_eager(rng.permutation(n_cache)[:args.batch])
+
     step = eager_step
-    if args.graph:
+    if args.workload == "task0":
+        args.graph = 2 if getattr(task0_step, "__self__", None) is not None else 0
+
+        def step():  # noqa: F811
+            return task0_step(rng.permutation(n_cache)[:args.batch])
+    elif args.graph:
         from nas_segm_amd.engine.graphed import GraphedSegmenterStep
         if args.workload == "depth480":
             graphed = GraphedSegmenterStep(segmenter, image, depth, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
@@ -384,62 +498,56 @@ def main():
             lib.profiler = LaunchProfiler()
         eager_step()
         eager_step()
-        summary = lib.profiler.summary() if rank == 0 else {}
-        rows = roofline_from_profile(summary)
+        torch.cuda.synchronize()
+        records = lib.profiler.records if rank == 0 else []
+        rows, groups, launches = roofline_from_profile(records)
         lib.profiler = None
         if rows:
-            top = rows[0]
             total_ms = sum(r["ms"] for r in rows)
             # depthwise forward + backward-data launches (plain and with the fused BN-backward sums)
             dwr = [r for r in rows if r["kernel"].replace("nasseg_bf16_", "nasseg_")
                    in ("nasseg_dwconv", "nasseg_dwconv_bwd_data_bn")]
             dw = ([{"gbs": sum(r["bytes"] for r in dwr) / 1e9 / (sum(r["ms"] for r in dwr) / 1e3)}]
                   if dwr and sum(r["ms"] for r in dwr) > 0 else [])
-            # the __global__ function (rocprofv3's kernel name) behind each entry point: the roofline
-            # is quoted per kernel family so that it can be held against the rocprof summary and the
-            # PMC traffic of the same name under profiles/
-            fam = {"nasseg_conv_fwd": "conv_fwd_kernel", "nasseg_conv_bwd_data_bn": "conv_fwd_kernel",
-                   "nasseg_conv_wgrad": "conv_wgrad_kernel", "nasseg_conv_wgrad_bn": "conv_wgrad_bn_kernel",
-                   "nasseg_dwconv": "dw_fwd_strip", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
-                   "nasseg_dwconv_wgrad": "dw_wgrad_strip", "nasseg_dwconv_wgrad_bn": "dw_wgrad_strip",
-                   "nasseg_bn_bwd_apply": "bn_bwd_apply_kernel", "nasseg_affine_act": "affine_act_kernel",
-                   "nasseg_bn_stats": "colred_kernel", "nasseg_bn_bwd_reduce": "colred_kernel"}
-            groups = {}
-            for r in rows:
-                base = r["kernel"].replace("nasseg_bf16_", "nasseg_")
-                grp = groups.setdefault(fam.get(base, base), {"ms": 0.0, "bytes": 0, "launches": 0, "entries": []})
-                grp["ms"] += r["ms"]
-                grp["bytes"] += r["bytes"]
-                grp["launches"] += r["launches"]
-                grp["entries"].append(r["kernel"])
             name, top = max(groups.items(), key=lambda kv: kv[1]["ms"])
             gbs = top["bytes"] / 1e9 / (top["ms"] / 1e3)
-            roof = {"bound": "hbm", "kernel": name, "entry_points": top["entries"],
+            # HBM traffic from the PMC counters: only from a summary collected with THIS build of the
+            # kernels and this command (fp32 headline), else null
+            fams, step_bytes = (pmc_summary() if args.dtype == "f32" and args.workload == "headline"
+                                and args.batch == wl[3] else (None, None))
+            unfused = {"headline": 24.98e9, "arch1": 35.12e9}.get(args.workload)
+            roof = {"bound": "hbm", "kernel": name, "entry_points": sorted(top["entries"]),
                     "top5": [{"kernel": r["kernel"], "gbs": round(r["gbs"], 1),
                               "frac": round(r["gbs"] / HBM_PEAK_GBS, 3),
                               "share": round(r["ms"] / total_ms, 3)} for r in rows[:5]],
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "traffic": (pmc_traffic(name) if args.dtype == "f32" and args.workload == "headline"
-                                else None),
+                    "traffic": fams.get(name) if fams else None,
                     "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                     "avg_launch_ms": top["ms"] / top["launches"], "launches_per_step": top["launches"] / 2,
                     "share_of_kernel_time": top["ms"] / total_ms,
+                    "nasseg_calls_per_step": len(launches) / 2,
+                    "step_traffic": step_bytes,
+                    "step_traffic_vs_unfused": (step_bytes / (unfused * args.batch)
+                                                if step_bytes and unfused else None),
+                    "pmc_lib": lib_hash() if fams else None,
                     "depthwise_gbs": dw[0]["gbs"] if dw else None,
                     "depthwise_frac": dw[0]["gbs"] / HBM_PEAK_GBS if dw else None}
         if args.breakdown:
             for r in rows:
                 sys.stderr.write("{kernel:28s} n={launches:5d} {ms:9.3f} ms {gbs:9.1f} GB/s\n".format(**r))
+            for fam_name, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+                sys.stderr.write("family {:26s} n={:5d} {:9.3f} ms {:9.1f} GB/s\n".format(
+                    fam_name, g["launches"], g["ms"], g["bytes"] / 1e6 / g["ms"] if g["ms"] > 0 else 0.0))
             if args.shapes:
                 by_shape = {}
-                for name, (n, ms, recs) in summary.items():
-                    for t, a in recs:
-                        key = (name,) + tuple(v for v in a if isinstance(v, (int, float)) and abs(v) < (1 << 31))
-                        ent = by_shape.setdefault(key, [0, 0.0, 0])
-                        ent[0] += 1
-                        ent[1] += t
-                        ent[2] += algorithmic_bytes(name, a)
-                top = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[: args.shapes]
-                for key, (n, ms, nb) in top:
+                for lname, a, t in launches:
+                    key = (lname,) + tuple(v for v in a if isinstance(v, (int, float)) and abs(v) < (1 << 31))
+                    ent = by_shape.setdefault(key, [0, 0.0, 0])
+                    ent[0] += 1
+                    ent[1] += t
+                    ent[2] += algorithmic_bytes(lname, a)
+                top_shapes = sorted(by_shape.items(), key=lambda kv: -kv[1][1])[: args.shapes]
+                for key, (n, ms, nb) in top_shapes:
                     sys.stderr.write("{:9.3f} ms n={:3d} {:8.1f} GB/s  {} {}\n".format(
                         ms, n, nb / 1e6 / ms if ms > 0 else 0.0, key[0], list(key[1:])))
     if world > 1:
@@ -448,11 +556,26 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "headline":
         cpu = cpu_baseline(args.height, args.width)
+        # the GPU's inference forward at the same 1x3xHxW, beside the CPU's fwd_only figure
+        segmenter.eval()
+        with torch.no_grad():
+            one = image[:1].contiguous(memory_format=torch.channels_last)
+            for _ in range(3):
+                segmenter(one)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                segmenter(one)
+            torch.cuda.synchronize()
+            cpu["gpu_fwd_only_images_per_sec"] = 10.0 / (time.perf_counter() - t0)
+        segmenter.train()
 
     if rank == 0:
         imgs = args.batch * world * args.steps
         out = {
-            "metric": "images/sec (fwd+bwd+optimizer step) {} {}x{} bs={}/GPU".format(
+            "metric": "images/sec ({}) {} {}x{} bs={}/GPU".format(
+                "decoder-only fwd+bwd+optimizer step on cached encoder features" if args.workload == "task0"
+                else "fwd+bwd+optimizer step",
                 "WACV arch0" if args.workload == "headline" else args.workload, args.width, args.height,
                 args.batch),
             "value": imgs / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -465,7 +588,8 @@ def main():
                                        args.workload, wl[6], args.batch, args.height, args.width),
                        "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
                        "loss": loss_value, "reward": reward,
-                       "launch": ("host", "hipGraph(fwd+loss+bwd)", "hipGraph(whole step)")[args.graph]},
+                       "launch": ("host", "hipGraph(fwd+loss+bwd)", "hipGraph(whole step)" if args.workload != "task0"
+                                  else "hipGraph(gather+fwd+loss+bwd), chosen by engine.graphed.auto_graph")[args.graph]},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if cpu:

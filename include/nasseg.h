@@ -182,6 +182,10 @@ int nasseg_chan_copy(const float* x, int64_t ldx, int xoff, float* y, int64_t ld
                      const float* mref, int64_t ldm, int moff, int64_t P, int C, int act, int mact,
                      void* stream);
 int nasseg_chan_fold(const float* dy, float* dx, int64_t P, int C, int rep, void* stream);
+/* dst[i] = src[idx[i]], rows of row_bytes bytes, idx an int64 DEVICE array clamped to [0, n_src):
+ * the batch of the task0 feature cache (Xy_train[k][indices], src/engine/trainer.py:128-137) */
+int nasseg_gather_rows(const void* src, const int64_t* idx, void* dst, int n, int64_t row_bytes,
+                       int64_t n_src, void* stream);
 
 /* ---- pooling: Pool (layer_factory.py:161-178); mode 0 max, 1 avg ------------- */
 int nasseg_pool_fwd(int mode, const float* x, float* y, uint8_t* idx, int B, int H, int W, int C,

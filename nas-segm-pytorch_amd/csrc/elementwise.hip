@@ -137,6 +137,20 @@ __global__ __launch_bounds__(256) void chan_fold_kernel(const act_t* __restrict_
   }
 }
 
+// dst[i] = src[idx[i]] for rows of `row_bytes` bytes (a multiple of V): the per-step batch of the
+// task0 feature cache, gathered on the device (the reference indexes the cache with a shuffled
+// index array, src/engine/trainer.py:128-137)
+template <typename V>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const V* __restrict__ src, const int64_t* __restrict__ idx,
+                                                          V* __restrict__ dst, int64_t per_row, int64_t n_src) {
+  const int64_t row = blockIdx.y;
+  int64_t s = idx[row];
+  s = s < 0 ? 0 : (s >= n_src ? n_src - 1 : s);  // (never out of the cache, whatever the index says)
+  const V* in = src + s * per_row;
+  V* out = dst + row * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_row; i += (int64_t)gridDim.x * 256) out[i] = in[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,5 +226,31 @@ int NASSEG_FN(chan_fold)(const act_t* dy, act_t* dx, int64_t P, int C, int rep, 
   NASSEG_LAUNCH_CHECK("chan_fold");
   return NASSEG_OK;
 }
+
+#if NASSEG_FP32_ONLY
+// dst[i][:] = src[idx[i]][:], i < n: rows of row_bytes bytes (feature maps of one sample, fp32 or
+// bf16, or its int64 label map); idx on the device, clamped to [0, n_src)
+int nasseg_gather_rows(const void* src, const int64_t* idx, void* dst, int n, int64_t row_bytes, int64_t n_src,
+                       void* stream) {
+  NASSEG_REQUIRE(src && idx && dst && n >= 0 && row_bytes > 0 && n_src > 0 && n <= 65535,
+                 "gather_rows: bad arguments");
+  if (n == 0) return NASSEG_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool a16 = row_bytes % 16 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+  const bool a4 = row_bytes % 4 == 0 && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
+  const int64_t per = a16 ? row_bytes / 16 : (a4 ? row_bytes / 4 : row_bytes);
+  int64_t gx = (per + 255) / 256;
+  if (gx > 1024) gx = 1024;
+  const dim3 grid((unsigned)gx, (unsigned)n);
+  if (a16)
+    hipLaunchKernelGGL(gather_rows_kernel<float4>, grid, dim3(256), 0, s, (const float4*)src, idx, (float4*)dst, per, n_src);
+  else if (a4)
+    hipLaunchKernelGGL(gather_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)src, idx, (float*)dst, per, n_src);
+  else
+    hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, grid, dim3(256), 0, s, (const uint8_t*)src, idx, (uint8_t*)dst, per, n_src);
+  NASSEG_LAUNCH_CHECK("gather_rows");
+  return NASSEG_OK;
+}
+#endif  // NASSEG_FP32_ONLY
 
 }  // extern "C"

@@ -1,28 +1,54 @@
-"""Training step replayed from a hipGraph.
+"""Training steps replayed from a hipGraph.
 
 A sampled candidate issues 700-1500 small launches per step (many of them at
 11x11 ... 81x81 in the CVPR cells); issued one by one from Python the host, not
-the GPU, sets the step time at 321x321.  The whole forward + loss + backward of
-``segmenter_step`` (engine/trainer.py; reference src/engine/trainer.py:229-257)
-touches nothing on the host - every nasseg entry point takes device pointers and
-the current stream, allocates nothing and keeps BatchNorm's ``num_batches_tracked``
-on the device - so it is captured ONCE per candidate into a hipGraph
-(``torch.cuda.CUDAGraph`` is hipGraph on ROCm) and replayed with one launch per
-step.  What stays outside the graph is what genuinely needs the host or the
-network: copying the next batch into the static input buffers, the RCCL gradient
-all-reduce, and (unless ``capture_optimisers``) clipping + optimiser steps.
+the GPU, sets the step time up to 713x713.  The whole forward + loss + backward of
+``segmenter_step`` / of a decoder-only task0 step (engine/trainer.py; reference
+src/engine/trainer.py:128-160,229-257) touches nothing on the host - every nasseg
+entry point takes device pointers and the current stream, allocates nothing and keeps
+BatchNorm's ``num_batches_tracked`` on the device - so it is captured ONCE per
+candidate into a hipGraph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm) and replayed
+with one launch per step.  What stays outside the graph is what genuinely needs the
+host or the network: copying the next batch (or the next batch's cache indices) into
+the static input buffers, the RCCL gradient all-reduce, and (unless
+``capture_optimisers``) clipping + optimiser steps.
 
 Gradients are cleared (``grad = None``) before the capture, so backward writes them as
 fresh tensors of the graph's private pool: every replay refills the same addresses and no
 accumulation kernels are recorded.  When data parallel they are packed into one flat fp32
 bucket (one multi-tensor copy) and all-reduced with one collective after the replay.
+
+``train_segmenter`` / ``train_task0`` use these steppers by themselves where they win
+(``auto_graph``): one process (or independent candidates per rank), at most
+``AUTO_GRAPH_MAX_PIXELS`` image pixels per step - above that the step is GPU-bound and a
+replay runs at the speed of host launches (measured: 4x1024x2048 195.9 eager / 195.7 replayed
+images/s, 8x713x713 467 / 610, 8x480x640 445 / 590, 16x321x321 682 / 1062).
 """
+import logging
+import os
+
 import torch
 import torch.distributed as dist
 from torch import nn
 
 from .. import functional as F
-from .trainer import _clip_and_step, _inner
+from .trainer_common import clip_and_step, inner
+
+logger = logging.getLogger(__name__)
+
+# NASSEG_GRAPH: "auto" (default) | "0" (always launch from the host) | "1" (always replay)
+AUTO_GRAPH_MAX_PIXELS = 6 << 20
+
+
+def auto_graph(segmenter, n_pixels):
+    """Should the engine replay this candidate's steps from a hipGraph?  n_pixels = B*H*W of the
+    images one step consumes."""
+    mode = os.environ.get("NASSEG_GRAPH", "auto")
+    if mode == "0":
+        return False
+    if getattr(segmenter, "world_size", 1) > 1:
+        return False  # (data parallel: host launches - see DESIGN.md section 5)
+    return mode == "1" or n_pixels <= AUTO_GRAPH_MAX_PIXELS
 
 
 def _capturable(optim):
@@ -36,37 +62,20 @@ def _capturable(optim):
     return all(bool(g.get("capturable", False)) for g in optim.param_groups)
 
 
-class GraphedSegmenterStep(object):
-    """``segmenter_step`` with forward/loss/backward replayed from a hipGraph.
+class _GraphedStep(object):
+    """Capture / replay machinery shared by the two steppers.  A subclass provides
+    ``_forward_loss()`` (device tensors of ``self`` in, device scalar out), the modules whose
+    parameters train (``self._trained``) and the clip / optimiser groups (``self.groups``)."""
 
-    step(image, target) -> device loss (a static tensor, valid until the next step).
-    Shapes are fixed at construction (a new candidate or a new crop size needs a new
-    object - the reference rebuilds the segmenter per candidate anyway).
-    """
-
-    def __init__(self, segmenter, image, target, optim_enc, optim_dec, ignore_index=255,
-                 enc_grad_clip=0.0, dec_grad_clip=0.0, aux_weight=-1, capture_optimisers=False,
-                 warmup=2, loss_fn=None):
-        """loss_fn(output, target) -> scalar replaces the softmax/NLL (+ aux heads) of the
-        segmentation step, e.g. ``F.berhu_loss`` for a depth head; it must be capturable (device
-        tensors in, device scalar out, no host synchronisation)."""
+    def _init_common(self, segmenter, capture_optimisers, optimisers, warmup):
         self.segmenter = segmenter
-        self.model = _inner(segmenter)
-        self.optim_enc, self.optim_dec = optim_enc, optim_dec
-        self.ignore_index = ignore_index
-        self.aux_weight = aux_weight
-        self.loss_fn = loss_fn
+        self.model = inner(segmenter)
         self.world = int(getattr(segmenter, "world_size", 1))
-        self.groups = [
-            (list(self.model.encoder.parameters()), enc_grad_clip, optim_enc),
-            (list(self.model.decoder.parameters()), dec_grad_clip, optim_dec),
-        ]
         self.capture_optimisers = bool(capture_optimisers and self.world == 1
-                                       and _capturable(optim_enc) and _capturable(optim_dec))
-        self.image = image.detach().clone(memory_format=torch.channels_last)
-        self.target = target.detach().clone()
-        self.flat = self._views = self._used = None
-        self._params = list(self.model.parameters())
+                                       and all(_capturable(o) for o in optimisers))
+        self._optimisers = [o for o in optimisers if o is not None]
+        self.flat = self._views = None
+        self._params = [p for m in self._trained for p in m.parameters()]
         self._pack_memo = F.PackMemo()  # (owns the packed-weight buffers the graph reads)
         # A capture that fails on ONE rank (HIP out of memory, say) must fail on all of them: the
         # others would otherwise wait for it in the first gradient all-reduce.
@@ -76,10 +85,10 @@ class GraphedSegmenterStep(object):
         except RuntimeError as e:
             error = e
         if self.world > 1:
-            flag = torch.tensor([1.0 if error is not None else 0.0], device=self.image.device)
+            flag = torch.tensor([1.0 if error is not None else 0.0], device=self._params[0].device)
             dist.all_reduce(flag, group=getattr(segmenter, "process_group", None))
             if error is None and float(flag) > 0:
-                error = RuntimeError("GraphedSegmenterStep: the capture failed on a peer rank")
+                error = RuntimeError("graphed step: the capture failed on a peer rank")
         if error is not None:
             raise error
 
@@ -88,23 +97,11 @@ class GraphedSegmenterStep(object):
         for p in self._params:
             p.grad = None
         with F.packed_once(self._pack_memo):  # (one re-pack launch for all chains, recorded too)
-            output = self.segmenter(self.image)
-            aux_outs = []
-            if isinstance(output, tuple):
-                output, aux_outs = output
-            if self.loss_fn is not None:
-                loss = self.loss_fn(output, self.target)
-            else:
-                target = F.nearest_label_resize(self.target, output.size()[2:])
-                loss = F.log_softmax_nll(output, target, self.ignore_index)
-                if self.aux_weight > 0:
-                    for aux_out in aux_outs:
-                        aux_out = F.bilinear_resize(aux_out, target.size()[1:])
-                        loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
+            loss = self._forward_loss()
             with F.deferred_wgrad(params=self._params):  # (gradients were cleared above)
                 loss.backward()
         if with_optimisers:
-            _clip_and_step(self.groups)
+            clip_and_step(self.groups)
         return loss.detach()
 
     def _bn_buffers(self):
@@ -131,8 +128,8 @@ class GraphedSegmenterStep(object):
                 # optimiser state was created lazily by the warm-up: back to "never stepped"
                 for p, s in zip(self.model.parameters(), saved_params):
                     p.copy_(s)
-                for optim in (self.optim_enc, self.optim_dec):
-                    for st in (optim.state.values() if optim is not None else ()):
+                for optim in self._optimisers:
+                    for st in optim.state.values():
                         for v in st.values():
                             if torch.is_tensor(v):
                                 v.zero_()
@@ -143,7 +140,7 @@ class GraphedSegmenterStep(object):
             self.loss = self._fwd_bwd(self.capture_optimisers)
         # capturing executes nothing: state is exactly as restored above.  The gradients the
         # capture left in ``param.grad`` are the static tensors every replay refills.
-        self._static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
+        self._static_grads = [(p, p.grad) for p in self._params if p.grad is not None]
         if self.world > 1:
             used = [p for p, _ in self._static_grads]
             self.flat = torch.zeros(sum(p.numel() for p in used), device=used[0].device,
@@ -161,19 +158,119 @@ class GraphedSegmenterStep(object):
         for (p, _), v in zip(self._static_grads, self._views):
             p.grad = v
 
-    # -- per step ----------------------------------------------------------------------
-    def step(self, image=None, target=None):
-        if image is not None and image.data_ptr() != self.image.data_ptr():
-            self.image.copy_(image, non_blocking=True)
-        if target is not None and target.data_ptr() != self.target.data_ptr():
-            self.target.copy_(target, non_blocking=True)
+    def _replay(self):
         self.graph.replay()
         for p, g in self._static_grads:  # (an eager step in between may have re-pointed them)
             p.grad = g
         if not self.capture_optimisers:
             if self.world > 1:
                 self._all_reduce()
-            _clip_and_step(self.groups)
+            clip_and_step(self.groups)
         return self.loss
+
+
+class GraphedSegmenterStep(_GraphedStep):
+    """``segmenter_step`` with forward/loss/backward replayed from a hipGraph.
+
+    step(image, target) -> device loss (a static tensor, valid until the next step).
+    Shapes are fixed at construction (a new candidate or a new crop size needs a new
+    object - the reference rebuilds the segmenter per candidate anyway).
+    """
+
+    def __init__(self, segmenter, image, target, optim_enc, optim_dec, ignore_index=255,
+                 enc_grad_clip=0.0, dec_grad_clip=0.0, aux_weight=-1, capture_optimisers=False,
+                 warmup=2, loss_fn=None):
+        """loss_fn(output, target) -> scalar replaces the softmax/NLL (+ aux heads) of the
+        segmentation step, e.g. ``F.berhu_loss`` for a depth head; it must be capturable (device
+        tensors in, device scalar out, no host synchronisation)."""
+        model = inner(segmenter)
+        self.optim_enc, self.optim_dec = optim_enc, optim_dec
+        self.ignore_index = ignore_index
+        self.aux_weight = aux_weight
+        self.loss_fn = loss_fn
+        self._trained = [model.encoder, model.decoder]
+        self.groups = [
+            (list(model.encoder.parameters()), enc_grad_clip, optim_enc),
+            (list(model.decoder.parameters()), dec_grad_clip, optim_dec),
+        ]
+        self.image = image.detach().clone(memory_format=torch.channels_last)
+        self.target = target.detach().clone()
+        self._init_common(segmenter, capture_optimisers, (optim_enc, optim_dec), warmup)
+
+    def _forward_loss(self):
+        output = self.segmenter(self.image)
+        aux_outs = []
+        if isinstance(output, tuple):
+            output, aux_outs = output
+        if self.loss_fn is not None:
+            return self.loss_fn(output, self.target)
+        target = F.nearest_label_resize(self.target, output.size()[2:])
+        loss = F.log_softmax_nll(output, target, self.ignore_index)
+        if self.aux_weight > 0:
+            for aux_out in aux_outs:
+                aux_out = F.bilinear_resize(aux_out, target.size()[1:])
+                loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
+        return loss
+
+    def matches(self, image, target):
+        return (tuple(image.shape) == tuple(self.image.shape) and image.dtype == self.image.dtype
+                and tuple(target.shape) == tuple(self.target.shape) and target.dtype == self.target.dtype)
+
+    def step(self, image=None, target=None):
+        if image is not None and image.data_ptr() != self.image.data_ptr():
+            self.image.copy_(image, non_blocking=True)
+        if target is not None and target.data_ptr() != self.target.data_ptr():
+            self.target.copy_(target, non_blocking=True)
+        return self._replay()
+
+    __call__ = step
+
+
+class GraphedTask0Step(_GraphedStep):
+    """A decoder-only step on the device-resident feature cache (``train_task0``), replayed from
+    a hipGraph: the batch is gathered from the cache by index INSIDE the graph
+    (nasseg_gather_rows), so a step costs the host one copy of ``batch_size`` indices and one
+    graph launch.
+
+    step(indices) -> device loss; ``indices``: int64 tensor / array of ``batch_size`` cache rows.
+    """
+
+    def __init__(self, Xy_train, segmenter, optim_dec, batch_size, ignore_index=255, dec_grad_clip=0.0,
+                 aux_weight=0, capture_optimisers=False, warmup=2):
+        model = inner(segmenter)
+        self.cache = Xy_train
+        self.feat_keys = [k for k in Xy_train.keys() if k not in ("y", "kd_y", "out_size")]
+        self.out_size = tuple(int(v) for v in Xy_train["out_size"])
+        self.optim_dec = optim_dec
+        self.ignore_index = ignore_index
+        self.aux_weight = aux_weight
+        self._trained = [model.decoder]
+        self.groups = [(list(model.decoder.parameters()), dec_grad_clip, optim_dec)]
+        self.decoder = model.decoder
+        self.index = torch.arange(batch_size, device=Xy_train["y"].device, dtype=torch.int64)
+        self._init_common(segmenter, capture_optimisers, (optim_dec,), warmup)
+
+    def _forward_loss(self):
+        feats = [F.gather_rows(self.cache[k], self.index) for k in self.feat_keys]
+        target = F.gather_rows(self.cache["y"], self.index)
+        output = self.decoder(feats)
+        aux_outs = []
+        if isinstance(output, tuple):
+            output, aux_outs = output
+        output = F.bilinear_resize(output, self.out_size)
+        loss = F.log_softmax_nll(output, target, self.ignore_index)
+        if self.aux_weight > 0:
+            for aux_out in aux_outs:
+                aux_out = F.bilinear_resize(aux_out, self.out_size)
+                loss = loss + F.log_softmax_nll(aux_out, target, self.ignore_index) * self.aux_weight
+        return loss
+
+    def step(self, indices):
+        idx = torch.as_tensor(indices, dtype=torch.int64)
+        if tuple(idx.shape) != tuple(self.index.shape):
+            raise F.NassegError("GraphedTask0Step: batches of {} indices (got {})".format(
+                self.index.numel(), tuple(idx.shape)))
+        self.index.copy_(idx, non_blocking=True)
+        return self._replay()
 
     __call__ = step

@@ -31,7 +31,7 @@ def build_candidate(config, ctrl_version="wacv", num_classes=19, agg_size=48, au
     Decoder = MicroDecoder if ctrl_version == "cvpr" else TemplateDecoder
     decoder = Decoder(inp_sizes=list(encoder.out_sizes), num_classes=num_classes, config=config,
                       agg_size=agg_size, aux_cell=aux_cell, repeats=repeats)
-    return RankParallel(Segmenter(encoder, decoder).to(device), broadcast=False)
+    return RankParallel(Segmenter(encoder, decoder).to(device), independent=True)
 
 
 def evaluate_candidate(config, train_batches, val_batches, ctrl_version="wacv", num_classes=19,

@@ -49,19 +49,25 @@ class RankParallel(nn.Module):
     confusion-matrix all-reduce of validation.
     """
 
-    def __init__(self, module, process_group=None, broadcast=True):
+    def __init__(self, module, process_group=None, broadcast=True, independent=False):
+        """independent: this rank trains a candidate of its OWN (BASELINE config 4: one sampled
+        architecture per GPU) - no parameter broadcast, no gradient or confusion-matrix
+        all-reduce, whatever the process group's size."""
         super(RankParallel, self).__init__()
         self.module = module
         self.process_group = process_group
+        self.independent = bool(independent)
         self._flat = None
         self._views = None
         self._plist = None
         self._status = None
-        if broadcast:
+        if broadcast and not independent:
             self.broadcast_parameters()
 
     @property
     def world_size(self):
+        if self.independent:
+            return 1
         if dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.process_group)
         return 1

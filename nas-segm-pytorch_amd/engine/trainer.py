@@ -20,12 +20,10 @@ from torch import nn
 from .. import functional as F
 from ..helpers.utils import AverageMeter, try_except
 from ..nn.modules import TREE_VERSION
+from .trainer_common import clip_and_step as _clip_and_step
+from .trainer_common import inner as _inner
 
 logger = logging.getLogger(__name__)
-
-
-def _inner(segmenter):
-    return segmenter.module if hasattr(segmenter, "module") else segmenter
 
 
 def _set_stage(loader, stage):
@@ -74,16 +72,6 @@ def _polyak_update(params, avg_param, decay):
             avg_p.mul_(decay).add_(p.data, alpha=1.0 - decay)
 
 
-def _clip_and_step(groups):
-    """groups: [(parameters, max_norm, optimiser)]"""
-    for params, max_norm, _ in groups:
-        if max_norm > 0:
-            nn.utils.clip_grad_norm_(params, max_norm)
-    for _, _, optim in groups:
-        if optim is not None:
-            optim.step()
-
-
 def _zero_grads(segmenter, optimisers):
     """every ``param.grad`` back to None (not zeros): deferred_wgrad relies on autograd ADOPTING
     the fresh gradient tensors of backward"""
@@ -107,39 +95,162 @@ def _loss_value(segmenter, loss):
     return loss.item()
 
 
+def _graphed():
+    from . import graphed  # (graphed imports this module's helpers)
+
+    return graphed
+
+
+def _bn_modes(module):
+    return tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+
+
+def _cached_stepper(owner, slot, key, build):
+    """one stepper per (owner, slot): rebuilt when the key - shapes, optimisers, module tree,
+    BatchNorm modes ... - changes; a capture that fails once is not attempted again for that key"""
+    ent = getattr(owner, slot, None)
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    try:
+        stepper = build()
+    except RuntimeError as e:  # e.g. HIP out of memory while capturing: launch from the host
+        logger.warning(" hipGraph capture failed (%s): launching from the host", e)
+        stepper = None
+    setattr(owner, slot, (key, stepper))
+    return stepper
+
+
+def _task0_stepper(Xy_train, segmenter, optim_dec, batch_size, ignore, dec_grad_clip, aux_weight, freeze_bn):
+    model = _inner(segmenter)
+    key = (TREE_VERSION[0], id(optim_dec), batch_size, ignore, dec_grad_clip, aux_weight, _bn_modes(model.decoder),
+           tuple((k, v.data_ptr(), tuple(v.shape)) for k, v in Xy_train.items() if k != "out_size"))
+    return _cached_stepper(model, "_nasseg_task0_stepper", key, lambda: _graphed().GraphedTask0Step(
+        Xy_train, segmenter, optim_dec, batch_size, ignore, dec_grad_clip, aux_weight))
+
+
+def _segmenter_stepper(segmenter, image, target, optim_enc, optim_dec, ignore, enc_grad_clip, dec_grad_clip,
+                       aux_weight):
+    model = _inner(segmenter)
+    key = (TREE_VERSION[0], id(optim_enc), id(optim_dec), tuple(image.shape), image.dtype, tuple(target.shape),
+           target.dtype, ignore, enc_grad_clip, dec_grad_clip, aux_weight, _bn_modes(model))
+    return _cached_stepper(model, "_nasseg_task1_stepper", key, lambda: _graphed().GraphedSegmenterStep(
+        segmenter, image, target, optim_enc, optim_dec, ignore, enc_grad_clip, dec_grad_clip, aux_weight))
+
+
 @try_except
 def populate_task0(segmenter, train_loader, kd_net, n_train, do_kd=False):
     """Run the encoder (eval, no grad, one image at a time) over ``n_train``
     samples and keep its feature maps, the nearest-resized labels and optionally
     the teacher's logits on the device.  Returns the cache dict
-    {0..S-1: (N,C,h,w), 'y': (N,h,w) int64, ['kd_y'], 'out_size': (h,w)}."""
-    cache = defaultdict(list)
+    {0..S-1: (N,C,h,w), 'y': (N,h,w) int64, ['kd_y'], 'out_size': (h,w)}.
+
+    The cache is DEVICE-RESIDENT and NHWC: every entry keeps the reference's (N, C, h, w) shape
+    and is stored channels_last, pre-allocated for ``n_train`` samples on the first batch and
+    filled in place by copy kernels (no list of slices, no torch.stack, no layout change), so
+    that a training step gathers its batch with one nasseg_gather_rows per entry.  Data
+    parallel, every rank caches the samples of ITS loader: the cache is sharded."""
+    cache = {}
     segmenter.eval()
     _set_stage(train_loader, "train")
     if hasattr(train_loader, "batch_sampler") and train_loader.batch_sampler is not None:
         train_loader.batch_sampler.batch_size = 1
     model = _inner(segmenter)
     device = _model_device(model)
+
+    def slot(key, like, seen, b):
+        """rows [seen, seen+b) of cache[key] (allocated on first use for n_train + b - 1 rows:
+        the loop below stops at the first batch that reaches n_train)"""
+        if key not in cache:
+            shape = (n_train + b - 1,) + tuple(like.shape[1:])
+            cache[key] = (torch.empty(shape, device=device, dtype=like.dtype, memory_format=torch.channels_last)
+                          if like.dim() == 4 else torch.empty(shape, device=device, dtype=like.dtype))
+        return cache[key][seen:seen + b]
+
+    def store(key, t, seen):
+        F.copy_into(slot(key, t, seen, t.shape[0]), t)
+
     with torch.no_grad():
         seen = 0
         for sample in train_loader:
             image = _to_device_image(sample["image"], device)
+            b = image.size(0)
             feats = model.encoder(image)
             for i, f in enumerate(feats):
-                cache[i].extend(f.unbind(0))
+                store(i, f, seen)
             size = feats[0].size()[2:]
-            cache["y"].extend(F.nearest_label_resize(_labels(sample["mask"], device), size).unbind(0))
+            labels = _labels(sample["mask"], device)
+            F.nearest_label_resize(labels, size, out=slot(
+                "y", torch.empty((1,) + tuple(size), dtype=torch.int64), seen, b))
             if do_kd:
-                cache["kd_y"].extend(F.bilinear_resize(kd_net(image), size).unbind(0))
-            seen += image.size(0)
+                store("kd_y", F.bilinear_resize(kd_net(image), size), seen)
+            seen += b
             if seen >= n_train:
-                cache["out_size"] = size
                 logger.info(" Populated Xy_train, N = {}".format(seen))
+                for k in list(cache):
+                    cache[k] = cache[k][:seen]
+                cache["out_size"] = size
                 break
-        for k, v in cache.items():
-            if k != "out_size":
-                cache[k] = torch.stack(v)
+        else:
+            for k in list(cache):  # (loader exhausted first - as in the reference, no 'out_size' then)
+                cache[k] = cache[k][:seen]
     return cache
+
+
+def make_task0_step(Xy_train, segmenter, optim_dec, batch_size, ignore_index=255, dec_grad_clip=0.0, aux_weight=0,
+                    freeze_bn=False, do_kd=False, kd_coeff=0.0, kd_crit=None):
+    """step(batch_idx) -> device loss: one decoder-only training step on the cache rows
+    ``batch_idx`` (a host array of ``batch_size`` indices).  Small batches are launch-bound, so the
+    step is replayed from a hipGraph where that wins (engine/graphed.py: auto_graph; the stepper
+    lives with the model for as long as cache, decoder, BatchNorm modes and optimiser stay the
+    same); otherwise - and always with a distillation term or data parallel - it is launched from
+    the host: gather the batch (one kernel per cache entry), decoder forward, bilinear resize to
+    ``out_size``, softmax/NLL (+ aux heads), backward, [all-reduce], clip, optimiser."""
+    decoder = _inner(segmenter).decoder
+    feat_keys = [k for k in Xy_train.keys() if k not in ("y", "kd_y", "out_size")]
+    out_size = tuple(Xy_train["out_size"])
+    device = Xy_train["y"].device
+    dec_params = list(decoder.parameters())
+    pack_memo = F.PackMemo()
+    n_pixels = batch_size * int(Xy_train[feat_keys[0]].shape[2]) * int(Xy_train[feat_keys[0]].shape[3]) * 16
+    if not do_kd and device.type == "cuda" and _graphed().auto_graph(segmenter, n_pixels):
+        stepper = _task0_stepper(Xy_train, segmenter, optim_dec, batch_size, ignore_index, dec_grad_clip,
+                                 aux_weight, freeze_bn)
+        if stepper is not None:
+            return stepper.step
+
+    def step(batch_idx):
+        idx = torch.as_tensor(batch_idx, dtype=torch.int64).to(device, non_blocking=True)
+        try:
+            with F.packed_once(pack_memo):  # (one weight re-pack launch per step)
+                feats = [F.gather_rows(Xy_train[k], idx) for k in feat_keys]
+                target = F.gather_rows(Xy_train["y"], idx)
+                output = decoder(feats)
+                aux_outs = []
+                if isinstance(output, tuple):
+                    output, aux_outs = output
+                output = F.bilinear_resize(output, out_size)
+                loss = F.log_softmax_nll(output, target, ignore_index)
+                if do_kd:
+                    loss = loss + kd_coeff * kd_crit(output, F.gather_rows(Xy_train["kd_y"], idx))
+                if aux_weight > 0:
+                    for aux_out in aux_outs:
+                        aux_out = F.bilinear_resize(aux_out, out_size)
+                        loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
+                _zero_grads(segmenter, (optim_dec,))
+                with F.deferred_wgrad(params=dec_params):
+                    loss.backward()
+        except RuntimeError:
+            if _distributed(segmenter):
+                segmenter.sync_gradients(failed=True)  # (the peers are waiting in this collective)
+            raise
+        if _distributed(segmenter):
+            # the feature cache is sharded: every rank steps on its own cached samples and the
+            # decoder gradients are averaged (the reference runs this stage on one GPU)
+            segmenter.sync_gradients()
+        _clip_and_step([(dec_params, dec_grad_clip, optim_dec)])
+        return loss
+
+    return step
 
 
 @try_except
@@ -156,44 +267,12 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
     decoder.train()
     if freeze_bn:
         _freeze_bn(decoder)
-    ignore = _ignore_index(segm_crit)
     np.random.shuffle(indices)
-    dec_params = list(decoder.parameters())
-    pack_memo = F.PackMemo()
-    feat_keys = [k for k in Xy_train.keys() if k not in ("y", "kd_y", "out_size")]
-    out_size = tuple(Xy_train["out_size"])
+    step = make_task0_step(Xy_train, segmenter, optim_dec, batch_size, _ignore_index(segm_crit), dec_grad_clip,
+                           aux_weight, freeze_bn, do_kd, kd_coeff, kd_crit)
     for i in range(n_passes):
         start = time.time()
-        idx = torch.as_tensor(indices[i * batch_size:(i + 1) * batch_size],
-                              device=Xy_train["y"].device)
-        feats = [Xy_train[k][idx] for k in feat_keys]
-        target = Xy_train["y"][idx]
-        try:
-            with F.packed_once(pack_memo):  # (one weight re-pack launch per step)
-                output = decoder(feats)
-                aux_outs = []
-                if isinstance(output, tuple):
-                    output, aux_outs = output
-                output = F.bilinear_resize(output, out_size)
-                loss = F.log_softmax_nll(output, target, ignore)
-                if do_kd:
-                    loss = loss + kd_coeff * kd_crit(output, Xy_train["kd_y"][idx])
-                if aux_weight > 0:
-                    for aux_out in aux_outs:
-                        aux_out = F.bilinear_resize(aux_out, out_size)
-                        loss = loss + F.log_softmax_nll(aux_out, target, ignore) * aux_weight
-                _zero_grads(segmenter, (optim_dec,))
-                with F.deferred_wgrad(params=dec_params):
-                    loss.backward()
-        except RuntimeError:
-            if _distributed(segmenter):
-                segmenter.sync_gradients(failed=True)  # (the peers are waiting in this collective)
-            raise
-        if _distributed(segmenter):
-            # the feature cache is sharded: every rank steps on its own cached samples and the
-            # decoder gradients are averaged (the reference runs this stage on one GPU)
-            segmenter.sync_gradients()
-        _clip_and_step([(dec_params, dec_grad_clip, optim_dec)])
+        loss = step(indices[i * batch_size:(i + 1) * batch_size])
         losses.update(_loss_value(segmenter, loss))
         batch_time.update(time.time() - start)
         if do_polyak:
@@ -272,8 +351,17 @@ def train_segmenter(segmenter, train_loader, optim_enc, optim_dec, epoch, segm_c
         start = time.time()
         image = _to_device_image(sample["image"], device)
         target = _labels(sample["mask"], device)
-        loss = segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore,
-                              enc_grad_clip, dec_grad_clip, aux_weight)
+        stepper = None
+        if device.type == "cuda" and _graphed().auto_graph(segmenter, image.shape[0] * image.shape[2] * image.shape[3]):
+            # launch-bound sizes: forward + loss + backward replayed from a hipGraph captured on
+            # this candidate's first batch (bit-identical to the eager step)
+            stepper = _segmenter_stepper(segmenter, image, target, optim_enc, optim_dec, ignore,
+                                         enc_grad_clip, dec_grad_clip, aux_weight)
+        if stepper is not None:
+            loss = stepper.step(image, target)
+        else:
+            loss = segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore,
+                                  enc_grad_clip, dec_grad_clip, aux_weight)
         if do_polyak:
             _polyak_update(segmenter.parameters(), avg_param, polyak_decay)
         losses.update(_loss_value(segmenter, loss))

@@ -1520,14 +1520,55 @@ def berhu_loss(pred, target):
     return _BerHu.apply(pred, target)
 
 
-def nearest_label_resize(target, size):
-    """F.interpolate(target[:, None].float(), size, mode='nearest').long()[:, 0]."""
+def nearest_label_resize(target, size, out=None):
+    """F.interpolate(target[:, None].float(), size, mode='nearest').long()[:, 0]; ``out``: a
+    contiguous int64 (B, Ho, Wo) tensor to write into (a slice of the task0 label cache)."""
     target, esz = _label_tensor(target)
     B, H, W = target.shape
     Ho, Wo = int(size[0]), int(size[1])
-    y = torch.empty((B, Ho, Wo), device=target.device, dtype=torch.int64)
-    lib.call("nasseg_nearest_label", ptr(target), esz, ptr(y), B, H, W, Ho, Wo, current_stream())
-    return y
+    if out is None:
+        out = torch.empty((B, Ho, Wo), device=target.device, dtype=torch.int64)
+    elif (tuple(out.shape) != (B, Ho, Wo) or out.dtype != torch.int64 or not out.is_contiguous()
+          or out.device != target.device):
+        raise NassegError("nearest_label_resize: bad output tensor")
+    lib.call("nasseg_nearest_label", ptr(target), esz, ptr(out), B, H, W, Ho, Wo, current_stream())
+    return out
+
+
+def copy_into(dst, src):
+    """dst[...] = src for two densely stored activations of one shape and dtype (a slice of the
+    task0 cache receiving an encoder output): one copy kernel on the current stream."""
+    require_device(dst, src)
+    if tuple(dst.shape) != tuple(src.shape) or dst.dtype != src.dtype:
+        raise NassegError("copy_into: shapes / dtypes differ")
+    src = src.contiguous(memory_format=torch.channels_last) if src.dim() == 4 else src.contiguous()
+    C = src.shape[1] if src.dim() == 4 else 0
+    if (src.dim() == 4 and C % 4 == 0 and src.dtype in (torch.float32, torch.bfloat16)
+            and dst.is_contiguous(memory_format=torch.channels_last)):
+        lib.call(_k("nasseg_chan_copy", src), ptr(src), C, 0, ptr(dst), C, 0, None, 0, 0,
+                 src.numel() // C, C, ACT_NONE, ACT_NONE, current_stream())
+    else:
+        dst.copy_(src)  # (3-channel or integer maps: a plain device copy)
+    return dst
+
+
+def gather_rows(src, idx, out=None):
+    """src[idx] along dim 0 for a densely stored tensor (NCHW-contiguous or channels_last: one
+    sample = one contiguous row) with an int64 DEVICE index: the batch of the task0 feature cache,
+    one copy kernel, no ATen indexing and no layout change (src/engine/trainer.py:128-137)."""
+    require_device(src, idx)
+    if idx.dtype != torch.int64 or idx.dim() != 1 or not idx.is_contiguous():
+        raise NassegError("gather_rows: the index must be a contiguous 1-D int64 tensor")
+    n = idx.shape[0]
+    cl = src.dim() == 4 and src.is_contiguous(memory_format=torch.channels_last)
+    if not (cl or src.is_contiguous()):
+        raise NassegError("gather_rows: the source must be stored densely")
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), device=src.device, dtype=src.dtype,
+                          memory_format=torch.channels_last if cl else torch.contiguous_format)
+    row_bytes = (src.numel() // max(src.shape[0], 1)) * src.element_size()
+    lib.call("nasseg_gather_rows", ptr(src), ptr(idx), ptr(out), n, row_bytes, src.shape[0], current_stream())
+    return out
 
 
 def argmax_confusion(logits, gt, n_classes, cm=None, out_size=None, return_preds=False):

@@ -182,8 +182,13 @@ def _torch_functional():
 
     from nas_segm_amd import functional as F
 
-    F.nearest_label_resize = lambda t, size: TF.interpolate(
-        t[:, None].float(), size=tuple(size), mode="nearest").long()[:, 0]
+    def nearest_label_resize(t, size, out=None):
+        y = TF.interpolate(t[:, None].float(), size=tuple(size), mode="nearest").long()[:, 0]
+        return y if out is None else out.copy_(y)
+
+    F.nearest_label_resize = nearest_label_resize
+    F.copy_into = lambda dst, src: dst.copy_(src)
+    F.gather_rows = lambda src, idx, out=None: src[idx]
     F.log_softmax_nll = lambda logits, target, ignore_index=255: TF.nll_loss(
         TF.log_softmax(logits, 1), target, ignore_index=ignore_index)
     F.bilinear_resize = lambda x, size: x if tuple(x.shape[2:]) == tuple(size) else TF.interpolate(

@@ -61,6 +61,9 @@ def test_engine_matches_reference_run(name, monkeypatch):
     from nas_segm_amd.engine.inference import validate
     from nas_segm_amd.engine.trainer import populate_task0, train_segmenter, train_task0
 
+    # (the per-call loss values are read on the host: steps launched from the host, not replayed
+    #  from a hipGraph - test_engine_auto_graph_equals_host_launches covers the replayed form)
+    monkeypatch.setenv("NASSEG_GRAPH", "0")
     rec = ENG_META[name]
     net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], rec["seed"])
     assert_checksums_close(checksums(net.state_dict()), rec["init_checksums"], what="init")
@@ -154,6 +157,65 @@ def test_engine_matches_reference_run(name, monkeypatch):
         elif ("decoder." + k) not in noise:
             check("task0 " + k, got0[k][1], sa, sens["task0_mass"][k])
     assert not bad, "{} of the reference run's numbers missed:\n{}".format(len(bad), "\n".join(bad[:40]))
+
+
+@pytest.mark.parametrize("name", sorted(ENG_META))
+def test_engine_auto_graph_equals_host_launches(name, monkeypatch):
+    """train_segmenter / populate_task0 / train_task0 pick hipGraph replay by themselves at these
+    sizes (engine.graphed.auto_graph): parameters, running statistics, the feature cache and the
+    reward afterwards are bit for bit those of the same calls launched from the host.  The cache
+    is stored NHWC (channels_last) with the reference's shapes."""
+    from nas_segm_amd.engine import RankParallel, graphed
+    from nas_segm_amd.engine.inference import validate
+    from nas_segm_amd.engine.trainer import populate_task0, train_segmenter, train_task0
+
+    rec = ENG_META[name]
+    batches = [{"image": torch.from_numpy(ENG_NPZ["{}/train/image/{}".format(name, i)]),
+                "mask": torch.from_numpy(ENG_NPZ["{}/train/mask/{}".format(name, i)])} for i in range(2)]
+    vb = [{"image": torch.from_numpy(ENG_NPZ["{}/val/image/{}".format(name, i)]),
+           "mask": torch.from_numpy(ENG_NPZ["{}/val/mask/{}".format(name, i)])} for i in range(2)]
+    made = []
+    for cls in ("GraphedSegmenterStep", "GraphedTask0Step"):
+        orig = getattr(graphed, cls)
+
+        def counted(*a, _orig=orig, _cls=cls, **k):
+            made.append(_cls)
+            return _orig(*a, **k)
+
+        monkeypatch.setattr(graphed, cls, counted)
+
+    def run(mode):
+        monkeypatch.setenv("NASSEG_GRAPH", mode)
+        del made[:]
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], rec["seed"])
+        segmenter = RankParallel(net.to(DEV))
+        oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        for epoch in range(2):
+            assert train_segmenter.__wrapped__(segmenter, Loader(batches), oe, od, epoch, _Crit(), False, 3.0, 3.0,
+                                               False, print_every=100, aux_weight=rec["aux_weight"]) is None
+        reward = validate.__wrapped__(segmenter, Loader(vb), 0, 0, num_classes=rec["classes"], print_every=100,
+                                      omit_classes=[0])
+        loader1 = Loader([{"image": b["image"][i:i + 1], "mask": b["mask"][i:i + 1]} for b in batches for i in range(2)])
+        Xy = populate_task0.__wrapped__(segmenter, loader1, None, 4, do_kd=False)
+        for k, v in Xy.items():
+            if k not in ("y", "out_size"):
+                assert v.dim() == 4 and v.shape[0] == 4 and v.is_contiguous(memory_format=torch.channels_last), k
+        od0 = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        for epoch in range(2):
+            np.random.seed(123 + epoch)
+            assert train_task0.__wrapped__(Xy, segmenter, od0, epoch, _Crit(), None, 2, False, False, 0.0, 3.0, False,
+                                           aux_weight=max(rec["aux_weight"], 0)) is None
+        return _cpu_sd(net), reward, {str(k): v.cpu() for k, v in Xy.items() if k != "out_size"}, list(made)
+
+    sd0, r0, c0, made0 = run("0")
+    sd1, r1, c1, made1 = run("auto")
+    assert made0 == [] and made1 == ["GraphedSegmenterStep", "GraphedTask0Step"], (made0, made1)
+    assert r0 == r1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    for k in c0:
+        assert torch.equal(c0[k], c1[k]), k
 
 
 def test_step_is_deterministic_run_to_run():

@@ -946,3 +946,23 @@ def test_registry_ops_with_and_without_the_fused_stage(name, stride, training):
         assert_close(a, b, 2e-4 * float(b.abs().max()) + 1e-7, 1e-4, "parameter gradient")
     for k in b0:
         assert_close(b1[k], b0[k], 1e-6, 1e-5, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gather_rows_is_an_index_select_without_a_layout_change(dtype):
+    """the task0 batch: cache[idx] for NHWC feature maps and int64 label maps, index on the device"""
+    Fm = F()
+    g = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, 11, (7,), generator=g).to(DEV)
+    feats = dev(rnd(11, 24, 9, 13, seed=1)).to(dtype)
+    out = Fm.gather_rows(feats, idx)
+    assert out.is_contiguous(memory_format=torch.channels_last) and out.dtype == dtype
+    assert torch.equal(out, feats[idx])
+    view = feats[:9]  # (a trimmed cache is a view of the allocation)
+    assert torch.equal(Fm.gather_rows(view, idx.clamp(max=8)), view[idx.clamp(max=8)])
+    labels = torch.randint(0, 255, (11, 9, 13), generator=g).to(DEV)
+    assert torch.equal(Fm.gather_rows(labels, idx), labels[idx])
+    odd = torch.arange(11 * 3, dtype=torch.uint8).view(11, 3).to(DEV)  # rows of 3 bytes
+    assert torch.equal(Fm.gather_rows(odd, idx), odd[idx])
+    with pytest.raises(RuntimeError):
+        Fm.gather_rows(feats, idx.int())

@@ -30,9 +30,17 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             fam[base][1] += float(r["Counter_Value"])
     res[c] = fam
 keys = sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]), key=lambda k: -(res["FETCH_SIZE"].get(k, [0, 0])[1]))
+import hashlib
+lib_hash = hashlib.sha256(open("nas-segm-pytorch_amd/libnasseg_hip.so", "rb").read()).hexdigest()[:16]
+STEPS = 3  # (bench.py --steps 2 --warmup 1)
+# HBM bytes of one step: every kernel of the run (2 x FETCH_SIZE: gfx950 counts half of wide reads) / steps
+step_bytes = sum(2.0 * res["FETCH_SIZE"].get(k, [0, 0.0])[1] + res["WRITE_SIZE"].get(k, [0, 0.0])[1]
+                 for k in keys) * 1024.0 / STEPS
 with open("gpurun_out/pmc_summary.txt", "w") as fo:
+    fo.write("# lib %s steps %d step_bytes %.0f  (bench.py uses this file only while the hash matches its "
+             "libnasseg_hip.so)\n" % (lib_hash, STEPS, step_bytes))
     fo.write("kernel family, launches, FETCH_SIZE KB/launch (raw), WRITE_SIZE KB/launch (raw)\n")
-    for k in keys[:30]:
+    for k in keys[:40]:
         nf, vf = res["FETCH_SIZE"].get(k, [0, 0.0]); nw, vw = res["WRITE_SIZE"].get(k, [0, 0.0])
         fo.write("%s, %d, %.1f, %.1f\n" % (k, max(nf, nw), vf / max(nf, 1), vw / max(nw, 1)))
 print(open("gpurun_out/pmc_summary.txt").read())
