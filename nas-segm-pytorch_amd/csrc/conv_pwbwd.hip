@@ -1,0 +1,306 @@
+// Backward of a POINTWISE convolution that is followed by a BatchNorm, in ONE kernel:
+// the second half of the BatchNorm backward (applied as g and z are loaded), the weight
+// gradient AND the input gradient.  fp32 / bf16 storage, NHWC, fp32 matrix cores, gfx950.
+//
+// Reference: autograd of Conv2d(K, N, 1) -> BatchNorm2d at src/nn/layer_factory.py:96-98,
+// 117-122 (conv_bn / conv_bn_relu / conv_1x1_bn_relu6), :139-152 (InvertedResidual's
+// expansion) and :243-255 (SepConv's pointwise stage).
+//
+// The two-kernel form (conv_wgrad_bn + conv_fwd as backward-data) writes
+//   dz = scale*(g' - sum(g')/M - xhat*sum(g'*xhat)/M)
+// once and reads it back: 2*N*4 bytes per pixel, which for the expansions of the encoder
+// (16 -> 96 at 512x1024, 24 -> 144 at 256x512, 32 -> 192 at 128x256: N >> K) is most of
+// what the backward of the layer moves.  Here a workgroup walks a contiguous slab of
+// pixels 64 at a time: the dz tile (64 x N) and the input tile (64 x K, through the
+// forward's input prologue) are built in LDS, then
+//   dx[p][k]  = sum_n W[n][k] * dz[p][n]          (reduction over n: B operand = LDS rows)
+//   dW[n][k] += sum_p dz[p][n] * x[p][k]          (reduction over the tile's pixels)
+// both on v_mfma_f32_16x16x4_f32.  dz never reaches HBM.  Each wave owns 16 of the 64
+// pixels for both products and keeps the whole N x K accumulator (N*K <= 6144); waves are
+// combined through LDS in a fixed order, slabs by the deterministic second stage of
+// conv_wgrad.hip (nasseg_wgrad_finalize_many) - no float atomics.
+#include "conv_common.h"
+
+extern "C" int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* const* dw,
+                                          const int* dims, void* stream);
+
+namespace {
+
+constexpr int kPwTile = 64;         // pixels per tile (16 per wave)
+constexpr int kPwMaxTiles = 24;     // (n, k) accumulator tiles per wave
+
+struct PwArgs {
+  const act_t* x;
+  const act_t* g;
+  const act_t* z;
+  act_t* dx;
+  float* partial;   // [slab][N][K]
+  const float* wb;  // [K][N]: backward-data layout (pack mode 1)
+  const float* in_scale;
+  const float* in_shift;
+  int in_act;
+  const float* bn_scale;
+  const float* bn_shift;
+  const float* bn_mean;
+  const float* bn_invstd;
+  const float* bn_sums;  // [2][N]
+  int bn_train, bn_act;
+  float invM;
+  int K, N, KP, NP;  // channels, rounded up to multiples of 16
+  int M, pix_per_slab;
+};
+
+// NT / KT: 16-wide tiles of N / K held per wave (>= the actual counts: surplus tiles only cost
+// idle MFMAs); PRO: the forward read x through act(in_scale*x + in_shift)
+template <int NT, int KT, bool PRO>
+__global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
+  extern __shared__ float smem[];
+  const int LSN = a.NP + 4, LSK = a.KP + 4;
+  float* dzt = smem;                       // [64][LSN]
+  float* xt = dzt + kPwTile * LSN;         // [64][LSK]
+  float* cst = xt + kPwTile * LSK;         // ca | cb | cd | cs [NP each], psc | psh [KP each]
+  float* ca = cst;
+  float* cb = ca + a.NP;
+  float* cd = cb + a.NP;
+  float* cs = cd + a.NP;
+  float* psc = cs + a.NP;
+  float* psh = psc + a.KP;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int N = a.N, K = a.K;
+
+  // dz = ca*g' + cb*z + cd  ==  scale*(g' - sum(g')/M - xhat*sum(g'*xhat)/M), xhat = (z - mean)*invstd,
+  // g' = g * act'(scale*z + shift) when g arrives without its activation mask (bn_act != 0)
+  for (int n = tid; n < a.NP; n += 256) {
+    float va = 0.f, vb = 0.f, vd = 0.f, vs = 0.f;
+    if (n < N) {
+      const float sc = a.bn_scale[n];
+      va = sc;
+      vs = a.bn_act ? a.bn_shift[n] : 0.f;
+      if (a.bn_train) {
+        const float is = a.bn_invstd[n], mu = a.bn_mean[n];
+        const float s0 = a.bn_sums[n] * a.invM, s1 = a.bn_sums[N + n] * a.invM;
+        vb = -sc * is * s1;
+        vd = sc * (mu * is * s1 - s0);
+      }
+    }
+    ca[n] = va; cb[n] = vb; cd[n] = vd; cs[n] = vs;
+  }
+  for (int k = tid; k < a.KP; k += 256) {
+    psc[k] = (PRO && a.in_scale && k < K) ? a.in_scale[k] : 1.f;
+    psh[k] = (PRO && a.in_shift && k < K) ? a.in_shift[k] : 0.f;
+  }
+  const ActSel pact = act_sel(a.in_act);
+
+  f32x4 acc2[NT][KT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) acc2[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int p_begin = blockIdx.x * a.pix_per_slab;
+  int p_end = p_begin + a.pix_per_slab;
+  if (p_end > a.M) p_end = a.M;
+  const int n4 = a.NP >> 2, k4 = a.KP >> 2;
+  for (int t0 = p_begin; t0 < p_end; t0 += kPwTile) {
+    __syncthreads();  // (the previous tile's operands have been read; first pass: constants are in place)
+    // ---- the dz tile: all 256 threads, float4 along n -----------------------------------------
+    for (int it = tid; it < kPwTile * n4; it += 256) {
+      const int px = it / n4, n = (it - px * n4) * 4;
+      const int p = t0 + px;
+      const bool ok = p < p_end && n < N;
+      const int64_t off = (int64_t)(p < p_end ? p : p_end - 1) * N + (n < N ? n : 0);
+      float4 gv = lda4(a.g + off);
+      const float4 zv = lda4(a.z + off);
+      const float4 va = ld4(ca + n), vb = ld4(cb + n), vd = ld4(cd + n);
+      if (a.bn_act) {
+        const float4 y = fma4(zv, va, ld4(cs + n));
+        gv = make_float4(gv.x * act_mask(y.x, a.bn_act), gv.y * act_mask(y.y, a.bn_act),
+                         gv.z * act_mask(y.z, a.bn_act), gv.w * act_mask(y.w, a.bn_act));
+      }
+      float4 dz = fma4(gv, va, fma4(zv, vb, vd));
+#ifdef NASSEG_BF16
+      // (what the two-kernel form stores and reads back)
+      dz = make_float4(bf16_to_f32(f32_to_bf16(dz.x)), bf16_to_f32(f32_to_bf16(dz.y)),
+                       bf16_to_f32(f32_to_bf16(dz.z)), bf16_to_f32(f32_to_bf16(dz.w)));
+#endif
+      *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(dz, ok);
+    }
+    // ---- the input tile, through the forward's prologue ---------------------------------------
+    for (int it = tid; it < kPwTile * k4; it += 256) {
+      const int px = it / k4, k = (it - px * k4) * 4;
+      const int p = t0 + px;
+      const bool ok = p < p_end && k < K;
+      float4 xv = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
+      if (PRO) xv = act_apply4(fma4(xv, ld4(psc + k), ld4(psh + k)), pact);
+      *reinterpret_cast<float4*>(&xt[px * LSK + k]) = keep_if(xv, ok);
+    }
+    __syncthreads();
+    // ---- input gradient of this wave's 16 pixels: dx[p][k] = sum_n wb[k][n] * dz[p][n] -----------
+    {
+      f32x4 acc1[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) acc1[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* brow = dzt + (wave * 16 + j) * LSN;
+      for (int ns = 0; ns < (a.NP >> 4); ++ns) {
+        const int n = ns * 16 + kg * 4;
+        const float4 bv = *reinterpret_cast<const float4*>(brow + n);
+        float4 av[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const int k = kt * 16 + j;
+          av[kt] = keep_if(ld4(a.wb + (int64_t)(k < K ? k : 0) * N + (n < N ? n : 0)), k < K && n < N);
+        }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          acc1[kt] = mfma16(av[kt].x, bv.x, acc1[kt]);
+          acc1[kt] = mfma16(av[kt].y, bv.y, acc1[kt]);
+          acc1[kt] = mfma16(av[kt].z, bv.z, acc1[kt]);
+          acc1[kt] = mfma16(av[kt].w, bv.w, acc1[kt]);
+        }
+      }
+      const int p = t0 + wave * 16 + j;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const int k = kt * 16 + kg * 4;
+        if (p < p_end && k < K)
+          sta4(a.dx + (int64_t)p * K + k, make_float4(acc1[kt][0], acc1[kt][1], acc1[kt][2], acc1[kt][3]));
+      }
+    }
+    // ---- weight gradient: dW[n][k] += sum over this wave's 16 pixels of dz[p][n] * x[p][k] -------
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pl = wave * 16 + u * 4 + kg;  // (the MFMA's 4 reduction slots are 4 pixels)
+      float av[NT], bv[KT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) av[nt] = nt * 16 < a.NP ? dzt[pl * LSN + nt * 16 + j] : 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) bv[kt] = kt * 16 < a.KP ? xt[pl * LSK + kt * 16 + j] : 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) acc2[nt][kt] = mfma16(av[nt], bv[kt], acc2[nt][kt]);
+    }
+  }
+
+  // ---- waves -> workgroup partial, one (n, k) tile at a time, fixed order -------------------------
+  float* red = smem;  // [3][64][4]
+  float* pout = a.partial + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      __syncthreads();
+      if (wave > 0) *reinterpret_cast<f32x4*>(&red[((wave - 1) * 64 + lane) * 4]) = acc2[nt][kt];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc2[nt][kt][r] + red[(0 * 64 + lane) * 4 + r] + red[(1 * 64 + lane) * 4 + r] +
+                          red[(2 * 64 + lane) * 4 + r];
+          const int n = nt * 16 + 4 * kg + r, k = kt * 16 + j;  // D row <-> n, D col <-> k
+          if (n < N && k < K) pout[(int64_t)n * K + k] = v;
+        }
+      }
+    }
+}
+
+struct PwPlan {
+  int ok, nt, kt, nslab, pix_per_slab;
+};
+inline int pw_round_nt(int nt) {
+  const int allowed[] = {2, 3, 4, 6, 9, 12};
+  for (int v : allowed)
+    if (nt <= v) return v;
+  return 0;
+}
+inline PwPlan pw_plan(int64_t M, int N, int K) {
+  PwPlan p = {};
+  if (N % 4 || K % 4 || N <= 0 || K <= 0 || M <= 0 || M >= 2147483647LL) return p;
+  const int kt0 = cdiv(K, 16);
+  p.kt = kt0 <= 1 ? 1 : (kt0 <= 2 ? 2 : (kt0 <= 4 ? 4 : 0));
+  p.nt = pw_round_nt(cdiv(N, 16));
+  if (!p.kt || !p.nt || p.nt * p.kt > kPwMaxTiles) return p;
+  // Slabs: a power of two times 256 CUs - 4 workgroups per CU, 2 when the tiles take more than
+  // 40 KB of LDS - each at least 4 tiles long, partials <= 16 MiB.  Measured (tools/kbench_pwbwd.py,
+  // 16 -> 96 at 4x512x1024): 1024 slabs 457 us, 2048 457, 1490 532, 763 519, 512 572; 24 -> 144 at
+  // 4x256x512: 512 slabs 280 us, 1024 288, 745 366 - counts that leave the CUs with unequal numbers of
+  // resident workgroups cost 15-30 %.
+  const int64_t lds = (int64_t)kPwTile * (((N + 15) & ~15) + ((K + 15) & ~15) + 8) * 4;
+  int64_t s = lds > (40 << 10) ? 512 : 1024;
+  const int64_t cap = (int64_t)(16 << 20) / ((int64_t)N * K * 4);
+  while (s > 1 && (s > cap || s > M / (4 * kPwTile))) s >>= 1;
+  int64_t ppb = cdiv64(M, s);
+  ppb = (ppb + kPwTile - 1) / kPwTile * kPwTile;
+  p.pix_per_slab = (int)ppb;
+  p.nslab = (int)cdiv64(M, ppb);
+  p.ok = 1;
+  return p;
+}
+
+template <int NT, int KT>
+void pw_launch(const PwArgs& a, int nslab, size_t lds, bool pro, hipStream_t s) {
+  if (pro) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true>), dim3(nslab), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, false>), dim3(nslab), dim3(256), lds, s, a);
+}
+
+}  // namespace
+
+extern "C" {
+
+#if NASSEG_FP32_ONLY
+// number of partial rows [N][K] nasseg_conv_pw_bwd_bn leaves in its workspace (the workspace holds
+// that many * N * K floats); 0: the geometry has no fused kernel (N*K too large, channels not
+// multiples of 4) - use nasseg_conv_wgrad_bn + the backward-data call
+int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N) {
+  const PwPlan p = pw_plan((int64_t)B * H * W, N, K);
+  return p.ok ? p.nslab : 0;
+}
+#endif  // NASSEG_FP32_ONLY
+
+// Backward of y = BatchNorm(conv1x1(in_act(in_scale*x + in_shift))):
+//   g [P][N]: gradient w.r.t. the BatchNorm output - masked already (bn_act == 0) or to be masked with
+//   act'(scale*z + shift) here; z [P][N] the conv's raw output; sums[2][N] = {sum g', sum g'*xhat};
+//   wb: the weight packed for backward-data ([K][N], pack mode 1); P = B*H*W pixels.
+// Writes dx [P][K] = the gradient w.r.t. the conv's (prologue-transformed) input and the weight
+// gradient: dw (N,K,1,1) when given, else only the partial rows in ws (nasseg_conv_pw_bwd_slabs rows
+// of N*K floats) for nasseg_wgrad_finalize_many (taps 1, flat 0).
+int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, const float* wb, act_t* dx,
+                              float* dw, float* ws, const float* in_scale, const float* in_shift,
+                              int in_act, const float* bn_scale, const float* bn_shift,
+                              const float* bn_mean, const float* bn_invstd, const float* bn_sums,
+                              int bn_train, int bn_act, int B, int H, int W, int K, int N, void* stream) {
+  NASSEG_REQUIRE(x && g && z && wb && dx && ws && bn_scale, "conv_pw_bwd_bn: null tensor");
+  NASSEG_REQUIRE((!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
+                 "conv_pw_bwd_bn: missing BatchNorm tensors");
+  NASSEG_REQUIRE(B > 0 && H > 0 && W > 0, "conv_pw_bwd_bn: bad geometry");
+  const int64_t M = (int64_t)B * H * W;
+  const PwPlan p = pw_plan(M, N, K);
+  NASSEG_REQUIRE(p.ok, "conv_pw_bwd_bn: no fused kernel for K=%d N=%d", K, N);
+  PwArgs a = {};
+  a.x = x; a.g = g; a.z = z; a.dx = dx; a.partial = ws; a.wb = wb;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
+  a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+  a.bn_sums = bn_sums; a.bn_train = bn_train; a.bn_act = bn_act;
+  a.invM = (float)(1.0 / (double)M);
+  a.K = K; a.N = N; a.KP = (K + 15) & ~15; a.NP = (N + 15) & ~15;
+  a.M = (int)M; a.pix_per_slab = p.pix_per_slab;
+  const size_t lds = ((size_t)kPwTile * (a.NP + 4 + a.KP + 4) + 4 * a.NP + 2 * a.KP) * sizeof(float);
+  const bool pro = in_scale || in_shift || in_act;
+  hipStream_t s = (hipStream_t)stream;
+#define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_) pw_launch<NT_, KT_>(a, p.nslab, lds, pro, s); else
+  PW_CASE(2, 1) PW_CASE(3, 1) PW_CASE(4, 1) PW_CASE(6, 1) PW_CASE(9, 1) PW_CASE(12, 1)
+  PW_CASE(2, 2) PW_CASE(3, 2) PW_CASE(4, 2) PW_CASE(6, 2) PW_CASE(9, 2) PW_CASE(12, 2)
+  PW_CASE(2, 4) PW_CASE(3, 4) PW_CASE(4, 4) PW_CASE(6, 4)
+  return nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_pw_bwd_bn: no kernel for nt=%d kt=%d", p.nt, p.kt);
+#undef PW_CASE
+  NASSEG_LAUNCH_CHECK("conv_pw_bwd_kernel");
+  if (!dw) return NASSEG_OK;
+  const float* parts[1] = {ws};
+  float* outs[1] = {dw};
+  const int dims[5] = {p.nslab, 1, N, K, 0};
+  return nasseg_wgrad_finalize_many(1, parts, outs, dims, stream);
+}
+
+}  // extern "C"

@@ -157,6 +157,25 @@ def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
     return dwt
 
 
+def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops, in_act0, fused_in0):
+    """> 0: this op's whole backward (BatchNorm backward on load, weight gradient, input gradient)
+    runs as ONE kernel, nasseg_conv_pw_bwd_bn (the value is its number of partial rows): a
+    pointwise conv with a BatchNorm behind it, both gradients wanted, a map large enough to fill
+    the GPU with slabs, and NO BatchNorm / activation of the chain in front of it whose backward
+    the separate backward-data kernel would fuse into its epilogue."""
+    if not (FUSE_PW_BWD and kind == "dense" and need_dw and need_dx):
+        return 0
+    N, K, kh, kw = w.shape
+    if not (kh == 1 and kw == 1 and stride == 1 and pad == 0):
+        return 0
+    if (cur.numel() + z.numel()) * cur.element_size() <= _PW_BWD_MIN_BYTES:
+        return 0
+    if K % 4 == 0 and ((i > 0 and ops[i - 1][4]) or (i == 0 and in_act0 and fused_in0)):
+        return 0  # (bn_prev in _ConvChain.backward)
+    B, _, H, W = cur.shape
+    return lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N)
+
+
 def _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
     """Can this layer's weight-gradient kernel apply the BatchNorm backward on load
     (nasseg_conv_wgrad_bn / nasseg_dwconv_wgrad_bn)?  Large maps only: the launches of small ones
@@ -595,6 +614,11 @@ def _identity_vectors(like, n):
     return ent
 
 
+# backward of pointwise conv + BatchNorm as one kernel where the chain allows it (csrc/conv_pwbwd.hip),
+# for maps whose input + output exceed this many bytes (tools/kbench_pwbwd.py: 32 -> 32 at 4x128x256,
+# 33 MB, one kernel 21 us / two kernels 26 us; 64 -> 64 at 4x32x64, 4 MB, 35 / 19 us - too few slabs)
+FUSE_PW_BWD = os.environ.get("NASSEG_FUSE_PW_BWD", "1") != "0"
+_PW_BWD_MIN_BYTES = 24 << 20
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
 FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
 
@@ -840,7 +864,11 @@ class _ConvChain(torch.autograd.Function):
                 if not (need_dw or need_dx):
                     g = None
                     break
-                if need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
+                pw_bact = ACT_NONE if pre is not None else act
+                pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops, in_act0, fused_in0)
+                if pw_nsl > 0:
+                    dz = None  # (the one-kernel pointwise backward below applies the BatchNorm backward on load)
+                elif need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
                     # the weight-gradient kernel below computes dz while it loads g and z (masking
                     # g first if it did not arrive masked) and leaves it behind for the
                     # backward-data kernel
@@ -852,6 +880,7 @@ class _ConvChain(torch.autograd.Function):
                              ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
             else:
                 dz = g
+                pw_nsl = 0
                 if not (need_dw or need_dx):
                     g = None
                     break
@@ -885,6 +914,21 @@ class _ConvChain(torch.autograd.Function):
                     g, pre = _dw_backward_data(dz, wb, k, (Bc, K, H, W), stride, pad, dil, bn_prev)
             else:
                 _, _, kh, kw = w.shape
+                if pw_nsl > 0:
+                    # pointwise conv + BatchNorm, nothing to fuse towards the producer: BatchNorm
+                    # backward on load, weight gradient and input gradient in ONE kernel - dz is
+                    # neither written nor read back (csrc/conv_pwbwd.hip)
+                    nsl, bact_ = pw_nsl, pw_bact
+                    dwt = torch.empty_like(w)
+                    ws = _ws(cur, nsl * N * K)
+                    g_in = _new(cur, Bc, K, H, W)
+                    lib.call(_k("nasseg_conv_pw_bwd_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(wb), ptr(g_in),
+                             _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, ptr(scale),
+                             ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), bact_, Bc, H, W,
+                             K, N, s)
+                    grads[6 * i] = dwt
+                    g = g_in
+                    continue
                 if fused_bn is not None:
                     grads[6 * i], dz = _wgrad_bn("dense", cur, g, z, w, psc, psh, pact, fused_bn,
                                                  (Bc, H, W, K, N))

@@ -966,3 +966,102 @@ def test_gather_rows_is_an_index_select_without_a_layout_change(dtype):
     assert torch.equal(Fm.gather_rows(odd, idx), odd[idx])
     with pytest.raises(RuntimeError):
         Fm.gather_rows(feats, idx.int())
+
+
+# ---------------------------------------------------------------------------
+# backward of pointwise conv + BatchNorm in one kernel (csrc/conv_pwbwd.hip)
+@pytest.mark.parametrize("case", [
+    # B, H, W, K, N
+    (2, 13, 17, 16, 96), (2, 24, 20, 24, 144), (1, 31, 33, 32, 192), (2, 16, 16, 32, 32),
+    (3, 9, 11, 24, 64), (2, 12, 14, 64, 64), (2, 10, 10, 48, 48), (1, 70, 65, 8, 16), (2, 7, 5, 40, 80),
+], ids=lambda c: "B{}_{}x{}_K{}N{}".format(*c))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pro,bact,train", [(False, 0, True), (True, 1, True), (True, 2, False)])
+def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train):
+    """nasseg_conv_pw_bwd_bn against the two-kernel form it replaces (nasseg_conv_wgrad_bn, which
+    also writes dz, + nasseg_conv_fwd as backward-data over that dz): same dz arithmetic, MFMA sums
+    in another order - dx and dw agree to fp32 rounding of the sums."""
+    Fm = F()
+    lib, ptr, stream = Fm.lib, Fm.ptr, Fm.current_stream
+    B, H, W, K, N = case
+    nsl = lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N)
+    assert nsl > 0
+    M = B * H * W
+    x = dev(rnd(B, K, H, W, seed=1)).to(dtype)
+    g = dev(rnd(B, N, H, W, seed=2)).to(dtype)
+    z = dev(rnd(B, N, H, W, seed=3)).to(dtype)
+    w = dev(rnd(N, K, 1, 1, seed=4) * 0.3)
+    wb = torch.empty(N * K, device=DEV)
+    lib.call("nasseg_conv_pack_weight", ptr(w), ptr(wb), N, K, 1, 1, 1, stream())
+    psc = (rnd(K, seed=5) * 0.2 + 1).to(DEV) if pro else None
+    psh = (rnd(K, seed=6) * 0.2).to(DEV) if pro else None
+    pact = 2 if pro else 0
+    scale, shift = (rnd(N, seed=7) * 0.2 + 1).to(DEV), (rnd(N, seed=8) * 0.2).to(DEV)
+    mean, invstd = (rnd(N, seed=9) * 0.1).to(DEV), (rnd(N, seed=10).abs() + 0.5).to(DEV)
+    sums = (rnd(2 * N, seed=11) * 3).to(DEV)
+    name = lambda op: Fm._k(op, x)  # noqa: E731
+    # two kernels
+    dz = torch.empty_like(z)
+    dw_ref = torch.empty_like(w)
+    ws = torch.empty(lib.query("nasseg_conv_wgrad_workspace", B, H, W, N, K, 1, 1), device=DEV)
+    lib.call(name("nasseg_conv_wgrad_bn"), ptr(x), K, ptr(g), N, ptr(z), N, ptr(dz), N, ptr(dw_ref), ptr(ws),
+             ptr(psc), ptr(psh), pact, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact,
+             B, H, W, K, N, stream())
+    dx_ref = torch.empty_like(x)
+    lib.call(name("nasseg_conv_fwd"), ptr(dz), N, ptr(wb), ptr(dx_ref), K, None, None, 0, None, None, 0, None, 0,
+             B, H, W, N, H, W, K, 1, 1, 1, 0, 1, 1, None, stream())
+    # one kernel
+    dx = torch.full_like(x, float("nan"))
+    dw = torch.full_like(w, float("nan"))
+    ws2 = torch.full((nsl * N * K,), float("nan"), device=DEV)
+    lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), ptr(dw), ptr(ws2), ptr(psc),
+             ptr(psh), pact, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
+             K, N, stream())
+    rel = 2e-5 if dtype == torch.float32 else 1e-2  # (bf16: dx is stored rounded)
+    assert_close(dx, dx_ref, rel * float(dx_ref.float().abs().max()), rel, "dx")
+    assert_close(dw, dw_ref, 5e-5 * float(dw_ref.abs().max()) * max(1.0, (M / 4096.0) ** 0.5), 1e-4, "dw")
+    # dw == NULL: partial rows only, finalised by nasseg_wgrad_finalize_many
+    ws3 = torch.full_like(ws2, float("nan"))
+    lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws3), ptr(psc),
+             ptr(psh), pact, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
+             K, N, stream())
+    assert torch.equal(ws3.view(nsl, N, K).double().sum(0).float(), ws2.view(nsl, N, K).double().sum(0).float())
+
+
+def test_chain_backward_is_the_same_with_and_without_the_one_kernel_pointwise_backward(monkeypatch):
+    """SepConv / InvertedResidual / conv_bn_relu chains with the fused pointwise backward on and off
+    (weight-gradient thresholds lowered so that these small maps take the large-map paths)"""
+    from nas_segm_amd.nn.layer_factory import OPS, InvertedResidual, conv_bn_relu
+
+    Fm = F()
+    monkeypatch.setattr(Fm, "_GROUP_WGRAD_BYTES", 0)
+    monkeypatch.setattr(Fm, "_PW_BWD_MIN_BYTES", 0)
+    torch.manual_seed(5)
+    mods = [OPS["sep_conv_5x5"](32, 32, 1, True, 2), InvertedResidual(16, 24, 2, 6), InvertedResidual(24, 24, 1, 6),
+            conv_bn_relu(24, 64, 1, 1, 0), OPS["max_pool_3x3"](24, 48, 2, True)]
+    for mod in mods:
+        mod = mod.to(DEV).train()
+        cin = next(mod.parameters()).shape[1] if not hasattr(mod, "op") else 32
+        x0 = dev(rnd(2, cin, 29, 31, seed=2))
+        seen, res = [], []
+        orig = Fm.lib.call
+
+        def rec(fn, *a):
+            seen.append(fn)
+            return orig(fn, *a)
+
+        for fuse in (True, False):
+            monkeypatch.setattr(Fm, "FUSE_PW_BWD", fuse)
+            monkeypatch.setattr(Fm.lib, "call", rec)
+            del seen[:]
+            mod.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = mod(x)
+            y.backward(dev(rnd(*y.shape, seed=3)))
+            monkeypatch.setattr(Fm.lib, "call", orig)
+            assert ("nasseg_conv_pw_bwd_bn" in seen) == fuse, (type(mod).__name__, fuse, sorted(set(seen)))
+            res.append((x.grad.clone(), [p.grad.clone() for p in mod.parameters()]))
+        (dx1, g1), (dx0, g0) = res
+        assert_close(dx1, dx0, 1e-4 * float(dx0.abs().max()), 1e-4, "dx")
+        for a, b in zip(g1, g0):
+            assert_close(a, b, 2e-4 * float(b.abs().max()) + 1e-7, 2e-4, "parameter gradient")
