@@ -139,12 +139,14 @@ int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float
 /* The whole backward of a pointwise conv followed by BatchNorm in one kernel: BatchNorm backward on load (as
  * nasseg_conv_wgrad_bn), weight gradient AND input gradient; dz never reaches HBM.  wb = the weight packed for
  * backward-data ([K][N], pack mode 1); dx [B][H][W][K]; ws: nasseg_conv_pw_bwd_slabs(...) * N * K floats (0 slabs:
- * no fused kernel for these channel counts - N*K <= 6144, K <= 64); dw == NULL: partial rows only. */
+ * no fused kernel for these channel counts - N*K <= 6144 with K <= 64, or N <= 64 with K <= 384); dx_act != 0
+ * (= in_act, no input affine): dx additionally multiplied by in_act'(x); dw == NULL: partial rows only. */
 int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N);
 int nasseg_conv_pw_bwd_bn(const float* x, const float* g, const float* z, const float* wb, float* dx, float* dw,
-                          float* ws, const float* in_scale, const float* in_shift, int in_act, const float* bn_scale,
-                          const float* bn_shift, const float* bn_mean, const float* bn_invstd, const float* bn_sums,
-                          int bn_train, int bn_act, int B, int H, int W, int K, int N, void* stream);
+                          float* ws, const float* in_scale, const float* in_shift, int in_act, int dx_act,
+                          const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                          const float* bn_sums, int bn_train, int bn_act, int B, int H, int W, int K, int N,
+                          void* stream);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
@@ -248,7 +250,7 @@ int nasseg_compute_ius_accs(const int64_t* cm, int n, double* iu, int64_t* n_pix
 typedef uint16_t nasseg_bf16_t;
 int nasseg_bf16_conv_pw_bwd_bn(const nasseg_bf16_t* x, const nasseg_bf16_t* g, const nasseg_bf16_t* z, const float* wb,
                                nasseg_bf16_t* dx, float* dw, float* ws, const float* in_scale, const float* in_shift,
-                               int in_act, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                               int in_act, int dx_act, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act, int B, int H,
                                int W, int K, int N, void* stream);
 int nasseg_bf16_sepconv_fwd(const nasseg_bf16_t* x, const float* wdw, const float* wpw, nasseg_bf16_t* zdw,

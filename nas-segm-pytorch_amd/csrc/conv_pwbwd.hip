@@ -46,9 +46,18 @@ struct PwArgs {
   const float* bn_sums;  // [2][N]
   int bn_train, bn_act;
   float invM;
+  int dx_act;  // != 0: dx is multiplied by act'(x) - the forward applied this activation to x on load
   int K, N, KP, NP;  // channels, rounded up to multiples of 16
   int M, pix_per_slab;
 };
+
+// act'(x) recovered from the ACTIVATED value a = act(x) held in the input tile (no affine in
+// front of the activation): ReLU: a > 0; ReLU6: 0 < a < 6
+__device__ __forceinline__ float4 act_mask_of(float4 v, int act) {
+  const float hi = act == NASSEG_ACT_RELU6 ? 6.f : __builtin_inff();
+  return make_float4((v.x > 0.f && v.x < hi) ? 1.f : 0.f, (v.y > 0.f && v.y < hi) ? 1.f : 0.f,
+                     (v.z > 0.f && v.z < hi) ? 1.f : 0.f, (v.w > 0.f && v.w < hi) ? 1.f : 0.f);
+}
 
 // NT / KT: 16-wide tiles of N / K held per wave (>= the actual counts: surplus tiles only cost
 // idle MFMAs); PRO: the forward read x through act(in_scale*x + in_shift)
@@ -164,8 +173,10 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
         const int k = kt * 16 + kg * 4;
-        if (p < p_end && k < K)
-          sta4(a.dx + (int64_t)p * K + k, make_float4(acc1[kt][0], acc1[kt][1], acc1[kt][2], acc1[kt][3]));
+        float4 o = make_float4(acc1[kt][0], acc1[kt][1], acc1[kt][2], acc1[kt][3]);
+        if (a.dx_act && k < a.KP)
+          o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LSK + k]), a.dx_act));
+        if (p < p_end && k < K) sta4(a.dx + (int64_t)p * K + k, o);
       }
     }
     // ---- weight gradient: dW[n][k] += sum over this wave's 16 pixels of dz[p][n] * x[p][k] -------
@@ -206,8 +217,168 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
     }
 }
 
+// The same for WIDE inputs (K up to 384, N <= 64: pre_clf 224 -> 64, the CVPR decoder's adapt
+// convs 320 -> 64): the N x K accumulator does not fit one wave, so the four waves split N -
+// wave w owns output channels [16w, 16w+16) and walks ALL 64 pixels of a tile for the weight
+// gradient (no cross-wave sum at the end); the input gradient stays 16 pixels per wave.  The
+// input tile is staged 64 channels at a time (the dz tile stays), which keeps LDS at ~36 KB and
+// four workgroups per CU resident - with the whole 64 x K tile in LDS only one fits and nothing
+// hides the latencies (measured: 950 us against 690 us for the two kernels on 224 -> 64).
+// Status: at parity with the two-kernel form on 224 -> 64 at 4x256x512 (681 / 688 us; it is
+// issue-bound at ~32 % of the fp32 MFMA rate - unrolling the 16-wide steps with their weight
+// loads in flight together costs the registers of a resident wave and ends at 995 us) and slower
+// on smaller maps, so the host does not select it by default (functional._PW_BWD_WIDE).
+// KC: number of 64-channel chunks (>= ceil(K / 64)).
+constexpr int kPwChunk = 64;
+template <int KC, bool PRO>
+__global__ __launch_bounds__(256) void conv_pw_bwd_wide_kernel(PwArgs a) {
+  extern __shared__ float smem[];
+  const int LSN = a.NP + 4;
+  constexpr int LSK = kPwChunk + 4;
+  float* dzt = smem;                   // [64][LSN]
+  float* xt = dzt + kPwTile * LSN;     // [64][LSK]: one 64-channel chunk of the input tile
+  float* cst = xt + kPwTile * LSK;
+  float* ca = cst;
+  float* cb = ca + a.NP;
+  float* cd = cb + a.NP;
+  float* cs = cd + a.NP;
+  float* psc = cs + a.NP;              // [KC * 64]
+  float* psh = psc + KC * kPwChunk;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int N = a.N, K = a.K;
+  for (int n = tid; n < a.NP; n += 256) {
+    float va = 0.f, vb = 0.f, vd = 0.f, vs = 0.f;
+    if (n < N) {
+      const float sc = a.bn_scale[n];
+      va = sc;
+      vs = a.bn_act ? a.bn_shift[n] : 0.f;
+      if (a.bn_train) {
+        const float is = a.bn_invstd[n], mu = a.bn_mean[n];
+        const float s0 = a.bn_sums[n] * a.invM, s1 = a.bn_sums[N + n] * a.invM;
+        vb = -sc * is * s1;
+        vd = sc * (mu * is * s1 - s0);
+      }
+    }
+    ca[n] = va; cb[n] = vb; cd[n] = vd; cs[n] = vs;
+  }
+  for (int k = tid; k < KC * kPwChunk; k += 256) {
+    psc[k] = (PRO && a.in_scale && k < K) ? a.in_scale[k] : 1.f;
+    psh[k] = (PRO && a.in_shift && k < K) ? a.in_shift[k] : 0.f;
+  }
+  const ActSel pact = act_sel(a.in_act);
+  f32x4 acc2[KC][4];  // dW[16*wave + 4*kg + r][64*c + 16*q + j]
+#pragma unroll
+  for (int c = 0; c < KC; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc2[c][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int p_begin = blockIdx.x * a.pix_per_slab;
+  int p_end = p_begin + a.pix_per_slab;
+  if (p_end > a.M) p_end = a.M;
+  const int n4 = a.NP >> 2;
+  const bool own = wave * 16 < a.NP;  // (N = 48: the fourth wave has no output channels of its own)
+  for (int t0 = p_begin; t0 < p_end; t0 += kPwTile) {
+    __syncthreads();
+    for (int it = tid; it < kPwTile * n4; it += 256) {
+      const int px = it / n4, n = (it - px * n4) * 4;
+      const int p = t0 + px;
+      const bool ok = p < p_end && n < N;
+      const int64_t off = (int64_t)(p < p_end ? p : p_end - 1) * N + (n < N ? n : 0);
+      float4 gv = lda4(a.g + off);
+      const float4 zv = lda4(a.z + off);
+      const float4 va = ld4(ca + n), vb = ld4(cb + n), vd = ld4(cd + n);
+      if (a.bn_act) {
+        const float4 y = fma4(zv, va, ld4(cs + n));
+        gv = make_float4(gv.x * act_mask(y.x, a.bn_act), gv.y * act_mask(y.y, a.bn_act),
+                         gv.z * act_mask(y.z, a.bn_act), gv.w * act_mask(y.w, a.bn_act));
+      }
+      float4 dz = fma4(gv, va, fma4(zv, vb, vd));
+#ifdef NASSEG_BF16
+      dz = make_float4(bf16_to_f32(f32_to_bf16(dz.x)), bf16_to_f32(f32_to_bf16(dz.y)),
+                       bf16_to_f32(f32_to_bf16(dz.z)), bf16_to_f32(f32_to_bf16(dz.w)));
+#endif
+      *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(dz, ok);
+    }
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int kc = c * kPwChunk;
+      if (kc < a.KP) {  // (uniform)
+        if (c) __syncthreads();  // (the previous chunk's operands have been read)
+        for (int it = tid; it < kPwTile * (kPwChunk / 4); it += 256) {
+          const int px = it / (kPwChunk / 4), kl = (it - px * (kPwChunk / 4)) * 4;
+          const int k = kc + kl;
+          const int p = t0 + px;
+          const bool ok = p < p_end && k < K;
+          float4 xv = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
+          if (PRO) xv = act_apply4(fma4(xv, ld4(psc + k), ld4(psh + k)), pact);
+          *reinterpret_cast<float4*>(&xt[px * LSK + kl]) = keep_if(xv, ok);
+        }
+        __syncthreads();
+        // input gradient of this wave's 16 pixels, this chunk's 64 input channels
+        {
+          const float* brow = dzt + (wave * 16 + j) * LSN;
+          const int p = t0 + wave * 16 + j;
+          f32x4 acc1[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int ns = 0; ns < (a.NP >> 4); ++ns) {
+            const int n = ns * 16 + kg * 4;
+            const float4 bv = *reinterpret_cast<const float4*>(brow + n);
+            float4 av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int k = kc + q * 16 + j;
+              av[q] = keep_if(ld4(a.wb + (int64_t)(k < K ? k : 0) * N + (n < N ? n : 0)), k < K && n < N);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc1[q] = mfma16(av[q].x, bv.x, acc1[q]);
+              acc1[q] = mfma16(av[q].y, bv.y, acc1[q]);
+              acc1[q] = mfma16(av[q].z, bv.z, acc1[q]);
+              acc1[q] = mfma16(av[q].w, bv.w, acc1[q]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int kl = q * 16 + kg * 4;
+            float4 o = make_float4(acc1[q][0], acc1[q][1], acc1[q][2], acc1[q][3]);
+            if (a.dx_act)
+              o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LSK + kl]), a.dx_act));
+            if (p < p_end && kc + kl < K) sta4(a.dx + (int64_t)p * K + kc + kl, o);
+          }
+        }
+        // weight gradient rows of this wave: all 64 pixels of the tile, 4 per MFMA
+        if (own) {
+          for (int u = 0; u < kPwTile / 4; ++u) {
+            const int pl = u * 4 + kg;
+            const float av = dzt[pl * LSN + wave * 16 + j];
+            float bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = xt[pl * LSK + q * 16 + j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc2[c][q] = mfma16(av, bv[q], acc2[c][q]);
+          }
+        }
+      }
+    }
+  }
+  if (own) {
+    float* pout = a.partial + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+    for (int c = 0; c < KC; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = wave * 16 + 4 * kg + r, k = c * kPwChunk + q * 16 + j;
+          if (n < N && k < K) pout[(int64_t)n * K + k] = acc2[c][q][r];
+        }
+  }
+}
+
 struct PwPlan {
-  int ok, nt, kt, nslab, pix_per_slab;
+  int ok, nt, kt, nslab, pix_per_slab, wide;
 };
 inline int pw_round_nt(int nt) {
   const int allowed[] = {2, 3, 4, 6, 9, 12};
@@ -221,15 +392,21 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
   const int kt0 = cdiv(K, 16);
   p.kt = kt0 <= 1 ? 1 : (kt0 <= 2 ? 2 : (kt0 <= 4 ? 4 : 0));
   p.nt = pw_round_nt(cdiv(N, 16));
-  if (!p.kt || !p.nt || p.nt * p.kt > kPwMaxTiles) return p;
+  if (!p.kt || !p.nt || p.nt * p.kt > kPwMaxTiles) {
+    // wide inputs: the four waves split N (conv_pw_bwd_wide_kernel), K in 64-channel chunks
+    if (N > 64 || K > 384) return p;
+    p.wide = 1;
+    p.nt = cdiv(N, 16);
+    p.kt = cdiv(K, kPwChunk);  // chunks: 2 .. 6
+  }
   // Slabs: a power of two times 256 CUs - 4 workgroups per CU, 2 when the tiles take more than
   // 40 KB of LDS - each at least 4 tiles long, partials <= 16 MiB.  Measured (tools/kbench_pwbwd.py,
   // 16 -> 96 at 4x512x1024): 1024 slabs 457 us, 2048 457, 1490 532, 763 519, 512 572; 24 -> 144 at
   // 4x256x512: 512 slabs 280 us, 1024 288, 745 366 - counts that leave the CUs with unequal numbers of
   // resident workgroups cost 15-30 %.
-  const int64_t lds = (int64_t)kPwTile * (((N + 15) & ~15) + ((K + 15) & ~15) + 8) * 4;
+  const int64_t lds = (int64_t)kPwTile * (((N + 15) & ~15) + (p.wide ? kPwChunk : ((K + 15) & ~15)) + 8) * 4;
   int64_t s = lds > (40 << 10) ? 512 : 1024;
-  const int64_t cap = (int64_t)(16 << 20) / ((int64_t)N * K * 4);
+  const int64_t cap = (int64_t)((p.wide ? 64 : 16) << 20) / ((int64_t)N * K * 4);
   while (s > 1 && (s > cap || s > M / (4 * kPwTile))) s >>= 1;
   int64_t ppb = cdiv64(M, s);
   ppb = (ppb + kPwTile - 1) / kPwTile * kPwTile;
@@ -263,12 +440,14 @@ int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N) {
 //   g [P][N]: gradient w.r.t. the BatchNorm output - masked already (bn_act == 0) or to be masked with
 //   act'(scale*z + shift) here; z [P][N] the conv's raw output; sums[2][N] = {sum g', sum g'*xhat};
 //   wb: the weight packed for backward-data ([K][N], pack mode 1); P = B*H*W pixels.
+// dx_act != 0 (= in_act, with in_scale = in_shift = NULL): dx is multiplied by in_act'(x), i.e. it is
+// the gradient w.r.t. x itself (the ReLU that pre_clf applies to its input on load).
 // Writes dx [P][K] = the gradient w.r.t. the conv's (prologue-transformed) input and the weight
 // gradient: dw (N,K,1,1) when given, else only the partial rows in ws (nasseg_conv_pw_bwd_slabs rows
 // of N*K floats) for nasseg_wgrad_finalize_many (taps 1, flat 0).
 int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, const float* wb, act_t* dx,
                               float* dw, float* ws, const float* in_scale, const float* in_shift,
-                              int in_act, const float* bn_scale, const float* bn_shift,
+                              int in_act, int dx_act, const float* bn_scale, const float* bn_shift,
                               const float* bn_mean, const float* bn_invstd, const float* bn_sums,
                               int bn_train, int bn_act, int B, int H, int W, int K, int N, void* stream) {
   NASSEG_REQUIRE(x && g && z && wb && dx && ws && bn_scale, "conv_pw_bwd_bn: null tensor");
@@ -284,11 +463,34 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
   a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
   a.bn_sums = bn_sums; a.bn_train = bn_train; a.bn_act = bn_act;
   a.invM = (float)(1.0 / (double)M);
+  NASSEG_REQUIRE(!dx_act || (dx_act == in_act && !in_scale && !in_shift),
+                 "conv_pw_bwd_bn: dx can only be masked with the derivative of a bare input activation");
+  a.dx_act = dx_act;
   a.K = K; a.N = N; a.KP = (K + 15) & ~15; a.NP = (N + 15) & ~15;
   a.M = (int)M; a.pix_per_slab = p.pix_per_slab;
   const size_t lds = ((size_t)kPwTile * (a.NP + 4 + a.KP + 4) + 4 * a.NP + 2 * a.KP) * sizeof(float);
   const bool pro = in_scale || in_shift || in_act;
   hipStream_t s = (hipStream_t)stream;
+  if (p.wide) {
+    const size_t ldsw = ((size_t)kPwTile * (a.NP + 4 + kPwChunk + 4) + 4 * a.NP + 2 * p.kt * kPwChunk) * sizeof(float);
+#define PW_WIDE(KC_)                                                                                         \
+  do {                                                                                                       \
+    if (pro) hipLaunchKernelGGL((conv_pw_bwd_wide_kernel<KC_, true>), dim3(p.nslab), dim3(256), ldsw, s, a);  \
+    else hipLaunchKernelGGL((conv_pw_bwd_wide_kernel<KC_, false>), dim3(p.nslab), dim3(256), ldsw, s, a);     \
+  } while (0)
+    if (p.kt <= 2) PW_WIDE(2);
+    else if (p.kt == 3) PW_WIDE(3);
+    else if (p.kt == 4) PW_WIDE(4);
+    else if (p.kt == 5) PW_WIDE(5);
+    else PW_WIDE(6);
+#undef PW_WIDE
+    NASSEG_LAUNCH_CHECK("conv_pw_bwd_wide_kernel");
+    if (!dw) return NASSEG_OK;
+    const float* parts_w[1] = {ws};
+    float* outs_w[1] = {dw};
+    const int dims_w[5] = {p.nslab, 1, N, K, 0};
+    return nasseg_wgrad_finalize_many(1, parts_w, outs_w, dims_w, stream);
+  }
 #define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_) pw_launch<NT_, KT_>(a, p.nslab, lds, pro, s); else
   PW_CASE(2, 1) PW_CASE(3, 1) PW_CASE(4, 1) PW_CASE(6, 1) PW_CASE(9, 1) PW_CASE(12, 1)
   PW_CASE(2, 2) PW_CASE(3, 2) PW_CASE(4, 2) PW_CASE(6, 2) PW_CASE(9, 2) PW_CASE(12, 2)

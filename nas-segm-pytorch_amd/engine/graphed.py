@@ -24,6 +24,7 @@ bucket (one multi-tensor copy) and all-reduced with one collective after the rep
 replay runs at the speed of host launches (measured: 4x1024x2048 195.9 eager / 195.7 replayed
 images/s, 8x713x713 467 / 610, 8x480x640 445 / 590, 16x321x321 682 / 1062).
 """
+import gc
 import logging
 import os
 
@@ -91,6 +92,14 @@ class _GraphedStep(object):
                 error = RuntimeError("graphed step: the capture failed on a peer rank")
         if error is not None:
             raise error
+        # The modules were needed to RECORD the step; replaying needs parameters, optimisers and
+        # static tensors only.  Dropping them here means a stepper cached on its model (engine/
+        # trainer.py) forms no reference cycle: the candidate's graph and its memory pool go away
+        # with the candidate, by reference counting, not at some later garbage collection.
+        self._process_group = getattr(segmenter, "process_group", None)
+        self.segmenter = self.model = self._trained = None
+        if hasattr(self, "decoder"):
+            self.decoder = None
 
     # -- the captured region ---------------------------------------------------------
     def _fwd_bwd(self, with_optimisers):
@@ -135,9 +144,20 @@ class _GraphedStep(object):
                                 v.zero_()
             for b, s in zip(buffers, saved):
                 b.copy_(s)
+        # No garbage collection while the stream is capturing: a collected cycle may hold device
+        # tensors or another candidate's hipGraph, whose destruction inside a capture aborts the
+        # process (torch >= 2.9 no longer collects before a capture by itself).  Collect now,
+        # hold the collector off for the capture.
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._fwd_bwd(self.capture_optimisers)
+        gc.collect()
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._fwd_bwd(self.capture_optimisers)
+        finally:
+            if gc_was_enabled:
+                gc.enable()
         # capturing executes nothing: state is exactly as restored above.  The gradients the
         # capture left in ``param.grad`` are the static tensors every replay refills.
         self._static_grads = [(p, p.grad) for p in self._params if p.grad is not None]
@@ -152,8 +172,7 @@ class _GraphedStep(object):
 
     def _all_reduce(self):
         torch._foreach_copy_(self._views, [g for _, g in self._static_grads])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM,
-                        group=getattr(self.segmenter, "process_group", None))
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self._process_group)
         self.flat.div_(self.world)
         for (p, _), v in zip(self._static_grads, self._views):
             p.grad = v

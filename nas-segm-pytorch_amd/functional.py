@@ -157,12 +157,13 @@ def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
     return dwt
 
 
-def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops, in_act0, fused_in0):
+def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops):
     """> 0: this op's whole backward (BatchNorm backward on load, weight gradient, input gradient)
     runs as ONE kernel, nasseg_conv_pw_bwd_bn (the value is its number of partial rows): a
     pointwise conv with a BatchNorm behind it, both gradients wanted, a map large enough to fill
-    the GPU with slabs, and NO BatchNorm / activation of the chain in front of it whose backward
-    the separate backward-data kernel would fuse into its epilogue."""
+    the GPU with slabs, and NO BatchNorm of the chain in front of it whose backward the separate
+    backward-data kernel would fuse into its epilogue (an activation applied on load to the
+    chain's input - pre_clf's ReLU - is handled: the kernel masks dx with its derivative)."""
     if not (FUSE_PW_BWD and kind == "dense" and need_dw and need_dx):
         return 0
     N, K, kh, kw = w.shape
@@ -170,8 +171,10 @@ def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops, in_act
         return 0
     if (cur.numel() + z.numel()) * cur.element_size() <= _PW_BWD_MIN_BYTES:
         return 0
-    if K % 4 == 0 and ((i > 0 and ops[i - 1][4]) or (i == 0 and in_act0 and fused_in0)):
-        return 0  # (bn_prev in _ConvChain.backward)
+    if K % 4 == 0 and i > 0 and ops[i - 1][4]:
+        return 0  # (bn_prev in _ConvChain.backward: the producer's BatchNorm backward goes with backward-data)
+    if K > 64 and not _PW_BWD_WIDE:
+        return 0
     B, _, H, W = cur.shape
     return lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N)
 
@@ -619,6 +622,9 @@ def _identity_vectors(like, n):
 # 33 MB, one kernel 21 us / two kernels 26 us; 64 -> 64 at 4x32x64, 4 MB, 35 / 19 us - too few slabs)
 FUSE_PW_BWD = os.environ.get("NASSEG_FUSE_PW_BWD", "1") != "0"
 _PW_BWD_MIN_BYTES = 24 << 20
+# the wide-input variant (K > 64: the four waves split N) is only at parity with the two kernels
+# where it is best (224 -> 64 at 4x256x512: 681 / 688 us): not selected unless asked for
+_PW_BWD_WIDE = os.environ.get("NASSEG_PW_BWD_WIDE", "0") == "1"
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
 FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
 
@@ -838,6 +844,7 @@ class _ConvChain(torch.autograd.Function):
         grads = [None] * (6 * n_ops)
         dres = g if (has_res and ctx.needs_input_grad[2]) else None
         pre = None  # BatchNorm-backward partial rows of op i that came with g (fused dgrad epilogue)
+        masked_in0 = False  # dx already multiplied by in_act0' (one-kernel pointwise backward of op 0)
         for i in range(n_ops - 1, -1, -1):
             kind, stride, pad, dil, has_bn, act, training, momentum, eps = ops[i]
             cur, psc, psh, z, stats, w, wb = sv[7 * i:7 * i + 7]
@@ -865,7 +872,7 @@ class _ConvChain(torch.autograd.Function):
                     g = None
                     break
                 pw_bact = ACT_NONE if pre is not None else act
-                pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops, in_act0, fused_in0)
+                pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops)
                 if pw_nsl > 0:
                     dz = None  # (the one-kernel pointwise backward below applies the BatchNorm backward on load)
                 elif need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
@@ -922,12 +929,15 @@ class _ConvChain(torch.autograd.Function):
                     dwt = torch.empty_like(w)
                     ws = _ws(cur, nsl * N * K)
                     g_in = _new(cur, Bc, K, H, W)
+                    # (op 0 of a chain that applies an activation to its input on load: dx masked here)
+                    dx_act = pact if (i == 0 and in_act0 and psc is None and psh is None) else ACT_NONE
                     lib.call(_k("nasseg_conv_pw_bwd_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(wb), ptr(g_in),
-                             _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, ptr(scale),
-                             ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), bact_, Bc, H, W,
-                             K, N, s)
+                             _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, dx_act,
+                             ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), bact_,
+                             Bc, H, W, K, N, s)
                     grads[6 * i] = dwt
                     g = g_in
+                    masked_in0 = bool(dx_act)
                     continue
                 if fused_bn is not None:
                     grads[6 * i], dz = _wgrad_bn("dense", cur, g, z, w, psc, psh, pact, fused_bn,
@@ -952,7 +962,7 @@ class _ConvChain(torch.autograd.Function):
         dx = None
         if g is not None and ctx.needs_input_grad[1]:
             dx = g
-            if in_act0 and pre is None:
+            if in_act0 and pre is None and not masked_in0:
                 # the chain started with an activation applied on load and the backward-data
                 # kernel had no fused mask for this geometry
                 dx = _act_bwd(dx, sv[0], in_act0)

@@ -974,6 +974,8 @@ def test_gather_rows_is_an_index_select_without_a_layout_change(dtype):
     # B, H, W, K, N
     (2, 13, 17, 16, 96), (2, 24, 20, 24, 144), (1, 31, 33, 32, 192), (2, 16, 16, 32, 32),
     (3, 9, 11, 24, 64), (2, 12, 14, 64, 64), (2, 10, 10, 48, 48), (1, 70, 65, 8, 16), (2, 7, 5, 40, 80),
+    # wide inputs: the four waves split N
+    (2, 16, 20, 224, 64), (1, 11, 13, 320, 64), (2, 9, 9, 96, 48), (1, 12, 12, 192, 64), (2, 8, 8, 128, 32),
 ], ids=lambda c: "B{}_{}x{}_K{}N{}".format(*c))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("pro,bact,train", [(False, 0, True), (True, 1, True), (True, 2, False)])
@@ -1015,7 +1017,7 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
     dw = torch.full_like(w, float("nan"))
     ws2 = torch.full((nsl * N * K,), float("nan"), device=DEV)
     lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), ptr(dw), ptr(ws2), ptr(psc),
-             ptr(psh), pact, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
+             ptr(psh), pact, 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
              K, N, stream())
     rel = 2e-5 if dtype == torch.float32 else 1e-2  # (bf16: dx is stored rounded)
     assert_close(dx, dx_ref, rel * float(dx_ref.float().abs().max()), rel, "dx")
@@ -1023,9 +1025,22 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
     # dw == NULL: partial rows only, finalised by nasseg_wgrad_finalize_many
     ws3 = torch.full_like(ws2, float("nan"))
     lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws3), ptr(psc),
-             ptr(psh), pact, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
+             ptr(psh), pact, 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
              K, N, stream())
     assert torch.equal(ws3.view(nsl, N, K).double().sum(0).float(), ws2.view(nsl, N, K).double().sum(0).float())
+    if not pro:
+        # a bare activation applied to x on load (pre_clf's ReLU): dx masked with its derivative
+        for a_ in (1, 2):
+            lib.call(name("nasseg_conv_wgrad_bn"), ptr(x), K, ptr(g), N, ptr(z), N, ptr(dz), N, ptr(dw_ref), ptr(ws),
+                     None, None, a_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact,
+                     B, H, W, K, N, stream())
+            lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), ptr(dw), ptr(ws2), None,
+                     None, a_, a_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B,
+                     H, W, K, N, stream())
+            xf = x.float()
+            m_ = ((xf > 0) & ((xf < 6) | (a_ == 1))).float()
+            assert_close(dx, dx_ref.float() * m_, rel * float(dx_ref.float().abs().max()), rel, "masked dx")
+            assert_close(dw, dw_ref, 5e-5 * float(dw_ref.abs().max()) * max(1.0, (M / 4096.0) ** 0.5), 1e-4, "dw, act")
 
 
 def test_chain_backward_is_the_same_with_and_without_the_one_kernel_pointwise_backward(monkeypatch):

@@ -12,7 +12,8 @@ from nas_segm_amd import functional as F  # noqa: E402
 lib, ptr, stream = F.lib, F.ptr, F.current_stream
 DEV = "cuda:0"
 CASES = [(4, 512, 1024, 16, 96), (4, 256, 512, 24, 144), (4, 128, 256, 32, 192), (4, 512, 1024, 32, 32),
-         (4, 256, 512, 24, 64), (4, 128, 256, 64, 64), (4, 128, 256, 32, 32), (4, 32, 64, 64, 64)]
+         (4, 256, 512, 24, 64), (4, 128, 256, 64, 64), (4, 128, 256, 32, 32), (4, 32, 64, 64, 64), (4, 256, 512, 224, 64), (16, 81, 81, 192, 64),
+         (16, 11, 11, 320, 64)]
 
 
 def timeit(fn, reps=20):
@@ -50,7 +51,7 @@ for B, H, W, K, N in CASES:
 
     def one():
         lib.call("nasseg_conv_pw_bwd_bn", ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws2), None, None, 0,
-                 ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N, s)
+                 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N, s)
 
     t2, t1 = timeit(two), (timeit(one) if nsl else float("nan"))
     mb = 4e-6 * B * H * W * (2 * K + 2 * N)
