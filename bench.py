@@ -85,8 +85,11 @@ def algorithmic_bytes(name, a):
         B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17]
         return 4 * (B * Hs * Ws * K + B * Ho * Wo * N + N * K * kh * kw)
     if name == "nasseg_conv_pw_bwd_bn":  # x, g, z read, dx written; dz never leaves the CU
-        B, H, W, K, N = a[17], a[18], a[19], a[20], a[21]
+        B, H, W, K, N = a[18], a[19], a[20], a[21], a[22]
         return 4 * (B * H * W * (2 * K + 2 * N) + 2 * N * K)
+    if name == "nasseg_dwconv_bwd_bn":  # xz, g, z read, ge written
+        B, H, W, C, Ho, Wo = a[20], a[21], a[22], a[23], a[24], a[25]
+        return 4 * (2 * B * C * H * W + 2 * B * C * Ho * Wo + 18 * C)
     if name == "nasseg_conv_wgrad_bn":  # x, g, z read, dz written (BatchNorm backward applied on load)
         B, H, W, K, N = a[20], a[21], a[22], a[23], a[24]
         return 4 * (B * H * W * (K + 3 * N) + N * K)
@@ -284,7 +287,7 @@ def kernel_family(name, a):
             return "conv3x3_lds_kernel"
         return "conv_fwd_kernel"
     fam = {"nasseg_conv_bwd_data_bn": "conv_fwd_kernel", "nasseg_sepconv_fwd": "sepconv_fwd_kernel",
-           "nasseg_conv_pw_bwd_bn": "conv_pw_bwd_kernel",
+           "nasseg_conv_pw_bwd_bn": "conv_pw_bwd_kernel", "nasseg_dwconv_bwd_bn": "dw3x3_bwd_bn_kernel",
            "nasseg_conv_wgrad": "conv_wgrad_kernel", "nasseg_conv_wgrad_bn": "conv_wgrad_bn_kernel",
            "nasseg_dwconv": "dw_fwd_strip", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
            "nasseg_dwconv_wgrad": "dw_wgrad_strip", "nasseg_dwconv_wgrad_bn": "dw_wgrad_strip",

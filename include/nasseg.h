@@ -61,6 +61,17 @@ int nasseg_dwconv_bwd_data_bn(const float* dy, const float* wt, float* g, const 
                               float* stats, void* stream);
 int64_t nasseg_dwconv_bwd_data_bn_blocks(int B, int C, int Ho, int Wo, int K, int stride, int pad,
                                          int dil, int transposed);
+/* the whole backward of a 3x3 depthwise conv between two BatchNorms of a chain (InvertedResidual, layer_factory.py:
+ * 139-152) in one kernel: BatchNorm backward behind the conv on load, weight gradient, input gradient masked with
+ * the activation of the BatchNorm in front (in_*) and that BatchNorm's backward partial sums; xz, g, z read once,
+ * ge written once.  rows = workgroups = partial rows of ws [rows][9][C] and stats [rows][2][C]; 0 = not served */
+int64_t nasseg_dwconv_bwd_bn_rows(int B, int C, int H, int W, int K, int stride, int pad, int dil);
+int nasseg_dwconv_bwd_bn(const float* xz, const float* g, const float* z, const float* wt, int wt_flipped, float* ge,
+                         float* dw, float* ws, const float* in_scale, const float* in_shift, const float* in_mean,
+                         const float* in_invstd, int in_act, const float* bn_scale, const float* bn_shift,
+                         const float* bn_mean, const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act,
+                         int B, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil, float* stats,
+                         void* stream);
 int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K);
 int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
                         const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
@@ -248,6 +259,12 @@ int nasseg_compute_ius_accs(const int64_t* cm, int n, double* iu, int64_t* n_pix
  * parameters, parameter gradients, workspaces and every per-channel vector stay fp32, and the
  * size / workspace queries are shared with the fp32 entry points. */
 typedef uint16_t nasseg_bf16_t;
+int nasseg_bf16_dwconv_bwd_bn(const nasseg_bf16_t* xz, const nasseg_bf16_t* g, const nasseg_bf16_t* z, const float* wt,
+                              int wt_flipped, nasseg_bf16_t* ge, float* dw, float* ws, const float* in_scale, const float* in_shift,
+                              const float* in_mean, const float* in_invstd, int in_act, const float* bn_scale,
+                              const float* bn_shift, const float* bn_mean, const float* bn_invstd, const float* bn_sums,
+                              int bn_train, int bn_act, int B, int H, int W, int C, int Ho, int Wo, int K, int stride,
+                              int pad, int dil, float* stats, void* stream);
 int nasseg_bf16_conv_pw_bwd_bn(const nasseg_bf16_t* x, const nasseg_bf16_t* g, const nasseg_bf16_t* z, const float* wb,
                                nasseg_bf16_t* dx, float* dw, float* ws, const float* in_scale, const float* in_shift,
                                int in_act, int dx_act, const float* bn_scale, const float* bn_shift, const float* bn_mean,

@@ -64,6 +64,8 @@ __device__ __forceinline__ void bnbwd_accumulate(float4& g, float4 z, const BnBw
   ssum[1] = fma4(v, xh, ssum[1]);
 }
 
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
 // ---------------------------------------------------------------------------
 // weight packing: (C,1,K,K) -> [tap][C], optional 180-degree flip
 // ---------------------------------------------------------------------------
@@ -634,6 +636,208 @@ __global__ __launch_bounds__(256) void dw_wgrad_finalize(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// The whole backward of a 3x3 depthwise conv that sits BETWEEN two BatchNorms of a chain
+// (InvertedResidual: 1x1 -> BN -> ReLU6 -> [3x3 depthwise] -> BN -> ReLU6 -> 1x1, src/nn/
+// layer_factory.py:139-152) in ONE pass over the conv's input grid:
+//   dz  = second half of the BatchNorm backward behind the conv, computed on load from g and z
+//         (as dw_wgrad_tile<.., BN> does) - never stored;
+//   dW[ty][tx] += xa[iy][ix] * dz[oy][ox]            xa = act(in_scale*xz + in_shift), the
+//   ge[iy][ix]  = act'(..) * sum_t w[ty][tx]*dz[oy][ox]   normalised input (never stored either)
+//   with (oy, ox) = ((iy + pad - ty)/stride, (ix + pad - tx)/stride) where that divides,
+//   plus the partial sums {sum ge, sum ge*xhat} of the BatchNorm in FRONT of the conv.
+// Both products of an input pixel use the same <= 9 dz values, so a thread (one input column -
+// or, stride 2, one 2x2 input quad column - and one channel group, walking down the rows) keeps a
+// window of dz rows in registers and touches each of xz, g, z exactly once per pass and ge once:
+// four tensor passes instead of the seven of dw_wgrad_strip<BN> + dw_fwd_strip<STATS = 2> (xz
+// read twice, dz written and read back).  Weight-gradient and statistics partials per workgroup
+// as in dw_wgrad_tile; deterministic.
+// ---------------------------------------------------------------------------
+struct DwBwdArgs {
+  const act_t* xz;  // raw output of the conv in front: [B][H][W][C]
+  const act_t* g;   // gradient w.r.t. this conv's BatchNorm output [B][Ho][Wo][C]
+  const act_t* z;   // this conv's raw output
+  const float* wt;  // [tap][C], un-flipped
+  act_t* ge;        // [B][H][W][C]
+  float* partial;   // [blocks][9][C]
+  float* stats;     // [blocks][2][C]
+  const float* in_scale; const float* in_shift; const float* in_mean; const float* in_invstd; int in_act;
+  const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
+  const float* bn_sums; int bn_train, bn_act; float invM;
+  int B, H, W, C4, Ho, Wo, rows_per_item;
+  int flip;  // wt is the 180-degree rotated packing (what a stride-1 chain keeps for backward-data)
+};
+
+struct DzConst {
+  float4 ca, cb, cd, cs;
+};
+__device__ __forceinline__ DzConst dz_const(const DwBwdArgs& q, int c4) {
+  DzConst k;
+  const int C = q.C4 * 4;
+  k.ca = lda4(q.bn_scale + c4 * 4);
+  k.cs = q.bn_act ? lda4(q.bn_shift + c4 * 4) : f4zero();
+  k.cb = f4zero();
+  k.cd = f4zero();
+  if (q.bn_train) {
+    const float4 is = lda4(q.bn_invstd + c4 * 4), mu = lda4(q.bn_mean + c4 * 4);
+    const float4 s0 = lda4(q.bn_sums + c4 * 4), s1 = lda4(q.bn_sums + C + c4 * 4);
+    const float m = q.invM;
+    k.cb = make_float4(-k.ca.x * is.x * (s1.x * m), -k.ca.y * is.y * (s1.y * m), -k.ca.z * is.z * (s1.z * m),
+                       -k.ca.w * is.w * (s1.w * m));
+    k.cd = make_float4(k.ca.x * (mu.x * is.x * (s1.x * m) - s0.x * m), k.ca.y * (mu.y * is.y * (s1.y * m) - s0.y * m),
+                       k.ca.z * (mu.z * is.z * (s1.z * m) - s0.z * m), k.ca.w * (mu.w * is.w * (s1.w * m) - s0.w * m));
+  }
+  return k;
+}
+// dz at output pixel (oy, ox) of image b (zero outside the map); loads are unconditional from a
+// clamped address
+__device__ __forceinline__ float4 dz_at(const DwBwdArgs& q, const DzConst& k, int b, int oy, int ox, int c4) {
+  const bool ok = oy >= 0 && oy < q.Ho && ox >= 0 && ox < q.Wo;
+  const int oyc = oy < 0 ? 0 : (oy >= q.Ho ? q.Ho - 1 : oy), oxc = ox < 0 ? 0 : (ox >= q.Wo ? q.Wo - 1 : ox);
+  const size_t off = (((size_t)b * q.Ho + oyc) * q.Wo + oxc) * (q.C4 * 4) + c4 * 4;
+  float4 gv = lda4(q.g + off);
+  const float4 zv = lda4(q.z + off);
+  if (q.bn_act) {
+    const float4 y = fma4(zv, k.ca, k.cs);
+    gv = make_float4(gv.x * act_mask(y.x, q.bn_act), gv.y * act_mask(y.y, q.bn_act), gv.z * act_mask(y.z, q.bn_act),
+                     gv.w * act_mask(y.w, q.bn_act));
+  }
+  float4 v = fma4(gv, k.ca, fma4(zv, k.cb, k.cd));
+#ifdef NASSEG_BF16
+  v = make_float4(bf16_to_f32(f32_to_bf16(v.x)), bf16_to_f32(f32_to_bf16(v.y)), bf16_to_f32(f32_to_bf16(v.z)),
+                  bf16_to_f32(f32_to_bf16(v.w)));  // (what the two-kernel form stores and reads back)
+#endif
+  return keep_if(v, ok);
+}
+
+// STRIDE 1 or 2; 3x3, pad 1, dilation 1
+#ifndef NASSEG_DWBWD_MINB
+#define NASSEG_DWBWD_MINB 1
+#endif
+template <int STRIDE>
+__global__ __launch_bounds__(256, NASSEG_DWBWD_MINB) void dw3x3_bwd_bn_kernel(DwBwdArgs q) {
+  __shared__ float4 lw[9][64];
+  __shared__ float4 red[3][4][64];
+  const int C4 = q.C4, C = C4 * 4, H = q.H, W = q.W;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 9 * C4; i += 256) {
+    const int t = i / C4;
+    lw[t][i % C4] = lda4(q.wt + (size_t)(q.flip ? 8 - t : t) * C + (i % C4) * 4);
+  }
+  __syncthreads();
+  const int Wq = STRIDE == 1 ? W : (W + 1) >> 1;   // columns of threads
+  const int Hq = STRIDE == 1 ? H : (H + 1) >> 1;   // rows a thread walks (quad rows for stride 2)
+  const int base = blockIdx.x * 256;
+  const int idx = base + tid;
+  const bool live = idx < Wq * C4;
+  const int xq = live ? idx / C4 : 0;
+  const int c4 = live ? idx - xq * C4 : 0;
+  const DzConst kc = dz_const(q, c4);
+  BnBwd bn = {q.xz, q.in_scale, q.in_shift, q.in_mean, q.in_invstd, q.in_act};
+  const BnBwdLane bl = bnbwd_lane(bn, c4);
+  Prologue pro;  // (scale / shift shared with bl)
+  pro.sc = bl.sc;
+  pro.sh = bl.sh;
+  pro.lo = q.in_act ? 0.f : -INFINITY;
+  pro.hi = q.in_act == NASSEG_ACT_RELU6 ? 6.f : INFINITY;
+  float4 dwa[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dwa[t] = f4zero();
+  float4 ssum[2] = {f4zero(), f4zero()};
+  const int nchunk = cdiv_dev(Hq, q.rows_per_item);
+  const int nwork = q.B * nchunk;
+  for (int wk = blockIdx.y; wk < nwork; wk += gridDim.y) {
+    const int b = wk / nchunk;
+    const int r0 = (wk - b * nchunk) * q.rows_per_item;
+    int r1 = r0 + q.rows_per_item;
+    if (r1 > Hq) r1 = Hq;
+    if (!live) continue;
+    if (STRIDE == 1) {
+      // window d[ry][cx] = dz[iy - 1 + ry][ix - 1 + cx]; tap (ty, tx) pairs input (iy, ix) with
+      // output (iy + 1 - ty, ix + 1 - tx) = d[2 - ty][2 - tx]
+      float4 d[3][3];
+#pragma unroll
+      for (int cx = 0; cx < 3; ++cx) {
+        d[1][cx] = dz_at(q, kc, b, r0 - 1, xq - 1 + cx, c4);
+        d[2][cx] = dz_at(q, kc, b, r0, xq - 1 + cx, c4);
+      }
+      for (int iy = r0; iy < r1; ++iy) {
+#pragma unroll
+        for (int cx = 0; cx < 3; ++cx) {
+          d[0][cx] = d[1][cx];
+          d[1][cx] = d[2][cx];
+          d[2][cx] = dz_at(q, kc, b, iy + 1, xq - 1 + cx, c4);
+        }
+        const size_t off = (((size_t)b * H + iy) * W + xq) * C + c4 * 4;
+        const float4 zin = lda4(q.xz + off);
+        const float4 xa = apply_prologue(zin, pro);
+        float4 o = f4zero();
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const float4 dv = d[2 - ty][2 - tx];
+            o = fma4(lw[ty * 3 + tx][c4], dv, o);
+            dwa[ty * 3 + tx] = fma4(xa, dv, dwa[ty * 3 + tx]);
+          }
+        bnbwd_accumulate(o, zin, bl, q.in_act, true, ssum);
+        sta4(q.ge + off, o);
+      }
+    } else {
+      // a 2x2 input quad (2a + py, 2b + px) receives from dz[a + ry][b + rx], ry, rx in {0, 1}:
+      // tap ty feeds input parity py = (ty + 1) & 1 from row ry = (py + 1 - ty) / 2
+      float4 d[2][2];
+#pragma unroll
+      for (int rx = 0; rx < 2; ++rx) d[1][rx] = dz_at(q, kc, b, r0, xq + rx, c4);
+      for (int aq = r0; aq < r1; ++aq) {
+#pragma unroll
+        for (int rx = 0; rx < 2; ++rx) {
+          d[0][rx] = d[1][rx];
+          d[1][rx] = dz_at(q, kc, b, aq + 1, xq + rx, c4);
+        }
+        float4 o[2][2], xa[2][2], zin[2][2];
+        bool ok[2][2];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int iy = 2 * aq + py, ix = 2 * xq + px;
+            ok[py][px] = iy < H && ix < W;
+            const size_t off = (((size_t)b * H + (iy < H ? iy : H - 1)) * W + (ix < W ? ix : W - 1)) * C + c4 * 4;
+            zin[py][px] = lda4(q.xz + off);
+            xa[py][px] = keep_if(apply_prologue(zin[py][px], pro), ok[py][px]);
+            o[py][px] = f4zero();
+          }
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) {
+            const int py = (ty + 1) & 1, px = (tx + 1) & 1;
+            const int ry = (py + 1 - ty) / 2, rx = (px + 1 - tx) / 2;
+            const float4 dv = d[ry][rx];
+            o[py][px] = fma4(lw[ty * 3 + tx][c4], dv, o[py][px]);
+            dwa[ty * 3 + tx] = fma4(xa[py][px], dv, dwa[ty * 3 + tx]);
+          }
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            bnbwd_accumulate(o[py][px], zin[py][px], bl, q.in_act, ok[py][px], ssum);
+            if (ok[py][px])
+              sta4(q.ge + (((size_t)b * H + 2 * aq + py) * W + 2 * xq + px) * C + c4 * 4, o[py][px]);
+          }
+      }
+    }
+  }
+  const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+  if (!live) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwa[t] = f4zero();
+  }
+  block_reduce_groups<9, 3>(dwa, red, q.partial + blk * 9 * C, base, C4);
+  block_reduce_groups<2, 2>(ssum, reinterpret_cast<float4(*)[4][64]>(&red[0][0][0]), q.stats + blk * 2 * C, base, C4);
+}
+
 }  // namespace
 
 extern "C" {
@@ -984,6 +1188,88 @@ int NASSEG_FN(dwconv_wgrad_many)(int count, const int64_t* desc, void* stream) {
 #undef GO_DW
     NASSEG_LAUNCH_CHECK("dw_wgrad_group_kernel");
   }
+  return NASSEG_OK;
+}
+
+#if NASSEG_FP32_ONLY
+// grid of nasseg_dwconv_bwd_bn: {columns of workgroups, rows of workgroups}; 0 rows: unsupported
+static void dw_bwd_grid(int B, int C, int H, int W, int stride, int* gx, int* gy, int* rpi) {
+  const int C4 = C / 4;
+  const int Wq = stride == 1 ? W : (W + 1) / 2, Hq = stride == 1 ? H : (H + 1) / 2;
+  *gx = cdiv(Wq * C4, 256);
+  *rpi = stride == 1 ? 16 : 8;  // input rows (quad rows) per work item: 2 / 16 (1 / 8) extra dz rows
+  const int64_t items = (int64_t)B * cdiv(Hq, *rpi);
+  int64_t y = 1024 / *gx;
+  if (y > items) y = items;
+  if (y < 1) y = 1;
+  *gy = (int)y;
+}
+// workgroups (= partial rows of the weight gradient [9][C] and of the statistics [2][C]) of
+// nasseg_dwconv_bwd_bn; 0: geometry not served (3x3, pad 1, dilation 1, stride 1 or 2, C % 4 == 0,
+// C <= 256)
+int64_t nasseg_dwconv_bwd_bn_rows(int B, int C, int H, int W, int K, int stride, int pad, int dil) {
+  if (K != 3 || pad != 1 || dil != 1 || (stride != 1 && stride != 2) || C % 4 || C / 4 > 64 || B <= 0 || H <= 0 ||
+      W <= 0)
+    return 0;
+  int gx, gy, rpi;
+  dw_bwd_grid(B, C, H, W, stride, &gx, &gy, &rpi);
+  return (int64_t)gx * gy;
+}
+#else
+int64_t nasseg_dwconv_bwd_bn_rows(int B, int C, int H, int W, int K, int stride, int pad, int dil);
+static void dw_bwd_grid(int B, int C, int H, int W, int stride, int* gx, int* gy, int* rpi) {
+  const int C4 = C / 4;
+  const int Wq = stride == 1 ? W : (W + 1) / 2, Hq = stride == 1 ? H : (H + 1) / 2;
+  *gx = cdiv(Wq * C4, 256);
+  *rpi = stride == 1 ? 16 : 8;
+  const int64_t items = (int64_t)B * cdiv(Hq, *rpi);
+  int64_t y = 1024 / *gx;
+  if (y > items) y = items;
+  if (y < 1) y = 1;
+  *gy = (int)y;
+}
+#endif  // NASSEG_FP32_ONLY
+
+// Backward of  z = dwconv3x3(act(in_scale*xz + in_shift)),  y = BatchNorm(z) (+ activation), inside a
+// chain whose previous link is the BatchNorm (in_*) that produced the conv's input - all of it in one
+// kernel (see dw3x3_bwd_bn_kernel):
+//   wt: the weight packed [tap][C] (pack kind 3), or its rotated packing (kind 4) with wt_flipped != 0;
+//   g: gradient w.r.t. y (masked already: bn_act == 0, or masked here), sums = {sum g', sum g'*xhat};
+//   ge (out) [B][H][W][C]: gradient w.r.t. the previous BatchNorm's output, multiplied by in_act';
+//   stats (out): rows [r][2][C] of {sum ge, sum ge*xhat_in}, r < nasseg_dwconv_bwd_bn_rows(...);
+//   ws: rows [r][9][C] of weight-gradient partials; dw (C,1,3,3) when given, else partials only
+//   (nasseg_wgrad_finalize_many: taps 9, N = C, K = 1).
+int NASSEG_FN(dwconv_bwd_bn)(const act_t* xz, const act_t* g, const act_t* z, const float* wt, int wt_flipped,
+                             act_t* ge, float* dw, float* ws, const float* in_scale, const float* in_shift,
+                             const float* in_mean, const float* in_invstd, int in_act, const float* bn_scale,
+                             const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                             const float* bn_sums, int bn_train, int bn_act, int B, int H, int W, int C, int Ho,
+                             int Wo, int K, int stride, int pad, int dil, float* stats, void* stream) {
+  NASSEG_REQUIRE(xz && g && z && wt && ge && ws && stats && in_scale && in_shift && in_mean && in_invstd && bn_scale,
+                 "dwconv_bwd_bn: null tensor");
+  NASSEG_REQUIRE((!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
+                 "dwconv_bwd_bn: missing BatchNorm tensors");
+  NASSEG_REQUIRE(nasseg_dwconv_bwd_bn_rows(B, C, H, W, K, stride, pad, dil) > 0,
+                 "dwconv_bwd_bn: geometry not served (3x3, pad 1, stride 1 or 2)");
+  NASSEG_REQUIRE(Ho == (H + 2 * pad - 3) / stride + 1 && Wo == (W + 2 * pad - 3) / stride + 1,
+                 "dwconv_bwd_bn: output size does not match");
+  int gx, gy, rpi;
+  dw_bwd_grid(B, C, H, W, stride, &gx, &gy, &rpi);
+  DwBwdArgs q = {};
+  q.xz = xz; q.g = g; q.z = z; q.wt = wt; q.ge = ge; q.partial = ws; q.stats = stats;
+  q.in_scale = in_scale; q.in_shift = in_shift; q.in_mean = in_mean; q.in_invstd = in_invstd; q.in_act = in_act;
+  q.bn_scale = bn_scale; q.bn_shift = bn_shift; q.bn_mean = bn_mean; q.bn_invstd = bn_invstd; q.bn_sums = bn_sums;
+  q.bn_train = bn_train; q.bn_act = bn_act;
+  q.invM = (float)(1.0 / ((double)B * Ho * Wo));
+  q.B = B; q.H = H; q.W = W; q.C4 = C / 4; q.Ho = Ho; q.Wo = Wo; q.rows_per_item = rpi;
+  q.flip = wt_flipped != 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (stride == 1) hipLaunchKernelGGL(dw3x3_bwd_bn_kernel<1>, dim3(gx, gy), dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(dw3x3_bwd_bn_kernel<2>, dim3(gx, gy), dim3(256), 0, s, q);
+  NASSEG_LAUNCH_CHECK("dw3x3_bwd_bn_kernel");
+  if (!dw) return NASSEG_OK;
+  hipLaunchKernelGGL(dw_wgrad_finalize, dim3(cdiv(9 * C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws, dw, gx * gy, 9, C);
+  NASSEG_LAUNCH_CHECK("dw_wgrad_finalize");
   return NASSEG_OK;
 }
 

@@ -179,6 +179,22 @@ def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops):
     return lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N)
 
 
+FUSE_DW_BWD = os.environ.get("NASSEG_FUSE_DW_BWD", "1") != "0"
+_DW_BWD_MIN_BYTES = 24 << 20
+
+
+def _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops):
+    """> 0: this depthwise op's whole backward runs as ONE kernel, nasseg_dwconv_bwd_bn (the value
+    is its number of partial rows): 3x3, between two BatchNorms of the chain (the previous op has
+    one - InvertedResidual's expansion), both gradients wanted, a large map."""
+    if not (FUSE_DW_BWD and kind == "dw" and need_dw and need_dx and i > 0 and ops[i - 1][4]):
+        return 0
+    if (cur.numel() + z.numel()) * cur.element_size() <= _DW_BWD_MIN_BYTES:
+        return 0
+    B, C, H, W = cur.shape
+    return lib.query("nasseg_dwconv_bwd_bn_rows", B, C, H, W, w.shape[-1], stride, pad, dil)
+
+
 def _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
     """Can this layer's weight-gradient kernel apply the BatchNorm backward on load
     (nasseg_conv_wgrad_bn / nasseg_dwconv_wgrad_bn)?  Large maps only: the launches of small ones
@@ -873,7 +889,8 @@ class _ConvChain(torch.autograd.Function):
                     break
                 pw_bact = ACT_NONE if pre is not None else act
                 pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops)
-                if pw_nsl > 0:
+                dw_rows = _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops)
+                if pw_nsl > 0 or dw_rows > 0:
                     dz = None  # (the one-kernel pointwise backward below applies the BatchNorm backward on load)
                 elif need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
                     # the weight-gradient kernel below computes dz while it loads g and z (masking
@@ -887,7 +904,7 @@ class _ConvChain(torch.autograd.Function):
                              ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
             else:
                 dz = g
-                pw_nsl = 0
+                pw_nsl = dw_rows = 0
                 if not (need_dw or need_dx):
                     g = None
                     break
@@ -908,6 +925,23 @@ class _ConvChain(torch.autograd.Function):
                     bn_prev = (cur, one, zero, zero, one, in_act0)
                 else:
                     bn_prev = (cur, None, None, None, None, in_act0)  # mask-only epilogue
+            if kind == "dw" and dw_rows > 0:
+                # 3x3 depthwise conv between two BatchNorms of the chain: its whole backward in one
+                # pass (csrc/dwconv.hip: dw3x3_bwd_bn_kernel) - BatchNorm backward on load, weight
+                # gradient, masked input gradient + the partial sums of the BatchNorm in front
+                zp, psc_, psh_, pmu_, pis_, pact_ = bn_prev
+                dwt = torch.empty_like(w)
+                ws = _ws(cur, dw_rows * 9 * K)
+                part = _ws(cur, (dw_rows + 64) * 2 * K)
+                g_in = _new(cur, Bc, K, H, W)
+                # (wb: what forward packed for this op's backward-data - rotated for stride 1, plain else)
+                lib.call(_k("nasseg_dwconv_bwd_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(wb), int(stride == 1),
+                         ptr(g_in), _finish_wgrad(ws, dwt, 9, K, 1, 0), ptr(ws), ptr(psc_), ptr(psh_), ptr(pmu_),
+                         ptr(pis_), pact_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training),
+                         pw_bact, Bc, H, W, K, Ho, Wo, 3, stride, pad, dil, ptr(part), s)
+                grads[6 * i] = dwt
+                g, pre = g_in, (part, dw_rows)
+                continue
             if kind == "dw":
                 k = w.shape[-1]
                 if fused_bn is not None:

@@ -27,7 +27,9 @@ def _labels(gen, B, H, W, classes):
 def test_train_step_at_size_matches_the_oracle(monkeypatch):
     """WACV arch0 (the BASELINE headline network), train-mode forward + loss + backward of
     engine.trainer.segmenter_step at 2x3x1024x2048 with NATURAL dispatch - nothing monkeypatched:
-    BatchNorm backward applied by the weight-gradient kernels (maps > 48 MB), ConcatReduce
+    one-kernel backward of pointwise conv + BatchNorm and of the depthwise convs between
+    BatchNorms, BatchNorm backward applied by the weight-gradient kernels (maps > 48 MB),
+    one-kernel SepConv stages, ConcatReduce
     without the concatenation (>= 2^24 elements per input), two-level bn_finalize (> 512 partial
     rows), multi-slab and grouped weight gradients, deferred finalisation, one weight re-pack per
     step - against the CPU oracle (which tests/test_oracle_golden.py pins to the reference).
@@ -81,9 +83,9 @@ def test_train_step_at_size_matches_the_oracle(monkeypatch):
     loss = segmenter_step(net, xd, td, None, None, 255, 0.0, 0.0, -1)
     torch.cuda.synchronize()
     # the paths this size is here for were taken
-    for name in ("nasseg_conv_wgrad_bn", "nasseg_dwconv_wgrad_bn", "nasseg_conv_bwd_data_bn",
-                 "nasseg_dwconv_bwd_data_bn", "nasseg_wgrad_finalize_many", "nasseg_conv_wgrad_many",
-                 "nasseg_dwconv_wgrad_many", "nasseg_pack_weights"):
+    for name in ("nasseg_conv_wgrad_bn", "nasseg_conv_pw_bwd_bn", "nasseg_dwconv_bwd_bn", "nasseg_conv_bwd_data_bn",
+                 "nasseg_dwconv_bwd_data_bn", "nasseg_sepconv_fwd", "nasseg_wgrad_finalize_many",
+                 "nasseg_conv_wgrad_many", "nasseg_dwconv_wgrad_many", "nasseg_pack_weights"):
         assert name in seen, name
     assert n_split[0] >= 1, "ConcatReduce never took its no-concatenation path"
 
@@ -130,7 +132,8 @@ def _assert_additive(whole, parts, weights, what):
         comb = sum(w * p[k] for w, p in zip(weights, parts))
         scale = float(g.abs().max())
         err = float((g - comb).abs().max())
-        if err > 3e-4 * scale + 1e-7:
+        # (1e-6: BatchNorm biases whose per-pixel terms nearly cancel - the sum's fp32 noise)
+        if err > 3e-4 * scale + 1e-6:
             bad.append((k, err, scale))
     assert not bad, "{}: {} of {} gradients are not additive over the batch: {}".format(
         what, len(bad), len(whole), bad[:6])

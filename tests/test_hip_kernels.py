@@ -1051,6 +1051,7 @@ def test_chain_backward_is_the_same_with_and_without_the_one_kernel_pointwise_ba
     Fm = F()
     monkeypatch.setattr(Fm, "_GROUP_WGRAD_BYTES", 0)
     monkeypatch.setattr(Fm, "_PW_BWD_MIN_BYTES", 0)
+    monkeypatch.setattr(Fm, "_DW_BWD_MIN_BYTES", 0)
     torch.manual_seed(5)
     mods = [OPS["sep_conv_5x5"](32, 32, 1, True, 2), InvertedResidual(16, 24, 2, 6), InvertedResidual(24, 24, 1, 6),
             conv_bn_relu(24, 64, 1, 1, 0), OPS["max_pool_3x3"](24, 48, 2, True)]
@@ -1067,6 +1068,7 @@ def test_chain_backward_is_the_same_with_and_without_the_one_kernel_pointwise_ba
 
         for fuse in (True, False):
             monkeypatch.setattr(Fm, "FUSE_PW_BWD", fuse)
+            monkeypatch.setattr(Fm, "FUSE_DW_BWD", fuse)  # (... and the one-kernel depthwise backward)
             monkeypatch.setattr(Fm.lib, "call", rec)
             del seen[:]
             mod.zero_grad()
@@ -1075,8 +1077,83 @@ def test_chain_backward_is_the_same_with_and_without_the_one_kernel_pointwise_ba
             y.backward(dev(rnd(*y.shape, seed=3)))
             monkeypatch.setattr(Fm.lib, "call", orig)
             assert ("nasseg_conv_pw_bwd_bn" in seen) == fuse, (type(mod).__name__, fuse, sorted(set(seen)))
+            if isinstance(mod, InvertedResidual):
+                assert ("nasseg_dwconv_bwd_bn" in seen) == fuse, (fuse, sorted(set(seen)))
             res.append((x.grad.clone(), [p.grad.clone() for p in mod.parameters()]))
         (dx1, g1), (dx0, g0) = res
         assert_close(dx1, dx0, 1e-4 * float(dx0.abs().max()), 1e-4, "dx")
         for a, b in zip(g1, g0):
-            assert_close(a, b, 2e-4 * float(b.abs().max()) + 1e-7, 2e-4, "parameter gradient")
+            # (BatchNorm weight / bias gradients are sums of ~2000 terms of either sign that nearly cancel:
+            #  1e-5 absolute is their fp32 summation noise)
+            assert_close(a, b, 2e-4 * float(b.abs().max()) + 1e-5, 2e-4, "parameter gradient")
+
+
+# ---------------------------------------------------------------------------
+# backward of a 3x3 depthwise conv between two BatchNorms in one kernel (dwconv.hip)
+@pytest.mark.parametrize("case", [
+    # B, C, H, W, stride
+    (2, 96, 18, 22, 2), (2, 144, 13, 17, 1), (1, 32, 33, 40, 1), (2, 24, 17, 23, 2), (3, 192, 8, 9, 1),
+    (1, 8, 70, 65, 2), (2, 16, 9, 11, 1),
+], ids=lambda c: "B{}C{}_{}x{}_s{}".format(*c))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bact,train", [(0, True), (2, True), (1, False)])
+def test_depthwise_backward_between_batchnorms_in_one_kernel(case, dtype, bact, train):
+    """nasseg_dwconv_bwd_bn against the two kernels it replaces (nasseg_dwconv_wgrad_bn, which also
+    writes dz, + nasseg_dwconv_bwd_data_bn over that dz): the masked input gradient, the weight
+    gradient and the summed statistics rows agree to fp32 rounding of the sums."""
+    Fm = F()
+    lib, ptr, stream = Fm.lib, Fm.ptr, Fm.current_stream
+    B, C, H, W, stride = case
+    k, pad, dil = 3, 1, 1
+    Ho, Wo = Fm.conv_out_size(H, k, stride, pad, dil), Fm.conv_out_size(W, k, stride, pad, dil)
+    rows = lib.query("nasseg_dwconv_bwd_bn_rows", B, C, H, W, k, stride, pad, dil)
+    assert rows > 0
+    xz = dev(rnd(B, C, H, W, seed=1) * 2).to(dtype)
+    g = dev(rnd(B, C, Ho, Wo, seed=2)).to(dtype)
+    z = dev(rnd(B, C, Ho, Wo, seed=3)).to(dtype)
+    w = dev(rnd(C, 1, k, k, seed=4) * 0.3)
+    v = lambda seed, base=0.0, sc=0.2: (rnd(C, seed=seed) * sc + base).to(DEV)  # noqa: E731
+    isc, ish, imu, iis = v(5, 1.0), v(6), v(7), v(8, 1.0).abs() + 0.3
+    scale, shift, mean, invstd = v(9, 1.0), v(10), v(11), v(12, 1.0).abs() + 0.3
+    sums = (rnd(2 * C, seed=13) * 3).to(DEV)
+    iact = 2
+    name = lambda op: Fm._k(op, xz)  # noqa: E731
+    wt = torch.empty(9 * C, device=DEV)
+    wtf = torch.empty(9 * C, device=DEV)
+    lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wt), C, k, 0, stream())
+    lib.call("nasseg_dw_pack_weight", ptr(w), ptr(wtf), C, k, 1, stream())
+    # two kernels
+    dz = torch.empty_like(z)
+    dw_ref = torch.empty_like(w)
+    ws = torch.empty(lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, k), device=DEV)
+    lib.call(name("nasseg_dwconv_wgrad_bn"), ptr(xz), ptr(g), ptr(z), ptr(dz), ptr(dw_ref), ptr(ws), ptr(isc), ptr(ish),
+             iact, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W, C, Ho, Wo,
+             k, stride, pad, dil, stream())
+    if stride == 1:
+        geom = (B, Ho, Wo, C, H, W, k, 1, dil * (k - 1) - pad, dil, 0)
+        wb = wtf
+    else:
+        geom = (B, Ho, Wo, C, H, W, k, stride, pad, dil, 1)
+        wb = wt
+    nb = lib.query("nasseg_dwconv_bwd_data_bn_blocks", B, C, H, W, k, geom[7], geom[8], dil, geom[10])
+    assert nb > 0
+    ge_ref = torch.empty_like(xz)
+    part_ref = torch.empty((nb + 64) * 2 * C, device=DEV)
+    lib.call(name("nasseg_dwconv_bwd_data_bn"), ptr(dz), ptr(wb), ptr(ge_ref), ptr(xz), ptr(isc), ptr(ish), ptr(imu),
+             ptr(iis), iact, *geom, ptr(part_ref), stream())
+    # one kernel (given the packing the chain keeps for backward-data: rotated for stride 1)
+    ge = torch.full_like(xz, float("nan"))
+    dw = torch.full_like(w, float("nan"))
+    ws2 = torch.full((rows * 9 * C,), float("nan"), device=DEV)
+    part = torch.full(((rows + 64) * 2 * C,), float("nan"), device=DEV)
+    lib.call(name("nasseg_dwconv_bwd_bn"), ptr(xz), ptr(g), ptr(z), ptr(wb), int(stride == 1), ptr(ge), ptr(dw),
+             ptr(ws2), ptr(isc), ptr(ish), ptr(imu), ptr(iis), iact, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+             ptr(sums), int(train), bact, B, H, W, C, Ho, Wo, k, stride, pad, dil, ptr(part), stream())
+    rel = 2e-5 if dtype == torch.float32 else 1e-2
+    assert_close(ge, ge_ref, rel * float(ge_ref.float().abs().max()), rel, "ge")
+    M = B * Ho * Wo
+    assert_close(dw, dw_ref, 5e-5 * float(dw_ref.abs().max()) * max(1.0, (M / 4096.0) ** 0.5) + 1e-6, 1e-4, "dw")
+    s_ref = part_ref[:nb * 2 * C].view(nb, 2 * C).double().sum(0)
+    s_got = part[:rows * 2 * C].view(rows, 2 * C).double().sum(0)
+    tol = (2e-5 if dtype == torch.float32 else 2e-2) * float(s_ref.abs().max()) * max(1.0, (B * H * W / 4096.0) ** 0.5)
+    assert_close(s_got, s_ref, tol, 1e-4 if dtype == torch.float32 else 2e-2, "statistics rows")
