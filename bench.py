@@ -511,9 +511,10 @@ def main():
         lib.profiler = None
         if rows:
             total_ms = sum(r["ms"] for r in rows)
-            # depthwise forward + backward-data launches (plain and with the fused BN-backward sums)
+            # depthwise forward + backward launches (plain, with the fused BN-backward sums, and the
+            # one-kernel backward between two BatchNorms)
             dwr = [r for r in rows if r["kernel"].replace("nasseg_bf16_", "nasseg_")
-                   in ("nasseg_dwconv", "nasseg_dwconv_bwd_data_bn")]
+                   in ("nasseg_dwconv", "nasseg_dwconv_bwd_data_bn", "nasseg_dwconv_bwd_bn")]
             dw = ([{"gbs": sum(r["bytes"] for r in dwr) / 1e9 / (sum(r["ms"] for r in dwr) / 1e3)}]
                   if dwr and sum(r["ms"] for r in dwr) > 0 else [])
             name, top = max(groups.items(), key=lambda kv: kv[1]["ms"])

@@ -23,7 +23,7 @@ if [[ "$WHAT" == "all" || "$WHAT" == "smoke" ]]; then
   echo "smoke exit $?" >> $OUT/summary.log
 fi
 if [[ "$WHAT" == "all" || "$WHAT" == "bench" ]]; then
-  timeout 600 python bench.py --steps 5 --warmup 2 --breakdown > $OUT/bench.json 2> $OUT/bench.err
+  timeout 600 python bench.py --steps 8 --warmup 3 --breakdown --shapes 60 > $OUT/bench.json 2> $OUT/bench.err
   echo "bench exit $?" >> $OUT/summary.log
   cat $OUT/bench.json >> $OUT/summary.log
 fi
@@ -42,6 +42,10 @@ if [[ "$WHAT" == "all" || "$WHAT" == "graph" ]]; then
     timeout 300 python bench.py --workload $wl --dtype bf16 --steps 8 --warmup 2 --no-cpu-baseline > $OUT/bench_${wl}_bf16.json 2> $OUT/bench_${wl}_bf16.err
     echo "bench $wl bf16 exit $?" >> $OUT/summary.log; cat $OUT/bench_${wl}_bf16.json >> $OUT/summary.log
   done
+  timeout 300 python bench.py --workload task0 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_task0_auto.json 2> $OUT/bench_task0_auto.err
+  echo "bench task0 (auto graph) exit $?" >> $OUT/summary.log; cat $OUT/bench_task0_auto.json >> $OUT/summary.log
+  timeout 300 python bench.py --workload task0 --graph 0 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_task0_g0.json 2> $OUT/bench_task0_g0.err
+  echo "bench task0 --graph 0 exit $?" >> $OUT/summary.log; cat $OUT/bench_task0_g0.json >> $OUT/summary.log
   for wl in arch1 cvpr321 search713; do
     for g in 0 2; do
       timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --graph $g --no-cpu-baseline > $OUT/bench_${wl}_g$g.json 2> $OUT/bench_${wl}_g$g.err
