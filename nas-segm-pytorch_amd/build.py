@@ -16,6 +16,9 @@ LIB_PATH = os.path.join(HERE, "libnasseg_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function"]
+# experiments only (tools/kbench_*.py variants): extra -D flags; objects are rebuilt by mtime, so touch
+# the source that reads the macro
+FLAGS += os.environ.get("NASSEG_EXTRA_FLAGS", "").split()
 
 
 def sources():

@@ -689,25 +689,38 @@ __device__ __forceinline__ DzConst dz_const(const DwBwdArgs& q, int c4) {
   }
   return k;
 }
-// dz at output pixel (oy, ox) of image b (zero outside the map); loads are unconditional from a
-// clamped address
-__device__ __forceinline__ float4 dz_at(const DwBwdArgs& q, const DzConst& k, int b, int oy, int ox, int c4) {
-  const bool ok = oy >= 0 && oy < q.Ho && ox >= 0 && ox < q.Wo;
+// dz at output pixel (oy, ox) of image b (zero outside the map) in two halves, so that the loads of
+// the next row can be issued before the arithmetic of the current one: dz_load (unconditional loads
+// from a clamped address) and dz_make
+struct DzRaw {
+  float4 g, z;
+  bool ok;
+};
+__device__ __forceinline__ DzRaw dz_load(const DwBwdArgs& q, int b, int oy, int ox, int c4) {
+  DzRaw r;
+  r.ok = oy >= 0 && oy < q.Ho && ox >= 0 && ox < q.Wo;
   const int oyc = oy < 0 ? 0 : (oy >= q.Ho ? q.Ho - 1 : oy), oxc = ox < 0 ? 0 : (ox >= q.Wo ? q.Wo - 1 : ox);
   const size_t off = (((size_t)b * q.Ho + oyc) * q.Wo + oxc) * (q.C4 * 4) + c4 * 4;
-  float4 gv = lda4(q.g + off);
-  const float4 zv = lda4(q.z + off);
+  r.g = lda4(q.g + off);
+  r.z = lda4(q.z + off);
+  return r;
+}
+__device__ __forceinline__ float4 dz_make(const DwBwdArgs& q, const DzConst& k, const DzRaw& r) {
+  float4 gv = r.g;
   if (q.bn_act) {
-    const float4 y = fma4(zv, k.ca, k.cs);
+    const float4 y = fma4(r.z, k.ca, k.cs);
     gv = make_float4(gv.x * act_mask(y.x, q.bn_act), gv.y * act_mask(y.y, q.bn_act), gv.z * act_mask(y.z, q.bn_act),
                      gv.w * act_mask(y.w, q.bn_act));
   }
-  float4 v = fma4(gv, k.ca, fma4(zv, k.cb, k.cd));
+  float4 v = fma4(gv, k.ca, fma4(r.z, k.cb, k.cd));
 #ifdef NASSEG_BF16
   v = make_float4(bf16_to_f32(f32_to_bf16(v.x)), bf16_to_f32(f32_to_bf16(v.y)), bf16_to_f32(f32_to_bf16(v.z)),
                   bf16_to_f32(f32_to_bf16(v.w)));  // (what the two-kernel form stores and reads back)
 #endif
-  return keep_if(v, ok);
+  return keep_if(v, r.ok);
+}
+__device__ __forceinline__ float4 dz_at(const DwBwdArgs& q, const DzConst& k, int b, int oy, int ox, int c4) {
+  return dz_make(q, k, dz_load(q, b, oy, ox, c4));
 }
 
 // STRIDE 1 or 2; 3x3, pad 1, dilation 1
@@ -761,15 +774,29 @@ __global__ __launch_bounds__(256, NASSEG_DWBWD_MINB) void dw3x3_bwd_bn_kernel(Dw
         d[1][cx] = dz_at(q, kc, b, r0 - 1, xq - 1 + cx, c4);
         d[2][cx] = dz_at(q, kc, b, r0, xq - 1 + cx, c4);
       }
+      // the loads of row iy + 1 (three dz columns, one input pixel) are in flight while row iy is computed
+      DzRaw nxt[3];
+#pragma unroll
+      for (int cx = 0; cx < 3; ++cx) nxt[cx] = dz_load(q, b, r0 + 1, xq - 1 + cx, c4);
+      float4 zin_nxt = lda4(q.xz + (((size_t)b * H + r0) * W + xq) * C + c4 * 4);
       for (int iy = r0; iy < r1; ++iy) {
+        DzRaw cur[3];
+#pragma unroll
+        for (int cx = 0; cx < 3; ++cx) cur[cx] = nxt[cx];
+        const float4 zin = zin_nxt;
+        if (iy + 1 < r1) {
+          const int iyn = iy + 1 < H ? iy + 1 : H - 1;
+#pragma unroll
+          for (int cx = 0; cx < 3; ++cx) nxt[cx] = dz_load(q, b, iy + 2, xq - 1 + cx, c4);
+          zin_nxt = lda4(q.xz + (((size_t)b * H + iyn) * W + xq) * C + c4 * 4);
+        }
 #pragma unroll
         for (int cx = 0; cx < 3; ++cx) {
           d[0][cx] = d[1][cx];
           d[1][cx] = d[2][cx];
-          d[2][cx] = dz_at(q, kc, b, iy + 1, xq - 1 + cx, c4);
+          d[2][cx] = dz_make(q, kc, cur[cx]);
         }
         const size_t off = (((size_t)b * H + iy) * W + xq) * C + c4 * 4;
-        const float4 zin = lda4(q.xz + off);
         const float4 xa = apply_prologue(zin, pro);
         float4 o = f4zero();
 #pragma unroll
