@@ -26,6 +26,9 @@ extern "C" int nasseg_wgrad_finalize_many(int count, const float* const* partial
 
 namespace {
 
+#ifndef NASSEG_PW_CHUNK
+#define NASSEG_PW_CHUNK 3
+#endif
 constexpr int kPwTile = 64;         // pixels per tile (16 per wave)
 constexpr int kPwMaxTiles = 24;     // (n, k) accumulator tiles per wave
 
@@ -59,21 +62,41 @@ __device__ __forceinline__ float4 act_mask_of(float4 v, int act) {
                      (v.z > 0.f && v.z < hi) ? 1.f : 0.f, (v.w > 0.f && v.w < hi) ? 1.f : 0.f);
 }
 
+// LDS of the narrow kernel in floats: dz tile | input tile | per-channel constants | (WL) the weight
+__host__ __device__ constexpr int pw_lsn(int NT) { return NT * 16 + 4; }
+__host__ __device__ constexpr int pw_lsk(int KT) { return KT * 16 + 4; }
+__host__ __device__ constexpr int pw_lds_floats(int NT, int KT, bool WL) {
+  return kPwTile * (pw_lsn(NT) + pw_lsk(KT)) + 4 * NT * 16 + 2 * KT * 16 + (WL ? KT * 16 * pw_lsn(NT) : 0);
+}
+// the weight [K][N] is kept in LDS when everything still fits twice on a CU
+__host__ __device__ constexpr bool pw_weight_in_lds(int NT, int KT) {
+  return pw_lds_floats(NT, KT, true) * 4 <= (72 << 10);
+}
+// the next tile's loads are issued ahead when their registers (8*NT + 4*KT) still leave two waves per
+// SIMD next to the 4*NT*KT accumulators (32 -> 192 at 4x128x256 with one wave: 118 us, without
+// prefetch and two waves: 86 us)
+__host__ __device__ constexpr bool pw_prefetch(int NT, int KT) { return NT * KT <= 18; }
+
 // NT / KT: 16-wide tiles of N / K held per wave (>= the actual counts: surplus tiles only cost
-// idle MFMAs); PRO: the forward read x through act(in_scale*x + in_shift)
+// idle MFMAs and idle lanes of the tile loads); PRO: the forward read x through
+// act(in_scale*x + in_shift).  A workgroup walks its slab in tiles of 64 pixels: the tile's g, z and
+// x are loaded to registers - NT + NT + KT float4 per thread - while the PREVIOUS tile is computed
+// from LDS (nothing else hides the HBM latency: at most two to six workgroups are resident on a CU
+// and a tile's loads were issued, waited for and used in turn - 24 -> 144 at 4x256x512: 260 us before).
 template <int NT, int KT, bool PRO>
 __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   extern __shared__ float smem[];
-  const int LSN = a.NP + 4, LSK = a.KP + 4;
+  constexpr int LSN = pw_lsn(NT), LSK = pw_lsk(KT), NPc = NT * 16, KPc = KT * 16;
+  constexpr bool WL = pw_weight_in_lds(NT, KT), PF = pw_prefetch(NT, KT);
   float* dzt = smem;                       // [64][LSN]
   float* xt = dzt + kPwTile * LSN;         // [64][LSK]
-  float* cst = xt + kPwTile * LSK;         // ca | cb | cd | cs [NP each], psc | psh [KP each]
-  float* ca = cst;
-  float* cb = ca + a.NP;
-  float* cd = cb + a.NP;
-  float* cs = cd + a.NP;
-  float* psc = cs + a.NP;
-  float* psh = psc + a.KP;
+  float* ca = xt + kPwTile * LSK;          // ca | cb | cd | cs [NPc each], psc | psh [KPc each]
+  float* cb = ca + NPc;
+  float* cd = cb + NPc;
+  float* cs = cd + NPc;
+  float* psc = cs + NPc;
+  float* psh = psc + KPc;
+  float* wl = psh + KPc;                   // (WL) [KPc][LSN]: wb[k][n], zero beyond K / N
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
@@ -81,7 +104,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
 
   // dz = ca*g' + cb*z + cd  ==  scale*(g' - sum(g')/M - xhat*sum(g'*xhat)/M), xhat = (z - mean)*invstd,
   // g' = g * act'(scale*z + shift) when g arrives without its activation mask (bn_act != 0)
-  for (int n = tid; n < a.NP; n += 256) {
+  for (int n = tid; n < NPc; n += 256) {
     float va = 0.f, vb = 0.f, vd = 0.f, vs = 0.f;
     if (n < N) {
       const float sc = a.bn_scale[n];
@@ -96,9 +119,16 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
     }
     ca[n] = va; cb[n] = vb; cd[n] = vd; cs[n] = vs;
   }
-  for (int k = tid; k < a.KP; k += 256) {
+  for (int k = tid; k < KPc; k += 256) {
     psc[k] = (PRO && a.in_scale && k < K) ? a.in_scale[k] : 1.f;
     psh[k] = (PRO && a.in_shift && k < K) ? a.in_shift[k] : 0.f;
+  }
+  if (WL) {
+    for (int it = tid; it < KPc * (NPc / 4); it += 256) {
+      const int k = it / (NPc / 4), n = (it - k * (NPc / 4)) * 4;
+      const float4 v = keep_if(ld4(a.wb + (int64_t)(k < K ? k : 0) * N + (n < N ? n : 0)), k < K && n < N);
+      *reinterpret_cast<float4*>(&wl[k * LSN + n]) = v;
+    }
   }
   const ActSel pact = act_sel(a.in_act);
 
@@ -111,24 +141,51 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   const int p_begin = blockIdx.x * a.pix_per_slab;
   int p_end = p_begin + a.pix_per_slab;
   if (p_end > a.M) p_end = a.M;
-  const int n4 = a.NP >> 2, k4 = a.KP >> 2;
-  for (int t0 = p_begin; t0 < p_end; t0 += kPwTile) {
-    __syncthreads();  // (the previous tile's operands have been read; first pass: constants are in place)
-    // ---- the dz tile: all 256 threads, float4 along n -----------------------------------------
-    for (int it = tid; it < kPwTile * n4; it += 256) {
-      const int px = it / n4, n = (it - px * n4) * 4;
+
+  // item u of a thread: float4 number tid + 256*u of the [64][NPc] (or [64][KPc]) tile
+  float4 gv[PF ? NT : 1], zv[PF ? NT : 1], xv[KT];
+  auto issue_nz = [&](int t0, int u_lo, int u_hi, float4* G, float4* Z) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      if (u < u_lo || u >= u_hi) continue;
+      const int it = tid + 256 * u;
+      const int px = it / (NPc / 4), n = (it - px * (NPc / 4)) * 4;
       const int p = t0 + px;
-      const bool ok = p < p_end && n < N;
       const int64_t off = (int64_t)(p < p_end ? p : p_end - 1) * N + (n < N ? n : 0);
-      float4 gv = lda4(a.g + off);
-      const float4 zv = lda4(a.z + off);
+      G[u - u_lo] = lda4(a.g + off);
+      Z[u - u_lo] = lda4(a.z + off);
+    }
+  };
+  auto issue_x = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int it = tid + 256 * u;
+      const int px = it / (KPc / 4), k = (it - px * (KPc / 4)) * 4;
+      const int p = t0 + px;
+      xv[u] = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
+    }
+  };
+  auto issue = [&](int t0) {
+    issue_nz(t0, 0, NT, gv, zv);
+    issue_x(t0);
+  };
+  // registers -> the dz tile
+  auto place_nz = [&](int t0, int u_lo, int u_hi, const float4* G, const float4* Z) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      if (u < u_lo || u >= u_hi) continue;
+      const int it = tid + 256 * u;
+      const int px = it / (NPc / 4), n = (it - px * (NPc / 4)) * 4;
+      const bool ok = t0 + px < p_end && n < N;
       const float4 va = ld4(ca + n), vb = ld4(cb + n), vd = ld4(cd + n);
+      float4 g2 = G[u - u_lo];
+      const float4 z2 = Z[u - u_lo];
       if (a.bn_act) {
-        const float4 y = fma4(zv, va, ld4(cs + n));
-        gv = make_float4(gv.x * act_mask(y.x, a.bn_act), gv.y * act_mask(y.y, a.bn_act),
-                         gv.z * act_mask(y.z, a.bn_act), gv.w * act_mask(y.w, a.bn_act));
+        const float4 y = fma4(z2, va, ld4(cs + n));
+        g2 = make_float4(g2.x * act_mask(y.x, a.bn_act), g2.y * act_mask(y.y, a.bn_act),
+                         g2.z * act_mask(y.z, a.bn_act), g2.w * act_mask(y.w, a.bn_act));
       }
-      float4 dz = fma4(gv, va, fma4(zv, vb, vd));
+      float4 dz = fma4(g2, va, fma4(z2, vb, vd));
 #ifdef NASSEG_BF16
       // (what the two-kernel form stores and reads back)
       dz = make_float4(bf16_to_f32(f32_to_bf16(dz.x)), bf16_to_f32(f32_to_bf16(dz.y)),
@@ -136,16 +193,35 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
 #endif
       *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(dz, ok);
     }
-    // ---- the input tile, through the forward's prologue ---------------------------------------
-    for (int it = tid; it < kPwTile * k4; it += 256) {
-      const int px = it / k4, k = (it - px * k4) * 4;
-      const int p = t0 + px;
-      const bool ok = p < p_end && k < K;
-      float4 xv = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
-      if (PRO) xv = act_apply4(fma4(xv, ld4(psc + k), ld4(psh + k)), pact);
-      *reinterpret_cast<float4*>(&xt[px * LSK + k]) = keep_if(xv, ok);
+  };
+  if (PF && p_begin < p_end) issue(p_begin);
+  for (int t0 = p_begin; t0 < p_end; t0 += kPwTile) {
+    __syncthreads();  // (the previous tile's operands have been read; first pass: constants are in place)
+    // ---- registers -> the dz tile and the input tile (through the forward's prologue) ------------
+    if (PF) {
+      place_nz(t0, 0, NT, gv, zv);
+    } else {
+      // no room for a whole tile in registers: NASSEG_PW_CHUNK items at a time (3: two waves per SIMD)
+      issue_x(t0);
+#pragma unroll
+      for (int u0 = 0; u0 < NT; u0 += NASSEG_PW_CHUNK) {
+        float4 g4[NASSEG_PW_CHUNK], z4[NASSEG_PW_CHUNK];
+        issue_nz(t0, u0, u0 + NASSEG_PW_CHUNK, g4, z4);
+        place_nz(t0, u0, u0 + NASSEG_PW_CHUNK, g4, z4);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int it = tid + 256 * u;
+      const int px = it / (KPc / 4), k = (it - px * (KPc / 4)) * 4;
+      const bool ok = t0 + px < p_end && k < K;
+      float4 v = xv[u];
+      if (PRO) v = act_apply4(fma4(v, ld4(psc + k), ld4(psh + k)), pact);
+      *reinterpret_cast<float4*>(&xt[px * LSK + k]) = keep_if(v, ok);
     }
     __syncthreads();
+    if (PF && t0 + kPwTile < p_end) issue(t0 + kPwTile);  // in flight until the top of the next pass
     // ---- input gradient of this wave's 16 pixels: dx[p][k] = sum_n wb[k][n] * dz[p][n] -----------
     {
       f32x4 acc1[KT];
@@ -159,7 +235,8 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           const int k = kt * 16 + j;
-          av[kt] = keep_if(ld4(a.wb + (int64_t)(k < K ? k : 0) * N + (n < N ? n : 0)), k < K && n < N);
+          if (WL) av[kt] = *reinterpret_cast<const float4*>(&wl[k * LSN + n]);
+          else av[kt] = keep_if(ld4(a.wb + (int64_t)(k < K ? k : 0) * N + (n < N ? n : 0)), k < K && n < N);
         }
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
@@ -174,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
       for (int kt = 0; kt < KT; ++kt) {
         const int k = kt * 16 + kg * 4;
         float4 o = make_float4(acc1[kt][0], acc1[kt][1], acc1[kt][2], acc1[kt][3]);
-        if (a.dx_act && k < a.KP)
+        if (a.dx_act)
           o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LSK + k]), a.dx_act));
         if (p < p_end && k < K) sta4(a.dx + (int64_t)p * K + k, o);
       }
@@ -185,9 +262,9 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
       const int pl = wave * 16 + u * 4 + kg;  // (the MFMA's 4 reduction slots are 4 pixels)
       float av[NT], bv[KT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) av[nt] = nt * 16 < a.NP ? dzt[pl * LSN + nt * 16 + j] : 0.f;
+      for (int nt = 0; nt < NT; ++nt) av[nt] = dzt[pl * LSN + nt * 16 + j];
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt) bv[kt] = kt * 16 < a.KP ? xt[pl * LSK + kt * 16 + j] : 0.f;
+      for (int kt = 0; kt < KT; ++kt) bv[kt] = xt[pl * LSK + kt * 16 + j];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -404,7 +481,8 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
   // 16 -> 96 at 4x512x1024): 1024 slabs 457 us, 2048 457, 1490 532, 763 519, 512 572; 24 -> 144 at
   // 4x256x512: 512 slabs 280 us, 1024 288, 745 366 - counts that leave the CUs with unequal numbers of
   // resident workgroups cost 15-30 %.
-  const int64_t lds = (int64_t)kPwTile * (((N + 15) & ~15) + (p.wide ? kPwChunk : ((K + 15) & ~15)) + 8) * 4;
+  const int64_t lds = p.wide ? (int64_t)kPwTile * (((N + 15) & ~15) + kPwChunk + 8) * 4
+                             : (int64_t)pw_lds_floats(p.nt, p.kt, pw_weight_in_lds(p.nt, p.kt)) * 4;
   int64_t s = lds > (40 << 10) ? 512 : 1024;
   const int64_t cap = (int64_t)((p.wide ? 64 : 16) << 20) / ((int64_t)N * K * 4);
   while (s > 1 && (s > cap || s > M / (4 * kPwTile))) s >>= 1;
@@ -417,7 +495,14 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
 }
 
 template <int NT, int KT>
-void pw_launch(const PwArgs& a, int nslab, size_t lds, bool pro, hipStream_t s) {
+void pw_launch(const PwArgs& a, int nslab, bool pro, hipStream_t s) {
+  constexpr size_t lds = (size_t)pw_lds_floats(NT, KT, pw_weight_in_lds(NT, KT)) * sizeof(float);
+  if (lds > (64 << 10)) {  // above the default limit of dynamic LDS (per device: set on every launch)
+    if (pro) (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, false>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   if (pro) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true>), dim3(nslab), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, false>), dim3(nslab), dim3(256), lds, s, a);
 }
@@ -468,7 +553,6 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
   a.dx_act = dx_act;
   a.K = K; a.N = N; a.KP = (K + 15) & ~15; a.NP = (N + 15) & ~15;
   a.M = (int)M; a.pix_per_slab = p.pix_per_slab;
-  const size_t lds = ((size_t)kPwTile * (a.NP + 4 + a.KP + 4) + 4 * a.NP + 2 * a.KP) * sizeof(float);
   const bool pro = in_scale || in_shift || in_act;
   hipStream_t s = (hipStream_t)stream;
   if (p.wide) {
@@ -491,7 +575,7 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
     const int dims_w[5] = {p.nslab, 1, N, K, 0};
     return nasseg_wgrad_finalize_many(1, parts_w, outs_w, dims_w, stream);
   }
-#define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_) pw_launch<NT_, KT_>(a, p.nslab, lds, pro, s); else
+#define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_) pw_launch<NT_, KT_>(a, p.nslab, pro, s); else
   PW_CASE(2, 1) PW_CASE(3, 1) PW_CASE(4, 1) PW_CASE(6, 1) PW_CASE(9, 1) PW_CASE(12, 1)
   PW_CASE(2, 2) PW_CASE(3, 2) PW_CASE(4, 2) PW_CASE(6, 2) PW_CASE(9, 2) PW_CASE(12, 2)
   PW_CASE(2, 4) PW_CASE(3, 4) PW_CASE(4, 4) PW_CASE(6, 4)

@@ -816,22 +816,52 @@ __global__ __launch_bounds__(256, NASSEG_DWBWD_MINB) void dw3x3_bwd_bn_kernel(Dw
       float4 d[2][2];
 #pragma unroll
       for (int rx = 0; rx < 2; ++rx) d[1][rx] = dz_at(q, kc, b, r0, xq + rx, c4);
+      // the loads of quad row aq + 1 (two dz columns, four input pixels) are in flight while quad row aq
+      // is computed
+      DzRaw nxt[2];
+      float4 zin_nxt[2][2];
+#pragma unroll
+      for (int rx = 0; rx < 2; ++rx) nxt[rx] = dz_load(q, b, r0 + 1, xq + rx, c4);
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          const int iy = 2 * r0 + py, ix = 2 * xq + px;
+          zin_nxt[py][px] = lda4(q.xz + (((size_t)b * H + (iy < H ? iy : H - 1)) * W + (ix < W ? ix : W - 1)) * C + c4 * 4);
+        }
       for (int aq = r0; aq < r1; ++aq) {
+        DzRaw cur[2];
+        float4 o[2][2], xa[2][2], zin[2][2];
+        bool ok[2][2];
+#pragma unroll
+        for (int rx = 0; rx < 2; ++rx) cur[rx] = nxt[rx];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) zin[py][px] = zin_nxt[py][px];
+        if (aq + 1 < r1) {
+#pragma unroll
+          for (int rx = 0; rx < 2; ++rx) nxt[rx] = dz_load(q, b, aq + 2, xq + rx, c4);
+#pragma unroll
+          for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+              const int iy = 2 * (aq + 1) + py, ix = 2 * xq + px;
+              zin_nxt[py][px] =
+                  lda4(q.xz + (((size_t)b * H + (iy < H ? iy : H - 1)) * W + (ix < W ? ix : W - 1)) * C + c4 * 4);
+            }
+        }
 #pragma unroll
         for (int rx = 0; rx < 2; ++rx) {
           d[0][rx] = d[1][rx];
-          d[1][rx] = dz_at(q, kc, b, aq + 1, xq + rx, c4);
+          d[1][rx] = dz_make(q, kc, cur[rx]);
         }
-        float4 o[2][2], xa[2][2], zin[2][2];
-        bool ok[2][2];
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
           for (int px = 0; px < 2; ++px) {
             const int iy = 2 * aq + py, ix = 2 * xq + px;
             ok[py][px] = iy < H && ix < W;
-            const size_t off = (((size_t)b * H + (iy < H ? iy : H - 1)) * W + (ix < W ? ix : W - 1)) * C + c4 * 4;
-            zin[py][px] = lda4(q.xz + off);
             xa[py][px] = keep_if(apply_prologue(zin[py][px], pro), ok[py][px]);
             o[py][px] = f4zero();
           }
