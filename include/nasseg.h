@@ -107,7 +107,17 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     const float* out_scale, const float* out_shift, int out_act, const float* res,
                     int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
                     int stride, int pad, int dil, int transposed, float* stats, void* stream);
-int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N);
+/* rows of statistics a call with N output channels over B*Ho*Wo output pixels writes; K = its reduction
+ * channels; pointwise: 0 = any other geometry, 1 = a 1x1, stride-1, unpadded nasseg_conv_fwd call, 2 = such a
+ * nasseg_conv_bwd_data_bn call - those may take the persistent pointwise kernel (weight in LDS, inputs
+ * prefetched, one statistics row per workgroup of a grid that depends on K) */
+int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int pointwise);
+/* tuning / testing knob: which pointwise calls take the persistent kernel.  -2 (initial): where it measured
+ * faster; v >= 0: every call it supports over at least v output pixels (0 = all, a huge value = none);
+ * v == -1 only queries.  Returns the previous setting.  Outputs are bit-identical either way; BatchNorm
+ * statistics differ in the rounding of their partial sums.  Row counts from nasseg_conv_fwd_stats_blocks are
+ * valid for the setting they were asked under. */
+int64_t nasseg_conv_pw_min_pixels(int64_t v);
 /* dense twin of nasseg_dwconv_bwd_data_bn (arguments as nasseg_conv_fwd, transposed) */
 int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
                             const float* z, int ldz, const float* scale, const float* shift,

@@ -97,7 +97,23 @@ typedef bf16_t act_t;
 typedef float act_t;
 #define NASSEG_FN(name) nasseg_##name
 #define NASSEG_FP32_ONLY 1  // entry points that never touch activations exist once, in this build
+
 #endif
+
+// Sum over the 16 lanes of a DPP row (lanes 16*g .. 16*g+15), result in every lane of the row: the same
+// pairing as an xor butterfly over offsets 1, 2, 4, 8 (bit-identical), but four full-rate v_add_f32_dpp
+// instead of four ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
 
 __device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16(float f) {

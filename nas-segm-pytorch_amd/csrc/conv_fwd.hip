@@ -29,6 +29,14 @@
 //   mode 2 flat forward  : wp[N][tap*K + k]
 #include "conv_common.h"
 
+#include <atomic>
+
+// Which pointwise calls take the persistent kernel (conv_pw_kernel).  Default (-2): where it measured
+// faster (pw_fwd_plan).  v >= 0: every call it supports over at least v output pixels (0: all of them - what
+// the parity tests use; a huge value: none); v == -1 only queries.  Returns the previous setting.
+// Process-wide; outputs do not depend on it, BatchNorm statistics only in the rounding of their partial sums.
+extern "C" int64_t nasseg_conv_pw_min_pixels(int64_t v);
+
 namespace {
 
 struct FwdArgs {
@@ -66,6 +74,11 @@ enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
 // registers cost occupancy, and thread-level parallelism is what hides HBM latency here
 #ifndef NASSEG_CONV_KU
 #define NASSEG_CONV_KU 1
+#endif
+// initial setting of nasseg_conv_pw_min_pixels (experiments: -DNASSEG_PW_MIN_PIXELS=2000000000 turns
+// conv_pw_kernel off)
+#ifndef NASSEG_PW_MIN_PIXELS
+#define NASSEG_PW_MIN_PIXELS -2
 #endif
 
 // 4 floats along the reduction axis starting at k (clamped, always in range); the caller
@@ -310,12 +323,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
       }
       if (!kSums) continue;
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sx[r] += __shfl_xor(sx[r], off);
-          sq[r] += __shfl_xor(sq[r], off);
-        }
+      for (int r = 0; r < 4; ++r) {
+        sx[r] = row16_allsum(sx[r]);
+        sq[r] = row16_allsum(sq[r]);
       }
       if (WS) {
         // this wave alone owns these channels of the workgroup's pixels
@@ -395,6 +405,273 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     }
   }
 
+}
+
+// ---------------------------------------------------------------------------
+// Pointwise (1x1, stride 1) fast path: persistent waves, the weight in LDS, X in flight.
+// ---------------------------------------------------------------------------
+// conv_fwd_kernel above gives every wave one tile: it loads weights (L1) and X operand by operand
+// and all its latencies are hidden only by other resident waves - 2.6-3.6 TB/s on the large
+// pointwise convs of the encoder.  Here a workgroup loads the whole weight [N][K] into LDS once
+// and each of its waves walks a strided sequence of tiles (16*MT pixels x all N) as ONE flattened
+// stream of k-blocks: the X operands of the next kPwD k-blocks (of this or the next tile) are
+// always in flight while the current one is multiplied, the weight operand comes from LDS (no
+// vmcnt dependency), and there is no workgroup barrier inside the loop.  Same MFMA order per
+// accumulator as conv_fwd_kernel: results are bit-identical to it.  Statistics (STATS 1 / 2) are
+// accumulated per wave in LDS over all its tiles: one row per workgroup of a grid that is a few
+// hundred to two thousand workgroups instead of one row per 64*MT pixels.
+constexpr int kPwD = 4;
+
+struct PwFwdPlan {
+  int ok, nt, mt, grid;
+  size_t lds;
+};
+// smallest pixel count that takes this path (nasseg_conv_pw_min_pixels: a tuning / testing knob)
+#if NASSEG_FP32_ONLY
+std::atomic<int64_t> g_pw_min_pixels{NASSEG_PW_MIN_PIXELS};
+#endif
+inline int pw_round_tiles(int t) {
+  const int allowed[] = {1, 2, 3, 4, 6, 9, 12, 14};
+  for (int v : allowed)
+    if (t <= v) return v;
+  return 0;
+}
+// a function of (pixels, N, K, kind of call) only: nasseg_conv_fwd_stats_blocks must predict the grid.
+// mode 1: nasseg_conv_fwd, 2: nasseg_conv_bwd_data_bn.
+// Measured against conv_fwd_kernel on the headline step (tools/ab_breakdown.sh, us old -> new): it wins
+// where the reduction is long and the output narrow - 128->64 @128x256 51 -> 37, 192->32 46 -> 36,
+// 64->64 @256x512 129 -> 106 (forward) / 121 -> 99 (backward-data), 224->64 216 -> 199, 144->24 102 -> 96,
+// 32->32 @256x512 50 -> 43 - and loses on the expanding convs, where a tile is two k-blocks of
+// multiplies and then 9-12 output vectors and their statistics: 24->144 98 -> 118, 32->192 36 -> 50,
+// 64->128 36 -> 40, 24->24 27 -> 31; the exception is the backward-data call into 144 channels
+// (24->144 @256x512: 247 -> 187), where the general kernel splits N over its waves.
+inline PwFwdPlan pw_fwd_plan(int64_t M, int N, int K, int mode) {
+  PwFwdPlan p = {};
+  if (N <= 0 || K <= 0 || (N & 3) || (K & 3) || N > 224 || K > 256) return p;
+  const int64_t knob = nasseg_conv_pw_min_pixels(-1);
+  if (knob >= 0) {
+    if (M < knob) return p;
+  } else {
+    const bool narrow = K >= 32 && N <= K && M >= 65536;
+    const bool into144 = mode == 2 && N > 128 && N <= 144 && M >= 262144;
+    if (!narrow && !into144) return p;
+  }
+  p.nt = pw_round_tiles(cdiv(N, 16));
+  if (!p.nt) return p;
+  p.mt = p.nt <= 6 ? 2 : 1;
+  const int KP = (K + 15) & ~15;
+  p.lds = ((size_t)p.nt * 16 * (KP + 4) + 2 * KP + 4 * 2 * p.nt * 16) * sizeof(float);
+  if (p.lds > (size_t)(64 << 10)) return p;
+  // resident workgroups per CU by registers (the smallest over the STATS variants of a tile count)
+  int r = p.nt <= 2 ? 4 : (p.nt <= 4 ? 3 : (p.nt == 9 ? 3 : 2));
+  const int by_lds = (int)((size_t)(160 << 10) / p.lds);
+  if (r > by_lds) r = by_lds;
+  const int64_t wg_tiles = cdiv64(cdiv64(M, 16 * p.mt), 4);
+  p.grid = (int)(wg_tiles < 256LL * r ? wg_tiles : 256LL * r);
+  p.ok = 1;
+  return p;
+}
+
+template <int NT, int MT, int STATS>
+__global__ __launch_bounds__(256) void conv_pw_kernel(FwdArgs a) {
+  constexpr bool kSums = STATS == 1 || STATS == 2;
+  constexpr int NPc = NT * 16;
+  extern __shared__ float smem[];
+  const int K = a.K, N = a.N;
+  const int KP = (K + 15) & ~15, LSK = KP + 4, nkb = KP >> 4;
+  float* wl = smem;                 // [NPc][LSK]: w[n][k], zero beyond N / K
+  float* psc = wl + NPc * LSK;      // [KP] prologue scale | [KP] shift
+  float* psh = psc + KP;
+  float* sred = psh + KP;           // [4 waves][2][NPc]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int Mtot = a.g.B * a.g.Ho * a.g.Wo;
+  const int ntiles = (Mtot + 16 * MT - 1) / (16 * MT);
+
+  for (int it = tid; it < NPc * (KP >> 2); it += 256) {
+    const int n = it / (KP >> 2), k = (it - n * (KP >> 2)) * 4;
+    const float4 v = keep_if(lda4(a.w + (int64_t)(n < N ? n : 0) * K + (k < K ? k : 0)), n < N && k < K);
+    *reinterpret_cast<float4*>(&wl[n * LSK + k]) = v;
+  }
+  const bool pro = a.in_scale || a.in_shift || a.in_act;
+  for (int k = tid; k < KP; k += 256) {
+    psc[k] = (a.in_scale && k < K) ? a.in_scale[k] : 1.f;
+    psh[k] = (a.in_shift && k < K) ? a.in_shift[k] : 0.f;
+  }
+  for (int t = tid; t < 4 * 2 * NPc; t += 256) sred[t] = 0.f;
+  __syncthreads();
+  const ActSel pact = act_sel(a.in_act);
+  float* my_red = sred + wave * 2 * NPc;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wstride = gridDim.x * 4;
+  // the loader runs kPwD k-blocks ahead of the multiplier through the same (tile, k-block) sequence
+  int tl = blockIdx.x * 4 + wave, kl = 0;
+  float4 ring[kPwD][MT];
+  auto load_step = [&](float4* dst) {
+    const int tc = tl < ntiles ? tl : ntiles - 1;  // (past the end: a valid address, never used)
+    const int k = kl * 16 + kg * 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = tc * (16 * MT) + mt * 16 + j;
+      dst[mt] = lda4(a.x + (int64_t)(m < Mtot ? m : Mtot - 1) * a.ldx + (k < K ? k : 0));
+    }
+    if (++kl == nkb) {
+      kl = 0;
+      tl += wstride;
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < kPwD; ++d) load_step(ring[d]);
+
+  int tc = blockIdx.x * 4 + wave, kc = 0;
+  bool more = tc < ntiles;
+  while (more) {
+#pragma unroll
+    for (int d = 0; d < kPwD; ++d) {
+      if (tc >= ntiles) {
+        more = false;
+        break;
+      }
+      float4 bv[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bv[mt] = ring[d][mt];
+      load_step(ring[d]);
+      const int k = kc * 16 + kg * 4;
+      if (pro) {
+        const float4 sc = *reinterpret_cast<const float4*>(&psc[k]);
+        const float4 sh = *reinterpret_cast<const float4*>(&psh[k]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) bv[mt] = act_apply4(fma4(bv[mt], sc, sh), pact);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bv[mt] = keep_if(bv[mt], k < K);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float4 av = *reinterpret_cast<const float4*>(&wl[(nt * 16 + j) * LSK + k]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt][nt] = mfma16(av.x, bv[mt].x, acc[mt][nt]);
+          acc[mt][nt] = mfma16(av.y, bv[mt].y, acc[mt][nt]);
+          acc[mt][nt] = mfma16(av.z, bv[mt].z, acc[mt][nt]);
+          acc[mt][nt] = mfma16(av.w, bv[mt].w, acc[mt][nt]);
+        }
+      }
+      if (++kc < nkb) continue;
+      // ---- the tile is complete: epilogue, lane holds pixel j of each subtile, channels 4*kg + {0..3} ----
+      kc = 0;
+      const int m_base = tc * (16 * MT);
+      tc += wstride;
+      int pm[MT];
+      bool pok[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + j;
+        pok[mt] = m < Mtot;
+        pm[mt] = pok[mt] ? m : Mtot - 1;
+      }
+      // the per-channel vectors of the epilogue are re-read (L1) per tile: hoisted out of the tile loop
+      // they would occupy 8-16 registers per channel tile for the whole kernel
+      const float* e_sc = STATS == 0 ? a.out_scale : a.b_scale;
+      const float* e_sh = STATS == 0 ? a.out_shift : a.b_shift;
+      const float* e_mu = a.b_mean;
+      const float* e_is = a.b_invstd;
+      asm volatile("" : "+s"(e_sc), "+s"(e_sh), "+s"(e_mu), "+s"(e_is));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + kg * 4;
+        const bool nok = n < N;
+        const int nc = nok ? n : 0;
+        if (STATS == 0) {
+          float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+          if (e_sc) sc = lda4(e_sc + nc);
+          if (e_sh) sh = lda4(e_sh + nc);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 c = acc[mt][nt];
+            float4 o = make_float4(c[0], c[1], c[2], c[3]);
+            if (e_sc || e_sh) o = fma4(o, sc, sh);
+            if (a.out_act) o = act_apply4(o, a.out_act);
+            if (a.res) o = add4(o, lda4(a.res + (int64_t)pm[mt] * a.ldres + nc));
+            if (nok && pok[mt]) sta4(a.y + (int64_t)pm[mt] * a.ldy + n, o);
+          }
+        } else {
+          float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+          float bsc[4] = {1.f, 1.f, 1.f, 1.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f},
+                bis[4] = {0.f, 0.f, 0.f, 0.f};
+          if (STATS >= 2) {
+            if (e_sc) { const float4 t = lda4(e_sc + nc); bsc[0] = t.x; bsc[1] = t.y; bsc[2] = t.z; bsc[3] = t.w; }
+            if (e_sh) { const float4 t = lda4(e_sh + nc); bsh[0] = t.x; bsh[1] = t.y; bsh[2] = t.z; bsh[3] = t.w; }
+          }
+          if (STATS == 2) {
+            const float4 t2 = lda4(e_mu + nc), t3 = lda4(e_is + nc);
+            bmu[0] = t2.x; bmu[1] = t2.y; bmu[2] = t2.z; bmu[3] = t2.w;
+            bis[0] = t3.x; bis[1] = t3.y; bis[2] = t3.z; bis[3] = t3.w;
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            f32x4 c = acc[mt][nt];
+            if (STATS >= 2) {
+              const float4 z4 = lda4(a.bz + (int64_t)pm[mt] * a.ldbz + nc);
+              const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float g = c[r] * act_mask(fmaf(zz[r], bsc[r], bsh[r]), a.b_act);
+                c[r] = g;
+                if (STATS == 2) {
+                  const float v = keep_if(g, pok[mt]);
+                  sx[r] += v;
+                  sq[r] = fmaf(v, (zz[r] - bmu[r]) * bis[r], sq[r]);
+                }
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = keep_if(c[r], pok[mt]);
+                sx[r] += v;
+                sq[r] = fmaf(v, v, sq[r]);
+              }
+            }
+            if (nok && pok[mt]) sta4(a.y + (int64_t)pm[mt] * a.ldy + n, make_float4(c[0], c[1], c[2], c[3]));
+          }
+          if (kSums) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              sx[r] = row16_allsum(sx[r]);
+              sq[r] = row16_allsum(sq[r]);
+            }
+            if (j == 0) {  // (this wave's own row of sred: no other lane touches these entries)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                my_red[n + r] += sx[r];
+                my_red[NPc + n + r] += sq[r];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // (keeps the loads of at most two channel tiles of z / res in registers at a time)
+        if ((nt & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (kSums) {
+    __syncthreads();
+    for (int t = tid; t < NPc; t += 256) {
+      if (t < N) {
+        float* po = a.stats + (int64_t)blockIdx.x * 2 * N + t;
+        po[0] = (sred[t] + sred[2 * NPc + t]) + (sred[4 * NPc + t] + sred[6 * NPc + t]);
+        po[N] = (sred[NPc + t] + sred[3 * NPc + t]) + (sred[5 * NPc + t] + sred[7 * NPc + t]);
+      }
+    }
+  }
 }
 
 // OIHW (N,K,kh,kw) -> [tap][N][K] (mode 0), [tap][K][N] (mode 1), [N][tap*K+k] (mode 2)
@@ -700,6 +977,31 @@ int launch_small(const FwdArgs& a, const Mode& md, hipStream_t s) {
   return launch_one<1, NT, WS>(a, md, s);
 }
 
+template <int NT, int MT>
+int launch_pw_nt(const FwdArgs& a, const PwFwdPlan& p, int stats, hipStream_t s) {
+  const dim3 grid(p.grid), block(256);
+  switch (stats) {
+    case 0: hipLaunchKernelGGL((conv_pw_kernel<NT, MT, 0>), grid, block, p.lds, s, a); break;
+    case 1: hipLaunchKernelGGL((conv_pw_kernel<NT, MT, 1>), grid, block, p.lds, s, a); break;
+    case 2: hipLaunchKernelGGL((conv_pw_kernel<NT, MT, 2>), grid, block, p.lds, s, a); break;
+    default: hipLaunchKernelGGL((conv_pw_kernel<NT, MT, 3>), grid, block, p.lds, s, a); break;
+  }
+  NASSEG_LAUNCH_CHECK("conv_pw_kernel");
+  return NASSEG_OK;
+}
+int launch_pw(const FwdArgs& a, const PwFwdPlan& p, int stats, hipStream_t s) {
+  switch (p.nt) {
+    case 1: return launch_pw_nt<1, 2>(a, p, stats, s);
+    case 2: return launch_pw_nt<2, 2>(a, p, stats, s);
+    case 3: return launch_pw_nt<3, 2>(a, p, stats, s);
+    case 4: return launch_pw_nt<4, 2>(a, p, stats, s);
+    case 6: return launch_pw_nt<6, 2>(a, p, stats, s);
+    case 9: return launch_pw_nt<9, 1>(a, p, stats, s);
+    case 12: return launch_pw_nt<12, 1>(a, p, stats, s);
+    default: return launch_pw_nt<14, 1>(a, p, stats, s);
+  }
+}
+
 inline int fwd_pack_mode(int K, int kh, int kw) { return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0; }
 
 int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
@@ -723,6 +1025,14 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
                  "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
   const int tiles = cdiv(N, 16);
+  if (!md.gather && md.km != KM_FLAT) {
+    const PwFwdPlan pw = pw_fwd_plan((int64_t)g.B * g.Ho * g.Wo, N, K, stats_mode >= 2 ? 2 : 1);
+    if (pw.ok) {
+      // (the statistics rows were sized for this grid: no falling back to the general kernel)
+      NASSEG_REQUIRE(md.km == KM_VEC && md.vecn, "conv_fwd: pointwise path needs channel strides that are multiples of 4");
+      return launch_pw(a, pw, md.stats, s);
+    }
+  }
   // 3x3, stride 1, dilation <= 2, maps at least one tile large: input patch staged in LDS
   if (!g.transposed && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.dil <= 2 && md.km != KM_FLAT &&
       !md.pro && !md.stats && tiles <= 4 && g.Wo >= kLdsTW && g.Ho >= kLdsTH && g.B <= 65535 &&
@@ -805,10 +1115,20 @@ int nasseg_pack_weights(int count, const float* const* w, float* const* wp, cons
 #endif  // NASSEG_FP32_ONLY
 
 #if NASSEG_FP32_ONLY
+int64_t nasseg_conv_pw_min_pixels(int64_t v) {
+  return v == -1 ? g_pw_min_pixels.load() : g_pw_min_pixels.exchange(v < 0 ? -2 : v);
+}
+#endif  // NASSEG_FP32_ONLY
+
+#if NASSEG_FP32_ONLY
 // number of per-workgroup statistic rows nasseg_conv_fwd writes for this geometry
-int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N) {
+int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int pointwise) {
   const int64_t Mtot = (int64_t)B * Ho * Wo;
   const int tiles = cdiv(N, 16);
+  if (pointwise) {
+    const PwFwdPlan pw = pw_fwd_plan(Mtot, N, K, pointwise);
+    if (pw.ok) return pw.grid;
+  }
   return cdiv64(Mtot, (tiles > 4 ? 16 : 64) * pick_mt(Mtot, tiles));
 }
 #endif  // NASSEG_FP32_ONLY
@@ -830,7 +1150,7 @@ int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) { return fwd_pack_mode(K, k
 // (1x1, stride 1) convolutions with K % 4 == 0.
 // stats != null (needs N % 4 == 0 and no output epilogue): also writes
 //   stats[blk][0][n] = sum over the workgroup's pixels of y[.][n], stats[blk][1][n] = sum of y^2
-// for blk < nasseg_conv_fwd_stats_blocks(...) - the partials nasseg_bn_finalize consumes.
+// for blk < nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N, K, pointwise) - the partials nasseg_bn_finalize consumes.
 int NASSEG_FN(conv_fwd)(const act_t* x, int ldx, const float* wp, act_t* y, int ldy,
                     const float* in_scale, const float* in_shift, int in_act,
                     const float* out_scale, const float* out_shift, int out_act, const act_t* res,
@@ -852,7 +1172,7 @@ int NASSEG_FN(conv_fwd)(const act_t* x, int ldx, const float* wp, act_t* y, int 
 // fused with the first half of that BatchNorm's backward:
 //   g[p][k]  = act'(scale[k]*z[p][k] + shift[k]) * sum_{tap,n} w[tap][n][k] * dy[src(p,tap)][n]
 //   stats[blk][0][k] = sum_p g[p][k],  stats[blk][1][k] = sum_p g[p][k]*(z[p][k]-mean[k])*invstd[k]
-// over the pixels p of workgroup blk < nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N).
+// over the pixels p of workgroup blk < nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N, K, pointwise).
 // Arguments as nasseg_conv_fwd with transposed != 0: dy has dims (Hs,Ws) and K channels (the
 // forward conv's output channels), g and z dims (Ho,Wo) and N channels (N % 4 == 0), wp packed
 // with mode 1.  Summing the stats rows (nasseg_rows_sum) gives what nasseg_bn_bwd_reduce

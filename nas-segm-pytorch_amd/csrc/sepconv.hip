@@ -247,12 +247,9 @@ __global__ __launch_bounds__(256) void sepconv_fwd_kernel(SepArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          sx[nt][c] += __shfl_xor(sx[nt][c], off);
-          sq[nt][c] += __shfl_xor(sq[nt][c], off);
-        }
+      for (int c = 0; c < 4; ++c) {
+        sx[nt][c] = row16_allsum(sx[nt][c]);
+        sq[nt][c] = row16_allsum(sq[nt][c]);
       }
       if (j == 0) {
 #pragma unroll

@@ -784,7 +784,7 @@ class _ConvChain(torch.autograd.Function):
                     elif kind == "dw":
                         nblk = lib.query("nasseg_dwconv_stats_blocks", B, N, Ho, Wo, kh, stride, dil)
                     else:
-                        nblk = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N)
+                        nblk = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N, K, int(pointwise))
                     part = _ws(cur, (nblk + 64) * 2 * N)
             o_sc = o_sh = o_res = None
             o_act = ACT_NONE
@@ -984,7 +984,9 @@ class _ConvChain(torch.autograd.Function):
                     if bn_prev is not None:
                         g = _new(cur, Bc, K, H, W)
                         zp, psc_, psh_, pmu_, pis_, pact_ = bn_prev
-                        nb = lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K) if pmu_ is not None else 0
+                        nb = (lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K, N,
+                                        2 * int(kh == 1 and kw == 1 and stride == 1 and pad == 0))
+                              if pmu_ is not None else 0)
                         part = _ws(cur, (nb + 64) * 2 * K) if nb else None
                         lib.call(_k("nasseg_conv_bwd_data_bn", dz), ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
                                  ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
@@ -1297,7 +1299,7 @@ class _CatBNReluConv(torch.autograd.Function):
         need_bn = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         dbn = _vec(x, 4 * C) if need_bn else None  # [dbeta(2C) | dgamma(2C)]
         dw = torch.empty((N, 2 * C, 1, 1), device=x.device, dtype=torch.float32) if need_w else None
-        nb = lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, C)
+        nb = lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, C, N, 2)
         grads_in = [None, None]
         for h, (t, wb) in enumerate(((x, wb_lo), (y, wb_hi))):
             lo, hi = h * C, (h + 1) * C

@@ -465,7 +465,7 @@ def test_dense_backward_data_with_bn_backward_statistics(case, act):
     ws = torch.empty(f.lib.query("nasseg_colred_workspace", 1, B * H * W, K), device=DEV)
     f.lib.call("nasseg_bn_bwd_reduce", f.ptr(g_ref), K, f.ptr(z), K, B * H * W, K, f.ptr(scale), f.ptr(shift),
                f.ptr(mean), f.ptr(invstd), act, f.ptr(sums_ref), f.ptr(ws), s)
-    nb = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, K)
+    nb = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, K, N, 2 * int(k == 1 and stride == 1 and pad == 0))
     part = torch.full(((nb + 64) * 2 * K,), float("nan"), device=DEV)
     g = dev(torch.empty(B, K, H, W))
     f.lib.call("nasseg_conv_bwd_data_bn", f.ptr(dy), N, f.ptr(wp), f.ptr(g), K, f.ptr(z), K, f.ptr(scale),
@@ -1157,3 +1157,81 @@ def test_depthwise_backward_between_batchnorms_in_one_kernel(case, dtype, bact, 
     s_got = part[:rows * 2 * C].view(rows, 2 * C).double().sum(0)
     tol = (2e-5 if dtype == torch.float32 else 2e-2) * float(s_ref.abs().max()) * max(1.0, (B * H * W / 4096.0) ** 0.5)
     assert_close(s_got, s_ref, tol, 1e-4 if dtype == torch.float32 else 2e-2, "statistics rows")
+
+
+# ---------------------------------------------------------------------------
+# the persistent pointwise kernel (conv_pw_kernel) against the general one
+# ---------------------------------------------------------------------------
+PW_FAST_CASES = [
+    # B, H, W, K, N
+    (1, 40, 52, 16, 96), (2, 33, 47, 24, 144), (1, 37, 41, 32, 192), (1, 45, 49, 144, 24), (1, 35, 50, 224, 64),
+    (2, 31, 29, 64, 64), (1, 43, 45, 20, 36), (1, 40, 40, 32, 32), (1, 39, 42, 96, 16), (1, 36, 38, 64, 224), (1, 30, 31, 128, 224),
+    (1, 41, 43, 4, 8), (1, 34, 47, 48, 100),
+]
+
+
+class _pw_threshold(object):
+    """inside: pointwise calls over >= `pixels` output pixels take conv_pw_kernel (the queries are
+    memoised per threshold, hence the cache is dropped on both sides)"""
+
+    def __init__(self, pixels):
+        self.pixels = pixels
+
+    def __enter__(self):
+        f = F()
+        f.lib._memo.clear()
+        self.old = f.lib.query("nasseg_conv_pw_min_pixels", self.pixels)
+        f.lib._memo.clear()
+
+    def __exit__(self, *exc):
+        f = F()
+        f.lib.query("nasseg_conv_pw_min_pixels", self.old if self.old >= 0 else -2)
+        f.lib._memo.clear()
+
+
+@pytest.mark.parametrize("case", PW_FAST_CASES)
+@pytest.mark.parametrize("mode", ["plain", "prologue", "epilogue", "stats", "prologue_stats", "bwd_bn", "bwd_mask"])
+def test_persistent_pointwise_kernel_equals_the_general_one(case, mode):
+    f = F()
+    B, H, W, K, N = case
+    M = B * H * W
+    x = dev(rnd(B, K, H, W, seed=1))
+    w = rnd(N, K, 1, 1, seed=2, scale=0.3).to(DEV)
+    res = dev(rnd(B, N, H, W, seed=3))
+    z = dev(rnd(B, N, H, W, seed=4))
+    isc, ish = _bn_vectors(K, 5)[:2]
+    osc, osh, omu, ois = _bn_vectors(N, 6)
+    s = f.current_stream()
+
+    def run():
+        y = dev(torch.full((B, N, H, W), float("nan")))
+        out = [y]
+        nb = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, N, K, 2 if mode.startswith("bwd") else 1)
+        part = torch.full(((nb + 64) * 2 * N,), float("nan"), device=DEV)
+        sums = torch.empty(2 * N, device=DEV)
+        pro = (f.ptr(isc), f.ptr(ish), 2) if mode.startswith("prologue") else (None, None, 0)
+        if mode in ("plain", "prologue", "epilogue", "stats", "prologue_stats"):
+            epi = (f.ptr(osc), f.ptr(osh), 1, f.ptr(res), N) if mode == "epilogue" else (None, None, 0, None, 0)
+            st = f.ptr(part) if mode.endswith("stats") else None
+            f.lib.call("nasseg_conv_fwd", f.ptr(x), K, f.ptr(w), f.ptr(y), N, *pro, *epi, B, H, W, K, H, W, N, 1, 1,
+                       1, 0, 1, 0, st, s)
+        else:
+            st = f.ptr(part) if mode == "bwd_bn" else None
+            f.lib.call("nasseg_conv_bwd_data_bn", f.ptr(x), K, f.ptr(w), f.ptr(y), N, f.ptr(z), N, f.ptr(osc),
+                       f.ptr(osh), f.ptr(omu), f.ptr(ois), 2, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, st, s)
+        if st is not None:
+            f.lib.call("nasseg_rows_sum", f.ptr(part), nb, 2 * N, f.ptr(sums), s)
+            out.append(sums)
+        return out, nb
+
+    with _pw_threshold(1 << 40):
+        ref, nb_ref = run()
+    with _pw_threshold(0):
+        got, nb_new = run()
+    if N * (((K + 15) & ~15) + 4) * 4 <= 56 << 10:  # (its weight fits the 64 KB of LDS next to the rest)
+        assert nb_new != nb_ref, "the persistent kernel was not selected"
+    assert not torch.isnan(got[0]).any()
+    assert torch.equal(got[0], ref[0]), "outputs differ by {}".format(float((got[0] - ref[0]).abs().max()))
+    if len(ref) > 1:
+        tol = 1e-5 * float(M) ** 0.5 * (float(ref[1].abs().max()) / float(M) ** 0.5 + 1.0)
+        assert_close(got[1], ref[1], tol, 1e-4, "statistics")

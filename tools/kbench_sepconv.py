@@ -54,7 +54,7 @@ for case in CASES:
     lib.call("nasseg_dw_pack_weight", ptr(wdw), ptr(wt), C, k, 0, stream())
     z = torch.empty((B, C, Ho, Wo), device=DEV).contiguous(memory_format=torch.channels_last)
     y = torch.empty((B, N, Ho, Wo), device=DEV).contiguous(memory_format=torch.channels_last)
-    nb1 = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N)
+    nb1 = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N, C, 1)
     nb2 = lib.query("nasseg_sepconv_blocks", B, C, Ho, Wo, N, k, stride, dil)
     part = torch.empty((max(nb1, nb2) + 64) * 2 * N, device=DEV)
     s = stream()
