@@ -173,9 +173,9 @@ def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops):
         return 0
     if K % 4 == 0 and i > 0 and ops[i - 1][4]:
         return 0  # (bn_prev in _ConvChain.backward: the producer's BatchNorm backward goes with backward-data)
-    if K > 64 and not _PW_BWD_WIDE:
-        return 0
     B, _, H, W = cur.shape
+    if K > 64 and not (_PW_BWD_WIDE and B * H * W >= _PW_BWD_WIDE_MIN_PIXELS):
+        return 0
     return lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N)
 
 
@@ -638,9 +638,12 @@ def _identity_vectors(like, n):
 # 33 MB, one kernel 21 us / two kernels 26 us; 64 -> 64 at 4x32x64, 4 MB, 35 / 19 us - too few slabs)
 FUSE_PW_BWD = os.environ.get("NASSEG_FUSE_PW_BWD", "1") != "0"
 _PW_BWD_MIN_BYTES = 24 << 20
-# the wide-input variant (K > 64: the four waves split N) is only at parity with the two kernels
-# where it is best (224 -> 64 at 4x256x512: 681 / 688 us): not selected unless asked for
-_PW_BWD_WIDE = os.environ.get("NASSEG_PW_BWD_WIDE", "0") == "1"
+# the wide-input variant (K > 64: the four waves split N): 224 -> 64 at 4x256x512 (pre_clf, whose input
+# gradient also carries the ReLU mask) 680 us against 447 + 404 us for the two kernels in the step
+# (headline 230.3 -> 232.2 img/s); on small maps it loses (192 -> 64 at 16x81x81: 143 / 118 us,
+# 320 -> 64 at 16x11x11: 217 / 22 us), hence the pixel floor
+_PW_BWD_WIDE = os.environ.get("NASSEG_PW_BWD_WIDE", "1") == "1"
+_PW_BWD_WIDE_MIN_PIXELS = 1 << 18
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
 FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
 

@@ -1051,10 +1051,12 @@ def test_chain_backward_is_the_same_with_and_without_the_one_kernel_pointwise_ba
     Fm = F()
     monkeypatch.setattr(Fm, "_GROUP_WGRAD_BYTES", 0)
     monkeypatch.setattr(Fm, "_PW_BWD_MIN_BYTES", 0)
+    monkeypatch.setattr(Fm, "_PW_BWD_WIDE_MIN_PIXELS", 0)
     monkeypatch.setattr(Fm, "_DW_BWD_MIN_BYTES", 0)
     torch.manual_seed(5)
     mods = [OPS["sep_conv_5x5"](32, 32, 1, True, 2), InvertedResidual(16, 24, 2, 6), InvertedResidual(24, 24, 1, 6),
-            conv_bn_relu(24, 64, 1, 1, 0), OPS["max_pool_3x3"](24, 48, 2, True)]
+            conv_bn_relu(24, 64, 1, 1, 0), OPS["max_pool_3x3"](24, 48, 2, True),
+            conv_bn_relu(96, 48, 1, 1, 0)]  # (the last: K > 64, the wave-split variant of the kernel)
     for mod in mods:
         mod = mod.to(DEV).train()
         cin = next(mod.parameters()).shape[1] if not hasattr(mod, "op") else 32
