@@ -277,6 +277,15 @@ def kernel_family(name, a):
     roofline is quoted per kernel family so that it can be held against the rocprof summary and
     the PMC traffic of the same name under profiles/"""
     base = name.replace("nasseg_bf16_", "nasseg_")
+
+    def persistent_pointwise(B, Ho, Wo, N, K, mode):
+        # (conv_fwd.hip:pw_fwd_plan) the library's own answer: the statistics-row query returns the
+        # persistent kernel's grid for the calls that take it
+        from nas_segm_amd import functional as NF
+
+        return (NF.lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N, K, mode)
+                != NF.lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N, K, 0))
+
     if base == "nasseg_conv_fwd":
         # (conv_fwd.hip:conv_dispatch) 3x3, stride 1, dilation <= 2, plain forward form, at least one
         # 8x32 tile, N <= 64, not the flat small-K path: the LDS-tiled kernel
@@ -285,8 +294,19 @@ def kernel_family(name, a):
         if (not transposed and kh == 3 and kw == 3 and stride == 1 and dil <= 2 and kh * kw * K > 64 and not pro
                 and not a[26] and N <= 64 and Wo >= 32 and Ho >= 8 and 0 <= pad <= 2 * dil):
             return "conv3x3_lds_kernel"
+        if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and (Hs, Ws) == (Ho, Wo)
+                and persistent_pointwise(B, Ho, Wo, N, K, 1)):
+            return "conv_pw_kernel"
         return "conv_fwd_kernel"
-    fam = {"nasseg_conv_bwd_data_bn": "conv_fwd_kernel", "nasseg_sepconv_fwd": "sepconv_fwd_kernel",
+    if base == "nasseg_conv_bwd_data_bn":
+        B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil = a[12:24]
+        if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and (Hs, Ws) == (Ho, Wo)
+                and persistent_pointwise(B, Ho, Wo, N, K, 2)):
+            return "conv_pw_kernel"
+        return "conv_fwd_kernel"
+    if base == "nasseg_conv_pw_bwd_bn" and a[21] > 64:
+        return "conv_pw_bwd_wide_kernel"
+    fam = {"nasseg_sepconv_fwd": "sepconv_fwd_kernel",
            "nasseg_conv_pw_bwd_bn": "conv_pw_bwd_kernel", "nasseg_dwconv_bwd_bn": "dw3x3_bwd_bn_kernel",
            "nasseg_conv_wgrad": "conv_wgrad_kernel", "nasseg_conv_wgrad_bn": "conv_wgrad_bn_kernel",
            "nasseg_dwconv": "dw_fwd_strip", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
