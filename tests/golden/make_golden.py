@@ -668,6 +668,82 @@ def gen_engine():
     json.dump(meta, open(os.path.join(OUT, "engine_meta.json"), "w"))
 
 
+def gen_engine_kd():
+    """Knowledge distillation through the task0 path (src/engine/trainer.py:53-61,147-149): the
+    teacher's logits are cached next to the encoder features (bilinear to the first feature map's
+    size) and ``kd_coeff * kd_crit(output, kd_y)`` joins the decoder-only loss.  The teacher here is
+    a small seeded conv net - the engine only ever calls ``kd_net(image)``; the reference's own
+    teacher (src/kd/rf_lw, a ResNet-152 RefineNet-LW) needs a downloaded checkpoint.  Run five
+    times (as is + four 1e-6 input perturbations) like gen_engine."""
+    import engine.trainer as ref_tr
+    from utils.solvers import create_optimisers
+
+    st = Store()
+    name, kind, geno, classes, kw, aux_weight = ENGINE_NETS[1]
+    gen = torch.Generator().manual_seed(777)
+    H, W = 97, 129
+    batches = []
+    for i in range(4):
+        img = torch.randn(1, 3, H, W, generator=gen)
+        batches.append({"image": img, "mask": make_labels(gen, 1, H, W, classes).to(torch.uint8)})
+        st.put("image/{}".format(i), img)
+        st.put("mask/{}".format(i), batches[-1]["mask"])
+    torch.manual_seed(31)
+    teacher = nn.Sequential(nn.Conv2d(3, 16, 3, stride=2, padding=1), nn.ReLU(),
+                            nn.Conv2d(16, classes, 3, stride=4, padding=1)).eval()
+    for k, v in teacher.state_dict().items():
+        st.put("teacher/" + k, v)
+    crit = nn.NLLLoss(ignore_index=255)
+    kd_coeff = 0.5
+
+    def run(noise_seed):
+        out = {}
+        net = build_ref_net(kind, geno, classes, kw, seed=11)
+        segmenter = nn.DataParallel(_Seg(net.encoder, net.decoder))
+        Xy = ref_tr.populate_task0(segmenter, FakeLoader(_perturbed(batches, noise_seed)), teacher, 4, do_kd=True)
+        assert not isinstance(Xy, int), "reference populate_task0 failed"
+        out["kd_y_checksum"] = checksums({"kd_y": Xy["kd_y"]})["kd_y"]
+        out["kd_y_shape"] = list(Xy["kd_y"].shape)
+        _, optim_dec0 = create_optimisers(
+            "sgd", "adam", 1e-3, 3e-3, 0.9, 0.9, 1e-5, 1e-5,
+            segmenter.module.encoder.parameters(), segmenter.module.decoder.parameters())
+        np.random.seed(321)
+        seg_vals, kd_vals = [], []
+
+        def rec_crit(inp, tgt):
+            v = crit(inp, tgt)
+            seg_vals.append(float(v))
+            return v
+
+        def rec_kd(inp, tgt):
+            v = nn.functional.mse_loss(inp, tgt)
+            kd_vals.append(float(v))
+            return v
+
+        ret = ref_tr.train_task0(Xy, segmenter, optim_dec0, 0, rec_crit, rec_kd, 2, False, True, kd_coeff,
+                                 3.0, False, aux_weight=max(aux_weight, 0))
+        assert ret is None, "reference train_task0 failed"
+        out["crit_values"], out["kd_values"] = seg_vals, kd_vals
+        out["checksums"] = checksums(segmenter.module.decoder.state_dict())
+        return out
+
+    base = run(0)
+    sens = {"crit": [0.0] * len(base["crit_values"]), "kd": [0.0] * len(base["kd_values"]), "kd_y": 0.0,
+            "mass": {k: 0.0 for k in base["checksums"]}}
+    for ns in range(1, 5):
+        other = run(ns)
+        sens["crit"] = [max(s, abs(a - b)) for s, a, b in zip(sens["crit"], other["crit_values"], base["crit_values"])]
+        sens["kd"] = [max(s, abs(a - b)) for s, a, b in zip(sens["kd"], other["kd_values"], base["kd_values"])]
+        sens["kd_y"] = max(sens["kd_y"], abs(other["kd_y_checksum"][1] - base["kd_y_checksum"][1]))
+        for k in sens["mass"]:
+            sens["mass"][k] = max(sens["mass"][k], abs(other["checksums"][k][1] - base["checksums"][k][1]))
+    rec = {"net": name, "kind": kind, "genotype": GENOTYPES[geno], "classes": classes, "dec_kwargs": kw, "seed": 11,
+           "aux_weight": aux_weight, "kd_coeff": kd_coeff, "sensitivity": sens}
+    rec.update(base)
+    st.save("engine_kd.npz")
+    json.dump(rec, open(os.path.join(OUT, "engine_kd_meta.json"), "w"))
+
+
 def gen_engine_optim():
     """The optimiser side of train_segmenter in isolation: the gradients the reference's backward
     left in ``param.grad`` at every step (before clipping) are recorded together with the
@@ -782,6 +858,7 @@ if __name__ == "__main__":
     warnings.filterwarnings("ignore")
     shutil.rmtree(TMP, ignore_errors=True)
     build_cython()
-    which = sys.argv[1:] or ["ops", "nets", "miou", "engine", "controller", "nets_sampled", "engine_optim"]
+    which = sys.argv[1:] or ["ops", "nets", "miou", "engine", "controller", "nets_sampled", "engine_optim",
+                             "engine_kd"]
     for w in which:
         globals()["gen_" + w]()

@@ -573,3 +573,68 @@ def test_bench_prints_the_contract_line():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cpu, key
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+
+
+def test_task0_with_knowledge_distillation_matches_reference_run(monkeypatch):
+    """populate_task0(do_kd=True) caches the teacher's logits (bilinear to the first feature map) and
+    train_task0 adds kd_coeff * kd_crit(output, kd_y) (src/engine/trainer.py:53-61,147-149): losses,
+    the cached logits and the decoder after two steps against the reference's own run
+    (tests/golden/engine_kd*, make_golden.py:gen_engine_kd).  The teacher is any module the caller
+    hands in - here the recorded small conv net, running on torch's own GPU convolutions."""
+    from nas_segm_amd.engine import RankParallel
+    from nas_segm_amd.engine.trainer import populate_task0, train_task0
+
+    monkeypatch.setenv("NASSEG_GRAPH", "0")
+    rec = load_json("engine_kd_meta.json")
+    npz = load_npz("engine_kd.npz")
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], rec["seed"])
+    segmenter = RankParallel(net.to(DEV))
+    teacher = torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, stride=2, padding=1), torch.nn.ReLU(),
+                                  torch.nn.Conv2d(16, rec["classes"], 3, stride=4, padding=1))
+    teacher.load_state_dict({k[len("teacher/"):]: torch.from_numpy(npz[k]) for k in npz.files
+                             if k.startswith("teacher/")})
+    teacher = teacher.to(DEV).eval()
+    loader = Loader([{"image": torch.from_numpy(npz["image/{}".format(i)]),
+                      "mask": torch.from_numpy(npz["mask/{}".format(i)])} for i in range(4)])
+    sens = rec["sensitivity"]
+    bad = []
+
+    def check(what, got, want, floor, rel=1e-4, abs_=1e-6):
+        tol = rel * abs(want) + abs_ + 3.0 * floor
+        if not abs(got - want) <= tol:
+            bad.append("{}: {} vs {} (tol {:.3e}, floor {:.3e})".format(what, got, want, tol, floor))
+
+    Xy = populate_task0.__wrapped__(segmenter, loader, teacher, 4, do_kd=True)
+    assert list(Xy["kd_y"].shape) == rec["kd_y_shape"]
+    check("cached teacher logits", checksums({"kd_y": Xy["kd_y"].float().cpu()})["kd_y"][1], rec["kd_y_checksum"][1],
+          sens["kd_y"], rel=2e-5)
+    values = _record_losses(monkeypatch)
+    kd_values = []
+
+    def kd_crit(inp, tgt):
+        v = torch.nn.functional.mse_loss(inp, tgt)
+        kd_values.append(float(v.detach()))
+        return v
+
+    optim_dec0 = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+    np.random.seed(321)
+    ret = train_task0.__wrapped__(Xy, segmenter, optim_dec0, 0, _Crit(), kd_crit, 2, False, True, rec["kd_coeff"],
+                                  3.0, False, aux_weight=max(rec["aux_weight"], 0))
+    assert ret is None
+    assert len(values) == len(rec["crit_values"]) and len(kd_values) == len(rec["kd_values"])
+    for i, (v, w, f) in enumerate(zip(values, rec["crit_values"], sens["crit"])):
+        check("segmentation loss {}".format(i), v, w, f, abs_=1e-4)
+    for i, (v, w, f) in enumerate(zip(kd_values, rec["kd_values"], sens["kd"])):
+        check("distillation loss {}".format(i), v, w, f, abs_=1e-5)
+    # (zero-gradient parameters - see test_engine_matches_reference_run - are identified by the
+    #  reference's end-to-end run of the same network)
+    eng = ENG_META[rec["net"]]
+    full_step = {k: eng["numel"][k] * 3e-3 * 2 for k in eng["numel"]}
+    noise = {k for k, m in eng["task1_delta_mass"].items() if k.startswith("decoder.") and m < 0.05 * full_step[k]}
+    got = checksums(_cpu_sd(net.decoder))
+    for k, (s, sa) in rec["checksums"].items():
+        if "num_batches_tracked" in k:
+            assert got[k][0] == s, k
+        elif ("decoder." + k) not in noise:
+            check("decoder " + k, got[k][1], sa, sens["mass"][k])
+    assert not bad, "{} of the reference run's numbers missed:\n{}".format(len(bad), "\n".join(bad[:40]))
