@@ -1028,9 +1028,11 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   if (!md.gather && md.km != KM_FLAT) {
     const PwFwdPlan pw = pw_fwd_plan((int64_t)g.B * g.Ho * g.Wo, N, K, stats_mode >= 2 ? 2 : 1);
     if (pw.ok) {
-      // (the statistics rows were sized for this grid: no falling back to the general kernel)
-      NASSEG_REQUIRE(md.km == KM_VEC && md.vecn, "conv_fwd: pointwise path needs channel strides that are multiples of 4");
-      return launch_pw(a, pw, md.stats, s);
+      const bool aligned = md.km == KM_VEC && md.vecn;
+      // (statistics rows were sized for this kernel's grid: with them there is no falling back)
+      NASSEG_REQUIRE(aligned || (md.stats != 1 && md.stats != 2),
+                     "conv_fwd: the pointwise statistics path needs channel strides that are multiples of 4");
+      if (aligned) return launch_pw(a, pw, md.stats, s);
     }
   }
   // 3x3, stride 1, dilation <= 2, maps at least one tile large: input patch staged in LDS
