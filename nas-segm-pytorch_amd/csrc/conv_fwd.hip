@@ -420,7 +420,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
 // accumulator as conv_fwd_kernel: results are bit-identical to it.  Statistics (STATS 1 / 2) are
 // accumulated per wave in LDS over all its tiles: one row per workgroup of a grid that is a few
 // hundred to two thousand workgroups instead of one row per 64*MT pixels.
-constexpr int kPwD = 4;
+#ifndef NASSEG_PW_D
+#define NASSEG_PW_D 4
+#endif
+constexpr int kPwD = NASSEG_PW_D;
 
 struct PwFwdPlan {
   int ok, nt, mt, grid;

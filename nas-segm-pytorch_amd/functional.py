@@ -646,6 +646,9 @@ _PW_BWD_WIDE = os.environ.get("NASSEG_PW_BWD_WIDE", "1") == "1"
 _PW_BWD_WIDE_MIN_PIXELS = 1 << 18
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
 FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
+# which pointwise forward / backward-data calls take the persistent kernel (include/nasseg.h:
+# nasseg_conv_pw_min_pixels): unset = where it measured faster, 0 = wherever it can, a huge number = nowhere
+_PW_MIN_PIXELS = os.environ.get("NASSEG_PW_MIN_PIXELS")
 
 
 # elements of the stage's depthwise output above which a 5x5 stage runs as two kernels when the
@@ -1690,3 +1693,15 @@ def argmax_confusion(logits, gt, n_classes, cm=None, out_size=None, return_preds
     lib.call("nasseg_argmax_cm", ptr(logits), ptr(gt), ptr(preds), B, h, w, C, H, W,
              int(n_classes), ptr(cm) if gt is not None else None, current_stream())
     return (cm, preds) if return_preds else cm
+
+
+def _apply_library_knobs():
+    if _PW_MIN_PIXELS is not None:
+        lib.query("nasseg_conv_pw_min_pixels", int(_PW_MIN_PIXELS))
+        lib._memo.clear()
+
+
+try:
+    _apply_library_knobs()
+except (OSError, NassegError):  # (no library yet - a CPU-only import before the build; set again after loading)
+    pass
