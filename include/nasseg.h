@@ -161,7 +161,8 @@ int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float
  * nasseg_conv_wgrad_bn), weight gradient AND input gradient; dz never reaches HBM.  wb = the weight packed for
  * backward-data ([K][N], pack mode 1); dx [B][H][W][K]; ws: nasseg_conv_pw_bwd_slabs(...) * N * K floats (0 slabs:
  * no fused kernel for these channel counts - N*K <= 6144 with K <= 64, or N <= 64 with K <= 384); dx_act != 0
- * (= in_act, no input affine): dx additionally multiplied by in_act'(x); dw == NULL: partial rows only. */
+ * (= in_act): dx additionally multiplied by in_act'(in_scale*x + in_shift), i.e. the gradient w.r.t. the affine's
+ * output (w.r.t. x itself for a bare activation); dw == NULL: partial rows only. */
 int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N);
 int nasseg_conv_pw_bwd_bn(const float* x, const float* g, const float* z, const float* wb, float* dx, float* dw,
                           float* ws, const float* in_scale, const float* in_shift, int in_act, int dx_act,

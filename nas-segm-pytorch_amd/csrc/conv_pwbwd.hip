@@ -525,8 +525,10 @@ int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N) {
 //   g [P][N]: gradient w.r.t. the BatchNorm output - masked already (bn_act == 0) or to be masked with
 //   act'(scale*z + shift) here; z [P][N] the conv's raw output; sums[2][N] = {sum g', sum g'*xhat};
 //   wb: the weight packed for backward-data ([K][N], pack mode 1); P = B*H*W pixels.
-// dx_act != 0 (= in_act, with in_scale = in_shift = NULL): dx is multiplied by in_act'(x), i.e. it is
-// the gradient w.r.t. x itself (the ReLU that pre_clf applies to its input on load).
+// dx_act != 0 (= in_act): dx is multiplied by in_act'(in_scale*x + in_shift), i.e. it is the gradient
+// w.r.t. the affine's output - w.r.t. x itself for a bare activation (the ReLU that pre_clf applies to its
+// input on load), w.r.t. the output of the BatchNorm in front for a conv inside a chain.  The mask is taken
+// from the activated tile (a > 0, a < 6), which is the same thing.
 // Writes dx [P][K] = the gradient w.r.t. the conv's (prologue-transformed) input and the weight
 // gradient: dw (N,K,1,1) when given, else only the partial rows in ws (nasseg_conv_pw_bwd_slabs rows
 // of N*K floats) for nasseg_wgrad_finalize_many (taps 1, flat 0).
@@ -548,8 +550,8 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
   a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
   a.bn_sums = bn_sums; a.bn_train = bn_train; a.bn_act = bn_act;
   a.invM = (float)(1.0 / (double)M);
-  NASSEG_REQUIRE(!dx_act || (dx_act == in_act && !in_scale && !in_shift),
-                 "conv_pw_bwd_bn: dx can only be masked with the derivative of a bare input activation");
+  NASSEG_REQUIRE(!dx_act || dx_act == in_act,
+                 "conv_pw_bwd_bn: dx can only be masked with the derivative of the input activation");
   a.dx_act = dx_act;
   a.K = K; a.N = N; a.KP = (K + 15) & ~15; a.NP = (N + 15) & ~15;
   a.M = (int)M; a.pix_per_slab = p.pix_per_slab;

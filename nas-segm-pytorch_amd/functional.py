@@ -171,8 +171,13 @@ def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops):
         return 0
     if (cur.numel() + z.numel()) * cur.element_size() <= _PW_BWD_MIN_BYTES:
         return 0
-    if K % 4 == 0 and i > 0 and ops[i - 1][4]:
-        return 0  # (bn_prev in _ConvChain.backward: the producer's BatchNorm backward goes with backward-data)
+    if K % 4 == 0 and i > 0 and ops[i - 1][4] and not (N >= K and K <= 64):
+        # bn_prev in _ConvChain.backward: the producer's BatchNorm backward goes with the backward-data
+        # kernel (statistics epilogue) - except where this conv widens (N >= K): there the one kernel plus
+        # a bn_bwd_reduce pass over the K-channel gradient moves fewer bytes (4K + 2N per pixel) than
+        # weight-gradient + backward-data with dz in between (3K + 4N): 16 -> 96 behind a BatchNorm,
+        # which is what MobileNetV2's merged stem / stage-1 / stage-2 chain contains
+        return 0
     B, _, H, W = cur.shape
     if K > 64 and not (_PW_BWD_WIDE and B * H * W >= _PW_BWD_WIDE_MIN_PIXELS):
         return 0
@@ -866,6 +871,7 @@ class _ConvChain(torch.autograd.Function):
         grads = [None] * (6 * n_ops)
         dres = g if (has_res and ctx.needs_input_grad[2]) else None
         pre = None  # BatchNorm-backward partial rows of op i that came with g (fused dgrad epilogue)
+        g_masked = False  # g already carries act' of op i's activation (with or without such rows)
         masked_in0 = False  # dx already multiplied by in_act0' (one-kernel pointwise backward of op 0)
         for i in range(n_ops - 1, -1, -1):
             kind, stride, pad, dil, has_bn, act, training, momentum, eps = ops[i]
@@ -885,7 +891,8 @@ class _ConvChain(torch.autograd.Function):
                 else:
                     ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
                     lib.call(_k("nasseg_bn_bwd_reduce", g), ptr(g), N, ptr(z), N, M, N, ptr(scale),
-                             ptr(shift), ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
+                             ptr(shift), ptr(mean), ptr(invstd), ACT_NONE if g_masked else act, ptr(sums),
+                             ptr(ws), s)
                 if ctx.needs_input_grad[3 + 6 * i + 1]:
                     grads[6 * i + 1] = sums[N:2 * N]
                 if ctx.needs_input_grad[3 + 6 * i + 2]:
@@ -893,7 +900,8 @@ class _ConvChain(torch.autograd.Function):
                 if not (need_dw or need_dx):
                     g = None
                     break
-                pw_bact = ACT_NONE if pre is not None else act
+                act_left = ACT_NONE if (pre is not None or g_masked) else act  # (the mask still to be applied to g)
+                pw_bact = act_left
                 pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops)
                 dw_rows = _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops)
                 if pw_nsl > 0 or dw_rows > 0:
@@ -902,12 +910,12 @@ class _ConvChain(torch.autograd.Function):
                     # the weight-gradient kernel below computes dz while it loads g and z (masking
                     # g first if it did not arrive masked) and leaves it behind for the
                     # backward-data kernel
-                    fused_bn = (scale, shift, mean, invstd, sums, training, ACT_NONE if pre is not None else act)
+                    fused_bn = (scale, shift, mean, invstd, sums, training, act_left)
                     dz = None
                 else:
                     dz = torch.empty_like(z)
                     lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean),
-                             ptr(invstd), ptr(sums), M, N, int(training), act, ptr(dz), s)
+                             ptr(invstd), ptr(sums), M, N, int(training), act_left, ptr(dz), s)
             else:
                 dz = g
                 pw_nsl = dw_rows = 0
@@ -916,6 +924,7 @@ class _ConvChain(torch.autograd.Function):
                     break
             Bc, K, H, W = cur.shape
             pre = None
+            g_masked = False
             bn_prev = None
             if need_dx and i > 0 and ops[i - 1][4] and K % 4 == 0:
                 # the producer of this conv's input is a BatchNorm of the chain: fuse the first
@@ -969,15 +978,20 @@ class _ConvChain(torch.autograd.Function):
                     dwt = torch.empty_like(w)
                     ws = _ws(cur, nsl * N * K)
                     g_in = _new(cur, Bc, K, H, W)
-                    # (op 0 of a chain that applies an activation to its input on load: dx masked here)
-                    dx_act = pact if (i == 0 and in_act0 and psc is None and psh is None) else ACT_NONE
+                    # op 0 of a chain that applies an activation to its input on load, or a widening conv
+                    # behind a BatchNorm of the chain (_pw_bwd_slabs): dx is masked with act' here - the
+                    # kernel takes the mask from the ACTIVATED input tile it holds - and what goes on to op
+                    # i - 1 is the gradient w.r.t. its BatchNorm's output
+                    behind_bn = i > 0 and ops[i - 1][4]
+                    dx_act = pact if ((i == 0 and in_act0 and psc is None and psh is None) or behind_bn) else ACT_NONE
                     lib.call(_k("nasseg_conv_pw_bwd_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(wb), ptr(g_in),
                              _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, dx_act,
                              ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), bact_,
                              Bc, H, W, K, N, s)
                     grads[6 * i] = dwt
                     g = g_in
-                    masked_in0 = bool(dx_act)
+                    masked_in0 = bool(dx_act) and i == 0
+                    g_masked = behind_bn
                     continue
                 if fused_bn is not None:
                     grads[6 * i], dz = _wgrad_bn("dense", cur, g, z, w, psc, psh, pact, fused_bn,

