@@ -1237,3 +1237,45 @@ def test_persistent_pointwise_kernel_equals_the_general_one(case, mode):
     if len(ref) > 1:
         tol = 1e-5 * float(M) ** 0.5 * (float(ref[1].abs().max()) / float(M) ** 0.5 + 1.0)
         assert_close(got[1], ref[1], tol, 1e-4, "statistics")
+
+
+@pytest.mark.parametrize("taps", [[1, 2], [1, 2, 4, 6]])
+def test_encoder_units_merged_into_one_chain_equal_the_separate_chains(taps):
+    """MobileNetV2 runs consecutive units without a skip connection or a returned map in between as one
+    fused chain (nn/encoders.py): feature maps bit-identical to unit-by-unit execution (the boundary's
+    normalisation is the same fma, applied on load instead of in a pass of its own), gradients equal to
+    rounding (the BatchNorm-backward sums of the boundary are reduced in a different order)."""
+    from nas_segm_amd.nn.encoders import MobileNetV2, mbv2
+
+    torch.manual_seed(3)
+    enc = mbv2(pretrained=False, return_layers=taps).to(DEV).train()
+    x0 = dev(rnd(2, 3, 97, 129, seed=4))
+    results = []
+    try:
+        for merge in (True, False):
+            MobileNetV2.merge_units = merge
+            enc.zero_grad()
+            for m in enc.modules():  # (same running statistics at the start of both passes)
+                if hasattr(m, "running_mean") and m.running_mean is not None:
+                    m.running_mean.zero_()
+                    m.running_var.fill_(1.0)
+            x = x0.clone().requires_grad_(True)
+            outs = enc(x)
+            sum((o.float() ** 2).mean() for o in outs).backward()
+            results.append(([o.detach().clone() for o in outs], x.grad.clone(),
+                            {k: p.grad.clone() for k, p in enc.named_parameters()},
+                            {k: b.clone() for k, b in enc.named_buffers()}))
+    finally:
+        MobileNetV2.merge_units = True
+    (o1, dx1, g1, b1), (o0, dx0, g0, b0) = results
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for k in b0:
+        if "num_batches_tracked" not in k:  # (it counts both passes)
+            assert_close(b1[k].float(), b0[k].float(), 1e-6, 1e-5, "buffer " + k)
+    assert_close(dx1, dx0, 2e-4 * float(dx0.abs().max()), 1e-3, "dx")
+    # (BatchNorm weights in front of another BatchNorm have near-cancelling gradients: rounding noise of
+    #  the network's gradient scale, not of their own)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        assert_close(g1[k], g0[k], 2e-4 * float(g0[k].abs().max()) + 1e-5 * gmax, 1e-3, "grad " + k)
