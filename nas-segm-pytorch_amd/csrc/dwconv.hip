@@ -25,6 +25,16 @@
 
 #include "dw_common.h"
 
+// output rows per thread of the forward strip kernel: 3x3 with consecutive input rows (stride 1, any
+// dilation) 8 - ten input rows for eight outputs instead of six for four (144ch 256x512: 157 -> 140 us, 32ch
+// 512x1024: 150 -> 128 us); at stride 2 the longer strip loses (96ch 512x1024: 210 -> 221 us) and 5x5 has no
+// registers for it: 4
+#ifndef NASSEG_DW_P3
+#define NASSEG_DW_P3 8
+#endif
+// (maps of fewer than 128 rows keep 4: the launch is short of workgroups there, not of bandwidth)
+static inline int dw_fwd_rows(int K, int e, int Ho) { return (K == 3 && e == 1 && Ho >= 128) ? NASSEG_DW_P3 : 4; }
+
 namespace {
 
 // BatchNorm whose backward statistics a backward-data kernel gathers in its epilogue: the
@@ -941,8 +951,8 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
   const bool pro = in_scale || in_shift || in_act;
   const bool strip_ok = !transposed && (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2) && B <= 65535;
   if (strip_ok) {
-    constexpr int P = 4;
-    const int nchunk = cdiv(Ho, P * sc.g);
+    constexpr int P = 4, P3 = NASSEG_DW_P3;  // output rows per thread (see dw_fwd_rows)
+    const int nchunk = cdiv(Ho, dw_fwd_rows(K, sc.e, Ho) * sc.g);
     dim3 grid(cdiv(Wo * C4, 256), nchunk * sc.g, B);
     NASSEG_REQUIRE(grid.y <= 65535, "dwconv: too many row chunks");
     NASSEG_REQUIRE(stats_mode != 2 || !pro, "dwconv_bwd_data_bn: no input prologue on this path");
@@ -963,10 +973,21 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
     else LAUNCH_FWD3(KK, EE, WL, false, 0);                       \
   } while (0)
     const bool wl = C4 <= 64;
-    if (K == 3 && sc.e == 1) LAUNCH_FWD(3, 1, false);
+    if (K == 5 && sc.e == 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
+    else if (K == 5) { if (wl) LAUNCH_FWD(5, 2, true); else LAUNCH_FWD(5, 2, false); }
+#undef LAUNCH_FWD3
+#define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                              \
+  hipLaunchKernelGGL((dw_fwd_strip<KK, P3, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
+                     in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk,  \
+                     act, stats, bn)
+    if (K == 3 && sc.e == 1 && dw_fwd_rows(K, sc.e, Ho) == P3) LAUNCH_FWD(3, 1, false);
+#undef LAUNCH_FWD3
+#define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                             \
+  hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
+                     in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, \
+                     act, stats, bn)
+    if (K == 3 && sc.e == 1 && dw_fwd_rows(K, sc.e, Ho) == P) LAUNCH_FWD(3, 1, false);
     else if (K == 3 && sc.e == 2) LAUNCH_FWD(3, 2, false);
-    else if (K == 5 && sc.e == 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
-    else { if (wl) LAUNCH_FWD(5, 2, true); else LAUNCH_FWD(5, 2, false); }
 #undef LAUNCH_FWD3
 #undef LAUNCH_FWD
     NASSEG_LAUNCH_CHECK("dw_fwd_strip");
@@ -1051,7 +1072,7 @@ int nasseg_dwconv_strip_ok(int K, int stride, int dil) {
 int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil) {
   if (!nasseg_dwconv_strip_ok(K, stride, dil)) return 0;
   StripCfg sc = strip_cfg(stride, dil);
-  return (int64_t)cdiv(Wo * (C / 4), 256) * cdiv(Ho, 4 * sc.g) * sc.g * B;
+  return (int64_t)cdiv(Wo * (C / 4), 256) * cdiv(Ho, dw_fwd_rows(K, sc.e, Ho) * sc.g) * sc.g * B;
 }
 #endif  // NASSEG_FP32_ONLY
 
