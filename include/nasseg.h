@@ -152,6 +152,14 @@ int nasseg_conv_wgrad_bn(const float* x, int ldx, const float* g, int ldg, const
                          int lddz, float* dw, float* ws, const float* in_scale, const float* in_shift, int in_act,
                          const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                          const float* bn_sums, int bn_train, int bn_act, int B, int H, int W, int K, int N, void* stream);
+/* nasseg_conv_wgrad_bn for a small-K k x k conv (kh*kw*K <= 64: nasseg_conv_fwd_pack_mode == 2 - MobileNetV2's
+ * stem, the first op of its chain) whose input needs no gradient: the BatchNorm backward is applied to g on load and dz is
+ * never written (instead of nasseg_bn_bwd_apply + nasseg_conv_wgrad).  Geometry as nasseg_conv_wgrad. */
+int nasseg_conv_wgrad_bn_flat(const float* x, int ldx, const float* g, int ldg, const float* z, int ldz, float* dw,
+                              float* ws, const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                              const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act, int B, int Hs,
+                              int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad, int dil,
+                              void* stream);
 int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float* dz, float* dw, float* ws,
                            const float* in_scale, const float* in_shift, int in_act, const float* bn_scale, const float* bn_shift,
                            const float* bn_mean, const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act,
@@ -353,6 +361,11 @@ int nasseg_bf16_conv_wgrad_bn(const nasseg_bf16_t* x, int ldx, const nasseg_bf16
                               const float* in_scale, const float* in_shift, int in_act, const float* bn_scale, const float* bn_shift,
                               const float* bn_mean, const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act,
                               int B, int H, int W, int K, int N, void* stream);
+int nasseg_bf16_conv_wgrad_bn_flat(const nasseg_bf16_t* x, int ldx, const nasseg_bf16_t* g, int ldg,
+                                   const nasseg_bf16_t* z, int ldz, float* dw, float* ws, const float* bn_scale,
+                                   const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                                   const float* bn_sums, int bn_train, int bn_act, int B, int Hs, int Ws, int K, int Ho,
+                                   int Wo, int N, int kh, int kw, int stride, int pad, int dil, void* stream);
 int nasseg_bf16_dwconv_wgrad_bn(const nasseg_bf16_t* x, const nasseg_bf16_t* g, const nasseg_bf16_t* z,
                                 nasseg_bf16_t* dz, float* dw, float* ws, const float* in_scale,
                                 const float* in_shift, int in_act, const float* bn_scale, const float* bn_shift, const float* bn_mean,

@@ -149,7 +149,7 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const 
   // dz = ca*g' + cb*z + cd  ==  scale*(g' - sum(g')/M - xhat*sum(g'*xhat)/M), xhat = (z - mean)*invstd,
   // g' = g * act'(scale*z + shift) (bn_act != 0: g arrives without its activation mask)
   float ca[VN], cb[VN], cd[VN], cs[VN];
-  const bool wr = BN && kchunk == 0 && tap == 0;  // every dz element is written by exactly one lane
+  const bool wr = BN && a.dz && kchunk == 0 && tap == 0;  // every dz element is written by exactly one lane
   if (BN) {
 #pragma unroll
     for (int c = 0; c < VN; ++c) {
@@ -271,6 +271,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 template <int VN, int VK, bool PRO>
 __global__ __launch_bounds__(256) void conv_wgrad_bn_kernel(WgArgs a) {
   wgrad_tile<VN, VK, true, true, false, false, PRO, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// small-K k x k conv (flat mode: the 3-channel stem) followed by a BatchNorm, when nothing needs dz:
+// the BatchNorm backward is applied to dy on load and never stored
+template <int VN, int VK, bool ALN>
+__global__ __launch_bounds__(256) void conv_wgrad_bn_flat_kernel(WgArgs a) {
+  wgrad_tile<VN, VK, ALN, false, true, true, false, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several layers of ONE specialisation in one launch: weight gradients of small maps are
@@ -653,6 +660,50 @@ int NASSEG_FN(conv_wgrad_bn)(const act_t* x, int ldx, const act_t* g, int ldg, c
   if (!dw) return NASSEG_OK;
   hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64((int64_t)N * K, NASSEG_RP_ELEMS)), dim3(256), 0,
                      s, ws, dw, p.nslab, 1, N, K, 0);
+  NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
+  return NASSEG_OK;
+}
+
+// Weight gradient of a small-K k x k conv (kh*kw*K <= 64: nasseg_conv_fwd_pack_mode == 2, the stem)
+// followed by a BatchNorm, for the case that the conv's input needs no gradient: the BatchNorm backward
+// (as in nasseg_conv_wgrad_bn) is applied to g on load and dz is never written - instead of a
+// nasseg_bn_bwd_apply pass that writes dz and a weight-gradient kernel that reads it back.
+// Geometry arguments as nasseg_conv_wgrad; ws: nasseg_conv_wgrad_workspace floats.
+int NASSEG_FN(conv_wgrad_bn_flat)(const act_t* x, int ldx, const act_t* g, int ldg, const act_t* z, int ldz,
+                                  float* dw, float* ws, const float* bn_scale, const float* bn_shift,
+                                  const float* bn_mean, const float* bn_invstd, const float* bn_sums,
+                                  int bn_train, int bn_act, int B, int Hs, int Ws, int K, int Ho, int Wo, int N,
+                                  int kh, int kw, int stride, int pad, int dil, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  NASSEG_REQUIRE(z && bn_scale && (!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
+                 "conv_wgrad_bn_flat: missing BatchNorm tensors");
+  NASSEG_REQUIRE(ldz >= N, "conv_wgrad_bn_flat: bad ldz");
+  WgSetup u;
+  int rc = wgrad_setup(u, x, ldx, g, ldg, ws, nullptr, nullptr, 0, B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil);
+  if (rc) return rc;
+  NASSEG_REQUIRE(u.m.flat, "conv_wgrad_bn_flat: kh*kw*K = %d is not a flat geometry", kh * kw * K);
+  const WgPlan& p = u.p;
+  // (the z / g vectors are read VN at a time: both need the alignment)
+  const bool aln = u.m.aln && (ldz % p.vn == 0);
+  u.a.z = z; u.a.ldz = ldz; u.a.dz = nullptr; u.a.lddz = 0;
+  u.a.bn_scale = bn_scale; u.a.bn_shift = bn_shift; u.a.bn_mean = bn_mean; u.a.bn_invstd = bn_invstd;
+  u.a.bn_sums = bn_sums;
+  u.a.bn_train = bn_train; u.a.bn_act = bn_act;
+  u.a.invM = (float)(1.0 / ((double)B * Ho * Wo));
+#define WG_CASE(VN_, VK_)                                                                                  \
+  if (p.vn == VN_ && p.vk == VK_) {                                                                        \
+    if (aln) hipLaunchKernelGGL((conv_wgrad_bn_flat_kernel<VN_, VK_, true>), u.grid, dim3(256), 0, s, u.a); \
+    else hipLaunchKernelGGL((conv_wgrad_bn_flat_kernel<VN_, VK_, false>), u.grid, dim3(256), 0, s, u.a);    \
+  } else
+  WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1)
+  WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
+  rc = nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_wgrad_bn_flat: no kernel for vn=%d vk=%d", p.vn, p.vk);
+#undef WG_CASE
+  if (rc) return rc;
+  NASSEG_LAUNCH_CHECK("conv_wgrad_bn_flat_kernel");
+  if (!dw) return NASSEG_OK;
+  hipLaunchKernelGGL(conv_wgrad_finalize, dim3((unsigned)cdiv64((int64_t)N * K * kh * kw, NASSEG_RP_ELEMS)), dim3(256),
+                     0, s, ws, dw, p.nslab, kh * kw, N, K, p.flat);
   NASSEG_LAUNCH_CHECK("conv_wgrad_finalize");
   return NASSEG_OK;
 }

@@ -186,6 +186,7 @@ def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops):
 
 FUSE_DW_BWD = os.environ.get("NASSEG_FUSE_DW_BWD", "1") != "0"
 _DW_BWD_MIN_BYTES = 24 << 20
+_FLAT_WGRAD_BN_MIN_BYTES = 24 << 20  # (output map of the stem above which its BatchNorm backward rides on the wgrad loads)
 
 
 def _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops):
@@ -904,7 +905,13 @@ class _ConvChain(torch.autograd.Function):
                 pw_bact = act_left
                 pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops)
                 dw_rows = _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops)
-                if pw_nsl > 0 or dw_rows > 0:
+                # the stem (small-K k x k conv, no gradient for the image): BatchNorm backward on load in the
+                # weight-gradient kernel, dz never written (nasseg_conv_wgrad_bn_flat)
+                flat_bn = (kind == "dense" and need_dw and not need_dx and psc is None and psh is None and not pact
+                           and w.shape[2] * w.shape[3] > 1 and N % 4 == 0
+                           and lib.query("nasseg_conv_fwd_pack_mode", w.shape[1], w.shape[2], w.shape[3]) == 2
+                           and z.numel() * z.element_size() > _FLAT_WGRAD_BN_MIN_BYTES)
+                if pw_nsl > 0 or dw_rows > 0 or flat_bn:
                     dz = None  # (the one-kernel pointwise backward below applies the BatchNorm backward on load)
                 elif need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
                     # the weight-gradient kernel below computes dz while it loads g and z (masking
@@ -919,6 +926,7 @@ class _ConvChain(torch.autograd.Function):
             else:
                 dz = g
                 pw_nsl = dw_rows = 0
+                flat_bn = False
                 if not (need_dw or need_dx):
                     g = None
                     break
@@ -970,6 +978,16 @@ class _ConvChain(torch.autograd.Function):
                     g, pre = _dw_backward_data(dz, wb, k, (Bc, K, H, W), stride, pad, dil, bn_prev)
             else:
                 _, _, kh, kw = w.shape
+                if flat_bn:
+                    dwt = torch.empty_like(w)
+                    ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", Bc, Ho, Wo, N, K, kh, kw))
+                    lib.call(_k("nasseg_conv_wgrad_bn_flat", cur), ptr(cur), K, ptr(g), N, ptr(z), N,
+                             _finish_wgrad(ws, dwt, kh * kw, N, K, 1), ptr(ws), ptr(scale), ptr(shift), ptr(mean),
+                             ptr(invstd), ptr(sums), int(training), act_left, Bc, H, W, K, Ho, Wo, N, kh, kw,
+                             stride, pad, dil, s)
+                    grads[6 * i] = dwt
+                    g = None
+                    continue
                 if pw_nsl > 0:
                     # pointwise conv + BatchNorm, nothing to fuse towards the producer: BatchNorm
                     # backward on load, weight gradient and input gradient in ONE kernel - dz is

@@ -1053,6 +1053,7 @@ def test_chain_backward_is_the_same_with_and_without_the_one_kernel_pointwise_ba
     monkeypatch.setattr(Fm, "_PW_BWD_MIN_BYTES", 0)
     monkeypatch.setattr(Fm, "_PW_BWD_WIDE_MIN_PIXELS", 0)
     monkeypatch.setattr(Fm, "_DW_BWD_MIN_BYTES", 0)
+    monkeypatch.setattr(Fm, "_FLAT_WGRAD_BN_MIN_BYTES", 0)
     torch.manual_seed(5)
     mods = [OPS["sep_conv_5x5"](32, 32, 1, True, 2), InvertedResidual(16, 24, 2, 6), InvertedResidual(24, 24, 1, 6),
             conv_bn_relu(24, 64, 1, 1, 0), OPS["max_pool_3x3"](24, 48, 2, True),
@@ -1279,3 +1280,35 @@ def test_encoder_units_merged_into_one_chain_equal_the_separate_chains(taps):
     gmax = max(float(v.abs().max()) for v in g0.values())
     for k in g0:
         assert_close(g1[k], g0[k], 2e-4 * float(g0[k].abs().max()) + 1e-5 * gmax, 1e-3, "grad " + k)
+
+
+@pytest.mark.parametrize("case", [(2, 33, 41, 3, 32, 3, 2, 1, 1), (1, 40, 37, 4, 16, 3, 1, 1, 1), (2, 21, 30, 3, 24, 3, 2, 1, 1)])
+@pytest.mark.parametrize("train,act", [(True, 2), (True, 0), (False, 1)])
+def test_stem_weight_gradient_with_bn_backward_on_load(case, train, act):
+    """nasseg_conv_wgrad_bn_flat (small-K k x k conv + BatchNorm, no input gradient wanted) against
+    nasseg_bn_bwd_apply followed by nasseg_conv_wgrad"""
+    f = F()
+    lib, ptr, stream = f.lib, f.ptr, f.current_stream
+    B, H, W, K, N, k, stride, pad, dil = case
+    Ho, Wo = f.conv_out_size(H, k, stride, pad, dil), f.conv_out_size(W, k, stride, pad, dil)
+    M = B * Ho * Wo
+    x = dev(rnd(B, K, H, W, seed=1))
+    g = dev(rnd(B, N, Ho, Wo, seed=2))
+    z = dev(rnd(B, N, Ho, Wo, seed=3))
+    scale, shift, mean, invstd = _bn_vectors(N, 4)
+    sums = (torch.randn(2 * N, generator=torch.Generator().manual_seed(5)) * 3).to(DEV)
+    s = stream()
+    assert lib.query("nasseg_conv_fwd_pack_mode", K, k, k) == 2
+    geom = (B, H, W, K, Ho, Wo, N, k, k, stride, pad, dil)
+    nws = lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, k, k)
+    dz = torch.empty_like(z)
+    lib.call("nasseg_bn_bwd_apply", ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), M, N,
+             int(train), act, ptr(dz), s)
+    dw_ref = torch.empty(N, K, k, k, device=DEV)
+    ws = torch.empty(nws, device=DEV)
+    lib.call("nasseg_conv_wgrad", ptr(x), K, ptr(dz), N, ptr(dw_ref), ptr(ws), None, None, 0, *geom, s)
+    dw = torch.full((N, K, k, k), float("nan"), device=DEV)
+    ws2 = torch.full((nws,), float("nan"), device=DEV)
+    lib.call("nasseg_conv_wgrad_bn_flat", ptr(x), K, ptr(g), N, ptr(z), N, ptr(dw), ptr(ws2), ptr(scale), ptr(shift),
+             ptr(mean), ptr(invstd), ptr(sums), int(train), act, *geom, s)
+    assert_close(dw, dw_ref, 2e-5 * float(dw_ref.abs().max()) * max(1.0, (M / 4096.0) ** 0.5), 1e-4, "dw")
