@@ -170,13 +170,15 @@ int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float
  * backward-data ([K][N], pack mode 1); dx [B][H][W][K]; ws: nasseg_conv_pw_bwd_slabs(...) * N * K floats (0 slabs:
  * no fused kernel for these channel counts - N*K <= 6144 with K <= 64, or N <= 64 with K <= 384); dx_act != 0
  * (= in_act): dx additionally multiplied by in_act'(in_scale*x + in_shift), i.e. the gradient w.r.t. the affine's
- * output (w.r.t. x itself for a bare activation); dw == NULL: partial rows only. */
+ * output (w.r.t. x itself for a bare activation); dw == NULL: partial rows only.  dx_stats != NULL (K <= 64; x is the
+ * raw output of a BatchNorm with statistics in_mean / in_invstd, dx_act = in_act): also that BatchNorm's backward
+ * sums {sum dx, sum dx*xhat} per slab, rows [slabs][2][K] for nasseg_rows_sum (buffer: slabs + 64 rows). */
 int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N);
 int nasseg_conv_pw_bwd_bn(const float* x, const float* g, const float* z, const float* wb, float* dx, float* dw,
                           float* ws, const float* in_scale, const float* in_shift, int in_act, int dx_act,
                           const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                           const float* bn_sums, int bn_train, int bn_act, int B, int H, int W, int K, int N,
-                          void* stream);
+                          const float* in_mean, const float* in_invstd, float* dx_stats, void* stream);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
@@ -288,7 +290,8 @@ int nasseg_bf16_conv_pw_bwd_bn(const nasseg_bf16_t* x, const nasseg_bf16_t* g, c
                                nasseg_bf16_t* dx, float* dw, float* ws, const float* in_scale, const float* in_shift,
                                int in_act, int dx_act, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act, int B, int H,
-                               int W, int K, int N, void* stream);
+                               int W, int K, int N, const float* in_mean, const float* in_invstd, float* dx_stats,
+                               void* stream);
 int nasseg_bf16_sepconv_fwd(const nasseg_bf16_t* x, const float* wdw, const float* wpw, nasseg_bf16_t* zdw,
                             nasseg_bf16_t* y, const float* in_scale, const float* in_shift, int in_act,
                             const float* out_scale, const float* out_shift, int out_act, int B, int H, int W, int C,

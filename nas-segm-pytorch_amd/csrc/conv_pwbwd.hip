@@ -50,6 +50,11 @@ struct PwArgs {
   int bn_train, bn_act;
   float invM;
   int dx_act;  // != 0: dx is multiplied by act'(x) - the forward applied this activation to x on load
+  // dx_stats != NULL (narrow kernel): also the first half of the backward of the BatchNorm in front, whose
+  // raw output x is - per slab {sum dx, sum dx*xhat}, xhat = (x - in_mean)*in_invstd, rows [slab][2][K]
+  const float* in_mean;
+  const float* in_invstd;
+  float* dx_stats;
   int K, N, KP, NP;  // channels, rounded up to multiples of 16
   int M, pix_per_slab;
 };
@@ -83,7 +88,9 @@ __host__ __device__ constexpr bool pw_prefetch(int NT, int KT) { return NT * KT 
 // x are loaded to registers - NT + NT + KT float4 per thread - while the PREVIOUS tile is computed
 // from LDS (nothing else hides the HBM latency: at most two to six workgroups are resident on a CU
 // and a tile's loads were issued, waited for and used in turn - 24 -> 144 at 4x256x512: 260 us before).
-template <int NT, int KT, bool PRO>
+// DXS: also emit the sums of the BatchNorm in front (a.dx_stats) - a separate instantiation: its 16*KT
+// registers per lane would cost every other call a resident wave
+template <int NT, int KT, bool PRO, bool DXS = false>
 __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   extern __shared__ float smem[];
   constexpr int LSN = pw_lsn(NT), LSK = pw_lsk(KT), NPc = NT * 16, KPc = KT * 16;
@@ -194,6 +201,16 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
       *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(dz, ok);
     }
   };
+  float4 sx[DXS ? KT : 1], sq[DXS ? KT : 1], smu[DXS ? KT : 1], sis[DXS ? KT : 1];
+#pragma unroll
+  for (int kt = 0; kt < (DXS ? KT : 0); ++kt) {
+    const int k = kt * 16 + kg * 4;
+    sx[kt] = sq[kt] = smu[kt] = sis[kt] = f4zero();
+    if (k < K) {
+      smu[kt] = lda4(a.in_mean + k);
+      sis[kt] = lda4(a.in_invstd + k);
+    }
+  }
   if (PF && p_begin < p_end) issue(p_begin);
   for (int t0 = p_begin; t0 < p_end; t0 += kPwTile) {
     __syncthreads();  // (the previous tile's operands have been read; first pass: constants are in place)
@@ -253,7 +270,22 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
         float4 o = make_float4(acc1[kt][0], acc1[kt][1], acc1[kt][2], acc1[kt][3]);
         if (a.dx_act)
           o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LSK + k]), a.dx_act));
-        if (p < p_end && k < K) sta4(a.dx + (int64_t)p * K + k, o);
+        const bool ok = p < p_end && k < K;
+        if (ok) sta4(a.dx + (int64_t)p * K + k, o);
+        if (DXS) {
+          // (the raw input once more - an L2 hit, the tile was loaded a moment ago: xhat cannot be taken
+          //  from the activated tile when the BatchNorm's weight is zero)
+          const float4 zr = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
+#ifdef NASSEG_BF16
+          o = make_float4(bf16_to_f32(f32_to_bf16(o.x)), bf16_to_f32(f32_to_bf16(o.y)), bf16_to_f32(f32_to_bf16(o.z)),
+                          bf16_to_f32(f32_to_bf16(o.w)));  // (what a separate pass would read back)
+#endif
+          const float4 gm = keep_if(o, ok);
+          const float4 xh = make_float4((zr.x - smu[kt].x) * sis[kt].x, (zr.y - smu[kt].y) * sis[kt].y,
+                                        (zr.z - smu[kt].z) * sis[kt].z, (zr.w - smu[kt].w) * sis[kt].w);
+          sx[kt] = add4(sx[kt], gm);
+          sq[kt] = fma4(gm, xh, sq[kt]);
+        }
       }
     }
     // ---- weight gradient: dW[n][k] += sum over this wave's 16 pixels of dz[p][n] * x[p][k] -------
@@ -272,6 +304,31 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
     }
   }
 
+  // ---- the slab's row of BatchNorm-backward sums: 16 pixel lanes (DPP), 4 waves (LDS), fixed order ----
+  if (DXS) {
+    __syncthreads();
+    float* sred = smem;  // [4 waves][2][KPc]
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const float vs[4] = {row16_allsum(sx[kt].x), row16_allsum(sx[kt].y), row16_allsum(sx[kt].z), row16_allsum(sx[kt].w)};
+      const float vq[4] = {row16_allsum(sq[kt].x), row16_allsum(sq[kt].y), row16_allsum(sq[kt].z), row16_allsum(sq[kt].w)};
+      if (j == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          sred[(wave * 2 + 0) * KPc + kt * 16 + kg * 4 + c] = vs[c];
+          sred[(wave * 2 + 1) * KPc + kt * 16 + kg * 4 + c] = vq[c];
+        }
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < KPc; t += 256) {
+      if (t < K) {
+        float* po = a.dx_stats + (int64_t)blockIdx.x * 2 * K + t;
+        po[0] = (sred[0 * KPc + t] + sred[2 * KPc + t]) + (sred[4 * KPc + t] + sred[6 * KPc + t]);
+        po[K] = (sred[1 * KPc + t] + sred[3 * KPc + t]) + (sred[5 * KPc + t] + sred[7 * KPc + t]);
+      }
+    }
+  }
   // ---- waves -> workgroup partial, one (n, k) tile at a time, fixed order -------------------------
   float* red = smem;  // [3][64][4]
   float* pout = a.partial + (int64_t)blockIdx.x * N * K;
@@ -498,12 +555,15 @@ template <int NT, int KT>
 void pw_launch(const PwArgs& a, int nslab, bool pro, hipStream_t s) {
   constexpr size_t lds = (size_t)pw_lds_floats(NT, KT, pw_weight_in_lds(NT, KT)) * sizeof(float);
   if (lds > (64 << 10)) {  // above the default limit of dynamic LDS (per device: set on every launch)
+    (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (pro) (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     else (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  if (pro) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true>), dim3(nslab), dim3(256), lds, s, a);
+  if (a.dx_stats) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true, true>), dim3(nslab), dim3(256), lds, s, a);
+  else if (pro) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true>), dim3(nslab), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, false>), dim3(nslab), dim3(256), lds, s, a);
 }
 
@@ -532,12 +592,18 @@ int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N) {
 // Writes dx [P][K] = the gradient w.r.t. the conv's (prologue-transformed) input and the weight
 // gradient: dw (N,K,1,1) when given, else only the partial rows in ws (nasseg_conv_pw_bwd_slabs rows
 // of N*K floats) for nasseg_wgrad_finalize_many (taps 1, flat 0).
+// dx_stats != NULL (K <= 64): x is the raw output of a BatchNorm in front (in_scale / in_shift / in_act its
+// normalisation, in_mean / in_invstd its statistics, dx_act = in_act): per slab the sums {sum dx, sum dx*xhat}
+// of THAT BatchNorm's backward are written to dx_stats[slab][2][K] (nasseg_conv_pw_bwd_slabs rows; add them with
+// nasseg_rows_sum, the buffer needs 64 more rows) - what a nasseg_bn_bwd_reduce pass over dx and x would return.
 int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, const float* wb, act_t* dx,
                               float* dw, float* ws, const float* in_scale, const float* in_shift,
                               int in_act, int dx_act, const float* bn_scale, const float* bn_shift,
                               const float* bn_mean, const float* bn_invstd, const float* bn_sums,
-                              int bn_train, int bn_act, int B, int H, int W, int K, int N, void* stream) {
+                              int bn_train, int bn_act, int B, int H, int W, int K, int N, const float* in_mean,
+                              const float* in_invstd, float* dx_stats, void* stream) {
   NASSEG_REQUIRE(x && g && z && wb && dx && ws && bn_scale, "conv_pw_bwd_bn: null tensor");
+  NASSEG_REQUIRE(!dx_stats || (in_mean && in_invstd), "conv_pw_bwd_bn: dx_stats needs in_mean / in_invstd");
   NASSEG_REQUIRE((!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
                  "conv_pw_bwd_bn: missing BatchNorm tensors");
   NASSEG_REQUIRE(B > 0 && H > 0 && W > 0, "conv_pw_bwd_bn: bad geometry");
@@ -553,11 +619,13 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
   NASSEG_REQUIRE(!dx_act || dx_act == in_act,
                  "conv_pw_bwd_bn: dx can only be masked with the derivative of the input activation");
   a.dx_act = dx_act;
+  a.in_mean = in_mean; a.in_invstd = in_invstd; a.dx_stats = dx_stats;
   a.K = K; a.N = N; a.KP = (K + 15) & ~15; a.NP = (N + 15) & ~15;
   a.M = (int)M; a.pix_per_slab = p.pix_per_slab;
   const bool pro = in_scale || in_shift || in_act;
   hipStream_t s = (hipStream_t)stream;
   if (p.wide) {
+    NASSEG_REQUIRE(!dx_stats, "conv_pw_bwd_bn: dx_stats is not available for K > 64");
     const size_t ldsw = ((size_t)kPwTile * (a.NP + 4 + kPwChunk + 4) + 4 * a.NP + 2 * p.kt * kPwChunk) * sizeof(float);
 #define PW_WIDE(KC_)                                                                                         \
   do {                                                                                                       \

@@ -1002,14 +1002,22 @@ class _ConvChain(torch.autograd.Function):
                     # i - 1 is the gradient w.r.t. its BatchNorm's output
                     behind_bn = i > 0 and ops[i - 1][4]
                     dx_act = pact if ((i == 0 and in_act0 and psc is None and psh is None) or behind_bn) else ACT_NONE
+                    # ... and, K <= 64, comes with the per-slab sums of that BatchNorm's backward (dx_stats)
+                    part = pmu_ = pis_ = None
+                    if behind_bn and K <= 64:
+                        stp = sv[7 * (i - 1) + 4]
+                        pmu_, pis_ = stp[0:K], stp[K:2 * K]
+                        part = _ws(cur, (nsl + 64) * 2 * K)
                     lib.call(_k("nasseg_conv_pw_bwd_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(wb), ptr(g_in),
                              _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, dx_act,
                              ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), bact_,
-                             Bc, H, W, K, N, s)
+                             Bc, H, W, K, N, ptr(pmu_), ptr(pis_), ptr(part), s)
                     grads[6 * i] = dwt
                     g = g_in
                     masked_in0 = bool(dx_act) and i == 0
                     g_masked = behind_bn
+                    if part is not None:
+                        pre = (part, nsl)
                     continue
                 if fused_bn is not None:
                     grads[6 * i], dz = _wgrad_bn("dense", cur, g, z, w, psc, psh, pact, fused_bn,

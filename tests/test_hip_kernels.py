@@ -1018,7 +1018,7 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
     ws2 = torch.full((nsl * N * K,), float("nan"), device=DEV)
     lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), ptr(dw), ptr(ws2), ptr(psc),
              ptr(psh), pact, 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
-             K, N, stream())
+             K, N, None, None, None, stream())
     rel = 2e-5 if dtype == torch.float32 else 1e-2  # (bf16: dx is stored rounded)
     assert_close(dx, dx_ref, rel * float(dx_ref.float().abs().max()), rel, "dx")
     assert_close(dw, dw_ref, 5e-5 * float(dw_ref.abs().max()) * max(1.0, (M / 4096.0) ** 0.5), 1e-4, "dw")
@@ -1026,7 +1026,7 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
     ws3 = torch.full_like(ws2, float("nan"))
     lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws3), ptr(psc),
              ptr(psh), pact, 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B, H, W,
-             K, N, stream())
+             K, N, None, None, None, stream())
     assert torch.equal(ws3.view(nsl, N, K).double().sum(0).float(), ws2.view(nsl, N, K).double().sum(0).float())
     if not pro:
         # a bare activation applied to x on load (pre_clf's ReLU): dx masked with its derivative
@@ -1036,7 +1036,7 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
                      B, H, W, K, N, stream())
             lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), ptr(dw), ptr(ws2), None,
                      None, a_, a_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B,
-                     H, W, K, N, stream())
+                     H, W, K, N, None, None, None, stream())
             xf = x.float()
             m_ = ((xf > 0) & ((xf < 6) | (a_ == 1))).float()
             assert_close(dx, dx_ref.float() * m_, rel * float(dx_ref.float().abs().max()), rel, "masked dx")
@@ -1312,3 +1312,47 @@ def test_stem_weight_gradient_with_bn_backward_on_load(case, train, act):
     lib.call("nasseg_conv_wgrad_bn_flat", ptr(x), K, ptr(g), N, ptr(z), N, ptr(dw), ptr(ws2), ptr(scale), ptr(shift),
              ptr(mean), ptr(invstd), ptr(sums), int(train), act, *geom, s)
     assert_close(dw, dw_ref, 2e-5 * float(dw_ref.abs().max()) * max(1.0, (M / 4096.0) ** 0.5), 1e-4, "dw")
+
+
+@pytest.mark.parametrize("case", [(2, 37, 45, 32, 32), (1, 50, 61, 16, 96), (2, 29, 31, 24, 144), (1, 33, 35, 64, 64)])
+@pytest.mark.parametrize("in_act", [0, 1, 2])
+def test_pointwise_backward_emits_the_sums_of_the_batchnorm_in_front(case, in_act):
+    """nasseg_conv_pw_bwd_bn with dx_stats: dx comes out masked with in_act' of the BatchNorm in front and the
+    per-slab rows add up to what nasseg_bn_bwd_reduce returns for (dx, x) - the backward of a widening
+    pointwise conv inside a chain (MobileNetV2's merged units) without a separate reduction pass"""
+    f = F()
+    lib, ptr, stream = f.lib, f.ptr, f.current_stream
+    B, H, W, K, N = case
+    M = B * H * W
+    x = dev(rnd(B, K, H, W, seed=1))
+    g = dev(rnd(B, N, H, W, seed=2))
+    z = dev(rnd(B, N, H, W, seed=3))
+    w = rnd(N, K, 1, 1, seed=4, scale=0.3).to(DEV)
+    wb = f._pack_dense(w, 1)
+    psc, psh, pmu, pis = _bn_vectors(K, 5)
+    scale, shift, mean, invstd = _bn_vectors(N, 6)
+    sums = (torch.randn(2 * N, generator=torch.Generator().manual_seed(7)) * 3).to(DEV)
+    s = stream()
+    nsl = lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N)
+    assert nsl > 0
+    dw, ws = torch.empty_like(w), torch.empty(nsl * N * K, device=DEV)
+    # reference: the kernel without dx_stats (dx masked), then a reduction pass over (dx, x)
+    dx_ref = dev(torch.empty(B, K, H, W))
+    lib.call("nasseg_conv_pw_bwd_bn", ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx_ref), ptr(dw), ptr(ws), ptr(psc),
+             ptr(psh), in_act, in_act, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N,
+             None, None, None, s)
+    sums_ref = torch.empty(2 * K, device=DEV)
+    wsr = torch.empty(lib.query("nasseg_colred_workspace", 1, M, K), device=DEV)
+    lib.call("nasseg_bn_bwd_reduce", ptr(dx_ref), K, ptr(x), K, M, K, ptr(psc), ptr(psh), ptr(pmu), ptr(pis), 0,
+             ptr(sums_ref), ptr(wsr), s)
+    dx = dev(torch.full((B, K, H, W), float("nan")))
+    part = torch.full(((nsl + 64) * 2 * K,), float("nan"), device=DEV)
+    dw2 = torch.empty_like(w)
+    lib.call("nasseg_conv_pw_bwd_bn", ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), ptr(dw2), ptr(ws), ptr(psc),
+             ptr(psh), in_act, in_act, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N,
+             ptr(pmu), ptr(pis), ptr(part), s)
+    assert torch.equal(dx, dx_ref) and torch.equal(dw2, dw)
+    got = torch.empty(2 * K, device=DEV)
+    lib.call("nasseg_rows_sum", ptr(part), nsl, 2 * K, ptr(got), s)
+    tol = 1e-5 * float(M) ** 0.5 * float(dx_ref.abs().max()) * (float(pis.max()) * 4 + 1)
+    assert_close(got, sums_ref, tol, 1e-4, "sums of the BatchNorm in front")
