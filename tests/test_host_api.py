@@ -232,3 +232,42 @@ def test_install_dropin_registers_reference_module_names():
             if k in ("nn", "rl", "helpers", "engine") or k.split(".")[0] in ("nn", "rl", "helpers", "engine"):
                 if k not in saved or saved[k] is None:
                     sys.modules.pop(k, None)
+
+
+@pytest.mark.parametrize("taps", [[1, 2], [1, 2, 4, 6]])
+def test_encoder_groups_units_into_chains_without_crossing_a_skip_or_a_returned_map(taps, monkeypatch):
+    """MobileNetV2.forward (host logic only: the fused runner is replaced by a recorder): a run of
+    units ends at every block with a skip connection - before it (its input is added back) and after it
+    (its sum is a tensor of its own) - and at every returned feature map; everything is run exactly
+    once, in order."""
+    import nas_segm_amd.nn.encoders as E
+    from nas_segm_amd.nn.layer_factory import InvertedResidual
+
+    enc = E.mbv2(pretrained=False, return_layers=taps)
+    order = [enc.layer1.__class__.__name__ + ":stem"]
+    names = {}
+    for idx in range(enc.max_layer + 1):
+        for b, unit in enumerate(getattr(enc, enc._stage_name(idx))):
+            names[id(unit.conv)] = (idx, b, unit.use_res_connect)
+    runs = []
+
+    def fake_run_fused(mods, x, residual=None, relu_in=False):
+        runs.append(["stem" if id(m) not in names else names[id(m)] for m in mods])
+        return x
+
+    monkeypatch.setattr(E, "run_fused", fake_run_fused)
+    monkeypatch.setattr(InvertedResidual, "forward", lambda self, x: (runs.append([names[id(self.conv)]]), x)[1])
+    outs = enc(torch.zeros(1, 3, 8, 8))
+    assert len(outs) == len(taps)
+    flat = [u for r in runs for u in r]
+    want = ["stem"] + [names[id(u.conv)] for idx in range(enc.max_layer + 1)
+                       for u in getattr(enc, enc._stage_name(idx))]
+    assert flat == want  # every unit once, in order
+    for r in runs:
+        for pos, u in enumerate(r):
+            if u != "stem" and u[2]:
+                assert len(r) == 1, r  # a block with a skip connection runs alone
+        stages_ended = [u[0] for u in r[:-1] if u != "stem" and
+                        u[1] == len(getattr(enc, enc._stage_name(u[0]))) - 1 and u[0] in taps]
+        assert not stages_ended, r  # no run continues past a returned map
+    assert runs[0][0] == "stem" and len(runs[0]) == 3  # stem + stage 1 + the first block of stage 2
