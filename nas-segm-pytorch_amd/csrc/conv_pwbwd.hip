@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   float* psc = cs + NPc;
   float* psh = psc + KPc;
   float* wl = psh + KPc;                   // (WL) [KPc][LSN]: wb[k][n], zero beyond K / N
+  float* xraw = wl + (WL ? KPc * LSN : 0); // (DXS) [64][LSK]: the input tile before its prologue
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
       const int px = it / (KPc / 4), k = (it - px * (KPc / 4)) * 4;
       const bool ok = t0 + px < p_end && k < K;
       float4 v = xv[u];
+      if (DXS) *reinterpret_cast<float4*>(&xraw[px * LSK + k]) = v;
       if (PRO) v = act_apply4(fma4(v, ld4(psc + k), ld4(psh + k)), pact);
       *reinterpret_cast<float4*>(&xt[px * LSK + k]) = keep_if(v, ok);
     }
@@ -273,9 +275,10 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
         const bool ok = p < p_end && k < K;
         if (ok) sta4(a.dx + (int64_t)p * K + k, o);
         if (DXS) {
-          // (the raw input once more - an L2 hit, the tile was loaded a moment ago: xhat cannot be taken
-          //  from the activated tile when the BatchNorm's weight is zero)
-          const float4 zr = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
+          // (the raw input, kept in LDS next to the activated tile: xhat cannot be taken from the activated
+          //  value when the BatchNorm's weight is zero, and a global re-load here would queue up behind the
+          //  next tile's loads that were just issued)
+          const float4 zr = *reinterpret_cast<const float4*>(&xraw[(wave * 16 + j) * LSK + k]);
 #ifdef NASSEG_BF16
           o = make_float4(bf16_to_f32(f32_to_bf16(o.x)), bf16_to_f32(f32_to_bf16(o.y)), bf16_to_f32(f32_to_bf16(o.z)),
                           bf16_to_f32(f32_to_bf16(o.w)));  // (what a separate pass would read back)
@@ -554,15 +557,16 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
 template <int NT, int KT>
 void pw_launch(const PwArgs& a, int nslab, bool pro, hipStream_t s) {
   constexpr size_t lds = (size_t)pw_lds_floats(NT, KT, pw_weight_in_lds(NT, KT)) * sizeof(float);
-  if (lds > (64 << 10)) {  // above the default limit of dynamic LDS (per device: set on every launch)
+  constexpr size_t lds_dxs = lds + (size_t)kPwTile * pw_lsk(KT) * sizeof(float);  // (+ the raw input tile)
+  if (lds_dxs > (64 << 10)) {  // above the default limit of dynamic LDS (per device: set on every launch)
     (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dxs);
     if (pro) (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     else (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, false>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  if (a.dx_stats) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true, true>), dim3(nslab), dim3(256), lds, s, a);
+  if (a.dx_stats) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true, true>), dim3(nslab), dim3(256), lds_dxs, s, a);
   else if (pro) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true>), dim3(nslab), dim3(256), lds, s, a);
   else hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, false>), dim3(nslab), dim3(256), lds, s, a);
 }
