@@ -52,7 +52,8 @@ WORKLOADS = {
               "CVPR search decoder, 256x256 crops bs64"),
 }
 NUM_CLASSES = 19
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6300.0  # (same guide: 6.29 TB/s measured with a float4 copy)
 
 
 def algorithmic_bytes(name, a):
@@ -272,6 +273,64 @@ def pmc_summary():
     return fams, step_bytes
 
 
+def collect_pmc(passthrough, timeout_s=300):
+    """HBM traffic measured in THIS run: two extra, untimed rocprofv3 passes of this command
+    (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` separately - they do not fit one pass - with
+    `--kernel-trace` only, as MI355X_MICROARCH.md's HBM section prescribes), 3 steps each.
+    Returns ({kernel family: HBM bytes per launch}, HBM bytes per step) with FETCH_SIZE doubled
+    for gfx950 (units: KB), or (None, None) when rocprofv3 is missing / a pass fails."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None
+    out = tempfile.mkdtemp(prefix="nasseg_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    n_steps = 3  # (--steps 2 --warmup 1)
+    res = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, c), "-o",
+                   "run", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-roofline", "--pmc", "0"] + list(passthrough)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL)
+            if r.returncode != 0:
+                return None, None
+            fam = collections.defaultdict(lambda: [0, 0.0])
+            for f in glob.glob(os.path.join(out, c, "**", "*counter_collection*.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") != c:
+                        continue
+                    name = re.sub(r"\(anonymous namespace\)::", "", row["Kernel_Name"])
+                    base = re.split(r"[<(]", re.sub(r"^void ", "", name))[0]
+                    fam[base][0] += 1
+                    fam[base][1] += float(row["Counter_Value"])
+            if not fam:
+                return None, None
+            res[c] = fam
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None, None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    fams, total = {}, 0.0
+    for k in set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]):
+        nf, vf = res["FETCH_SIZE"].get(k, [0, 0.0])
+        nw, vw = res["WRITE_SIZE"].get(k, [0, 0.0])
+        nbytes = (2.0 * vf + vw) * 1024.0
+        total += nbytes
+        fams[k] = nbytes / max(nf, nw, 1)
+    return fams, total / n_steps
+
+
 def kernel_family(name, a):
     """the __global__ function (rocprofv3's kernel name) an entry-point call dispatches to: the
     roofline is quoted per kernel family so that it can be held against the rocprof summary and
@@ -350,6 +409,58 @@ def roofline_from_profile(records, n_steps=2):
     return rows, groups, launches
 
 
+def _free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n_ranks, argv):
+    """`python bench.py --gpus N` started bare (no WORLD_SIZE in the environment): re-run this
+    command as N ranks of one node - one process per GPU, rendezvous on 127.0.0.1 - through
+    torch.distributed.run, exactly the line the module docstring shows.  Rank 0's stdout (the one
+    JSON line) passes through; the exit status is the launcher's."""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")  # (torchrun would set 1: the optimisers' host side is threaded)
+    return subprocess.call(cmd, env=env)
+
+
+def verified_world(device, backend):
+    """the number of ranks that REALLY take part in collectives: every rank contributes a one to an
+    all-reduce on the device the step runs on (RCCL when backend is nccl) - reported as
+    ``rccl_ranks`` so that a line printed by a run that silently fell back to one rank cannot
+    pass for an N-GPU measurement"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    one = torch.ones(1, device=device if backend == "nccl" or device.type == "cuda" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    n = int(round(float(one.item())))
+    if n != dist.get_world_size():
+        raise SystemExit("bench.py: all-reduce of ones gave {} on a world of {}".format(n, dist.get_world_size()))
+    return n
+
+
+def launch_selftest(args, world, rank):
+    """--launch-selftest: the launcher, the rendezvous and one real collective WITHOUT a GPU (gloo
+    on the CPU) - what tests/test_distributed_cpu.py runs here, where there is no device."""
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = verified_world(torch.device("cpu"), "gloo")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"selftest": "launch", "n_gpus": world, "rccl_ranks": n, "requested": args.gpus,
+                          "backend": "gloo"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -376,16 +487,39 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--shapes", type=int, default=0,
                     help="with --breakdown: also print the N most expensive (entry point, shape) rows")
+    ap.add_argument("--pmc", type=int, default=-1, choices=(-1, 0, 1),
+                    help="HBM traffic of the step from rocprofv3 PMC counters, collected in two extra untimed "
+                         "passes of this command: 1 = yes, 0 = no (the committed profiles/ summary is used while "
+                         "it matches the library), -1 = yes for the default 1-GPU headline run")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="only launch the ranks, rendezvous and all-reduce on the CPU (gloo): no GPU needed")
     args = ap.parse_args()
     args.graph_flag_given = any(a == "--graph" or a.startswith("--graph=") for a in sys.argv[1:])
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started bare: become the launcher of N ranks (one per GPU) and pass rank 0's line through
+        if not args.launch_selftest and not args.same_device:
+            n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if n_dev < args.gpus:
+                raise SystemExit("bench.py: --gpus {} but {} HIP device(s) visible".format(args.gpus, n_dev))
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus {} but WORLD_SIZE={} (one rank per GPU: launch with "
+                         "--nproc-per-node {})".format(args.gpus, world, args.gpus))
+    if args.launch_selftest:
+        return launch_selftest(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     if args.same_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank {} has no GPU of its own ({} visible)".format(
+            local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -393,7 +527,7 @@ def main():
         # not lazily inside the first collective
         extra = dict(device_id=device) if args.backend == "nccl" else {}
         dist.init_process_group(args.backend, rank=rank, world_size=world, **extra)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    rccl_ranks = verified_world(device, args.backend)
 
     import nas_segm_amd  # noqa: F401
     from nas_segm_amd._lib import LaunchProfiler, lib
@@ -458,14 +592,18 @@ def main():
         del loader
         segmenter.train()
         rng = np.random.RandomState(rank)
-        os.environ["NASSEG_GRAPH"] = {0: "0", 1: "1", 2: "1"}[args.graph] if args.graph_flag_given else \
-            os.environ.get("NASSEG_GRAPH", "auto")
+        env_graph = os.environ.get("NASSEG_GRAPH")  # (the user's setting is put back below)
+        if args.graph_flag_given:
+            os.environ["NASSEG_GRAPH"] = {0: "0", 1: "1", 2: "1"}[args.graph]
         task0_step = make_task0_step(Xy, segmenter, optim_dec, args.batch, 255, 3.0, 0.15)
         task0_eager = task0_step
         if getattr(task0_step, "__self__", None) is not None:  # (a stepper's bound method: replayed)
             os.environ["NASSEG_GRAPH"] = "0"
             task0_eager = make_task0_step(Xy, segmenter, optim_dec, args.batch, 255, 3.0, 0.15)
-            os.environ["NASSEG_GRAPH"] = "auto"
+        if env_graph is None:
+            os.environ.pop("NASSEG_GRAPH", None)
+        else:
+            os.environ["NASSEG_GRAPH"] = env_graph
 
         def eager_step():  # noqa: F811
             return task0_eager(rng.permutation(n_cache)[:args.batch])
@@ -541,22 +679,39 @@ def main():
             gbs = top["bytes"] / 1e9 / (top["ms"] / 1e3)
             # HBM traffic from the PMC counters: only from a summary collected with THIS build of the
             # kernels and this command (fp32 headline), else null
-            fams, step_bytes = (pmc_summary() if args.dtype == "f32" and args.workload == "headline"
-                                and args.batch == wl[3] else (None, None))
+            fams = step_bytes = None
+            pmc_source = None
+            if args.pmc == 1 or (args.pmc == -1 and os.environ.get("NASSEG_BENCH_PMC", "1") != "0"
+                                 and world == 1 and args.workload == "headline" and args.batch == wl[3]
+                                 and not args.graph):
+                passthrough = ["--workload", args.workload, "--dtype", args.dtype, "--batch", str(args.batch),
+                               "--height", str(args.height), "--width", str(args.width)]
+                torch.cuda.synchronize()
+                fams, step_bytes = collect_pmc(passthrough) if world == 1 else (None, None)
+                pmc_source = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run" if fams else None
+            if fams is None and args.dtype == "f32" and args.workload == "headline" and args.batch == wl[3]:
+                fams, step_bytes = pmc_summary()
+                pmc_source = "profiles/pmc_fetch_write_latest.txt (same library hash)" if fams else None
             unfused = {"headline": 24.98e9, "arch1": 35.12e9}.get(args.workload)
             roof = {"bound": "hbm", "kernel": name, "entry_points": sorted(top["entries"]),
                     "top5": [{"kernel": r["kernel"], "gbs": round(r["gbs"], 1),
                               "frac": round(r["gbs"] / HBM_PEAK_GBS, 3),
                               "share": round(r["ms"] / total_ms, 3)} for r in rows[:5]],
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                    "traffic": fams.get(name) if fams else None,
+                    "frac_of_achievable": gbs / HBM_ACHIEVABLE_GBS, "achievable": HBM_ACHIEVABLE_GBS,
+                    "launch_duration": "HIP events on the launch stream, minimum of 2 samples per launch",
+                    "traffic": fams.get(name) if fams else None, "traffic_source": pmc_source,
                     "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                     "avg_launch_ms": top["ms"] / top["launches"], "launches_per_step": top["launches"] / 2,
                     "share_of_kernel_time": top["ms"] / total_ms,
                     "nasseg_calls_per_step": len(launches) / 2,
+                    # launches that cost their dispatch whatever they move (finalisers, row sums, small maps)
+                    "tiny_launches_per_step": sum(1 for _, _, ms in launches if ms < 0.010) / 2,
+                    "tiny_launch_ms_per_step": sum(ms for _, _, ms in launches if ms < 0.010) / 2,
                     "step_traffic": step_bytes,
                     "step_traffic_vs_unfused": (step_bytes / (unfused * args.batch)
                                                 if step_bytes and unfused else None),
+                    "step_hbm_gbs": (step_bytes / 1e9 / (elapsed / args.steps) if step_bytes else None),
                     "pmc_lib": lib_hash() if fams else None,
                     "depthwise_gbs": dw[0]["gbs"] if dw else None,
                     "depthwise_frac": dw[0]["gbs"] / HBM_PEAK_GBS if dw else None}
@@ -606,7 +761,8 @@ def main():
                 else "fwd+bwd+optimizer step",
                 "WACV arch0" if args.workload == "headline" else args.workload, args.width, args.height,
                 args.batch),
-            "value": imgs / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "value": imgs / elapsed, "unit": "images/sec", "n_gpus": world, "rccl_ranks": rccl_ranks,
+            "collective_backend": (args.backend if world > 1 else None), "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 storage / f32 arithmetic",

@@ -19,8 +19,9 @@ accumulation kernels are recorded.  When data parallel they are packed into one 
 bucket (one multi-tensor copy) and all-reduced with one collective after the replay.
 
 ``train_segmenter`` / ``train_task0`` use these steppers by themselves where they win
-(``auto_graph``): one process (or independent candidates per rank), at most
-``AUTO_GRAPH_MAX_PIXELS`` image pixels per step - above that the step is GPU-bound and a
+(``auto_graph``): at most ``AUTO_GRAPH_MAX_PIXELS`` image pixels per step and rank (one process,
+independent candidates per rank, or data-parallel replicas whose gradient all-reduce follows the
+replay) - above that the step is GPU-bound and a
 replay runs at the speed of host launches (measured: 4x1024x2048 195.9 eager / 195.7 replayed
 images/s, 8x713x713 467 / 610, 8x480x640 445 / 590, 16x321x321 682 / 1062).
 """
@@ -43,13 +44,17 @@ AUTO_GRAPH_MAX_PIXELS = 6 << 20
 
 def auto_graph(segmenter, n_pixels):
     """Should the engine replay this candidate's steps from a hipGraph?  n_pixels = B*H*W of the
-    images one step consumes."""
+    images one step consumes (per rank).  Data parallel the rule is the same - what is replayed
+    is forward + loss + backward; packing the bucket, the RCCL all-reduce, clipping and the
+    optimisers stay outside the graph - unless NASSEG_GRAPH_DP=0 (host launches on every rank)."""
     mode = os.environ.get("NASSEG_GRAPH", "auto")
     if mode == "0":
         return False
-    if getattr(segmenter, "world_size", 1) > 1:
-        return False  # (data parallel: host launches - see DESIGN.md section 5)
-    return mode == "1" or n_pixels <= AUTO_GRAPH_MAX_PIXELS
+    if mode == "1":
+        return True
+    if getattr(segmenter, "world_size", 1) > 1 and os.environ.get("NASSEG_GRAPH_DP", "1") == "0":
+        return False
+    return n_pixels <= AUTO_GRAPH_MAX_PIXELS
 
 
 def _capturable(optim):
@@ -120,44 +125,73 @@ class _GraphedStep(object):
     def _capture(self, warmup):
         # The probe and warm-up passes (lazy initialisation must happen outside the
         # capture) leave no trace: running statistics and - when the optimisers are
-        # inside the graph - parameters and optimiser state are put back afterwards.
+        # inside the graph - parameters and optimiser state are put back afterwards,
+        # ALSO when the warm-up or the capture raises (HIP out of memory, say): the engine then
+        # launches this candidate from the host, and its BatchNorm statistics must not have
+        # advanced by the warm-up's momentum updates.
         buffers = self._bn_buffers()
         saved = [b.clone() for b in buffers]
-        saved_params = None
+        saved_params = saved_state = None
         if self.capture_optimisers:
             saved_params = [p.detach().clone() for p in self.model.parameters()]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                self._fwd_bwd(self.capture_optimisers)
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            if self.capture_optimisers:
-                # optimiser state was created lazily by the warm-up: back to "never stepped"
-                for p, s in zip(self.model.parameters(), saved_params):
-                    p.copy_(s)
-                for optim in self._optimisers:
-                    for st in optim.state.values():
-                        for v in st.values():
-                            if torch.is_tensor(v):
-                                v.zero_()
-            for b, s in zip(buffers, saved):
-                b.copy_(s)
-        # No garbage collection while the stream is capturing: a collected cycle may hold device
-        # tensors or another candidate's hipGraph, whose destruction inside a capture aborts the
-        # process (torch >= 2.9 no longer collects before a capture by itself).  Collect now,
-        # hold the collector off for the capture.
-        self.graph = torch.cuda.CUDAGraph()
-        gc.collect()
-        gc_was_enabled = gc.isenabled()
-        gc.disable()
+            # optimiser state that exists already (a stepper rebuilt in the middle of a
+            # candidate's training) is real momentum: keep a copy, not zeros
+            saved_state = [dict((id(p), dict((k, v.clone() if torch.is_tensor(v) else v) for k, v in st.items()))
+                                for p, st in optim.state.items()) for optim in self._optimisers]
+
+        def restore():
+            with torch.no_grad():
+                if self.capture_optimisers:
+                    for p, s in zip(self.model.parameters(), saved_params):
+                        p.copy_(s)
+                    for optim, before in zip(self._optimisers, saved_state):
+                        for p, st in optim.state.items():
+                            old = before.get(id(p))
+                            for k, v in st.items():
+                                if not torch.is_tensor(v):
+                                    continue
+                                if old is not None and torch.is_tensor(old.get(k)):
+                                    v.copy_(old[k])
+                                else:  # created lazily by the warm-up: back to "never stepped"
+                                    v.zero_()
+                for b, s in zip(buffers, saved):
+                    b.copy_(s)
+
+        done = False
         try:
-            with torch.cuda.graph(self.graph):
-                self.loss = self._fwd_bwd(self.capture_optimisers)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    self._fwd_bwd(self.capture_optimisers)
+            torch.cuda.current_stream().wait_stream(side)
+            restore()
+            # No garbage collection while the stream is capturing: a collected cycle may hold device
+            # tensors or another candidate's hipGraph, whose destruction inside a capture aborts the
+            # process (torch >= 2.9 no longer collects before a capture by itself).  Collect now,
+            # hold the collector off for the capture.
+            self.graph = torch.cuda.CUDAGraph()
+            gc.collect()
+            gc_was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.loss = self._fwd_bwd(self.capture_optimisers)
+            finally:
+                if gc_was_enabled:
+                    gc.enable()
+            done = True
         finally:
-            if gc_was_enabled:
-                gc.enable()
+            if not done:
+                # whatever the warm-up changed before it (or the capture) failed is undone, and no
+                # half-written gradient is left for the eager step that follows
+                try:
+                    torch.cuda.synchronize()
+                    restore()
+                finally:
+                    for p in self._params:
+                        p.grad = None
+                    self.graph = None
         # capturing executes nothing: state is exactly as restored above.  The gradients the
         # capture left in ``param.grad`` are the static tensors every replay refills.
         self._static_grads = [(p, p.grad) for p in self._params if p.grad is not None]
@@ -267,6 +301,7 @@ class GraphedTask0Step(_GraphedStep):
         self.groups = [(list(model.decoder.parameters()), dec_grad_clip, optim_dec)]
         self.decoder = model.decoder
         self.index = torch.arange(batch_size, device=Xy_train["y"].device, dtype=torch.int64)
+        self._cache_rows = int(Xy_train["y"].shape[0])
         self._init_common(segmenter, capture_optimisers, (optim_dec,), warmup)
 
     def _forward_loss(self):
@@ -289,6 +324,10 @@ class GraphedTask0Step(_GraphedStep):
         if tuple(idx.shape) != tuple(self.index.shape):
             raise F.NassegError("GraphedTask0Step: batches of {} indices (got {})".format(
                 self.index.numel(), tuple(idx.shape)))
+        if not idx.is_cuda and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= self._cache_rows):
+            # the reference's Xy_train[k][train_idx] raises here (trainer.py:132-137); the kernel's
+            # clamp is a memory-safety net only
+            raise IndexError("GraphedTask0Step: cache row index out of range [0, {})".format(self._cache_rows))
         self.index.copy_(idx, non_blocking=True)
         return self._replay()
 

@@ -64,7 +64,7 @@ def validate(segmenter, val_loader, epoch, epoch2, num_classes=-1, print_every=1
                     logger.info(" Val epoch: {} [{}/{}]\tMean IoU: {:.3f}".format(
                         epoch, i, len(val_loader),
                         np.mean([iu for iu in compute_iu(cm) if iu <= 1.0])))
-    except RuntimeError:
+    except Exception:  # (not only RuntimeError: a loader error on one rank must not strand its peers)
         # data parallel: the peers will wait in the confusion-matrix all-reduce - take part in
         # it with the failure flag set so that every rank scores this candidate 0
         if hasattr(segmenter, "reduce_confusion"):

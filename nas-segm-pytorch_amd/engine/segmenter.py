@@ -61,6 +61,7 @@ class RankParallel(nn.Module):
         self._views = None
         self._plist = None
         self._status = None
+        self.sync_count = 0  # gradient collectives this rank has taken part in
         if broadcast and not independent:
             self.broadcast_parameters()
 
@@ -126,6 +127,7 @@ class RankParallel(nn.Module):
         params = self._parameters_once()
         if self._flat is None:
             self._build_bucket()
+        self.sync_count += 1
         if failed:
             self._flat.zero_()
             self._status.fill_(1.0)

@@ -95,6 +95,47 @@ def _loss_value(segmenter, loss):
     return loss.item()
 
 
+def _syncs(segmenter):
+    return getattr(segmenter, "sync_count", 0)
+
+
+def _tell_peers(segmenter, exc, syncs_before=None, last_step=False):
+    """Data parallel, this rank is leaving its step loop with ``exc``: take part - once per
+    failure - in the gradient collective its peers are (or will be) waiting in, with zeros and
+    the failure status, so that they abandon the candidate too (RankParallel's failure
+    protocol).  ``syncs_before``: segmenter.sync_count at the start of the step - if this rank
+    has already joined the step's collective (the failure came later: clipping, the optimiser)
+    the flag reaches the peers in the NEXT step's collective and they all stop there; after the
+    epoch's last step there is no such collective and nothing is sent (the peers have finished
+    the epoch; every rank goes on to validation).  A PeerFailure needs no telling: every healthy
+    rank raised it at the same point."""
+    from .segmenter import PeerFailure
+
+    if not _distributed(segmenter) or isinstance(exc, PeerFailure) or getattr(exc, "_nasseg_peers_told", False):
+        return
+    try:
+        exc._nasseg_peers_told = True
+    except AttributeError:
+        pass
+    if last_step and syncs_before is not None and _syncs(segmenter) > syncs_before:
+        return
+    segmenter.sync_gradients(failed=True)
+
+
+def _agreed_count(segmenter, n):
+    """the smallest ``n`` over the data-parallel ranks (loaders / cache shards of unequal length
+    would otherwise issue different numbers of gradient all-reduces); ``n`` itself otherwise"""
+    if not _distributed(segmenter) or n is None:
+        return n
+    import torch.distributed as dist
+
+    t = torch.tensor([int(n)], device=_model_device(_inner(segmenter)), dtype=torch.int64)
+    if dist.get_backend(getattr(segmenter, "process_group", None)) == "gloo":
+        t = t.cpu()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=getattr(segmenter, "process_group", None))
+    return int(t.item())
+
+
 def _graphed():
     from . import graphed  # (graphed imports this module's helpers)
 
@@ -105,35 +146,58 @@ def _bn_modes(module):
     return tuple(m.training for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
 
 
-def _cached_stepper(owner, slot, key, build):
-    """one stepper per (owner, slot): rebuilt when the key - shapes, optimisers, module tree,
-    BatchNorm modes ... - changes; a capture that fails once is not attempted again for that key"""
+_STEPPERS_PER_CANDIDATE = 2  # captured shapes kept per candidate (the usual batch + a last, smaller one)
+
+
+def _trainable_signature(params, optimisers):
+    """what a captured graph has baked in besides shapes: which parameters receive gradients and
+    which tensors the optimisers step on (frozen / unfrozen parameters or edited param_groups
+    between epochs need a new capture)"""
+    return (tuple(p.requires_grad for p in params),
+            tuple(tuple(id(q) for g in o.param_groups for q in g["params"]) for o in optimisers if o is not None))
+
+
+def _cached_stepper(owner, slot, base_key, shape_key, build):
+    """The hipGraph steppers of one candidate: ``base_key`` = everything a capture depends on
+    except the batch's shape (optimisers, module tree, BatchNorm modes, trainable set ...) - when
+    it changes all steppers are dropped; ``shape_key`` selects among at most
+    _STEPPERS_PER_CANDIDATE captured shapes.  A shape beyond that (or one whose capture failed
+    once) returns None: that batch is launched from the host instead of paying two warm-up
+    passes and a capture for a batch that comes once per epoch."""
     ent = getattr(owner, slot, None)
-    if ent is not None and ent[0] == key:
-        return ent[1]
+    if ent is None or ent[0] != base_key:
+        ent = (base_key, {})
+        setattr(owner, slot, ent)
+    steppers = ent[1]
+    if shape_key in steppers:
+        return steppers[shape_key]
+    if len(steppers) >= _STEPPERS_PER_CANDIDATE:
+        return None
     try:
         stepper = build()
     except RuntimeError as e:  # e.g. HIP out of memory while capturing: launch from the host
         logger.warning(" hipGraph capture failed (%s): launching from the host", e)
         stepper = None
-    setattr(owner, slot, (key, stepper))
+    steppers[shape_key] = stepper
     return stepper
 
 
 def _task0_stepper(Xy_train, segmenter, optim_dec, batch_size, ignore, dec_grad_clip, aux_weight, freeze_bn):
     model = _inner(segmenter)
-    key = (TREE_VERSION[0], id(optim_dec), batch_size, ignore, dec_grad_clip, aux_weight, _bn_modes(model.decoder),
-           tuple((k, v.data_ptr(), tuple(v.shape)) for k, v in Xy_train.items() if k != "out_size"))
-    return _cached_stepper(model, "_nasseg_task0_stepper", key, lambda: _graphed().GraphedTask0Step(
+    base = (TREE_VERSION[0], id(optim_dec), ignore, dec_grad_clip, aux_weight, _bn_modes(model.decoder),
+            _trainable_signature(list(model.decoder.parameters()), (optim_dec,)))
+    shape = (batch_size, tuple((k, v.data_ptr(), tuple(v.shape)) for k, v in Xy_train.items() if k != "out_size"))
+    return _cached_stepper(model, "_nasseg_task0_stepper", base, shape, lambda: _graphed().GraphedTask0Step(
         Xy_train, segmenter, optim_dec, batch_size, ignore, dec_grad_clip, aux_weight))
 
 
 def _segmenter_stepper(segmenter, image, target, optim_enc, optim_dec, ignore, enc_grad_clip, dec_grad_clip,
                        aux_weight):
     model = _inner(segmenter)
-    key = (TREE_VERSION[0], id(optim_enc), id(optim_dec), tuple(image.shape), image.dtype, tuple(target.shape),
-           target.dtype, ignore, enc_grad_clip, dec_grad_clip, aux_weight, _bn_modes(model))
-    return _cached_stepper(model, "_nasseg_task1_stepper", key, lambda: _graphed().GraphedSegmenterStep(
+    base = (TREE_VERSION[0], id(optim_enc), id(optim_dec), ignore, enc_grad_clip, dec_grad_clip, aux_weight,
+            _bn_modes(model), _trainable_signature(list(model.parameters()), (optim_enc, optim_dec)))
+    shape = (tuple(image.shape), image.dtype, tuple(target.shape), target.dtype)
+    return _cached_stepper(model, "_nasseg_task1_stepper", base, shape, lambda: _graphed().GraphedSegmenterStep(
         segmenter, image, target, optim_enc, optim_dec, ignore, enc_grad_clip, dec_grad_clip, aux_weight))
 
 
@@ -211,6 +275,7 @@ def make_task0_step(Xy_train, segmenter, optim_dec, batch_size, ignore_index=255
     device = Xy_train["y"].device
     dec_params = list(decoder.parameters())
     pack_memo = F.PackMemo()
+    n_rows = int(Xy_train["y"].shape[0])
     n_pixels = batch_size * int(Xy_train[feat_keys[0]].shape[2]) * int(Xy_train[feat_keys[0]].shape[3]) * 16
     if not do_kd and device.type == "cuda" and _graphed().auto_graph(segmenter, n_pixels):
         stepper = _task0_stepper(Xy_train, segmenter, optim_dec, batch_size, ignore_index, dec_grad_clip,
@@ -219,8 +284,12 @@ def make_task0_step(Xy_train, segmenter, optim_dec, batch_size, ignore_index=255
             return stepper.step
 
     def step(batch_idx):
-        idx = torch.as_tensor(batch_idx, dtype=torch.int64).to(device, non_blocking=True)
+        syncs = _syncs(segmenter)
         try:
+            idx = torch.as_tensor(batch_idx, dtype=torch.int64)
+            if not idx.is_cuda and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= n_rows):
+                raise IndexError("train_task0: cache row index out of range [0, {})".format(n_rows))  # as Xy[k][idx]
+            idx = idx.to(device, non_blocking=True)
             with F.packed_once(pack_memo):  # (one weight re-pack launch per step)
                 feats = [F.gather_rows(Xy_train[k], idx) for k in feat_keys]
                 target = F.gather_rows(Xy_train["y"], idx)
@@ -239,15 +308,15 @@ def make_task0_step(Xy_train, segmenter, optim_dec, batch_size, ignore_index=255
                 _zero_grads(segmenter, (optim_dec,))
                 with F.deferred_wgrad(params=dec_params):
                     loss.backward()
-        except RuntimeError:
             if _distributed(segmenter):
-                segmenter.sync_gradients(failed=True)  # (the peers are waiting in this collective)
-            raise
-        if _distributed(segmenter):
-            # the feature cache is sharded: every rank steps on its own cached samples and the
-            # decoder gradients are averaged (the reference runs this stage on one GPU)
-            segmenter.sync_gradients()
-        _clip_and_step([(dec_params, dec_grad_clip, optim_dec)])
+                # the feature cache is sharded: every rank steps on its own cached samples and the
+                # decoder gradients are averaged (the reference runs this stage on one GPU)
+                segmenter.sync_gradients()
+            _clip_and_step([(dec_params, dec_grad_clip, optim_dec)])
+        except Exception as e:
+            if _syncs(segmenter) == syncs:
+                _tell_peers(segmenter, e)  # (the peers are waiting in this step's collective)
+            raise  # (a later failure - clipping, the optimiser - is the caller's to announce: train_task0)
         return loss
 
     return step
@@ -259,7 +328,9 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
                 aux_weight=0):
     """Decoder-only epoch over the cached encoder features (trainer.py:78-175)."""
     decoder = _inner(segmenter).decoder
-    n_examples = Xy_train[0].size(0)
+    # (data parallel the cache is sharded: every rank must issue the same number of gradient
+    #  all-reduces, so the shards agree on the smallest of their sizes first)
+    n_examples = _agreed_count(segmenter, Xy_train[0].size(0))
     batch_size = min(batch_size, n_examples)
     n_passes = n_examples // batch_size
     indices = np.arange(n_examples)
@@ -272,7 +343,12 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
                            aux_weight, freeze_bn, do_kd, kd_coeff, kd_crit)
     for i in range(n_passes):
         start = time.time()
-        loss = step(indices[i * batch_size:(i + 1) * batch_size])
+        syncs = _syncs(segmenter)
+        try:
+            loss = step(indices[i * batch_size:(i + 1) * batch_size])
+        except Exception as e:
+            _tell_peers(segmenter, e, syncs, i == n_passes - 1)
+            raise
         losses.update(_loss_value(segmenter, loss))
         batch_time.update(time.time() - start)
         if do_polyak:
@@ -298,6 +374,7 @@ def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=
         model._nasseg_step_params = cached
         model._nasseg_pack_memo = F.PackMemo()
     groups = cached[1]
+    syncs = _syncs(segmenter)
     # the parameters are constant until the optimiser steps below: all chains' weights are
     # re-packed by one launch at the start of the step
     try:
@@ -317,11 +394,11 @@ def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=
             # batched when backward is through
             with F.deferred_wgrad(params=groups[0] + groups[1]):
                 loss.backward()
-    except RuntimeError:
-        if _distributed(segmenter):
-            segmenter.sync_gradients(failed=True)  # (the peers are waiting in this collective)
-        raise
-    finish_step(segmenter, groups, optim_enc, optim_dec, enc_grad_clip, dec_grad_clip)
+        finish_step(segmenter, groups, optim_enc, optim_dec, enc_grad_clip, dec_grad_clip)
+    except Exception as e:
+        if _syncs(segmenter) == syncs:
+            _tell_peers(segmenter, e)  # (the peers are waiting in this step's collective)
+        raise  # (a later failure - clipping, the optimiser - is the caller's to announce: train_segmenter)
     return loss
 
 
@@ -347,25 +424,42 @@ def train_segmenter(segmenter, train_loader, optim_enc, optim_dec, epoch, segm_c
     batch_time, losses = AverageMeter(), AverageMeter()
     ignore = _ignore_index(segm_crit)
     device = _model_device(_inner(segmenter))
-    for i, sample in enumerate(train_loader):
+    # data parallel: the ranks agree on the number of steps (loaders of unequal length would leave
+    # the longer ones waiting in an all-reduce), and a rank that fails ANYWHERE in its step - the
+    # loader, the copy to the device, the optimiser - tells its peers before it leaves (_tell_peers)
+    n_steps = _agreed_count(segmenter, len(train_loader) if hasattr(train_loader, "__len__") else None)
+    batches = iter(train_loader)
+    i = 0
+    while n_steps is None or i < n_steps:
         start = time.time()
-        image = _to_device_image(sample["image"], device)
-        target = _labels(sample["mask"], device)
-        stepper = None
-        if device.type == "cuda" and _graphed().auto_graph(segmenter, image.shape[0] * image.shape[2] * image.shape[3]):
-            # launch-bound sizes: forward + loss + backward replayed from a hipGraph captured on
-            # this candidate's first batch (bit-identical to the eager step)
-            stepper = _segmenter_stepper(segmenter, image, target, optim_enc, optim_dec, ignore,
-                                         enc_grad_clip, dec_grad_clip, aux_weight)
-        if stepper is not None:
-            loss = stepper.step(image, target)
-        else:
-            loss = segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore,
-                                  enc_grad_clip, dec_grad_clip, aux_weight)
-        if do_polyak:
-            _polyak_update(segmenter.parameters(), avg_param, polyak_decay)
+        syncs = _syncs(segmenter)
+        try:
+            try:
+                sample = next(batches)
+            except StopIteration:
+                break
+            image = _to_device_image(sample["image"], device)
+            target = _labels(sample["mask"], device)
+            stepper = None
+            if device.type == "cuda" and _graphed().auto_graph(segmenter,
+                                                               image.shape[0] * image.shape[2] * image.shape[3]):
+                # launch-bound sizes: forward + loss + backward replayed from a hipGraph captured on
+                # this candidate's first batch (bit-identical to the eager step)
+                stepper = _segmenter_stepper(segmenter, image, target, optim_enc, optim_dec, ignore,
+                                             enc_grad_clip, dec_grad_clip, aux_weight)
+            if stepper is not None:
+                loss = stepper.step(image, target)
+            else:
+                loss = segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore,
+                                      enc_grad_clip, dec_grad_clip, aux_weight)
+            if do_polyak:
+                _polyak_update(segmenter.parameters(), avg_param, polyak_decay)
+        except Exception as e:
+            _tell_peers(segmenter, e, syncs, n_steps is not None and i == n_steps - 1)
+            raise
         losses.update(_loss_value(segmenter, loss))
         batch_time.update(time.time() - start)
         if i % print_every == 0:
             logger.info(" Train epoch: {} [{}/{}]\tAvg. Loss: {:.3f}\tAvg. Time: {:.3f}".format(
                 epoch, i, len(train_loader), losses.avg, batch_time.avg))
+        i += 1

@@ -427,3 +427,38 @@ def test_search_loop_feeds_the_controller_like_the_reference_gloo(tmp_path):
         epoch = int(l.decode("utf-8").strip("\n").split(":")[2].split(",")[0])  # num_uq.py:16
         assert arch.strip() == str(samples[k]["config"]) and epoch == k
         assert abs(reward - 0.01 * (k + 1)) < 1e-4
+
+
+def _run_bench(args, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"), **env_set):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    env.update(env_set)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=240)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started bare spawns two ranks itself (torch.distributed.run, rendezvous on
+    127.0.0.1) and reports the number of ranks a REAL all-reduce counted - here on the CPU (gloo, no device):
+    the launcher path of the N-GPU benchmark (src/main_search.py:507 is one process with nn.DataParallel)."""
+    import json
+
+    out = _run_bench(["--gpus", "2", "--launch-selftest"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["requested"] == 2
+
+
+def test_bench_refuses_a_world_that_is_not_what_was_asked():
+    # a launcher that started fewer ranks than --gpus says must not produce a line that reads as N GPUs
+    out = _run_bench(["--gpus", "2", "--launch-selftest"], env_drop=(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    assert out.returncode != 0 and "WORLD_SIZE=1" in (out.stderr + out.stdout)
+    # ... and without devices the real benchmark fails loudly instead of running one rank
+    out = _run_bench(["--gpus", "2"])
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)

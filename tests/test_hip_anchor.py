@@ -1,0 +1,263 @@
+"""Every FUSED kernel of the conv chains anchored directly to a plain PyTorch fp32 CPU reference of the same
+ops (round 2 compared each fused kernel with the kernel pair it replaced): conv -> BatchNorm(train) -> act
+sequences with the headline network's channel pairs on maps scaled to 1 x 64 x 128, thresholds lowered so
+that the large-map paths run (nasseg_conv_pw_bwd_bn incl. its wide and dx_stats forms, nasseg_dwconv_bwd_bn,
+nasseg_conv_wgrad_bn, nasseg_conv_wgrad_bn_flat, nasseg_sepconv_fwd, nasseg_conv_bwd_data_bn,
+nasseg_dwconv_bwd_data_bn) - output, input gradient, every parameter gradient and the BatchNorm buffers
+against torch.nn's own forward / autograd of the SAME module tree on the CPU
+(reference: src/nn/layer_factory.py:76-81,125-158,225-265 run these ops through torch.nn).
+Also: BatchNorm statistics when |mean| >> std."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+from _util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def F():
+    from nas_segm_amd import functional
+
+    return functional
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def dev(t):
+    t = t.to(DEV)
+    return t.contiguous(memory_format=torch.channels_last) if t.dim() == 4 else t
+
+
+def torch_reference(modules, x, residual=None, relu_in=False):
+    """the torch.nn forward of the (flattened) module list: every product leaf subclasses the torch.nn
+    module the reference instantiates, so its base class' forward IS the reference op"""
+    from nas_segm_amd.nn.modules import _flatten
+
+    y = torch.relu(x) if relu_in else x
+    for m in _flatten(modules):
+        base = [c for c in type(m).__mro__ if c.__module__.startswith("torch.nn")][0]
+        y = base.forward(m, y)
+    return y + residual if residual is not None else y
+
+
+def lower_thresholds(monkeypatch):
+    Fm = F()
+    for name in ("_GROUP_WGRAD_BYTES", "_PW_BWD_MIN_BYTES", "_PW_BWD_WIDE_MIN_PIXELS", "_DW_BWD_MIN_BYTES",
+                 "_FLAT_WGRAD_BN_MIN_BYTES"):
+        monkeypatch.setattr(Fm, name, 0)
+    return Fm
+
+
+def randomise(mods, seed):
+    """BatchNorm affine parameters and buffers away from their (1, 0, 0, 1) defaults"""
+    g = torch.Generator().manual_seed(seed)
+    for m in mods.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+
+
+def build(kind):
+    from nas_segm_amd.nn.layer_factory import (OPS, InvertedResidual, conv_bn_relu, conv_bn_relu6)
+    from nas_segm_amd.nn.modules import FusedSequential
+
+    torch.manual_seed(11)
+    if kind == "ir_16_24_s2":      # 16 -> 96 (one-kernel pointwise backward), dw 96 stride 2, 96 -> 24
+        return InvertedResidual(16, 24, 2, 6).conv, 16, (64, 128), False, False
+    if kind == "ir_24_24":         # 24 -> 144, dw 144, 144 -> 24 + residual
+        return InvertedResidual(24, 24, 1, 6).conv, 24, (64, 128), True, False
+    if kind == "ir_32_32":         # 32 -> 192, dw 192, 192 -> 32 + residual
+        return InvertedResidual(32, 32, 1, 6).conv, 32, (32, 64), True, False
+    if kind == "pre_clf":          # relu -> 224 -> 64 + BN + ReLU: the wave-split one-kernel backward
+        return conv_bn_relu(224, 64, 1, 1, 0), 224, (64, 128), False, True
+    if kind == "stem":             # 3 -> 32 3x3 stride 2 + BN + ReLU6: BatchNorm backward on the wgrad loads
+        return conv_bn_relu6(3, 32, 2), 3, (128, 256), False, False
+    if kind == "stem_stage1_2":    # the merged encoder chain: 32 -> 32, 16 -> 96 behind a BatchNorm (dx_stats)
+        return FusedSequential(conv_bn_relu6(3, 32, 2), InvertedResidual(32, 16, 1, 1).conv,
+                               InvertedResidual(16, 24, 2, 6).conv), 3, (128, 256), False, False
+    if kind == "sep3x3_r2":        # SepConv: dw -> pw as one forward kernel, twice
+        return OPS["sep_conv_3x3"](32, 32, 1, True, 2).op, 32, (64, 128), False, False
+    if kind == "sep5x5_24_64":
+        return OPS["sep_conv_5x5"](24, 64, 1, True, 1).op, 24, (64, 128), False, False
+    if kind == "sep5x5_dil6":
+        return OPS["sep_conv_5x5_dil6"](32, 32, 1, True, 2).op, 32, (64, 128), False, False
+    if kind == "dil3x3":
+        return OPS["dil_conv_3x3"](32, 32, 1, True).op, 32, (64, 128), False, False
+    raise KeyError(kind)
+
+
+EXPECT = {  # entry points the case is there for (fp32 names)
+    "ir_16_24_s2": ("nasseg_conv_pw_bwd_bn", "nasseg_dwconv_bwd_bn"),
+    "ir_24_24": ("nasseg_conv_pw_bwd_bn", "nasseg_dwconv_bwd_bn"),
+    "ir_32_32": ("nasseg_conv_pw_bwd_bn", "nasseg_dwconv_bwd_bn"),
+    "pre_clf": ("nasseg_conv_pw_bwd_bn",),
+    "stem": ("nasseg_conv_wgrad_bn_flat",),
+    "stem_stage1_2": ("nasseg_conv_wgrad_bn_flat", "nasseg_conv_pw_bwd_bn", "nasseg_dwconv_bwd_bn"),
+    "sep3x3_r2": ("nasseg_sepconv_fwd", "nasseg_conv_pw_bwd_bn"),
+    "sep5x5_24_64": ("nasseg_sepconv_fwd",),
+    "sep5x5_dil6": ("nasseg_sepconv_fwd",),
+    "dil3x3": (),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(EXPECT))
+def test_fused_chain_kernels_against_torch_cpu_autograd(kind, monkeypatch):
+    Fm = lower_thresholds(monkeypatch)
+    mods, cin, (H, W), residual, relu_in = build(kind)
+    randomise(mods, 5)
+    ref = copy.deepcopy(mods).train()
+    mods = mods.to(DEV).train()
+    x0 = rnd(1, cin, H, W, seed=2)
+    xc = x0.clone().requires_grad_(cin > 3)  # (the image needs no gradient: the stem's flat weight-gradient path)
+    yc = torch_reference(ref._modules.values(), xc, xc if residual else None, relu_in)
+    cot = rnd(*yc.shape, seed=3)
+    yc.backward(cot)
+
+    seen = []
+    orig = Fm.lib.call
+
+    def rec(fn, *a):
+        seen.append(fn)
+        return orig(fn, *a)
+
+    monkeypatch.setattr(Fm.lib, "call", rec)
+    xg = dev(x0.clone()).requires_grad_(cin > 3)
+    yg = mods(xg, residual=xg if residual else None, relu_in=relu_in)
+    yg.backward(dev(cot))
+    monkeypatch.setattr(Fm.lib, "call", orig)
+    for name in EXPECT[kind]:
+        assert name in seen, "{}: {} did not run ({})".format(kind, name, sorted(set(seen)))
+
+    def rel(a, b):
+        return float((a.detach().cpu().double() - b.detach().double()).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+    gp, cp = dict(mods.named_parameters()), dict(ref.named_parameters())
+    worst = {"y": rel(yg, yc)}
+    frac = 0.0
+    if cin > 3:
+        # an element whose pre-activation sits within rounding of a ReLU / ReLU6 kink may take the other
+        # branch: at most 2e-5 of the elements may miss, everything else to 1e-4 of the tensor's max
+        err = (xg.grad.cpu().double() - xc.grad.double()).abs()
+        tol = 1e-4 * float(xc.grad.abs().max()) + 1e-4 * xc.grad.abs().double()
+        frac = float((err > tol).double().mean())
+        worst["dx"] = rel(xg.grad, xc.grad)
+        worst["dx_frac_off"] = frac
+    for k in cp:
+        worst["d" + k] = rel(gp[k].grad, cp[k].grad)
+    print("ANCHOR {:14s} ".format(kind) + " ".join("{}={:.1e}".format(k, v) for k, v in sorted(
+        worst.items(), key=lambda kv: -kv[1])[:6]))
+    assert_close(yg, yc, 1e-4 * float(yc.abs().max()), 1e-4, kind + ": output")
+    assert frac <= 2e-5, "{}: dx: {:.2e} of the elements off (max rel err {:.2e})".format(kind, frac, worst["dx"])
+    for k in cp:
+        assert_close(gp[k].grad, cp[k].grad, 3e-4 * float(cp[k].grad.abs().max()) + 1e-6, 3e-4,
+                     "{}: gradient of {}".format(kind, k))
+    gb, cb = dict(mods.named_buffers()), dict(ref.named_buffers())
+    for k in cb:
+        if cb[k].dtype == torch.int64:
+            assert int(gb[k]) == int(cb[k]), k
+        else:
+            assert_close(gb[k], cb[k], 1e-6, 2e-5, "{}: buffer {}".format(kind, k))
+
+
+@pytest.mark.parametrize("path", ["bn_stats", "conv_epilogue", "dw_epilogue"])
+@pytest.mark.parametrize("ratio", [5.0, 50.0])
+def test_batchnorm_statistics_when_the_mean_dwarfs_the_deviation(path, ratio):
+    """train-mode BatchNorm of a tensor with |mean| = ratio * std (per channel, either sign): mean, biased
+    variance (through invstd) and the normalised output against float64.  The statistics are the
+    producer conv's epilogue sums (conv_epilogue: 1x1 conv with an identity weight; dw_epilogue: 3x3
+    depthwise with a centre tap of 1) or nasseg_bn_stats (bn_stats)."""
+    Fm = F()
+    B, C, H, W = 2, 32, 96, 128
+    g = torch.Generator().manual_seed(7)
+    sign = torch.where(torch.rand(C, generator=g) > 0.5, 1.0, -1.0)
+    std = torch.rand(C, generator=g) + 0.5
+    x = torch.randn(B, C, H, W, generator=g) * std.view(1, C, 1, 1) + (sign * ratio * std).view(1, C, 1, 1)
+    xd = x.double()
+    mean64 = xd.mean(dim=(0, 2, 3))
+    var64 = xd.var(dim=(0, 2, 3), unbiased=False)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    want = ((xd - mean64.view(1, C, 1, 1)) / torch.sqrt(var64 + 1e-5).view(1, C, 1, 1) * gamma.double().view(1, C, 1, 1)
+            + beta.double().view(1, C, 1, 1))
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    xg = dev(x)
+    if path == "bn_stats":
+        y = Fm.batch_norm_act(xg, gamma.to(DEV), beta.to(DEV), rm, rv, nbt, True, 0.1, 1e-5, 0, None)
+    elif path == "conv_epilogue":
+        w = torch.eye(C).view(C, C, 1, 1).to(DEV)
+        y = Fm.conv_bn_act(xg, w, gamma.to(DEV), beta.to(DEV), rm, rv, nbt, True, 0.1, 1e-5, 0)
+    else:
+        w = torch.zeros(C, 1, 3, 3)
+        w[:, 0, 1, 1] = 1.0
+        bn = (gamma.to(DEV), beta.to(DEV), rm, rv, nbt, True, 0.1, 1e-5)
+        y = Fm.conv_chain(xg, [(w.to(DEV), 1, 1, 1, True, bn, 0)])
+    unb = var64 * (B * H * W) / (B * H * W - 1)
+    # running_mean = 0.1 * mean, running_var = 0.9 + 0.1 * unbiased variance: 1e-4 of the batch variance
+    assert_close(rm.cpu().double() / 0.1, mean64, 1e-5 * float(std.max()) * ratio, 1e-6, "batch mean")
+    got_var = (rv.cpu().double() - 0.9) / 0.1
+    err = float(((got_var - unb) / unb).abs().max())
+    print("BNVAR {} ratio {}: max rel err of the variance {:.2e}".format(path, ratio, err))
+    assert err < 1e-4, "variance off by {:.2e} (relative) at |mean| = {} std".format(err, ratio)
+    assert_close(y, want, 2e-4, 1e-4, "normalised output")
+
+
+def test_a_failed_capture_leaves_batchnorm_and_gradients_untouched(monkeypatch):
+    """NASSEG_GRAPH=auto captures by default: if the warm-up or the capture raises, the engine launches
+    from the host - and the candidate's BatchNorm statistics must be what they were before the attempt
+    (engine/graphed.py:_capture restores in a finally block), no half-written gradients left."""
+    from nas_segm_amd.engine import graphed
+    from nas_segm_amd.engine.trainer import _segmenter_stepper
+    from nas_segm_amd.nn.encoders import mbv2
+    from nas_segm_amd.nn.micro_decoders import TemplateDecoder
+    from nas_segm_amd.engine import Segmenter
+
+    torch.manual_seed(0)
+    enc = mbv2(pretrained=False, return_layers=[1, 2])
+    dec = TemplateDecoder(enc.out_sizes, 19, [[[3, 0, 1], [4, 1, 1], [3, 1, 1]],
+                                              [[0, 1, 0, 0, 1], [2, 1, 2, 1, 0], [3, 1, 1, 1, 0]]], agg_size=32, repeats=1)
+    net = Segmenter(enc, dec).to(DEV).train()
+    oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9)
+    od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3)
+    image = dev(rnd(2, 3, 65, 97, seed=1))
+    target = torch.randint(0, 19, (2, 65, 97), generator=torch.Generator().manual_seed(2)).to(DEV)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    calls = {"n": 0}
+    orig = graphed._GraphedStep._fwd_bwd
+
+    def flaky(self, with_optimisers):
+        calls["n"] += 1
+        if calls["n"] == 2:  # (the second warm-up pass: the first has already updated every BatchNorm)
+            raise RuntimeError("HIP out of memory (injected)")
+        return orig(self, with_optimisers)
+
+    monkeypatch.setattr(graphed._GraphedStep, "_fwd_bwd", flaky)
+    stepper = _segmenter_stepper(net, image, target, oe, od, 255, 3.0, 3.0, -1)
+    assert stepper is None and calls["n"] == 2
+    after = net.state_dict()
+    for k, v in before.items():
+        assert torch.equal(v, after[k]), "{} changed by the failed capture".format(k)
+    assert all(p.grad is None for p in net.parameters())
+    # the failure is remembered for this shape (no second attempt), other shapes still get their try
+    assert _segmenter_stepper(net, image, target, oe, od, 255, 3.0, 3.0, -1) is None and calls["n"] == 2
+    monkeypatch.setattr(graphed._GraphedStep, "_fwd_bwd", orig)
+    other = dev(rnd(2, 3, 49, 65, seed=3))
+    t2 = target[:, :49, :65].contiguous()
+    s2 = _segmenter_stepper(net, other, t2, oe, od, 255, 3.0, 3.0, -1)
+    assert s2 is not None
+    # ... and at most _STEPPERS_PER_CANDIDATE shapes are captured per candidate: the third runs from the host
+    third = dev(rnd(2, 3, 33, 65, seed=4))
+    assert _segmenter_stepper(net, third, target[:, :33, :65].contiguous(), oe, od, 255, 3.0, 3.0, -1) is None
+    # freezing a parameter invalidates the captures (the graph has its gradient baked in)
+    next(net.decoder.parameters()).requires_grad_(False)
+    s3 = _segmenter_stepper(net, other, t2, oe, od, 255, 3.0, 3.0, -1)
+    assert s3 is not None and s3 is not s2
