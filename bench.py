@@ -491,6 +491,10 @@ def main():
                     help="HBM traffic of the step from rocprofv3 PMC counters, collected in two extra untimed "
                          "passes of this command: 1 = yes, 0 = no (the committed profiles/ summary is used while "
                          "it matches the library), -1 = yes for the default 1-GPU headline run")
+    ap.add_argument("--step-times", action="store_true",
+                    help="debug: every rank prints the host time of each timed step to stderr")
+    ap.add_argument("--sync-each-step", action="store_true",
+                    help="debug: read the loss on the host after every step (the engine's loss.item())")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only launch the ranks, rendezvous and all-reduce on the CPU (gloo): no GPU needed")
     args = ap.parse_args()
@@ -636,10 +640,20 @@ def main():
         loss = step()
     fence()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(args.steps):
         loss = step()
+        if args.sync_each_step:
+            float(loss)
+        if args.step_times:
+            stamps.append(time.perf_counter())
     fence()
     elapsed = time.perf_counter() - t0
+    if args.step_times:
+        sys.stderr.write("rank {} step ms (host, {}): {}  | fence +{:.1f}\n".format(
+            rank, "synced" if args.sync_each_step else "not synced",
+            " ".join("{:.1f}".format(1e3 * (b - a)) for a, b in zip(stamps, stamps[1:])),
+            1e3 * (t0 + elapsed - stamps[-1])))
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

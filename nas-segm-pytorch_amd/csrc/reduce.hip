@@ -90,6 +90,55 @@ __global__ __launch_bounds__(256) void colred_kernel(RedArgs q) {
   int64_t r1 = r0 + q.rows_per_blk;
   if (r1 > q.R) r1 = q.R;
 
+  if constexpr (MODE == RED_SUMSQ) {
+    // BatchNorm batch statistics: sum and sum of squares per thread and through the block in
+    // DOUBLE (the kernel is bandwidth-bound: the fp64 adds are free), rounded to fp32 once per
+    // block row.  With fp32 running sums the variance E[x^2] - mean^2 of a channel whose mean
+    // is 50 standard deviations lost 1.6e-4 of its value (tests/test_hip_anchor.py); now the only
+    // fp32 rounding is that of the <= 768 block rows, which the fp64 second pass averages out.
+    __shared__ double dred[2][256][VEC];
+    double s0[VEC], s1[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s0[v] = s1[v] = 0.0;
+    if (live) {
+      const act_t* pa = q.a + (int64_t)seg * q.R * q.lda + cv * VEC;
+#pragma unroll 8
+      for (int64_t r = r0 + rr; r < r1; r += rpi) {
+        const T va = V::ld(pa + r * q.lda);
+        const float* f = reinterpret_cast<const float*>(&va);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const double x = (double)f[v];
+          s0[v] += x;
+          s1[v] = fma(x, x, s1[v]);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      dred[0][tid][v] = s0[v];
+      dred[1][tid][v] = s1[v];
+    }
+    __syncthreads();
+    if (tid < CV) {
+      double t0[VEC], t1[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) t0[v] = t1[v] = 0.0;
+      for (int u = tid; u < rpi * CV; u += CV)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          t0[v] += dred[0][u][v];
+          t1[v] += dred[1][u][v];
+        }
+      float* po = q.partial + (((int64_t)seg * q.nblk + blk) * 2) * q.C + tid * VEC;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        po[v] = (float)t0[v];
+        po[q.C + v] = (float)t1[v];
+      }
+    }
+    return;
+  }
   T acc0 = V::zero(), acc1 = V::zero();
   T sc = V::zero(), sh = V::zero(), mu = V::zero(), is = V::zero();
   if (MODE == RED_BN_BWD && live) {
