@@ -781,6 +781,26 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
       for (int ks = 0; ks < nks; ++ks) {
         const int kl = ks * 16 + kg * 4;
         const int k = kc0 + kl;
+        const int rem = a.K - (kc0 + ks * 16);  // reduction channels left from this 16-wide step on
+        if (rem <= 8) {
+          // a short tail (the class head's backward-data reduces over 19 = 16 + 3 channels per tap): with
+          // the vector mapping k = 4*kg + component each of the four MFMAs of a step would carry one useful
+          // k-slot in four; here lane group kg takes channel 4*step + kg, so ceil(rem / 4) MFMAs do
+          for (int st = 0; st * 4 < rem; ++st) {
+            const int kls = ks * 16 + st * 4 + kg;
+            const int kk = kc0 + kls;
+            float bs[4], as[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) bs[mt] = tile[toff[mt] + tsh + kls];  // (zero beyond K)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) as[nt] = keep_if(wrow[nt][kk < a.K ? kk : 0], wok[nt] && kk < a.K);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(as[nt], bs[mt], acc[mt][nt]);
+          }
+          continue;
+        }
         float4 bv[4], av[NT];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)

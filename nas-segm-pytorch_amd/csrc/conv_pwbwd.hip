@@ -19,6 +19,8 @@
 // pixels for both products and keeps the whole N x K accumulator (N*K <= 6144); waves are
 // combined through LDS in a fixed order, slabs by the deterministic second stage of
 // conv_wgrad.hip (nasseg_wgrad_finalize_many) - no float atomics.
+#include <type_traits>
+
 #include "conv_common.h"
 
 extern "C" int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* const* dw,
@@ -358,34 +360,40 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
 // convs 320 -> 64): the N x K accumulator does not fit one wave, so the four waves split N -
 // wave w owns output channels [16w, 16w+16) and walks ALL 64 pixels of a tile for the weight
 // gradient (no cross-wave sum at the end); the input gradient stays 16 pixels per wave.  The
-// input tile is staged 64 channels at a time (the dz tile stays), which keeps LDS at ~36 KB and
-// four workgroups per CU resident - with the whole 64 x K tile in LDS only one fits and nothing
-// hides the latencies (measured: 950 us against 690 us for the two kernels on 224 -> 64).
-// Status: at parity with the two-kernel form on 224 -> 64 at 4x256x512 (681 / 688 us; it is
-// issue-bound at ~32 % of the fp32 MFMA rate - unrolling the 16-wide steps with their weight
-// loads in flight together costs the registers of a resident wave and ends at 995 us) and slower
-// on smaller maps, so the host does not select it by default (functional._PW_BWD_WIDE).
-// KC: number of 64-channel chunks (>= ceil(K / 64)).
+// input tile is staged 64 channels at a time (the dz tile stays).  KC: number of 64-channel chunks
+// (>= ceil(K / 64)).
 constexpr int kPwChunk = 64;
+// The loop is software-pipelined the way the narrow kernel is.  While the MFMAs of chunk c run out of LDS, the
+// loads of chunk c+1 - 64 input channels of the tile AND the matching 64 rows of the backward-data
+// weight - are in flight in registers, and during a tile's last chunk the next tile's g and z as
+// well.  Nothing in the MFMA phase touches global memory except the dx stores: a weight load issued
+// there would queue up behind the prefetch (loads return in order) and stall the first MFMA for a
+// whole HBM round trip, which is what kept the first form of this kernel (round 2: every chunk loaded,
+// waited for and used in turn, the weight read from L1 inside the loop) at ~30 % of the fp32 MFMA rate
+// with its two resident workgroups per CU: 224 -> 64 at 4x256x512 681 us, now 410-425 us (memory
+// phase alone 160 us, dW product +90, dx product and stores +125: the MFMA phases run near their peak,
+// what is left is that they do not yet overlap the memory phase).  The last chunk of K = 224 issues only the 16-wide steps it has
+// channels for (2 of 4).  LDS: three [64][68] tiles (dz, x chunk, weight chunk) + constants = 55 KB.
+constexpr int kW2LS = kPwChunk + 4;  // row stride of all three tiles (N <= 64)
 template <int KC, bool PRO>
-__global__ __launch_bounds__(256) void conv_pw_bwd_wide_kernel(PwArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_pw_bwd_wide_kernel(PwArgs a) {
   extern __shared__ float smem[];
-  const int LSN = a.NP + 4;
-  constexpr int LSK = kPwChunk + 4;
-  float* dzt = smem;                   // [64][LSN]
-  float* xt = dzt + kPwTile * LSN;     // [64][LSK]: one 64-channel chunk of the input tile
-  float* cst = xt + kPwTile * LSK;
-  float* ca = cst;
-  float* cb = ca + a.NP;
-  float* cd = cb + a.NP;
-  float* cs = cd + a.NP;
-  float* psc = cs + a.NP;              // [KC * 64]
+  constexpr int LS = kW2LS;
+  float* dzt = smem;                 // [64][LS]: dz[p][n]
+  float* xt = dzt + kPwTile * LS;    // [64][LS]: x[p][kc + .] through the forward's prologue
+  float* wt = xt + kPwTile * LS;     // [64][LS]: wb[kc + .][n] of chunks 1 .. KC-1, streamed with the x chunks
+  float* wt0 = wt + kPwChunk * LS;   // [64][LS]: chunk 0 of the weight - the same for every tile: loaded once
+  float* ca = wt0 + kPwChunk * LS;   // ca | cb | cd | cs [64 each], psc | psh [KC * 64 each]
+  float* cb = ca + 64;
+  float* cd = cb + 64;
+  float* cs = cd + 64;
+  float* psc = cs + 64;
   float* psh = psc + KC * kPwChunk;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int j = lane & 15, kg = lane >> 4;
   const int N = a.N, K = a.K;
-  for (int n = tid; n < a.NP; n += 256) {
+  for (int n = tid; n < 64; n += 256) {
     float va = 0.f, vb = 0.f, vd = 0.f, vs = 0.f;
     if (n < N) {
       const float sc = a.bn_scale[n];
@@ -413,90 +421,164 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_wide_kernel(PwArgs a) {
   const int p_begin = blockIdx.x * a.pix_per_slab;
   int p_end = p_begin + a.pix_per_slab;
   if (p_end > a.M) p_end = a.M;
-  const int n4 = a.NP >> 2;
-  const bool own = wave * 16 < a.NP;  // (N = 48: the fourth wave has no output channels of its own)
-  for (int t0 = p_begin; t0 < p_end; t0 += kPwTile) {
-    __syncthreads();
-    for (int it = tid; it < kPwTile * n4; it += 256) {
-      const int px = it / n4, n = (it - px * n4) * 4;
-      const int p = t0 + px;
-      const bool ok = p < p_end && n < N;
-      const int64_t off = (int64_t)(p < p_end ? p : p_end - 1) * N + (n < N ? n : 0);
-      float4 gv = lda4(a.g + off);
-      const float4 zv = lda4(a.z + off);
-      const float4 va = ld4(ca + n), vb = ld4(cb + n), vd = ld4(cd + n);
-      if (a.bn_act) {
-        const float4 y = fma4(zv, va, ld4(cs + n));
-        gv = make_float4(gv.x * act_mask(y.x, a.bn_act), gv.y * act_mask(y.y, a.bn_act),
-                         gv.z * act_mask(y.z, a.bn_act), gv.w * act_mask(y.w, a.bn_act));
+  const bool own = wave * 16 < a.NP;
+  const int NS = a.NP >> 4;
+  const float m_lo = a.bn_act ? 0.f : -__builtin_inff();
+  const float m_hi = a.bn_act == NASSEG_ACT_RELU6 ? 6.f : __builtin_inff();
+  // item u of a thread: float4 number tid + 256*u of a [64][64] tile (row = it / 16, column = 4*(it % 16))
+  const int irow = tid >> 4, icol = (tid & 15) * 4;  // (+ 16 rows per u)
+  float4 XN[4], WN[4], GN[4], ZN[4];
+  auto issue_gz = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = t0 + irow + 16 * u;
+      const int64_t off = (int64_t)(p < p_end ? p : p_end - 1) * N + (icol < N ? icol : 0);
+      GN[u] = lda4(a.g + off);
+      ZN[u] = lda4(a.z + off);
+    }
+  };
+  auto issue_xw = [&](int t0, int kc) {
+    const int k = kc + icol;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = t0 + irow + 16 * u;
+      XN[u] = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
+      if (kc) {  // (uniform; chunk 0 of the weight is resident)
+        const int kw = kc + irow + 16 * u;
+        WN[u] = ld4(a.wb + (int64_t)(kw < K ? kw : 0) * N + (icol < N ? icol : 0));
+      }
+    }
+  };
+  auto place_gz = [&](int t0) {
+    const float4 va = ld4(ca + icol), vb = ld4(cb + icol), vd = ld4(cd + icol), vs = ld4(cs + icol);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int px = irow + 16 * u;
+      const bool ok = t0 + px < p_end && icol < N;
+      float4 gv = GN[u];
+      const float4 zv = ZN[u];
+      {  // g' = g * act'(scale*z + shift), without a branch: the open interval (m_lo, m_hi) is where act' = 1
+        const float4 y = fma4(zv, va, vs);
+        gv = make_float4((y.x > m_lo && y.x < m_hi) ? gv.x : 0.f, (y.y > m_lo && y.y < m_hi) ? gv.y : 0.f,
+                         (y.z > m_lo && y.z < m_hi) ? gv.z : 0.f, (y.w > m_lo && y.w < m_hi) ? gv.w : 0.f);
       }
       float4 dz = fma4(gv, va, fma4(zv, vb, vd));
 #ifdef NASSEG_BF16
       dz = make_float4(bf16_to_f32(f32_to_bf16(dz.x)), bf16_to_f32(f32_to_bf16(dz.y)),
                        bf16_to_f32(f32_to_bf16(dz.z)), bf16_to_f32(f32_to_bf16(dz.w)));
 #endif
-      *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(dz, ok);
+      *reinterpret_cast<float4*>(&dzt[px * LS + icol]) = keep_if(dz, ok);
     }
+  };
+  auto place_xw = [&](int t0, int kc) {
+    const int k = kc + icol;
+    const float4 sc = ld4(psc + k), sh = ld4(psh + k);
 #pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int px = irow + 16 * u;
+      float4 xv = XN[u];
+      if (PRO) xv = act_apply4(fma4(xv, sc, sh), pact);
+      *reinterpret_cast<float4*>(&xt[px * LS + icol]) = keep_if(xv, t0 + px < p_end && k < K);
+      if (kc) *reinterpret_cast<float4*>(&wt[px * LS + icol]) = keep_if(WN[u], kc + px < K && icol < N);
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int kw = irow + 16 * u;
+    *reinterpret_cast<float4*>(&wt0[kw * LS + icol]) =
+        keep_if(ld4(a.wb + (int64_t)(kw < K ? kw : 0) * N + (icol < N ? icol : 0)), kw < K && icol < N);
+  }
+  if (p_begin < p_end) {
+    issue_gz(p_begin);
+    issue_xw(p_begin, 0);
+  }
+  for (int t0 = p_begin; t0 < p_end; t0 += kPwTile) {
+    __syncthreads();  // (the previous tile's operands have been read; first pass: the constants are in place)
+    place_gz(t0);
+    // (a run-time loop: unrolled, the KC copies of the body cost ~60 registers more than one copy - only the
+    //  weight-gradient accumulators differ per chunk, selected by the switch below)
+#pragma unroll 1
     for (int c = 0; c < KC; ++c) {
       const int kc = c * kPwChunk;
       if (kc < a.KP) {  // (uniform)
         if (c) __syncthreads();  // (the previous chunk's operands have been read)
-        for (int it = tid; it < kPwTile * (kPwChunk / 4); it += 256) {
-          const int px = it / (kPwChunk / 4), kl = (it - px * (kPwChunk / 4)) * 4;
-          const int k = kc + kl;
-          const int p = t0 + px;
-          const bool ok = p < p_end && k < K;
-          float4 xv = lda4(a.x + (int64_t)(p < p_end ? p : p_end - 1) * K + (k < K ? k : 0));
-          if (PRO) xv = act_apply4(fma4(xv, ld4(psc + k), ld4(psh + k)), pact);
-          *reinterpret_cast<float4*>(&xt[px * LSK + kl]) = keep_if(xv, ok);
-        }
+        place_xw(t0, kc);
         __syncthreads();
-        // input gradient of this wave's 16 pixels, this chunk's 64 input channels
-        {
-          const float* brow = dzt + (wave * 16 + j) * LSN;
-          const int p = t0 + wave * 16 + j;
-          f32x4 acc1[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          for (int ns = 0; ns < (a.NP >> 4); ++ns) {
-            const int n = ns * 16 + kg * 4;
-            const float4 bv = *reinterpret_cast<const float4*>(brow + n);
-            float4 av[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int k = kc + q * 16 + j;
-              av[q] = keep_if(ld4(a.wb + (int64_t)(k < K ? k : 0) * N + (n < N ? n : 0)), k < K && n < N);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              acc1[q] = mfma16(av[q].x, bv.x, acc1[q]);
-              acc1[q] = mfma16(av[q].y, bv.y, acc1[q]);
-              acc1[q] = mfma16(av[q].z, bv.z, acc1[q]);
-              acc1[q] = mfma16(av[q].w, bv.w, acc1[q]);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int kl = q * 16 + kg * 4;
-            float4 o = make_float4(acc1[q][0], acc1[q][1], acc1[q][2], acc1[q][3]);
-            if (a.dx_act)
-              o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LSK + kl]), a.dx_act));
-            if (p < p_end && kc + kl < K) sta4(a.dx + (int64_t)p * K + kc + kl, o);
-          }
+        // what the NEXT pass will place: in flight during this chunk's MFMAs
+        if (kc + kPwChunk < a.KP) {
+          issue_xw(t0, kc + kPwChunk);
+        } else if (t0 + kPwTile < p_end) {
+          issue_gz(t0 + kPwTile);
+          issue_xw(t0 + kPwTile, 0);
         }
-        // weight gradient rows of this wave: all 64 pixels of the tile, 4 per MFMA
-        if (own) {
-          for (int u = 0; u < kPwTile / 4; ++u) {
-            const int pl = u * 4 + kg;
-            const float av = dzt[pl * LSN + wave * 16 + j];
-            float bv[4];
+        const int nq = (a.KP - kc) >> 4;  // 16-wide steps this chunk has channels for (>= 4: all)
+        // The MFMA phase, specialised on the number of 16-wide steps (NQ): a run-time guard around the
+        // MFMAs turns every group into "LDS read, wait, one MFMA" (measured: the first version of this loop).
+        auto mfma_phase = [&](auto nq_tag) {
+          constexpr int NQ = decltype(nq_tag)::value;
+          // input gradient of this wave's 16 pixels, this chunk's 16*NQ input channels
+          {
+            const float* brow = dzt + (wave * 16 + j) * LS;
+            const float* wcur = c ? wt : wt0;
+            const int p = t0 + wave * 16 + j;
+            f32x4 acc1[NQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = xt[pl * LSK + q * 16 + j];
+            for (int q = 0; q < NQ; ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int ns = 0; ns < NS; ++ns) {
+              const int n = ns * 16 + kg * 4;
+              const float4 bv = *reinterpret_cast<const float4*>(brow + n);
+              float4 av[NQ];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc2[c][q] = mfma16(av, bv[q], acc2[c][q]);
+              for (int q = 0; q < NQ; ++q) av[q] = *reinterpret_cast<const float4*>(&wcur[(q * 16 + j) * LS + n]);
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) acc1[q] = mfma16(av[q].x, bv.x, acc1[q]);
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) acc1[q] = mfma16(av[q].y, bv.y, acc1[q]);
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) acc1[q] = mfma16(av[q].z, bv.z, acc1[q]);
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) acc1[q] = mfma16(av[q].w, bv.w, acc1[q]);
+            }
+            const bool pok = p < p_end;
+            act_t* prow = a.dx + (int64_t)(pok ? p : p_begin) * K + kc + kg * 4;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              const int kl = q * 16 + kg * 4;
+              float4 o = make_float4(acc1[q][0], acc1[q][1], acc1[q][2], acc1[q][3]);
+              if (a.dx_act)
+                o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LS + kl]), a.dx_act));
+              if (pok && kc + kl < K) sta4(prow + q * 16, o);
+            }
           }
-        }
+          // weight gradient rows of this wave: all 64 pixels of the tile, 4 per MFMA
+          if (own) {
+            auto dw_chunk = [&](f32x4 (&acc)[4]) {
+#pragma unroll 2
+              for (int u = 0; u < kPwTile / 4; ++u) {
+                const int pl = u * 4 + kg;
+                const float av = dzt[pl * LS + wave * 16 + j];
+                float bv[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) bv[q] = xt[pl * LS + q * 16 + j];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = mfma16(av, bv[q], acc[q]);
+              }
+            };
+            switch (c) {
+              case 0: dw_chunk(acc2[0]); break;
+              case 1: dw_chunk(acc2[1]); break;
+              case 2: if constexpr (KC > 2) dw_chunk(acc2[2]); break;
+              case 3: if constexpr (KC > 3) dw_chunk(acc2[3]); break;
+              case 4: if constexpr (KC > 4) dw_chunk(acc2[4]); break;
+              default: if constexpr (KC > 5) dw_chunk(acc2[5]); break;
+            }
+          }
+        };
+        if (nq >= 4) mfma_phase(std::integral_constant<int, 4>());
+        else if (nq == 3) mfma_phase(std::integral_constant<int, 3>());
+        else if (nq == 2) mfma_phase(std::integral_constant<int, 2>());
+        else mfma_phase(std::integral_constant<int, 1>());
       }
     }
   }
@@ -541,7 +623,7 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
   // 16 -> 96 at 4x512x1024): 1024 slabs 457 us, 2048 457, 1490 532, 763 519, 512 572; 24 -> 144 at
   // 4x256x512: 512 slabs 280 us, 1024 288, 745 366 - counts that leave the CUs with unequal numbers of
   // resident workgroups cost 15-30 %.
-  const int64_t lds = p.wide ? (int64_t)kPwTile * (((N + 15) & ~15) + kPwChunk + 8) * 4
+  const int64_t lds = p.wide ? (int64_t)(32 << 10)  // (two workgroups per CU by registers: 1024 and 512 slabs time alike)
                              : (int64_t)pw_lds_floats(p.nt, p.kt, pw_weight_in_lds(p.nt, p.kt)) * 4;
   int64_t s = lds > (40 << 10) ? 512 : 1024;
   const int64_t cap = (int64_t)((p.wide ? 64 : 16) << 20) / ((int64_t)N * K * 4);
@@ -630,11 +712,17 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
   hipStream_t s = (hipStream_t)stream;
   if (p.wide) {
     NASSEG_REQUIRE(!dx_stats, "conv_pw_bwd_bn: dx_stats is not available for K > 64");
-    const size_t ldsw = ((size_t)kPwTile * (a.NP + 4 + kPwChunk + 4) + 4 * a.NP + 2 * p.kt * kPwChunk) * sizeof(float);
+    const size_t ldsw2 = ((size_t)4 * kPwTile * kW2LS + 4 * 64 + 2 * p.kt * kPwChunk) * sizeof(float);
 #define PW_WIDE(KC_)                                                                                         \
   do {                                                                                                       \
-    if (pro) hipLaunchKernelGGL((conv_pw_bwd_wide_kernel<KC_, true>), dim3(p.nslab), dim3(256), ldsw, s, a);  \
-    else hipLaunchKernelGGL((conv_pw_bwd_wide_kernel<KC_, false>), dim3(p.nslab), dim3(256), ldsw, s, a);     \
+    if (ldsw2 > (64 << 10)) { /* above the default limit of dynamic LDS (per device: set on every launch) */ \
+      (void)hipFuncSetAttribute((const void*)conv_pw_bwd_wide_kernel<KC_, true>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw2);                     \
+      (void)hipFuncSetAttribute((const void*)conv_pw_bwd_wide_kernel<KC_, false>,                           \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw2);                     \
+    }                                                                                                        \
+    if (pro) hipLaunchKernelGGL((conv_pw_bwd_wide_kernel<KC_, true>), dim3(p.nslab), dim3(256), ldsw2, s, a); \
+    else hipLaunchKernelGGL((conv_pw_bwd_wide_kernel<KC_, false>), dim3(p.nslab), dim3(256), ldsw2, s, a);    \
   } while (0)
     if (p.kt <= 2) PW_WIDE(2);
     else if (p.kt == 3) PW_WIDE(3);

@@ -644,12 +644,13 @@ def _identity_vectors(like, n):
 # 33 MB, one kernel 21 us / two kernels 26 us; 64 -> 64 at 4x32x64, 4 MB, 35 / 19 us - too few slabs)
 FUSE_PW_BWD = os.environ.get("NASSEG_FUSE_PW_BWD", "1") != "0"
 _PW_BWD_MIN_BYTES = 24 << 20
-# the wide-input variant (K > 64: the four waves split N): 224 -> 64 at 4x256x512 (pre_clf, whose input
-# gradient also carries the ReLU mask) 680 us against 447 + 404 us for the two kernels in the step
-# (headline 230.3 -> 232.2 img/s); on small maps it loses (192 -> 64 at 16x81x81: 143 / 118 us,
-# 320 -> 64 at 16x11x11: 217 / 22 us), hence the pixel floor
+# the wide-input variant (K > 64: the four waves split N; round 3: chunks of the input and of the
+# backward-data weight prefetched while the previous chunk is multiplied): 224 -> 64 at 4x256x512 (pre_clf,
+# whose input gradient also carries the ReLU mask) 410-425 us against 710-730 us for the two kernels
+# (tools/kbench_pwbwd.py), 192 -> 64 at 16x81x81 98 / 120 us, 192 -> 48 at 8x179x179 155 / 251 us; on maps
+# too small for a slab per CU it loses (320 -> 64 at 16x11x11: 170 / 22 us), hence the pixel floor
 _PW_BWD_WIDE = os.environ.get("NASSEG_PW_BWD_WIDE", "1") == "1"
-_PW_BWD_WIDE_MIN_PIXELS = 1 << 18
+_PW_BWD_WIDE_MIN_PIXELS = 1 << 16
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
 FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
 # which pointwise forward / backward-data calls take the persistent kernel (include/nasseg.h:
