@@ -429,6 +429,13 @@ def self_launch(n_ranks, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")  # (torchrun would set 1: the optimisers' host side is threaded)
+    if "--same-device" in argv:
+        # debug mode, several ranks on ONE device: a replayed hipGraph fans its branches out over the
+        # process's hardware queues (4 by default); two processes doing that on one GPU oversubscribe its
+        # queues and stall for seconds at a time (profiles/r03_dp_graph_stall_hwqueues.txt: 5-58 s stalls
+        # with 4 queues per process, none with 1 or 2).  One process per GPU - the real layout - has the
+        # device's queues to itself.
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")
     return subprocess.call(cmd, env=env)
 
 

@@ -716,6 +716,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 // weights (pack kind 5) and pad' = d*(k-1) - pad.
 // ---------------------------------------------------------------------------
 constexpr int kLdsTH = 8, kLdsTW = 32, kLdsKC = 32, kLdsKS = kLdsKC + 4;
+constexpr int kLdsMaxIt = ((kLdsTH + 4) * (kLdsTW + 4) * (kLdsKC / 4) + 255) / 256;  // float4 of the patch per thread (d <= 2)
 
 template <int NT, bool VECN, bool VECK>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
@@ -753,54 +754,59 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
   const act_t* xb = a.x + (int64_t)b * H * W * a.ldx;
   for (int kc0 = 0; kc0 < a.K; kc0 += kLdsKC) {
     if (kc0) __syncthreads();
-    for (int idx = threadIdx.x; idx < TR * TC * (kLdsKC / 4); idx += 256) {
-      const int q = idx % (kLdsKC / 4);
-      const int p = idx / (kLdsKC / 4);
-      const int pc = p % TC, pr = p / TC;
-      const int iy = iy0 + pr, ix = ix0 + pc;
-      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-      const int k = kc0 + q * 4;
-      const act_t* src = xb + ((int64_t)iyc * W + ixc) * a.ldx;
-      float4 v = load4<VECK>(src, k, a.K);
-      if (!VECK) {
-        v.y = keep_if(v.y, k + 1 < a.K);
-        v.z = keep_if(v.z, k + 2 < a.K);
-        v.w = keep_if(v.w, k + 3 < a.K);
+    // The patch: (8+2d) x (32+2d) pixels x 8 float4 = 11 (d = 1) .. 14 (d = 2) float4 per thread.  ALL of a
+    // thread's loads are issued before the first is stored (clamped addresses, masks instead of branches):
+    // as a loop of load - store pairs this phase took ~15 us per 32-channel slice with one or two loads in
+    // flight per thread, and the workgroups of a CU run it in lockstep (class head 64 -> 16: 140 us of which
+    // 61 us are MFMA issue)
+    {
+      const int total = TR * TC * (kLdsKC / 4);
+      float4 rv[kLdsMaxIt];
+#pragma unroll
+      for (int it = 0; it < kLdsMaxIt; ++it) {
+        int idx = threadIdx.x + 256 * it;
+        idx = idx < total ? idx : total - 1;
+        const int q = idx % (kLdsKC / 4);
+        const int p = idx / (kLdsKC / 4);
+        const int pc = p % TC, pr = p / TC;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        const int k = kc0 + q * 4;
+        const act_t* src = xb + ((int64_t)iyc * W + ixc) * a.ldx;
+        rv[it] = load4<VECK>(src, VECK ? (k < a.K ? k : 0) : k, a.K);
       }
-      *reinterpret_cast<float4*>(&tile[p * kLdsKS + q * 4]) = keep_if(v, ok && k < a.K);
+#pragma unroll
+      for (int it = 0; it < kLdsMaxIt; ++it) {
+        const int idx = threadIdx.x + 256 * it;
+        const int q = idx % (kLdsKC / 4);
+        const int p = idx / (kLdsKC / 4);
+        const int pc = p % TC, pr = p / TC;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int k = kc0 + q * 4;
+        float4 v = rv[it];
+        if (!VECK) {
+          v.y = keep_if(v.y, k + 1 < a.K);
+          v.z = keep_if(v.z, k + 2 < a.K);
+          v.w = keep_if(v.w, k + 3 < a.K);
+        }
+        if (idx < total) *reinterpret_cast<float4*>(&tile[p * kLdsKS + q * 4]) = keep_if(v, ok && k < a.K);
+      }
     }
     __syncthreads();
     const int nks = (a.K - kc0 >= kLdsKC) ? kLdsKC / 16 : (a.K - kc0 + 15) / 16;
+    const int rem_last = a.K - kc0 - (nks - 1) * 16;  // channels of the slice's last 16-wide step (>= 16: full)
+    const int ntail = rem_last <= 8 ? (rem_last + 3) / 4 : 0;
+    const int nvec = ntail ? nks - 1 : nks;
     for (int tap = 0; tap < 9; ++tap) {
       const int ty = tap / 3, tx = tap - ty * 3;
       const int tsh = (ty * dil * TC + tx * dil) * kLdsKS;
       const float* wrow[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.w + ((int64_t)tap * a.N + wn[nt]) * a.K;
-      for (int ks = 0; ks < nks; ++ks) {
+      for (int ks = 0; ks < nvec; ++ks) {
         const int kl = ks * 16 + kg * 4;
         const int k = kc0 + kl;
-        const int rem = a.K - (kc0 + ks * 16);  // reduction channels left from this 16-wide step on
-        if (rem <= 8) {
-          // a short tail (the class head's backward-data reduces over 19 = 16 + 3 channels per tap): with
-          // the vector mapping k = 4*kg + component each of the four MFMAs of a step would carry one useful
-          // k-slot in four; here lane group kg takes channel 4*step + kg, so ceil(rem / 4) MFMAs do
-          for (int st = 0; st * 4 < rem; ++st) {
-            const int kls = ks * 16 + st * 4 + kg;
-            const int kk = kc0 + kls;
-            float bs[4], as[NT];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) bs[mt] = tile[toff[mt] + tsh + kls];  // (zero beyond K)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) as[nt] = keep_if(wrow[nt][kk < a.K ? kk : 0], wok[nt] && kk < a.K);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(as[nt], bs[mt], acc[mt][nt]);
-          }
-          continue;
-        }
         float4 bv[4], av[NT];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -824,6 +830,24 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
             acc[mt][nt] = mfma16(av[nt].z, bv[mt].z, acc[mt][nt]);
             acc[mt][nt] = mfma16(av[nt].w, bv[mt].w, acc[mt][nt]);
           }
+      }
+      // a short tail of the slice (the class head's backward-data reduces over 19 = 16 + 3 channels per
+      // tap): with the vector mapping k = 4*kg + component each of the four MFMAs of a 16-wide step would
+      // carry one useful k-slot in four; here lane group kg takes channel 4*step + kg, so ceil(rem / 4)
+      // MFMAs do.  (A loop of its own after the vector steps: as a branch inside them the two paths'
+      // accumulators were copied through 64 v_accvgpr_mov per step.)
+      for (int st = 0; st < ntail; ++st) {
+        const int kls = nvec * 16 + st * 4 + kg;
+        const int kk = kc0 + kls;
+        float bs[4], as[NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) bs[mt] = tile[toff[mt] + tsh + kls];  // (zero beyond K)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) as[nt] = keep_if(wrow[nt][kk < a.K ? kk : 0], wok[nt] && kk < a.K);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(as[nt], bs[mt], acc[mt][nt]);
       }
     }
   }

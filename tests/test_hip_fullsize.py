@@ -24,8 +24,11 @@ def _labels(gen, B, H, W, classes):
     return t
 
 
-def test_train_step_at_size_matches_the_oracle(monkeypatch):
-    """WACV arch0 (the BASELINE headline network), train-mode forward + loss + backward of
+@pytest.mark.parametrize("net_name", ["wacv_arch0", "wacv_arch1"])
+def test_train_step_at_size_matches_the_oracle(net_name, monkeypatch):
+    """WACV arch0 (the BASELINE headline network) and WACV arch1 (BASELINE config 3: 22 dilated 5x5
+    depthwise convs with a 12-pixel halo at up to 256x512, ParamSum aggregation), train-mode forward +
+    loss + backward of
     engine.trainer.segmenter_step at 2x3x1024x2048 with NATURAL dispatch - nothing monkeypatched:
     one-kernel backward of pointwise conv + BatchNorm and of the depthwise convs between
     BatchNorms, BatchNorm backward applied by the weight-gradient kernels (maps > 48 MB),
@@ -40,7 +43,7 @@ def test_train_step_at_size_matches_the_oracle(monkeypatch):
     from nas_segm_amd.engine.trainer import segmenter_step
     from oracle import engine as oeng
 
-    rec = load_json("nets_meta.json")["wacv_arch0"]
+    rec = load_json("nets_meta.json")[net_name]
     net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).train()
     sd0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
     pkeys = {k for k, _ in net.named_parameters()}
@@ -87,7 +90,8 @@ def test_train_step_at_size_matches_the_oracle(monkeypatch):
                  "nasseg_dwconv_bwd_data_bn", "nasseg_sepconv_fwd", "nasseg_wgrad_finalize_many",
                  "nasseg_conv_wgrad_many", "nasseg_dwconv_wgrad_many", "nasseg_pack_weights"):
         assert name in seen, name
-    assert n_split[0] >= 1, "ConcatReduce never took its no-concatenation path"
+    if net_name == "wacv_arch0":  # (arch1 aggregates with ParamSum)
+        assert n_split[0] >= 1, "ConcatReduce never took its no-concatenation path"
 
     err_out = float((got_out - want_out).abs().max())
     assert err_out <= 1e-4 + 4.0 * floor_out, (err_out, floor_out)
@@ -103,8 +107,8 @@ def test_train_step_at_size_matches_the_oracle(monkeypatch):
         if err > tol:
             bad.append((k, err, tol, float(ref.abs().max())))
     assert not bad, "{} of {} gradients off: {}".format(len(bad), len(want_g), bad[:8])
-    print("train step at size: logits err {:.2e} (floor {:.2e}), worst relative gradient error {:.2e}".format(
-        err_out, floor_out, worst))
+    print("train step at size ({}): logits err {:.2e} (floor {:.2e}), worst relative gradient error {:.2e}".format(
+        net_name, err_out, floor_out, worst))
 
 
 def _frozen_bn_gradients(net, x, backward):
@@ -288,6 +292,76 @@ def test_config5_shape_properties_at_full_size_bf16():
                 lo.backward()
                 _clip_and_step([(list(m.encoder.parameters()), 3.0, oe), (list(m.decoder.parameters()), 3.0, od)])
                 losses.append(float(lo))
+        return losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+    l0, sd0 = run(False)
+    assert all(np.isfinite(v) for v in l0)
+    l1, sd1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+
+
+def test_config2_shape_properties_at_full_size():
+    """BASELINE config 2 at its full shape: CVPR arch0 (MicroDecoder, 21 classes, agg 64, repeats 2, three
+    auxiliary heads), 16x3x321x321 - cells at 11x11 / 21x21 / 81x81, dense 3x3 convs with dilation 3 / 12,
+    global-average-pool branches: batch-split equality in inference (main and auxiliary outputs), additive
+    parameter gradients with frozen BatchNorm, eager == hipGraph replay over optimiser steps."""
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    rec = load_json("nets_meta.json")["cvpr_arch0"]
+    gen = torch.Generator().manual_seed(51)
+    B, H, W = 16, 321, 321
+    x = _cl(torch.randn(B, 3, H, W, generator=gen))
+    t = _labels(gen, B, H, W, 21).to(DEV)
+
+    def fresh():
+        return build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 5).to(DEV)
+
+    def halves_of(v):
+        return (v[:8].contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v[:8].contiguous(),
+                v[8:].contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v[8:].contiguous())
+
+    net = fresh().eval()
+    with torch.no_grad():
+        whole, aux = net(x)
+        parts = [net(h) for h in halves_of(x)]
+    assert tuple(whole.shape) == (B, 21, 81, 81) and len(aux) == 3
+    assert float((whole - torch.cat([p[0] for p in parts], 0)).abs().max()) <= 2e-6
+    for i, a in enumerate(aux):
+        assert float((a - torch.cat([p[1][i] for p in parts], 0)).abs().max()) <= 2e-6, i
+
+    def grads_of(xs, ts):
+        losses = []
+
+        def backward(out):
+            loss = F.log_softmax_nll(out, F.nearest_label_resize(ts, out.shape[2:]), 255)
+            losses.append(loss.detach())
+            loss.backward()
+        g = _frozen_bn_gradients(net, xs, backward)
+        return g, float(losses[0]), int((F.nearest_label_resize(ts, (81, 81)) != 255).sum())
+
+    g16, l16, n16 = grads_of(x, t)
+    (xa, xb), (ta, tb) = halves_of(x), halves_of(t)
+    ga, la, na = grads_of(xa, ta)
+    gb, lb, nb = grads_of(xb, tb)
+    assert n16 == na + nb and abs(l16 - (na * la + nb * lb) / n16) < 1e-5
+    _assert_additive(g16, [ga, gb], [na / n16, nb / n16], "config 2")
+
+    def run(graphed):
+        m = fresh().train()
+        oe = torch.optim.SGD(m.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(m.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        losses = []
+        if graphed:
+            stepper = GraphedSegmenterStep(m, x, t, oe, od, 255, 3.0, 3.0, 0.15)
+            for _ in range(2):
+                losses.append(float(stepper.step(x, t)))
+        else:
+            for _ in range(2):
+                losses.append(float(segmenter_step(m, x, t, oe, od, 255, 3.0, 3.0, 0.15)))
         return losses, {k: v.detach().cpu() for k, v in m.state_dict().items()}
 
     l0, sd0 = run(False)
