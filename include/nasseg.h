@@ -241,6 +241,10 @@ int nasseg_pool_bwd(int mode, const float* dy, const uint8_t* idx, float* dx, in
  * 236-238,245-247; inference.py:58-60) and nearest label resize (trainer.py:43-49,236-238). */
 int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream);
+/* nn.Upsample(size, mode="bilinear", align_corners=True) - src/kd/rf_lw/model_lw_v2.py:258,266,274 (the
+ * distillation teacher's decoder); forward only, C % 4 == 0, dense output [B][Ho][Wo][C] */
+int nasseg_bilinear_ac_fwd(const float* x, float* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                           void* stream);
 int64_t nasseg_bilinear_bwd_workspace(int B, int Hi, int Wi, int C, int Ho, int Wo);
 int nasseg_bilinear_bwd(const float* dy, int64_t lddy, int dyoff, float* dx, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, float* ws, void* stream);
@@ -315,6 +319,8 @@ int nasseg_bf16_pool_bwd(int mode, const nasseg_bf16_t* dy, const uint8_t* idx, 
                     int C, int Ho, int Wo, int K, int stride, int pad, void* stream);
 int nasseg_bf16_bilinear_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream);
+int nasseg_bf16_bilinear_ac_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                void* stream);
 int nasseg_bf16_bilinear_bwd(const nasseg_bf16_t* dy, int64_t lddy, int dyoff, nasseg_bf16_t* dx, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, float* ws, void* stream);
 int nasseg_bf16_ce_fwd(const nasseg_bf16_t* logits, const void* target, int elem_size, int64_t P, int C,

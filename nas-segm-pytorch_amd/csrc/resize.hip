@@ -41,6 +41,21 @@ __device__ __forceinline__ Lin lin_coeff(int dst, float scale, int in_size, int 
   return r;
 }
 
+// align_corners=True (the KD teacher's up-sampling, src/kd/rf_lw/model_lw_v2.py:258,266,274): torch's
+// area_pixel_compute_source_index with align_corners: src = dst * (in-1)/(out-1) (scale 0 when out == 1)
+__device__ __forceinline__ Lin lin_coeff_ac(int dst, float scale, int in_size) {
+  Lin r;
+  const float src = scale * (float)dst;
+  r.i0 = (int)src;
+  if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+  r.i1 = r.i0 + ((r.i0 < in_size - 1) ? 1 : 0);
+  float l1 = src - (float)r.i0;
+  l1 = fminf(fmaxf(l1, 0.f), 1.f);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+
 inline int rs_grid(int64_t n) {
   int64_t b = (n + 255) / 256;
   if (b > 4096) b = 4096;
@@ -48,6 +63,7 @@ inline int rs_grid(int64_t n) {
   return (int)b;
 }
 
+template <bool AC>
 __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const act_t* __restrict__ x,
                                                            act_t* __restrict__ y, int64_t ldy,
                                                            int yoff, int B, int Hi, int Wi, int C4,
@@ -62,8 +78,8 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const act_t* __restri
     const int64_t prow = p / Wo;
     const int oy = (int)(prow % Ho);
     const int b = (int)(prow / Ho);
-    const Lin ly = lin_coeff(oy, sh, Hi, Ho);
-    const Lin lx = lin_coeff(ox, sw, Wi, Wo);
+    const Lin ly = AC ? lin_coeff_ac(oy, sh, Hi) : lin_coeff(oy, sh, Hi, Ho);
+    const Lin lx = AC ? lin_coeff_ac(ox, sw, Wi) : lin_coeff(ox, sw, Wi, Wo);
     const act_t* xb = x + (int64_t)b * Hi * Wi * C + c4 * 4;
     const float4 v00 = lda4(xb + ((int64_t)ly.i0 * Wi + lx.i0) * C);
     const float4 v01 = lda4(xb + ((int64_t)ly.i0 * Wi + lx.i1) * C);
@@ -247,7 +263,7 @@ int NASSEG_FN(bilinear_fwd)(const act_t* x, act_t* y, int64_t ldy, int yoff, int
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   hipStream_t s = (hipStream_t)stream;
   if (C % 4 == 0 && ldy % 4 == 0 && yoff % 4 == 0) {
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(rs_grid((int64_t)B * Ho * Wo * (C / 4))),
+    hipLaunchKernelGGL(bilinear_fwd_kernel<false>, dim3(rs_grid((int64_t)B * Ho * Wo * (C / 4))),
                        dim3(256), 0, s, x, y, ldy, yoff, B, Hi, Wi, C / 4, Ho, Wo, sh, sw, act);
   } else {
     NASSEG_REQUIRE(ldy == C && yoff == 0 && act == 0,
@@ -256,6 +272,19 @@ int NASSEG_FN(bilinear_fwd)(const act_t* x, act_t* y, int64_t ldy, int yoff, int
                        dim3(256), 0, s, x, y, B, Hi, Wi, C, Ho, Wo, sh, sw);
   }
   NASSEG_LAUNCH_CHECK("bilinear_fwd");
+  return NASSEG_OK;
+}
+
+// the same with align_corners=True (nn.Upsample(size, mode="bilinear", align_corners=True)): forward only -
+// its one caller, the distillation teacher, runs under no_grad.  C %% 4 == 0.
+int NASSEG_FN(bilinear_ac_fwd)(const act_t* x, act_t* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                               void* stream) {
+  NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_ac_fwd: bad shape");
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL(bilinear_fwd_kernel<true>, dim3(rs_grid((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0,
+                     (hipStream_t)stream, x, y, (int64_t)C, 0, B, Hi, Wi, C / 4, Ho, Wo, sh, sw, 0);
+  NASSEG_LAUNCH_CHECK("bilinear_ac_fwd");
   return NASSEG_OK;
 }
 

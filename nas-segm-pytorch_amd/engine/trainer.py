@@ -246,7 +246,9 @@ def populate_task0(segmenter, train_loader, kd_net, n_train, do_kd=False):
             F.nearest_label_resize(labels, size, out=slot(
                 "y", torch.empty((1,) + tuple(size), dtype=torch.int64), seen, b))
             if do_kd:
-                store("kd_y", F.bilinear_resize(kd_net(image), size), seen)
+                # (the teacher runs in fp32 whatever the candidate's activation storage)
+                store("kd_y", F.bilinear_resize(kd_net(image if image.dtype == torch.float32 else image.float()),
+                                                size), seen)
             seen += b
             if seen >= n_train:
                 logger.info(" Populated Xy_train, N = {}".format(seen))

@@ -702,10 +702,13 @@ class _ConvChain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, x, residual, *tensors):
-        in_act0, ops = cfg
+        in_act0, ops = cfg[:2]
         x = _cl(x)
         s = current_stream()
-        needs_grad = any(ctx.needs_input_grad)
+        # (under no_grad ctx.needs_input_grad still reports the parameters' requires_grad flags: nothing
+        #  will ever call backward then, and inference may fold every BatchNorm into its conv's epilogue.
+        #  The grad mode is the CALLER's - cfg[2]: inside forward() autograd has switched it off)
+        needs_grad = cfg[2] and any(ctx.needs_input_grad)
         res = _cl(residual) if residual is not None else None
         cur, pend = x, ((None, None, in_act0) if in_act0 else None)
         saved, meta = [], []
@@ -864,7 +867,7 @@ class _ConvChain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         cfg, meta, has_res, x_shape = ctx.meta
-        in_act0, ops = cfg
+        in_act0, ops = cfg[:2]
         sv = ctx.saved_tensors
         fused_in0 = bool(in_act0)  # (forward packed op 0's backward-data weights for the fused kernel)
         g = _cl(dy)
@@ -1066,7 +1069,7 @@ def conv_chain(x, ops, in_act0=ACT_NONE, residual=None):
             cfg_ops.append(("dw" if depthwise else "dense", int(stride), int(padding), int(dilation),
                             True, int(act), bool(training), float(momentum), float(eps)))
             tensors.extend([weight, gamma, beta, rm, rv, nbt if training else None])
-    return _ConvChain.apply((int(in_act0), tuple(cfg_ops)), x, residual, *tensors)
+    return _ConvChain.apply((int(in_act0), tuple(cfg_ops), torch.is_grad_enabled()), x, residual, *tensors)
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, training,
@@ -1204,11 +1207,22 @@ class _Bilinear(torch.autograd.Function):
         return dx, None, None
 
 
-def bilinear_resize(x, size):
-    """nn.Upsample(size, mode='bilinear') / F.interpolate(..., align_corners=False)."""
+def bilinear_resize(x, size, align_corners=False):
+    """nn.Upsample(size, mode='bilinear') / F.interpolate(..., align_corners=False); align_corners=True
+    (the distillation teacher's decoder, src/kd/rf_lw/model_lw_v2.py:258) is forward-only."""
     Ho, Wo = int(size[0]), int(size[1])
     if tuple(x.shape[2:]) == (Ho, Wo):
         return x
+    if align_corners:
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NassegError("bilinear_resize(align_corners=True) has no backward (inference-only)")
+        x = _cl(x)
+        B, C, H, W = x.shape
+        if C % 4 != 0:
+            raise NassegError("bilinear_resize(align_corners=True): C % 4 != 0")
+        y = _new(x, B, C, Ho, Wo)
+        lib.call(_k("nasseg_bilinear_ac_fwd", x), ptr(x), ptr(y), B, H, W, C, Ho, Wo, current_stream())
+        return y
     return _Bilinear.apply(x, Ho, Wo)
 
 
@@ -1288,7 +1302,7 @@ class _CatBNReluConv(torch.autograd.Function):
     launches than the slab path)."""
 
     @staticmethod
-    def forward(ctx, x, y, gamma, beta, rm, rv, nbt, weight, training, momentum, eps):
+    def forward(ctx, x, y, gamma, beta, rm, rv, nbt, weight, training, momentum, eps, grad_mode=True):
         x, y = _cl(x), _cl(y)
         B, C, H, W = x.shape
         N = weight.shape[0]
@@ -1298,7 +1312,7 @@ class _CatBNReluConv(torch.autograd.Function):
                 tuple(x.shape), tuple(y.shape), tuple(w.shape)))
         M = B * H * W
         s = current_stream()
-        needs_grad = any(ctx.needs_input_grad)
+        needs_grad = grad_mode and any(ctx.needs_input_grad)  # (grad_mode: the caller's, see _ConvChain)
         stats = _vec(x, 8 * C)  # [mean | invstd | scale | shift] x [2C]
         mean, invstd, scale, shift = (stats[0:2 * C], stats[2 * C:4 * C], stats[4 * C:6 * C],
                                       stats[6 * C:8 * C])
@@ -1377,14 +1391,14 @@ class _CatBNReluConv(torch.autograd.Function):
                          ACT_NONE, s)
         dgamma = dbn[2 * C:4 * C] if ctx.needs_input_grad[2] else None
         dbeta = dbn[0:2 * C] if ctx.needs_input_grad[3] else None
-        return (grads_in[0], grads_in[1], dgamma, dbeta, None, None, None, dw, None, None, None)
+        return (grads_in[0], grads_in[1], dgamma, dbeta, None, None, None, dw, None, None, None, None)
 
 
 def cat_bn_relu_conv(x, y, gamma, beta, running_mean, running_var, num_batches_tracked, weight,
                      training, momentum=0.1, eps=1e-5):
     """conv1x1(relu(batch_norm(cat([x, y], 1)))) without materialising the concatenation."""
     return _CatBNReluConv.apply(x, y, gamma, beta, running_mean, running_var, num_batches_tracked,
-                                weight, bool(training), float(momentum), float(eps))
+                                weight, bool(training), float(momentum), float(eps), torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------

@@ -850,6 +850,43 @@ def gen_controller():
     print("wrote controller.json")
 
 
+# ---------------------------------------------------------------------------
+# H. the distillation teacher (src/kd/rf_lw/model_lw_v2.py): seeded random weights (no checkpoint can be
+#    downloaded), BatchNorm parameters and buffers randomised, eval forward at 2x3x97x129
+# ---------------------------------------------------------------------------
+TEACHER_SEED, TEACHER_BN_SEED, TEACHER_X_SEED = 123, 5, 6
+
+
+def gen_teacher():
+    from kd.rf_lw.model_lw_v2 import rf_lw152
+
+    torch.manual_seed(TEACHER_SEED)
+    net = rf_lw152(pretrained=False, num_classes=21)
+    randomize_bn(net, torch.Generator().manual_seed(TEACHER_BN_SEED))
+    net.eval()
+    x = torch.randn(2, 3, 97, 129, generator=torch.Generator().manual_seed(TEACHER_X_SEED))
+    taps = {}
+    hooks = [getattr(net, "layer{}".format(i)).register_forward_hook(
+        lambda m, inp, out, i=i: taps.__setitem__("l{}".format(i), out.detach().clone())) for i in (1, 2, 3, 4)]
+    with torch.no_grad():
+        logits = net(x)
+    for h in hooks:
+        h.remove()
+    st = Store()
+    st.put("x", x)
+    st.put("logits", logits)
+    st.put("l1_sample", taps["l1"][:, ::32, ::5, ::7])  # (thinned: the full maps are megabytes)
+    st.put("l4_sample", taps["l4"][:, ::128])
+    st.save("teacher.npz")
+    meta = {"seed": TEACHER_SEED, "bn_seed": TEACHER_BN_SEED, "x_seed": TEACHER_X_SEED, "num_classes": 21,
+            "n_params": sum(p.numel() for p in net.parameters()),
+            "tap_stats": {k: [float(v.double().mean()), float(v.double().abs().mean()), list(v.shape)]
+                          for k, v in taps.items()},
+            "checksums": checksums(net.state_dict())}
+    json.dump(meta, open(os.path.join(OUT, "teacher_meta.json"), "w"))
+    print("teacher: logits", tuple(logits.shape), "max |logit|", float(logits.abs().max()), "params", meta["n_params"])
+
+
 if __name__ == "__main__":
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
@@ -859,6 +896,6 @@ if __name__ == "__main__":
     shutil.rmtree(TMP, ignore_errors=True)
     build_cython()
     which = sys.argv[1:] or ["ops", "nets", "miou", "engine", "controller", "nets_sampled", "engine_optim",
-                             "engine_kd"]
+                             "engine_kd", "teacher"]
     for w in which:
         globals()["gen_" + w]()

@@ -318,3 +318,49 @@ def test_validate_reward(case):
                                   omit_classes=case["omit"])
     # random logits have no exact ties; a handful of interpolation near-ties may flip
     assert abs(reward - float(MIOU_NPZ[name + "/reward"])) < 2e-5
+
+
+def test_teacher_on_the_native_kernels_matches_the_reference_record():
+    """kd_net(image) - the ResNet-152 Light-Weight RefineNet teacher of the search - runs on the
+    nasseg kernels (conv + BatchNorm (+ ReLU, + skip) folded into one kernel per conv, 7x7 stride-2 stem,
+    3x3 / 5x5 max-pools, 256 ... 2048-channel 1x1 and 3x3 convs, align_corners=True up-sampling) and
+    reproduces the logits the imported reference computed for the same seeded weights and input
+    (tests/golden/teacher.npz).  The teacher always runs in fp32 (populate_task0 feeds it the fp32 image
+    whatever the candidate's activation storage: 50 residual blocks accumulate bf16 rounding to 2x the logits'
+    norm with random weights)."""
+    from _util import build_product_teacher
+    from nas_segm_amd import functional as F
+
+    meta = load_json("teacher_meta.json")
+    rec = load_npz("teacher.npz")
+    net = build_product_teacher(meta).to(DEV)
+    x = torch.from_numpy(rec["x"]).to(DEV).contiguous(memory_format=torch.channels_last)
+    want = torch.from_numpy(rec["logits"])
+    seen = set()
+    call = F.lib.call
+
+    def recording(name, *a):
+        seen.add(name)
+        return call(name, *a)
+
+    F.lib.call = recording
+    try:
+        with torch.no_grad():
+            got = net(x)
+    finally:
+        F.lib.call = call
+    assert tuple(got.shape) == tuple(want.shape) == (2, 21, 25, 33)
+    err = float((got.cpu() - want).abs().max())
+    print("teacher logits: max err {:.2e} of max {:.2e}".format(err, float(want.abs().max())))
+    assert err <= 1e-4 * float(want.abs().max()) + 1e-6, err
+    assert {"nasseg_conv_fwd", "nasseg_pool_fwd", "nasseg_bilinear_ac_fwd", "nasseg_axpby"} <= seen, sorted(seen)
+    assert "nasseg_affine_act" not in seen and "nasseg_bn_stats" not in seen  # (every BatchNorm was folded)
+    # the engine's use of it: populate_task0 keeps the teacher's logits, bilinearly resized, in the cache
+    with torch.no_grad():
+        kd = F.bilinear_resize(net(x), (49, 65))
+    assert tuple(kd.shape) == (2, 21, 49, 65) and bool(torch.isfinite(kd).all())
+    # training mode is refused (dropout)
+    net.train()
+    with pytest.raises(RuntimeError):
+        net(x)
+    net.eval()
