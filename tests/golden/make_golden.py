@@ -887,6 +887,99 @@ def gen_teacher():
     print("teacher: logits", tuple(logits.shape), "max |logit|", float(logits.abs().max()), "params", meta["n_params"])
 
 
+# ---------------------------------------------------------------------------
+# I. data pipeline (src/data/datasets.py): the transforms that do NOT call OpenCV, and the dataset class,
+#    run by the reference itself.  cv2 is not in this image: an EMPTY module of that name lets
+#    src/data/datasets.py import; no function of it exists, so nothing recorded here can depend on it
+#    (ResizeScale / RandomMirror / the resizing branch of ResizeShorter are therefore not recorded).
+# ---------------------------------------------------------------------------
+def gen_data():
+    import tempfile
+    import types
+
+    from PIL import Image
+
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from data import datasets as rds
+
+    class Seq(object):  # (torchvision.transforms.Compose is absent too; the dataset only calls its transform)
+        def __init__(self, ts):
+            self.transforms = list(ts)
+
+        def __call__(self, sample):
+            for t in self.transforms:
+                sample = t(sample)
+            return sample
+
+    rng = np.random.RandomState(77)
+    st = Store()
+    sizes = [(37, 53), (64, 48), (91, 90)]
+    cases = []
+    for i, (h, w) in enumerate(sizes):
+        img = (rng.rand(h, w, 3) * 255).astype(np.uint8)
+        msk = (rng.rand(h, w) * 21).astype(np.uint8)
+        st.put("in{}/image".format(i), img)
+        st.put("in{}/mask".format(i), msk)
+        sample = {"image": img, "mask": msk}
+        out = rds.Pad(70, [10, 20, 30], 255)(sample)
+        st.put("pad{}/image".format(i), out["image"]); st.put("pad{}/mask".format(i), out["mask"])
+        out = rds.CentralCrop(33)(sample)
+        st.put("ccrop{}/image".format(i), out["image"]); st.put("ccrop{}/mask".format(i), out["mask"])
+        np.random.seed(100 + i)
+        out = rds.RandomCrop(41)(sample)
+        st.put("rcrop{}/image".format(i), out["image"]); st.put("rcrop{}/mask".format(i), out["mask"])
+        out = rds.ResizeShorter(min(h, w))(sample)  # (shorter side already there: the no-resize branch)
+        st.put("rshort{}/image".format(i), out["image"])
+        norm = rds.Normalise(1.0 / 255, np.array([0.485, 0.456, 0.406]).reshape((1, 1, 3)),
+                             np.array([0.229, 0.224, 0.225]).reshape((1, 1, 3)))
+        out = rds.ToTensor()(norm(sample))
+        st.put("norm{}/image".format(i), out["image"]); st.put("norm{}/mask".format(i), out["mask"])
+        cases.append({"h": h, "w": w})
+    # the dataset class on files: two-column list, single-column list, a grey-scale image, both stages, set_config
+    tmp = tempfile.mkdtemp(prefix="nasseg_data_")
+    names = []
+    for i, (h, w) in enumerate(sizes):
+        img = (rng.rand(h, w, 3) * 255).astype(np.uint8) if i != 1 else (rng.rand(h, w) * 255).astype(np.uint8)
+        msk = (rng.rand(h, w) * 21).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(tmp, "img{}.png".format(i)))
+        Image.fromarray(msk).save(os.path.join(tmp, "msk{}.png".format(i)))
+        st.put("file{}/image".format(i), img); st.put("file{}/mask".format(i), msk)
+        names.append(("img{}.png".format(i), "msk{}.png".format(i)))
+    with open(os.path.join(tmp, "two.lst"), "w") as f:
+        f.write("".join("{}\t{}\n".format(a, b) for a, b in names))
+    with open(os.path.join(tmp, "one.lst"), "w") as f:
+        f.write("".join("{}\n".format(b) for _, b in names))
+    norm = rds.Normalise(1.0 / 255, np.array([0.485, 0.456, 0.406]).reshape((1, 1, 3)),
+                         np.array([0.229, 0.224, 0.225]).reshape((1, 1, 3)))
+    trn = Seq([rds.ResizeShorter(16), rds.CentralCrop(30), rds.RandomCrop(24), norm, rds.ToTensor()])
+    val = Seq([rds.CentralCrop(32), norm, rds.ToTensor()])
+    ds = rds.PascalCustomDataset(os.path.join(tmp, "two.lst"), tmp, trn, val)
+    assert len(ds) == 3
+    np.random.seed(9)
+    for i in range(3):
+        out = ds[i]
+        st.put("ds_trn{}/image".format(i), out["image"]); st.put("ds_trn{}/mask".format(i), out["mask"])
+    ds.set_stage("val")
+    for i in range(3):
+        out = ds[i]
+        st.put("ds_val{}/image".format(i), out["image"]); st.put("ds_val{}/mask".format(i), out["mask"])
+    ds.set_stage("train")
+    ds.set_config(20, 8)  # crop_size of transforms[2] (RandomCrop), resize_side of transforms[0]
+    np.random.seed(10)
+    out = ds[2]
+    st.put("ds_cfg/image", out["image"]); st.put("ds_cfg/mask", out["mask"])
+    try:
+        one = rds.PascalCustomDataset(os.path.join(tmp, "one.lst"), tmp, None, None)
+        single = [list(k) for k in one.datalist]
+    except Exception as e:  # (record what the reference does with a one-column list under Python 3)
+        single = "raises " + type(e).__name__
+    st.save("data.npz")
+    json.dump({"cases": cases, "pad": [70, [10, 20, 30], 255], "ccrop": 33, "rcrop": 41, "single_column": single,
+               "names": names}, open(os.path.join(OUT, "data_meta.json"), "w"))
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("data: single-column list ->", single)
+
+
 if __name__ == "__main__":
     torch.Tensor.cuda = lambda self, *a, **k: self
     nn.Module.cuda = lambda self, *a, **k: self
@@ -896,6 +989,6 @@ if __name__ == "__main__":
     shutil.rmtree(TMP, ignore_errors=True)
     build_cython()
     which = sys.argv[1:] or ["ops", "nets", "miou", "engine", "controller", "nets_sampled", "engine_optim",
-                             "engine_kd", "teacher"]
+                             "engine_kd", "teacher", "data"]
     for w in which:
         globals()["gen_" + w]()
