@@ -124,6 +124,11 @@ int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g
                             const float* mean, const float* invstd, int act, int B, int Hs, int Ws,
                             int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
                             int dil, float* stats, void* stream);
+/* 1: nasseg_conv_wgrad runs this call on its LDS-tiled 3x3 kernel (stride 1, dilation <= 2, N <= 32,
+ * K % 16 == 0, maps of at least 64 tiles of 8 x 32 pixels: the class heads, src/nn/micro_decoders.py:215,226,363),
+ * whose summation order differs from the generic kernel that nasseg_conv_wgrad_many always uses */
+int nasseg_conv_wgrad_lds3x3(int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride,
+                             int pad, int dil);
 int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw);
 /* weight gradients are read by the optimiser only: nasseg_conv_wgrad / nasseg_dwconv_wgrad called
  * with dw == NULL leave their per-slab partial sums in ws, and this call finalises many layers

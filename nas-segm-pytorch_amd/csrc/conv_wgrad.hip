@@ -502,12 +502,250 @@ int launch_wgrad_group(const WgGroup& g, const WgMode& m, hipStream_t s) {
   return NASSEG_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// 3x3 stride-1 weight gradient with the operands staged in LDS (the class heads: 64 -> 19 / 21 at
+// 256x512, src/nn/micro_decoders.py:215,226,363).  The generic kernel above runs one workgroup per
+// (slab, tap) and so reads x and dy nine times - the 134 MB input of the head does not fit the L2s, the
+// re-reads come from the Infinity Cache / HBM, and with N = 19 unaligned every dy load is scalar:
+// 335 us at 4x256x512, 22 % of the fp32 MFMA rate.  Here a workgroup owns a 16-channel slice of K and a
+// strided set of 8 x 32-pixel output tiles; per tile the (8+2d) x (32+2d) input patch of the slice and
+// the dy tile (transposed to [n][pixel]) are staged ONCE, all nine taps are computed from LDS, and the
+// next tile's operands are in flight in registers meanwhile (nothing but LDS is read in the MFMA phase,
+// so the prefetch is not waited for - loads return in order).
+//   dW[tap][n][k] += sum over the tile's pixels of dy[p][n] * x[p + tap][k]
+// MFMA: rows = n (A = dy, two 16-row tiles for N <= 32), cols = the slice's 16 k (B = x), four pixels per
+// instruction; each wave takes two of the tile's eight rows and keeps all 9 x 2 accumulators across
+// tiles; waves meet in LDS in a fixed order at the end, slabs in the deterministic second stage.
+// ---------------------------------------------------------------------------
+// LDS strides: every operand read is a ds_read_b32 (lane groups of 32 = two of the MFMA's four pixel slots x 16
+// rows / columns, bank = dword address mod 32): the patch's pixel stride of 16 dwords puts the two pixels on the
+// two halves of the banks, dyT's row stride of 258 = 2 mod 32 puts row li, pixel slot pk on bank 2*li + pk
+constexpr int kW3TH = 8, kW3TW = 32, kW3KS = 16, kW3XS = kW3KS;       // tile, k slice, pixel stride of the patch
+constexpr int kW3SP = kW3TH * kW3TW + 2;                              // row stride of dyT[n][pixel]
+constexpr int kW3MaxX = ((kW3TH + 4) * (kW3TW + 4) * (kW3KS / 4) + 255) / 256;  // float4 of the patch per thread (d <= 2)
+constexpr int kW3MaxN = 32;
+
+struct W3Args {
+  const act_t* x;
+  const act_t* dy;
+  float* partial;  // [nslab][9][N][K]
+  int B, H, W, K, Ho, Wo, N, pad, dil, nslab, tiles_x, tiles_y;
+};
+
+template <int NT>  // 16-row tiles of n: 1 (N <= 16) or 2
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
+  extern __shared__ float smem[];
+  const int dil = a.dil;
+  const int TR = kW3TH + 2 * dil, TC = kW3TW + 2 * dil;
+  float* xs = smem;                                      // [TR * TC][kW3XS]
+  float* dyT = xs + (kW3TH + 4) * (kW3TW + 4) * kW3XS;   // [16 * NT][kW3SP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, pk = lane >> 4;
+  const int slab = blockIdx.x, k0 = blockIdx.y * kW3KS;
+  const int N = a.N, K = a.K;
+  const int ntiles = a.B * a.tiles_y * a.tiles_x;
+  const int xtotal = TR * TC * (kW3KS / 4);
+
+  f32x4 acc[9][NT];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // patch item it of this thread: float4 (tid & 3) of patch pixel (pr, pc) - the same for every tile; what
+  // does not depend on the tile is computed once (the staging code is VALU work that the MFMAs of the
+  // CU's other workgroup do not hide: the two run in lockstep)
+  int xloc[kW3MaxX], xg[kW3MaxX], xl[kW3MaxX];
+#pragma unroll
+  for (int it = 0; it < kW3MaxX; ++it) {
+    int idx = tid + 256 * it;
+    idx = idx < xtotal ? idx : xtotal - 1;
+    const int p = idx >> 2;
+    const int pr = p / TC, pc = p - pr * TC;
+    xloc[it] = pr | (pc << 8);
+    xg[it] = (pr * a.W + pc) * K;              // offset from the patch's first pixel (interior tiles)
+    xl[it] = p * kW3XS + (tid & 3) * 4;
+  }
+  // dy: thread tid owns pixel (row tid / 32, column tid % 32) of the tile and loads its N channels (76 bytes
+  // for N = 19: not vectorisable, the lanes of a wave are 76 bytes apart); written transposed to dyT[n][pixel].
+  // (Measured alternative: the tile as 8 contiguous runs of 32 * N floats, one float per lane - fully coalesced,
+  //  but the (row, pixel, channel) bookkeeping per element costs more than the scattered loads: 260 / 224 us.)
+  const int dr_r = tid >> 5, dr_c = tid & 31;
+  // rows of dyT beyond N are read by the MFMAs and never written: zero them once
+  for (int n = N; n < 16 * NT; ++n) dyT[n * kW3SP + tid] = 0.f;
+  const int tpi = a.tiles_y * a.tiles_x;
+  const float inv_tpi = 1.f / (float)tpi, inv_tx = 1.f / (float)a.tiles_x;
+  auto fdiv = [](int n, int d, float inv) {  // n / d for 0 <= n < 2^22 (one float multiply and a fix-up)
+    int q = (int)((float)n * inv);
+    q -= (q * d > n) ? 1 : 0;
+    q += ((q + 1) * d <= n) ? 1 : 0;
+    return q;
+  };
+  float4 xr[kW3MaxX];
+  float dr[16 * NT];
+  struct TileGeo {
+    int b, oy0, ox0;
+    bool inner;  // the patch and the dy tile lie inside the image: no clamping, no masks
+  };
+  auto geo = [&](int tile) {
+    TileGeo g;
+    g.b = fdiv(tile, tpi, inv_tpi);
+    const int t2 = tile - g.b * tpi;
+    const int ty = fdiv(t2, a.tiles_x, inv_tx);
+    g.oy0 = ty * kW3TH;
+    g.ox0 = (t2 - ty * a.tiles_x) * kW3TW;
+    const int iy0 = g.oy0 - a.pad, ix0 = g.ox0 - a.pad;
+    g.inner = iy0 >= 0 && ix0 >= 0 && iy0 + TR <= a.H && ix0 + TC <= a.W && g.oy0 + kW3TH <= a.Ho &&
+              g.ox0 + kW3TW <= a.Wo;
+    return g;
+  };
+  auto issue = [&](const TileGeo& g) {
+    const int iy0 = g.oy0 - a.pad, ix0 = g.ox0 - a.pad;
+    const act_t* xb = a.x + (int64_t)g.b * a.H * a.W * K + k0 + (tid & 3) * 4;
+    if (g.inner) {  // (uniform)
+      const act_t* x0 = xb + ((int64_t)iy0 * a.W + ix0) * K;
+#pragma unroll
+      for (int it = 0; it < kW3MaxX; ++it) xr[it] = lda4(x0 + xg[it]);
+      const act_t* dp = a.dy + (((int64_t)g.b * a.Ho + g.oy0 + dr_r) * a.Wo + g.ox0 + dr_c) * N;
+#pragma unroll
+      for (int n = 0; n < 16 * NT; ++n)
+        if (n < N) dr[n] = lda1(dp + n);  // (uniform: the 13 surplus loads of N = 19 would each touch 38 lines)
+    } else {
+#pragma unroll
+      for (int it = 0; it < kW3MaxX; ++it) {
+        int iy = iy0 + (xloc[it] & 255), ix = ix0 + (xloc[it] >> 8);
+        iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+        xr[it] = lda4(xb + ((int64_t)iy * a.W + ix) * K);
+      }
+      int oy = g.oy0 + dr_r, ox = g.ox0 + dr_c;
+      oy = oy < a.Ho ? oy : a.Ho - 1;
+      ox = ox < a.Wo ? ox : a.Wo - 1;
+      const act_t* dp = a.dy + (((int64_t)g.b * a.Ho + oy) * a.Wo + ox) * N;
+#pragma unroll
+      for (int n = 0; n < 16 * NT; ++n)
+        if (n < N) dr[n] = lda1(dp + n);
+    }
+  };
+  auto place = [&](const TileGeo& g) {
+    if (g.inner) {  // (uniform)
+#pragma unroll
+      for (int it = 0; it < kW3MaxX; ++it)
+        if (tid + 256 * it < xtotal) *reinterpret_cast<float4*>(&xs[xl[it]]) = xr[it];
+#pragma unroll
+      for (int n = 0; n < 16 * NT; ++n)
+        if (n < N) dyT[n * kW3SP + tid] = dr[n];
+    } else {
+      const int iy0 = g.oy0 - a.pad, ix0 = g.ox0 - a.pad;
+#pragma unroll
+      for (int it = 0; it < kW3MaxX; ++it) {
+        const int iy = iy0 + (xloc[it] & 255), ix = ix0 + (xloc[it] >> 8);
+        const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        if (tid + 256 * it < xtotal) *reinterpret_cast<float4*>(&xs[xl[it]]) = keep_if(xr[it], ok);
+      }
+      const bool pok = g.oy0 + dr_r < a.Ho && g.ox0 + dr_c < a.Wo;
+#pragma unroll
+      for (int n = 0; n < 16 * NT; ++n)
+        if (n < N) dyT[n * kW3SP + tid] = keep_if(dr[n], pok);
+    }
+  };
+
+  int tile = slab;
+  TileGeo gcur = geo(tile < ntiles ? tile : 0), gnext = gcur;
+  if (tile < ntiles) issue(gcur);
+  for (; tile < ntiles; tile += a.nslab) {
+    __syncthreads();  // (the previous tile's operands have been read)
+    place(gcur);
+    __syncthreads();
+    if (tile + a.nslab < ntiles) {  // in flight during the MFMAs below
+      gnext = geo(tile + a.nslab);
+      issue(gnext);
+    }
+    // this wave's two rows of the tile: 64 pixels, four per MFMA.  The operands of step u + 1 are read from
+    // LDS before the MFMAs of step u are issued (explicit ping-pong, scheduling barriers in between: left to
+    // itself the compiler reads one tap, waits, issues its two MFMAs, reads the next - nine exposed LDS
+    // latencies per step)
+    auto load_ops = [&](int u, float (&av)[NT], float (&bv)[9]) {
+      const int pl = 4 * u + pk;                  // pixel within the wave's two rows
+      const int r = 2 * wave + (pl >> 5), c = pl & 31;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) av[nt] = dyT[(nt * 16 + li) * kW3SP + r * kW3TW + c];
+      const float* xp = xs + (r * TC + c) * kW3XS + li;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) bv[t] = xp[((t / 3) * dil * TC + (t % 3) * dil) * kW3XS];
+    };
+    auto mma = [&](const float (&av)[NT], const float (&bv)[9]) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma16(av[nt], bv[t], acc[t][nt]);
+    };
+    float a0[NT], b0[9], a1[NT], b1[9];
+    load_ops(0, a0, b0);
+#pragma unroll 1
+    for (int u = 0; u < 16; u += 2) {
+      load_ops(u + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 2 < 16) load_ops(u + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    gcur = gnext;
+  }
+
+  // waves -> workgroup partial, one tap at a time, fixed order (wave 0 + 1 + 2 + 3)
+  __syncthreads();
+  float* red = smem;  // [3 waves][NT tiles][64 lanes][4]
+  float* pout = a.partial + (int64_t)slab * 9 * N * K;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (t) __syncthreads();
+    if (wave > 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<f32x4*>(&red[(((wave - 1) * NT + nt) * 64 + lane) * 4]) = acc[t][nt];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float v = ((acc[t][nt][rr] + red[((0 * NT + nt) * 64 + lane) * 4 + rr]) +
+                           red[((1 * NT + nt) * 64 + lane) * 4 + rr]) + red[((2 * NT + nt) * 64 + lane) * 4 + rr];
+          const int n = nt * 16 + 4 * pk + rr, k = k0 + li;  // D row <-> n, D col <-> k
+          if (n < N && k < K) pout[((int64_t)t * N + n) * K + k] = v;
+        }
+    }
+  }
+}
+
+// does nasseg_conv_wgrad run this call on the LDS-tiled kernel (shape AND call details)?
+inline bool wgrad3x3_call_ok(int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                             int dil);
+// is the LDS-tiled kernel the one for this geometry?  (the plan below gives such layers a slab count that
+// suits it; everything else about the call - partial layout, second stage - is shared with the generic kernel)
+inline bool wgrad3x3_shape_ok(int N, int K, int kh, int kw, int Ho, int Wo) {
+  return kh == 3 && kw == 3 && N <= kW3MaxN && K % kW3KS == 0 && K >= kW3KS && Wo >= kW3TW && Ho >= kW3TH;
+}
+
+inline bool wgrad3x3_call_ok(int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
+                             int dil) {
+  return wgrad3x3_shape_ok(N, K, kh, kw, Ho, Wo) && stride == 1 && dil >= 1 && dil <= 2 && pad >= 0 && pad <= 2 * dil &&
+         Hs == Ho + 2 * dil - 2 * pad && Ws == Wo + 2 * dil - 2 * pad &&
+         (int64_t)B * Ho * Wo >= (int64_t)64 * kW3TH * kW3TW;
+}
+
 inline int pick_v(int len) { return len > 32 ? 4 : (len > 16 ? 2 : 1); }
 
 struct WgPlan {
   int vn, vk, nchunks, kchunks, nslab, flat, pix_per_block;
 };
-inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps) {
+inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps, int lds3x3 = 0) {
   WgPlan p;
   p.flat = (taps > 1 && taps * K <= 64) ? 1 : 0;
   const int Kq = p.flat ? taps * K : K;
@@ -526,6 +764,12 @@ inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps) {
   if (s > cap_bytes) s = cap_bytes;
   if (s > Mtot / kMinPix) s = Mtot / kMinPix;
   if (s < 1) s = 1;
+  // the LDS-tiled 3x3 kernel: (slabs x K / 16) workgroups, two resident per CU, several tiles each
+  if (lds3x3 && Mtot >= (int64_t)64 * kW3TH * kW3TW) {
+    s = 512 / (K / kW3KS);
+    if (s < 32) s = 32;
+    if (s > cap_bytes) s = cap_bytes;
+  }
   int64_t ppb = cdiv64(Mtot, s);
   ppb = (ppb + 63) / 64 * 64;
   p.pix_per_block = (int)ppb;
@@ -538,9 +782,17 @@ inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps) {
 extern "C" {
 
 #if NASSEG_FP32_ONLY
+// 1: nasseg_conv_wgrad runs this (dense, no input prologue) call on its LDS-tiled 3x3 kernel - whose sums are
+// ordered differently from the generic kernel's, so a caller that wants the SAME bits from its immediate and
+// its grouped (nasseg_conv_wgrad_many: always the generic kernel) code paths must not group such layers
+int nasseg_conv_wgrad_lds3x3(int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride,
+                             int pad, int dil) {
+  return wgrad3x3_call_ok(B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil) ? 1 : 0;
+}
+
 // floats of workspace needed by nasseg_conv_wgrad
 int64_t nasseg_conv_wgrad_workspace(int B, int Ho, int Wo, int N, int K, int kh, int kw) {
-  WgPlan p = wgrad_plan((int64_t)B * Ho * Wo, N, K, kh * kw);
+  WgPlan p = wgrad_plan((int64_t)B * Ho * Wo, N, K, kh * kw, wgrad3x3_shape_ok(N, K, kh, kw, Ho, Wo));
   return (int64_t)p.nslab * kh * kw * N * K;
 }
 #endif  // NASSEG_FP32_ONLY
@@ -566,7 +818,7 @@ static int wgrad_setup(WgSetup& u, const act_t* x, int ldx, const act_t* dy, int
                  "conv_wgrad: too many pixels");
   const int64_t Mtot = (int64_t)B * Ho * Wo;
   const int taps = kh * kw;
-  u.p = wgrad_plan(Mtot, N, K, taps);
+  u.p = wgrad_plan(Mtot, N, K, taps, wgrad3x3_shape_ok(N, K, kh, kw, Ho, Wo));
   const WgPlan& p = u.p;
   WgMode& m = u.m;
   m.flat = p.flat != 0;
@@ -601,12 +853,30 @@ int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, fl
                        kh, kw, stride, pad, dil);
   if (rc) return rc;
   const WgPlan& p = u.p;
+  if (wgrad3x3_call_ok(B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil) && ldx == K && lddy == N && !u.m.pro) {
+    W3Args w = {};
+    w.x = x; w.dy = dy; w.partial = ws;
+    w.B = B; w.H = Hs; w.W = Ws; w.K = K; w.Ho = Ho; w.Wo = Wo; w.N = N; w.pad = pad; w.dil = dil;
+    w.nslab = p.nslab; w.tiles_x = cdiv(Wo, kW3TW); w.tiles_y = cdiv(Ho, kW3TH);
+    const size_t lds = ((size_t)(kW3TH + 4) * (kW3TW + 4) * kW3XS + (size_t)kW3MaxN * kW3SP) * sizeof(float);
+    if (N <= 16) {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      hipLaunchKernelGGL(conv_wgrad3x3_lds_kernel<1>, dim3(p.nslab, K / kW3KS), dim3(256), lds, s, w);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+      hipLaunchKernelGGL(conv_wgrad3x3_lds_kernel<2>, dim3(p.nslab, K / kW3KS), dim3(256), lds, s, w);
+    }
+    NASSEG_LAUNCH_CHECK("conv_wgrad3x3_lds_kernel");
+  } else {
 #define WG_CASE(VN_, VK_) \
   if (p.vn == VN_ && p.vk == VK_) rc = launch_wgrad<VN_, VK_>(u.a, u.grid, u.m, s); else
   WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1)
   WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
   rc = nasseg_fail(NASSEG_ERR_UNSUPPORTED, "conv_wgrad: no kernel for vn=%d vk=%d", p.vn, p.vk);
 #undef WG_CASE
+  }
   if (rc) return rc;
   if (!dw) return NASSEG_OK;  // partial sums stay in ws for nasseg_wgrad_finalize_many
   const int taps = kh * kw;

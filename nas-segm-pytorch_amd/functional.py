@@ -146,7 +146,11 @@ def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
     dwt = torch.empty_like(w)
     ws = _ws(cur, lib.query("nasseg_conv_wgrad_workspace", B, Ho, Wo, N, K, kh, kw))
     flat = int(lib.query("nasseg_conv_fwd_pack_mode", K, kh, kw) == 2)
-    if deferred_wgrad.active and (B * Hs * Ws * K + B * Ho * Wo * N) * cur.element_size() <= _GROUP_WGRAD_BYTES:
+    # (layers that nasseg_conv_wgrad runs on its LDS-tiled 3x3 kernel are not grouped: the grouped launch always
+    #  uses the generic kernel, and deferred / immediate finalisation must give the same bits)
+    if (deferred_wgrad.active and (B * Hs * Ws * K + B * Ho * Wo * N) * cur.element_size() <= _GROUP_WGRAD_BYTES
+            and not (psc is None and psh is None and not pact
+                     and lib.query("nasseg_conv_wgrad_lds3x3", B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil))):
         desc = (ptr(cur), K, ptr(dz), N, ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
         deferred_wgrad.grouped.setdefault(("nasseg_conv_wgrad_many", cur.dtype), []).append(
             ((cur, dz, psc, psh), desc))

@@ -116,6 +116,14 @@ CONV_CASES = [
     (2, 16, 12, 40, 32, 3, 1, 0, 1, True),
     (1, 40, 8, 32, 21, 3, 1, 2, 1, True),
     (2, 64, 64, 64, 64, 3, 1, 1, 1, False),
+    # >= 16384 output pixels, N <= 32, K % 16 == 0: the LDS-tiled 3x3 weight gradient (conv_wgrad3x3_lds_kernel):
+    # the class heads (19 / 21 classes with bias), ragged tiles in both directions, one and two 16-row tiles
+    # of N, dilation 2, no padding, a 16- and a 128-channel input
+    (2, 64, 96, 128, 19, 3, 1, 1, 1, True),
+    (2, 64, 90, 100, 21, 3, 1, 1, 1, True),
+    (1, 32, 130, 131, 16, 3, 1, 2, 2, False),
+    (3, 16, 80, 96, 32, 3, 1, 0, 1, False),
+    (1, 128, 128, 160, 12, 3, 1, 1, 1, False),
 ]
 
 

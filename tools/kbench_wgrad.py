@@ -19,6 +19,10 @@ SHAPES = [  # B, K, H, W, N, k
 ]
 
 
+if os.environ.get("KB_ONLY_HEAD"):
+    SHAPES = [s for s in SHAPES if s[5] == 3 and s[4] == 19]
+
+
 def main():
     print("env:", {k: v for k, v in os.environ.items() if k.startswith("NASSEG_")})
     s = F.current_stream()
