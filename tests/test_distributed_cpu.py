@@ -314,6 +314,57 @@ def _engine_worker(rank, world, port, q):
         probe = torch.tensor([float(rank + 1)])
         dist.all_reduce(probe)
         out["task0_failure"] = (ret, float(probe))
+
+        # (5) round 3: the protocol covers the WHOLE step, and the ranks agree on their step counts.
+        # (a) loaders of unequal length: both ranks run min(len) = 2 steps, nobody waits for a third
+        net, dp, oe, od = candidate()
+        ret = train_segmenter(dp, _toy_batches(rank, 3 if rank == 0 else 2), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["uneven_loaders"] = (ret, net.encoder.calls, same_on_all_ranks(net), float(probe))
+
+        # (b) the LOADER of rank 1 raises while fetching its second batch (not inside forward / backward)
+        class FlakyLoader(list):
+            def __iter__(self):
+                for i, b in enumerate(list.__iter__(self)):
+                    if rank == 1 and i == 1:
+                        raise RuntimeError("DataLoader worker died (simulated)")
+                    yield b
+
+        net, dp, oe, od = candidate()
+        ret = train_segmenter(dp, FlakyLoader(_toy_batches(rank, 3)), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["loader_failure"] = (ret, net.encoder.calls, float(probe))
+
+        # (c) the optimiser of rank 0 raises AFTER the gradient all-reduce of step 1: the flag travels with
+        # the next step's collective, every rank stops there
+        net, dp, oe, od = candidate()
+        if rank == 0:
+            real_step, n_calls = od.step, [0]
+
+            def flaky_step(*a, **k):
+                n_calls[0] += 1
+                if n_calls[0] == 1:
+                    raise RuntimeError("optimizer state allocation failed (simulated)")
+                return real_step(*a, **k)
+
+            od.step = flaky_step
+        ret = train_segmenter(dp, _toy_batches(rank, 4), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["optimiser_failure"] = (ret, net.encoder.calls, float(probe))
+
+        # (d) cache shards of unequal size: train_task0 agrees on the smaller one's number of passes
+        net, dp, oe, od = candidate()
+        n_mine = 4 if rank == 0 else 2
+        shard = [{"image": b["image"][i:i + 1], "mask": b["mask"][i:i + 1]}
+                 for b in _toy_batches(rank, 2, seed=4) for i in range(2)][:n_mine]
+        Xy = populate_task0(dp, shard, None, n_mine, do_kd=False)
+        ret = train_task0(Xy, dp, od, 0, _Crit(), None, 2, False, False, 0.0, 3.0, False)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["uneven_shards"] = (ret, int(Xy[0].shape[0]), same_on_all_ranks(net.decoder), float(probe))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -345,6 +396,13 @@ def test_engine_entry_points_two_ranks_gloo():
         ret, n, yshape, same, moved, shards_differ = out["task0"]
         assert ret is None and n == 4 and yshape == (4, 4, 6) and same and moved and shards_differ, out["task0"]
         assert out["task0_failure"] == (0, 3.0), out["task0_failure"]
+        assert out["uneven_loaders"] == (None, 2, True, 3.0), out["uneven_loaders"]
+        ret, calls, probe = out["loader_failure"]
+        assert ret == 0 and probe == 3.0 and calls in (1, 2), out["loader_failure"]  # (rank 1 never ran step 2)
+        ret, calls, probe = out["optimiser_failure"]
+        assert ret == 0 and probe == 3.0 and calls <= 2, out["optimiser_failure"]
+        ret, n, same, probe = out["uneven_shards"]
+        assert ret is None and n == (4 if rank == 0 else 2) and same and probe == 3.0, out["uneven_shards"]
 
 
 def _ctrl_search_worker(rank, world, port, q, log_path):
