@@ -114,6 +114,12 @@ def algorithmic_bytes(name, a):
     if name in ("nasseg_pool_fwd", "nasseg_pool_bwd"):
         B, H, W, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
         return 4 * B * C * (H * W + Ho * Wo) + B * C * Ho * Wo  # + uint8 winner index
+    if name == "nasseg_maxpool_bn_fwd":  # z read, pooled map (+ uint8 winner index) written
+        B, H, W, C, Ho, Wo = a[5], a[6], a[7], a[8], a[9], a[10]
+        return 4 * B * C * (H * W + Ho * Wo) + (B * C * Ho * Wo if a[4] else 0)
+    if name == "nasseg_maxpool_bn_bwd":  # dy + index + z read, g written
+        B, H, W, C, Ho, Wo = a[7], a[8], a[9], a[10], a[11], a[12]
+        return 4 * B * C * (2 * H * W + Ho * Wo) + B * C * Ho * Wo
     if name == "nasseg_bilinear_fwd":
         B, Hi, Wi, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
         return 4 * B * C * (Hi * Wi + Ho * Wo)

@@ -240,6 +240,15 @@ int nasseg_pool_fwd(int mode, const float* x, float* y, uint8_t* idx, int B, int
                     int Ho, int Wo, int K, int stride, int pad, void* stream);
 int nasseg_pool_bwd(int mode, const float* dy, const uint8_t* idx, float* dx, int B, int H, int W,
                     int C, int Ho, int Wo, int K, int stride, int pad, void* stream);
+/* Pool's 1x1 conv + BatchNorm followed by 3x3 max pooling (src/nn/layer_factory.py:161-178) without the
+ * normalised map: the pooling applies scale*z + shift to the conv's raw output as it loads; backward gives
+ * the gradient w.r.t. the BatchNorm's output together with the per-workgroup sums of its backward. */
+int64_t nasseg_maxpool_bn_bwd_blocks(int B, int H, int W, int C, int K, int stride, int pad);
+int nasseg_maxpool_bn_fwd(const float* z, const float* scale, const float* shift, float* y, uint8_t* idx,
+                          int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, void* stream);
+int nasseg_maxpool_bn_bwd(const float* dy, const uint8_t* idx, const float* z, const float* mean,
+                          const float* invstd, float* g, float* stats, int B, int H, int W, int C, int Ho,
+                          int Wo, int stride, int pad, void* stream);
 
 /* ---- resize: nn.Upsample / F.interpolate bilinear, align_corners=False
  * (layer_factory.py:190-194,338-350; micro_decoders.py:11-25,46-51; trainer.py:141-143,
@@ -324,6 +333,11 @@ int nasseg_bf16_pool_bwd(int mode, const nasseg_bf16_t* dy, const uint8_t* idx, 
                     int C, int Ho, int Wo, int K, int stride, int pad, void* stream);
 int nasseg_bf16_bilinear_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream);
+int nasseg_bf16_maxpool_bn_fwd(const nasseg_bf16_t* z, const float* scale, const float* shift, nasseg_bf16_t* y, uint8_t* idx,
+                               int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, void* stream);
+int nasseg_bf16_maxpool_bn_bwd(const nasseg_bf16_t* dy, const uint8_t* idx, const nasseg_bf16_t* z, const float* mean,
+                               const float* invstd, nasseg_bf16_t* g, float* stats, int B, int H, int W, int C, int Ho,
+                               int Wo, int stride, int pad, void* stream);
 int nasseg_bf16_bilinear_ac_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                 void* stream);
 int nasseg_bf16_bilinear_bwd(const nasseg_bf16_t* dy, int64_t lddy, int dyoff, nasseg_bf16_t* dx, int B, int Hi, int Wi,

@@ -72,4 +72,78 @@ inline StripCfg strip_cfg(int stride, int dil) {
   return c;
 }
 
+// Sum acc[t] (t < NV) over all threads of the workgroup that share a channel group and
+// write out[t][C], RB values per LDS round (NV % RB == 0).  Thread `tid` of a workgroup whose
+// first flattened (x, c/4) index is `base` owns channel group (base + tid) % C4.  With
+// C4 > 256 only the groups present in the workgroup are written (caller zero-fills).
+// Lanes l, l+C4, l+2*C4, ... of a wave hold the same group: lanes < C4 gather them with
+// shuffles in a fixed order; the four waves then meet in LDS indexed by channel group.
+template <int NV, int RB>
+__device__ __forceinline__ void block_reduce_groups(float4 (&acc)[NV], float4 (*red)[4][64],
+                                                    float* __restrict__ out, int base, int C4) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int C = C4 * 4;
+  const int nown = C4 < 64 ? C4 : 64;
+  if (C4 < 64) {
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const float4 v = acc[t];
+      float4 s = v;
+      for (int off = C4; off < 64; off += C4) {
+        const int src = lane + off;
+        const bool ok = src < 64;
+        const int sl = ok ? src : lane;
+        const float ax = __shfl(v.x, sl), ay = __shfl(v.y, sl), az = __shfl(v.z, sl),
+                    aw = __shfl(v.w, sl);
+        if (ok) {
+          s.x += ax;
+          s.y += ay;
+          s.z += az;
+          s.w += aw;
+        }
+      }
+      acc[t] = s;
+    }
+  }
+  const int cc = (base + tid) % C4;  // channel group of this lane
+  if (C4 <= 64) {
+#pragma unroll
+    for (int r = 0; r < NV / RB; ++r) {
+      __syncthreads();
+      if (lane < nown) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) red[u][wave][cc] = acc[r * RB + u];
+      }
+      __syncthreads();
+      if (tid < C4) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+          const float4 s = add4(add4(red[u][0][tid], red[u][1][tid]),
+                                add4(red[u][2][tid], red[u][3][tid]));
+          sta4(out + (size_t)(r * RB + u) * C + tid * 4, s);
+        }
+      }
+    }
+  } else {
+    // C4 > 64: at most ceil(256 / C4) <= 3 threads of the workgroup share a group, so a
+    // direct strided sum by the first min(C4, 256) threads has no serial tail to speak of
+    float4* flat = &red[0][0][0];  // needs RB * 256 >= 256 float4
+    const int nsum = C4 < 256 ? C4 : 256;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      __syncthreads();
+      flat[tid] = acc[t];
+      __syncthreads();
+      if (tid < nsum) {
+        float4 s = f4zero();
+        for (int u = tid; u < 256; u += C4) s = add4(s, flat[u]);
+        sta4(out + (size_t)t * C + cc * 4, s);
+      }
+    }
+  }
+}
+
+
 }  // namespace

@@ -9,7 +9,7 @@
 // backward pass is a gather (deterministic, no atomics).
 #include <math.h>
 
-#include "common.h"
+#include "dw_common.h"
 
 namespace {
 
@@ -171,9 +171,192 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const act_t* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// Pool = 1x1 conv + BatchNorm, THEN 3x3 max pooling (src/nn/layer_factory.py:161-178): the pooling reads
+// the conv's RAW output z and applies the BatchNorm's affine as it loads (scale*z + shift - monotone only
+// for positive scales, so the comparison runs on the transformed values), the normalised map is never
+// written; backward, the gather over the <= 9 windows of an input pixel produces the gradient w.r.t. the
+// BatchNorm's output together with the per-workgroup sums of that BatchNorm's backward
+// {sum g, sum g*xhat} - no reduction pass over g and z.  All loads are unconditional (clamped
+// coordinates, masks): the kernels above put their loads under bounds branches, which the compiler
+// serialises (0.21-0.29 of the HBM peak).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3_bn_fwd_kernel(const act_t* __restrict__ z,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              act_t* __restrict__ y, uint8_t* __restrict__ idx,
+                                                              int B, int H, int W, int C4, int Ho, int Wo,
+                                                              int stride, int pad) {
+  const int C = C4 * 4;
+  const int64_t total = (int64_t)B * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    const act_t* zb = z + (int64_t)b * H * W * C + c4 * 4;
+    const float4 sc = scale ? lda4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? lda4(shift + c4 * 4) : f4zero();
+    float4 v[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = oy * stride - pad + t / 3, ix = ox * stride - pad + t % 3;
+      ok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+      v[t] = lda4(zb + ((int64_t)iyc * W + ixc) * C);
+    }
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int mx = 0, my = 0, mz = 0, mw = 0;
+    bool seeded = false;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float4 a = fma4(v[t], sc, sh);
+      // torch: take a when (a > max) or isnan(a); the first in-bounds tap seeds the index
+      const bool tx = ok[t] && (!seeded || a.x > m.x || a.x != a.x);
+      const bool ty = ok[t] && (!seeded || a.y > m.y || a.y != a.y);
+      const bool tz = ok[t] && (!seeded || a.z > m.z || a.z != a.z);
+      const bool tw = ok[t] && (!seeded || a.w > m.w || a.w != a.w);
+      m.x = tx ? a.x : m.x; mx = tx ? t : mx;
+      m.y = ty ? a.y : m.y; my = ty ? t : my;
+      m.z = tz ? a.z : m.z; mz = tz ? t : mz;
+      m.w = tw ? a.w : m.w; mw = tw ? t : mw;
+      seeded = seeded || ok[t];
+    }
+    sta4(y + i * 4, m);
+    if (idx) *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4((uint8_t)mx, (uint8_t)my, (uint8_t)mz, (uint8_t)mw);
+  }
+}
+
+// workgroup (bx, by): lanes = 256 consecutive (x, channel-group) positions of a row of the INPUT grid,
+// rows by, by + gdy, ... of the flattened (image, row) axis; g[b][iy][ix] = sum over the windows that took
+// this pixel; stats[blk][0][c] = sum g, stats[blk][1][c] = sum g * (z - mean) * invstd
+__global__ __launch_bounds__(256) void maxpool3_bn_bwd_kernel(const act_t* __restrict__ dy,
+                                                              const uint8_t* __restrict__ idx,
+                                                              const act_t* __restrict__ z,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              act_t* __restrict__ g, float* __restrict__ stats,
+                                                              int B, int H, int W, int C4, int Ho, int Wo,
+                                                              int stride, int pad) {
+  __shared__ float4 sred[2][4][64];
+  const int C = C4 * 4;
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 256;
+  const int pos = base + tid;
+  const bool live = pos < W * C4;
+  const int ix = live ? pos / C4 : 0;
+  const int c4 = live ? pos - ix * C4 : 0;
+  const float4 mu = lda4(mean + c4 * 4), is = lda4(invstd + c4 * 4);
+  // the <= 3 window columns that contain ix (tap column tx): ox = (ix + pad - tx) / stride
+  int oxs[3];
+  bool oxok[3];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int nx = ix + pad - tx;
+    const int ox = stride == 1 ? nx : (nx >> 1);
+    oxok[tx] = live && nx >= 0 && (stride == 1 || !(nx & 1)) && ox < Wo;
+    oxs[tx] = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
+  }
+  float4 ssum[2] = {f4zero(), f4zero()};
+  const int R = B * H;
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const int b = r / H, iy = r - b * H;
+    float4 acc = f4zero();
+    float4 d[9];
+    uchar4 w[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ny = iy + pad - t / 3;
+      const int oy = stride == 1 ? ny : (ny >> 1);
+      ok[t] = oxok[t % 3] && ny >= 0 && (stride == 1 || !(ny & 1)) && oy < Ho;
+      const int oyc = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy);
+      const int64_t o = ((((int64_t)b * Ho + oyc) * Wo + oxs[t % 3]) * C4 + c4) * 4;
+      w[t] = *reinterpret_cast<const uchar4*>(idx + o);
+      d[t] = lda4(dy + o);
+    }
+    const int64_t off = ((int64_t)r * W + ix) * C + c4 * 4;
+    const float4 zv = lda4(z + (live ? off : 0));
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc.x += (ok[t] && w[t].x == t) ? d[t].x : 0.f;
+      acc.y += (ok[t] && w[t].y == t) ? d[t].y : 0.f;
+      acc.z += (ok[t] && w[t].z == t) ? d[t].z : 0.f;
+      acc.w += (ok[t] && w[t].w == t) ? d[t].w : 0.f;
+    }
+    if (live) sta4(g + off, acc);
+#ifdef NASSEG_BF16
+    acc = make_float4(bf16_to_f32(f32_to_bf16(acc.x)), bf16_to_f32(f32_to_bf16(acc.y)),
+                      bf16_to_f32(f32_to_bf16(acc.z)), bf16_to_f32(f32_to_bf16(acc.w)));  // (what a reduction pass would read)
+#endif
+    const float4 gm = keep_if(acc, live);
+    ssum[0] = add4(ssum[0], gm);
+    ssum[1] = fma4(gm, make_float4((zv.x - mu.x) * is.x, (zv.y - mu.y) * is.y, (zv.z - mu.z) * is.z,
+                                   (zv.w - mu.w) * is.w), ssum[1]);
+  }
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  block_reduce_groups<2, 2>(ssum, sred, stats + (size_t)blk * 2 * C, base, C4);
+}
+
+struct PoolBnGrid {
+  int gx, gy;
+};
+inline PoolBnGrid pool_bn_grid(int B, int H, int W, int C) {
+  PoolBnGrid g;
+  g.gx = cdiv(W * (C / 4), 256);
+  int64_t gy = 2048 / g.gx;  // ~2048 workgroups, at least two rows each
+  const int64_t rows = (int64_t)B * H;
+  if (gy > rows / 2) gy = rows / 2;
+  if (gy < 1) gy = 1;
+  if (gy > 65535) gy = 65535;
+  g.gy = (int)gy;
+  return g;
+}
+
 }  // namespace
 
 extern "C" {
+
+#if NASSEG_FP32_ONLY
+// statistics rows of nasseg_maxpool_bn_bwd (0: geometry not served - use the unfused ops)
+int64_t nasseg_maxpool_bn_bwd_blocks(int B, int H, int W, int C, int K, int stride, int pad) {
+  if (K != 3 || pad != 1 || (stride != 1 && stride != 2) || C % 4 || C / 4 > 256 || B <= 0 || H <= 0 || W <= 0) return 0;
+  const PoolBnGrid g = pool_bn_grid(B, H, W, C);
+  return (int64_t)g.gx * g.gy;
+}
+#else
+int64_t nasseg_maxpool_bn_bwd_blocks(int B, int H, int W, int C, int K, int stride, int pad);
+#endif
+
+// y = maxpool3x3(scale*z + shift) (padding 1, stride 1 or 2; scale / shift null = identity); idx: uint8 winner
+// tap per output element (null when no backward will follow)
+int NASSEG_FN(maxpool_bn_fwd)(const act_t* z, const float* scale, const float* shift, act_t* y, uint8_t* idx,
+                              int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, void* stream) {
+  NASSEG_REQUIRE(C > 0 && C % 4 == 0 && stride > 0 && pad >= 0 && pad <= 2, "maxpool_bn_fwd: bad arguments");
+  const int64_t n4 = (int64_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3_bn_fwd_kernel, dim3(pool_grid(n4)), dim3(256), 0, (hipStream_t)stream, z, scale,
+                     shift, y, idx, B, H, W, C / 4, Ho, Wo, stride, pad);
+  NASSEG_LAUNCH_CHECK("maxpool_bn_fwd");
+  return NASSEG_OK;
+}
+
+// backward of the above w.r.t. the BatchNorm's output: g [B][H][W][C] and the rows
+// stats[blk][2][C] = {sum g, sum g*(z-mean)*invstd} for blk < nasseg_maxpool_bn_bwd_blocks(...) (the buffer
+// needs 64 rows more: nasseg_rows_sum)
+int NASSEG_FN(maxpool_bn_bwd)(const act_t* dy, const uint8_t* idx, const act_t* z, const float* mean,
+                              const float* invstd, act_t* g, float* stats, int B, int H, int W, int C, int Ho,
+                              int Wo, int stride, int pad, void* stream) {
+  NASSEG_REQUIRE(dy && idx && z && mean && invstd && g && stats, "maxpool_bn_bwd: null argument");
+  NASSEG_REQUIRE(nasseg_maxpool_bn_bwd_blocks(B, H, W, C, 3, stride, pad) > 0, "maxpool_bn_bwd: geometry not served");
+  const PoolBnGrid gr = pool_bn_grid(B, H, W, C);
+  hipLaunchKernelGGL(maxpool3_bn_bwd_kernel, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, dy, idx, z,
+                     mean, invstd, g, stats, B, H, W, C / 4, Ho, Wo, stride, pad);
+  NASSEG_LAUNCH_CHECK("maxpool_bn_bwd");
+  return NASSEG_OK;
+}
 
 // mode 0 = max (idx: uint8 [B][Ho][Wo][C] winner tap, may be null), 1 = avg
 int NASSEG_FN(pool_fwd)(int mode, const act_t* x, act_t* y, uint8_t* idx, int B, int H, int W, int C,

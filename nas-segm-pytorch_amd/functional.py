@@ -655,6 +655,8 @@ _PW_BWD_MIN_BYTES = 24 << 20
 # too small for a slab per CU it loses (320 -> 64 at 16x11x11: 170 / 22 us), hence the pixel floor
 _PW_BWD_WIDE = os.environ.get("NASSEG_PW_BWD_WIDE", "1") == "1"
 _PW_BWD_WIDE_MIN_PIXELS = 1 << 16
+# Pool's 1x1 conv + BatchNorm -> 3x3 max pooling as one node (csrc/pool.hip: nasseg_maxpool_bn_fwd / _bwd)
+FUSE_POOL_BN = os.environ.get("NASSEG_FUSE_POOL_BN", "1") != "0"
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
 FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
 # which pointwise forward / backward-data calls take the persistent kernel (include/nasseg.h:
@@ -857,21 +859,48 @@ class _ConvChain(torch.autograd.Function):
                 cur, pend = z, (scale, shift, act)
             else:
                 cur, pend = z, None
-        if pend is not None:
+        pool = cfg[3] if len(cfg) > 3 else None
+        pool_idx = None
+        pool_fused = False
+        if pool is not None:
+            # Pool (src/nn/layer_factory.py:161-178): 3x3 max pooling behind the chain's last BatchNorm.  With the
+            # BatchNorm still pending (training, or inference under autograd) the pooling applies it as it loads
+            # the raw conv output - the normalised map is never written; folded into the conv's epilogue
+            # (inference without grad) the pooling reads the finished map.  One node either way.
+            pk, ps, pp = pool
+            B, N, Hc, Wc = cur.shape
+            Hp, Wp = conv_out_size(Hc, pk, ps, pp, 1), conv_out_size(Wc, pk, ps, pp, 1)
+            if Hp <= 0 or Wp <= 0:
+                raise NassegError("max pooling output would be empty")
+            psc, psh = (pend[0], pend[1]) if pend is not None else (None, None)
+            if (res is not None or (pend is not None and pend[2] != ACT_NONE) or pk != 3 or pp != 1
+                    or ps not in (1, 2)):
+                raise NassegError("conv_chain: the pooled tail serves conv + BatchNorm -> 3x3 max pooling only")
+            y = _new(cur, B, N, Hp, Wp)
+            if needs_grad:
+                pool_idx = torch.empty((B, Hp, Wp, N), device=cur.device, dtype=torch.uint8)
+            lib.call(_k("nasseg_maxpool_bn_fwd", cur), ptr(cur), ptr(psc), ptr(psh), ptr(y), ptr(pool_idx), B, Hc,
+                     Wc, N, Hp, Wp, ps, pp, s)
+            pool_fused = pend is not None
+        elif pend is not None:
             y = _affine_act(cur, pend[0], pend[1], res, pend[2])
         elif res is not None:
             y = _axpby(cur, res, None, None)
         else:
             y = cur
         if needs_grad:
+            if pool is not None:
+                saved.append(pool_idx)
             ctx.save_for_backward(*[t for t in saved])
-            ctx.meta = (cfg, meta, residual is not None, tuple(x.shape))
+            ctx.meta = (cfg, meta, residual is not None, tuple(x.shape), pool_fused)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        cfg, meta, has_res, x_shape = ctx.meta
+        cfg, meta, has_res, x_shape = ctx.meta[:4]
+        pool_fused = ctx.meta[4] if len(ctx.meta) > 4 else False
         in_act0, ops = cfg[:2]
+        pool = cfg[3] if len(cfg) > 3 else None
         sv = ctx.saved_tensors
         fused_in0 = bool(in_act0)  # (forward packed op 0's backward-data weights for the fused kernel)
         g = _cl(dy)
@@ -881,6 +910,25 @@ class _ConvChain(torch.autograd.Function):
         dres = g if (has_res and ctx.needs_input_grad[2]) else None
         pre = None  # BatchNorm-backward partial rows of op i that came with g (fused dgrad epilogue)
         g_masked = False  # g already carries act' of op i's activation (with or without such rows)
+        if pool is not None:
+            # the pooled tail: gradient w.r.t. the last BatchNorm's output by a gather over the windows -
+            # together with that BatchNorm's backward sums when the pooling had applied it on load
+            pk, ps, pp = pool
+            pool_idx = sv[7 * n_ops]
+            z_last, st_last = sv[7 * (n_ops - 1) + 3], sv[7 * (n_ops - 1) + 4]
+            Bp, Np, Hz, Wz = z_last.shape
+            g_full = _new(g, Bp, Np, Hz, Wz)
+            nb = lib.query("nasseg_maxpool_bn_bwd_blocks", Bp, Hz, Wz, Np, pk, ps, pp) if pool_fused else 0
+            if nb > 0:
+                part = _ws(g, (nb + 64) * 2 * Np)
+                lib.call(_k("nasseg_maxpool_bn_bwd", g), ptr(g), ptr(pool_idx), ptr(z_last), ptr(st_last[0:Np]),
+                         ptr(st_last[Np:2 * Np]), ptr(g_full), ptr(part), Bp, Hz, Wz, Np, g.shape[2], g.shape[3],
+                         ps, pp, s)
+                pre = (part, nb)
+            else:
+                lib.call(_k("nasseg_pool_bwd", g), 0, ptr(g), ptr(pool_idx), ptr(g_full), Bp, Hz, Wz, Np,
+                         g.shape[2], g.shape[3], pk, ps, pp, s)
+            g = g_full
         masked_in0 = False  # dx already multiplied by in_act0' (one-kernel pointwise backward of op 0)
         for i in range(n_ops - 1, -1, -1):
             kind, stride, pad, dil, has_bn, act, training, momentum, eps = ops[i]
@@ -1059,9 +1107,11 @@ class _ConvChain(torch.autograd.Function):
         return (None, dx, dres) + tuple(grads)
 
 
-def conv_chain(x, ops, in_act0=ACT_NONE, residual=None):
+def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None):
     """ops: list of (weight, stride, padding, dilation, depthwise, bn, act) where ``bn`` is None
-    or (gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps)."""
+    or (gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps).
+    pool = (3, stride, 1): 3x3 max pooling of the chain's output (which must end in a BatchNorm without
+    activation and without residual - the reference's Pool op), fused behind it."""
     cfg_ops, tensors = [], []
     for weight, stride, padding, dilation, depthwise, bn, act in ops:
         if bn is None:
@@ -1073,7 +1123,10 @@ def conv_chain(x, ops, in_act0=ACT_NONE, residual=None):
             cfg_ops.append(("dw" if depthwise else "dense", int(stride), int(padding), int(dilation),
                             True, int(act), bool(training), float(momentum), float(eps)))
             tensors.extend([weight, gamma, beta, rm, rv, nbt if training else None])
-    return _ConvChain.apply((int(in_act0), tuple(cfg_ops), torch.is_grad_enabled()), x, residual, *tensors)
+    cfg = (int(in_act0), tuple(cfg_ops), torch.is_grad_enabled())
+    if pool is not None:
+        cfg = cfg + ((int(pool[0]), int(pool[1]), int(pool[2])),)
+    return _ConvChain.apply(cfg, x, residual, *tensors)
 
 
 def conv_bn_act(x, weight, gamma, beta, running_mean, running_var, num_batches_tracked, training,

@@ -110,6 +110,10 @@ class Pool(nn.Module):
             raise ValueError("Unknown pooling method {}".format(mode))
 
     def forward(self, x):
+        if isinstance(self.pool, MaxPool2d) and self.pool.kernel_size == 3 and self.pool.padding == 1 and \
+                self.pool.stride in (1, 2):
+            # conv + BatchNorm -> max pooling as ONE node: the pooling applies the BatchNorm on load
+            return self.conv1x1(x, pool=(3, self.pool.stride, 1))
         return self.pool(self.conv1x1(x))
 
 

@@ -126,7 +126,7 @@ def _bn_fusable(m):
             and m.weight is not None)
 
 
-def run_fused(modules, x, residual=None, relu_in=False):
+def run_fused(modules, x, residual=None, relu_in=False, pool=None):
     """FusedSequential.forward over an explicit list of modules - also used to run SEVERAL fused
     sequences as one (MobileNetV2 merges consecutive blocks whose boundary nobody else reads: the
     normalised activation between them is then never written).  relu_in: the input is to be passed
@@ -170,7 +170,11 @@ def run_fused(modules, x, residual=None, relu_in=False):
             res = None
             if not res_used and i == n:
                 res, res_used = residual, True
-            x = F.conv_chain(x, ops, in_act0, res)
+            tail = None
+            if (pool is not None and i == n and res is None and ops[-1][5] is not None and ops[-1][6] == F.ACT_NONE
+                    and F.FUSE_POOL_BN):
+                tail, pool = pool, None  # (3x3 max pooling fused behind the chain's last BatchNorm)
+            x = F.conv_chain(x, ops, in_act0, res, tail)
         elif isinstance(m, BatchNorm2d):
             act, step = F.ACT_NONE, 1
             if isinstance(nxt, nn.ReLU6):
@@ -187,6 +191,8 @@ def run_fused(modules, x, residual=None, relu_in=False):
             i += 1
     if not res_used:
         x = F.add(x, residual)
+    if pool is not None:  # (not fusable: the plain pooling op)
+        x = F.max_pool2d(x, pool[0], pool[1], pool[2])
     return x
 
 
@@ -196,8 +202,9 @@ class FusedSequential(nn.Sequential):
     between the convs, residual add in the last normalise pass).  Nested FusedSequentials
     (SepConv stages) are flattened first; anything else runs module by module."""
 
-    def forward(self, x, residual=None, relu_in=False):
+    def forward(self, x, residual=None, relu_in=False, pool=None):
         """relu_in: the input is to be passed through a ReLU first (the decoders' F.relu ahead of
-        pre_clf); fused into the first conv's loads when the sequence starts with a conv."""
-        return run_fused(self._modules.values(), x, residual, relu_in)
+        pre_clf); fused into the first conv's loads when the sequence starts with a conv.
+        pool = (3, stride, 1): 3x3 max pooling of the result (Pool), fused behind a final BatchNorm."""
+        return run_fused(self._modules.values(), x, residual, relu_in, pool)
 

@@ -93,6 +93,10 @@ def build(kind):
         return OPS["sep_conv_5x5_dil6"](32, 32, 1, True, 2).op, 32, (64, 128), False, False
     if kind == "dil3x3":
         return OPS["dil_conv_3x3"](32, 32, 1, True).op, 32, (64, 128), False, False
+    if kind == "pool_s2":          # Pool: 1x1 conv + BatchNorm -> 3x3 max pooling as one node (24 -> 48, stride 2)
+        return OPS["max_pool_3x3"](24, 48, 2, True), 24, (64, 127), False, False
+    if kind == "pool_s1":
+        return OPS["max_pool_3x3"](32, 32, 1, True), 32, (33, 64), False, False
     raise KeyError(kind)
 
 
@@ -107,6 +111,8 @@ EXPECT = {  # entry points the case is there for (fp32 names)
     "sep5x5_24_64": ("nasseg_sepconv_fwd",),
     "sep5x5_dil6": ("nasseg_sepconv_fwd",),
     "dil3x3": (),
+    "pool_s2": ("nasseg_maxpool_bn_fwd", "nasseg_maxpool_bn_bwd"),
+    "pool_s1": ("nasseg_maxpool_bn_fwd", "nasseg_maxpool_bn_bwd"),
 }
 
 
@@ -120,7 +126,14 @@ def test_fused_chain_kernels_against_torch_cpu_autograd(kind, monkeypatch):
     mods = mods.to(DEV).train()
     x0 = rnd(1, cin, H, W, seed=2)
     xc = x0.clone().requires_grad_(cin > 3)  # (the image needs no gradient: the stem's flat weight-gradient path)
-    yc = torch_reference(ref._modules.values(), xc, xc if residual else None, relu_in)
+    is_pool = kind.startswith("pool")
+
+    def reference(mod, xin):
+        if is_pool:  # (src/nn/layer_factory.py:161-178: conv1x1 + BN, then nn.MaxPool2d)
+            return nn.MaxPool2d.forward(mod.pool, torch_reference(mod.conv1x1._modules.values(), xin))
+        return torch_reference(mod._modules.values(), xin, xin if residual else None, relu_in)
+
+    yc = reference(ref, xc)
     cot = rnd(*yc.shape, seed=3)
     yc.backward(cot)
     # the same graph in float64: how far the fp32 REFERENCE is from the exact result bounds how close
@@ -128,7 +141,7 @@ def test_fused_chain_kernels_against_torch_cpu_autograd(kind, monkeypatch):
     # analytically zero gradient, and the reference's value for it is rounding noise of sums over
     # 32768 pixels (2e-4 here, next to gradients of order 1)
     xd = x0.double().requires_grad_(cin > 3)
-    yd = torch_reference(ref64._modules.values(), xd, xd if residual else None, relu_in)
+    yd = reference(ref64, xd)
     yd.backward(cot.double())
 
     seen = []
@@ -140,7 +153,7 @@ def test_fused_chain_kernels_against_torch_cpu_autograd(kind, monkeypatch):
 
     monkeypatch.setattr(Fm.lib, "call", rec)
     xg = dev(x0.clone()).requires_grad_(cin > 3)
-    yg = mods(xg, residual=xg if residual else None, relu_in=relu_in)
+    yg = mods(xg) if is_pool else mods(xg, residual=xg if residual else None, relu_in=relu_in)
     yg.backward(dev(cot))
     monkeypatch.setattr(Fm.lib, "call", orig)
     for name in EXPECT[kind]:
