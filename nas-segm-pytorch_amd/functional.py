@@ -655,6 +655,8 @@ _PW_BWD_MIN_BYTES = 24 << 20
 # too small for a slab per CU it loses (320 -> 64 at 16x11x11: 170 / 22 us), hence the pixel floor
 _PW_BWD_WIDE = os.environ.get("NASSEG_PW_BWD_WIDE", "1") == "1"
 _PW_BWD_WIDE_MIN_PIXELS = 1 << 16
+# ConcatReduce's BatchNorm -> ReLU -> 1x1 conv on the concat slab as one node (the conv normalises on load)
+FUSE_BN_RELU_CONV = os.environ.get("NASSEG_FUSE_BN_RELU_CONV", "1") != "0"
 # Pool's 1x1 conv + BatchNorm -> 3x3 max pooling as one node (csrc/pool.hip: nasseg_maxpool_bn_fwd / _bwd)
 FUSE_POOL_BN = os.environ.get("NASSEG_FUSE_POOL_BN", "1") != "0"
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
@@ -1456,6 +1458,88 @@ def cat_bn_relu_conv(x, y, gamma, beta, running_mean, running_var, num_batches_t
     """conv1x1(relu(batch_norm(cat([x, y], 1)))) without materialising the concatenation."""
     return _CatBNReluConv.apply(x, y, gamma, beta, running_mean, running_var, num_batches_tracked,
                                 weight, bool(training), float(momentum), float(eps), torch.is_grad_enabled())
+
+
+class _BNReluConv(torch.autograd.Function):
+    """BatchNorm -> ReLU -> 1x1 conv over ONE tensor (ConcatReduce's tail on its concat slab,
+    src/nn/layer_factory.py:369-382, below the size where the slab is avoided altogether): the conv applies
+    the BatchNorm on load, so the normalised slab is never written; backward, the backward-data kernel emits
+    the masked gradient with the BatchNorm-backward sums (no reduction pass over gradient and slab).  The
+    single-input form of _CatBNReluConv."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, nbt, weight, training, momentum, eps, grad_mode):
+        x = _cl(x)
+        B, C, H, W = x.shape
+        N = weight.shape[0]
+        w = weight.contiguous()
+        if tuple(w.shape) != (N, C, 1, 1):
+            raise NassegError("bn_relu_conv: shapes {} {}".format(tuple(x.shape), tuple(w.shape)))
+        M = B * H * W
+        s = current_stream()
+        needs_grad = grad_mode and any(ctx.needs_input_grad)
+        stats = _vec(x, 4 * C)  # mean | invstd | scale | shift
+        mean, invstd, scale, shift = stats[0:C], stats[C:2 * C], stats[2 * C:3 * C], stats[3 * C:]
+        if training:
+            if M <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input "
+                                 "size {}".format((B, C, H, W)))
+            ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
+            lib.call(_k("nasseg_bn_stats", x), ptr(x), C, M, C, float(eps), float(momentum), ptr(gamma), ptr(beta),
+                     ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(rm), ptr(rv), ptr(nbt), ptr(ws), s)
+        else:
+            lib.call("nasseg_bn_eval_params", C, float(eps), ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+                     ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
+        items = [(w, 0)]
+        if needs_grad:
+            items.append((w, 1))
+        packed = _pack_many(x, items)
+        out = _new(x, B, N, H, W)
+        lib.call(_k("nasseg_conv_fwd", x), ptr(x), C, ptr(packed[0]), ptr(out), N, ptr(scale), ptr(shift),
+                 ACT_RELU, None, None, ACT_NONE, None, 0, B, H, W, C, H, W, N, 1, 1, 1, 0, 1, 0, None, s)
+        if needs_grad:
+            ctx.save_for_backward(x, stats, packed[1], w)
+            ctx.cfg = (bool(training), N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, stats, wb, w = ctx.saved_tensors
+        training, N = ctx.cfg
+        dout = _cl(dout)
+        B, C, H, W = x.shape
+        M = B * H * W
+        s = current_stream()
+        mean, invstd, scale, shift = stats[0:C], stats[C:2 * C], stats[2 * C:3 * C], stats[3 * C:]
+        need_dx = ctx.needs_input_grad[0]
+        need_bn = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx = dgamma = dbeta = dw = None
+        if need_dx or need_bn:
+            nb = lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, C, N, 2)
+            g = _new(x, B, C, H, W)
+            part = _ws(x, (nb + 64) * 2 * C)
+            lib.call(_k("nasseg_conv_bwd_data_bn", dout), ptr(dout), N, ptr(wb), ptr(g), C, ptr(x), C, ptr(scale),
+                     ptr(shift), ptr(mean), ptr(invstd), ACT_RELU, B, H, W, N, H, W, C, 1, 1, 1, 0, 1, ptr(part), s)
+            sums = _vec(x, 2 * C)
+            lib.call("nasseg_rows_sum", ptr(part), nb, 2 * C, ptr(sums), s)
+            if ctx.needs_input_grad[1]:
+                dgamma = sums[C:2 * C]
+            if ctx.needs_input_grad[2]:
+                dbeta = sums[0:C]
+            if need_dx:
+                dx = torch.empty_like(x)
+                lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(x), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                         ptr(sums), M, C, int(training), ACT_NONE, ptr(dx), s)
+        if ctx.needs_input_grad[6]:
+            dw = _dense_wgrad(x, dout, w, scale, shift, ACT_RELU, (B, H, W, C, H, W, N, 1, 1, 1, 0, 1))
+        return dx, dgamma, dbeta, None, None, None, dw, None, None, None, None
+
+
+def bn_relu_conv(x, gamma, beta, running_mean, running_var, num_batches_tracked, weight, training,
+                 momentum=0.1, eps=1e-5):
+    """conv1x1(relu(batch_norm(x))) without materialising the normalised tensor."""
+    return _BNReluConv.apply(x, gamma, beta, running_mean, running_var, num_batches_tracked, weight,
+                             bool(training), float(momentum), float(eps), torch.is_grad_enabled())
 
 
 # ---------------------------------------------------------------------------

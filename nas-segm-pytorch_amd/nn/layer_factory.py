@@ -13,6 +13,8 @@ default initialisation order and the documented quirks of the reference
 kept.  Every leaf runs on gfx950 through ``functional``; nothing falls back to
 ATen.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -280,7 +282,7 @@ class ParamSum(nn.Module):
 
 # elements per input above which ConcatReduce skips the concatenation (F.cat_bn_relu_conv);
 # below it the slab path's fewer launches win
-_SPLIT_CAT_MIN = 1 << 24
+_SPLIT_CAT_MIN = int(os.environ.get("NASSEG_SPLIT_CAT_MIN", 1 << 24))
 
 
 class ConcatReduce(nn.Module):
@@ -310,6 +312,12 @@ class ConcatReduce(nn.Module):
                                       bn.num_batches_tracked if bn.training else None, conv.weight,
                                       bn.training, bn.momentum, bn.eps)
         z = F.concat_resize([x, y], x.shape[2:])
+        if (F.FUSE_BN_RELU_CONV and (2 * C) % 4 == 0 and conv.weight.shape[0] % 4 == 0 and bn.affine
+                and bn.momentum is not None and bn.track_running_stats):
+            # the slab's BatchNorm + ReLU are applied by the 1x1 conv as it loads (no normalised slab)
+            return F.bn_relu_conv(z, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked if bn.training else None, conv.weight, bn.training,
+                                  bn.momentum, bn.eps)
         return self.conv1x1(z)
 
 
