@@ -253,6 +253,13 @@ int nasseg_maxpool_bn_bwd(const float* dy, const uint8_t* idx, const float* z, c
 /* ---- resize: nn.Upsample / F.interpolate bilinear, align_corners=False
  * (layer_factory.py:190-194,338-350; micro_decoders.py:11-25,46-51; trainer.py:141-143,
  * 236-238,245-247; inference.py:58-60) and nearest label resize (trainer.py:43-49,236-238). */
+/* One input of ConcatReduce's torch.cat (src/nn/layer_factory.py:369-382, after Adapt's resize :316-350)
+ * written into its channel slice of the slab: resized when its size differs, the producer's still pending
+ * BatchNorm + activation applied as the source is loaded, and the slab's own BatchNorm statistics emitted
+ * as per-workgroup rows for nasseg_bn_finalize (the slab is not read again for them). */
+int64_t nasseg_cat_src_blocks(int B, int Ho, int Wo, int C);
+int nasseg_cat_src_fwd(const float* x, const float* scale, const float* shift, int act, float* y, int64_t ldy,
+                       int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo, void* stream);
 int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream);
 /* nn.Upsample(size, mode="bilinear", align_corners=True) - src/kd/rf_lw/model_lw_v2.py:258,266,274 (the
@@ -338,6 +345,9 @@ int nasseg_bf16_maxpool_bn_fwd(const nasseg_bf16_t* z, const float* scale, const
 int nasseg_bf16_maxpool_bn_bwd(const nasseg_bf16_t* dy, const uint8_t* idx, const nasseg_bf16_t* z, const float* mean,
                                const float* invstd, nasseg_bf16_t* g, float* stats, int B, int H, int W, int C, int Ho,
                                int Wo, int stride, int pad, void* stream);
+int nasseg_bf16_cat_src_fwd(const nasseg_bf16_t* x, const float* scale, const float* shift, int act, nasseg_bf16_t* y,
+                            int64_t ldy, int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                            void* stream);
 int nasseg_bf16_bilinear_ac_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                 void* stream);
 int nasseg_bf16_bilinear_bwd(const nasseg_bf16_t* dy, int64_t lddy, int dyoff, nasseg_bf16_t* dx, int B, int Hi, int Wi,

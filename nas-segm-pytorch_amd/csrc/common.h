@@ -165,7 +165,10 @@ __device__ __forceinline__ float4 mul4(float4 a, float4 b) {
 #define NASSEG_RP_SLICES 32
 __device__ __forceinline__ int rp_elem() { return threadIdx.x % NASSEG_RP_ELEMS; }
 __device__ __forceinline__ int rp_slice() { return threadIdx.x / NASSEG_RP_ELEMS; }
-__device__ __forceinline__ double reduce_partials16(const float* __restrict__ partial, int nblk,
+// SLICES = 32: 256 threads (the default); SLICES = 128: 1024 threads, for 512 < nblk <= 4096 rows in ONE launch
+// (1024 rows per round of 8 loads in flight) instead of a two-level finalisation in two.
+template <int SLICES>
+__device__ __forceinline__ double reduce_partials_n(const float* __restrict__ partial, int nblk,
                                                     int64_t per, int64_t e, bool valid,
                                                     double (*red)[NASSEG_RP_ELEMS + 1]) {
   const int slice = rp_slice();
@@ -175,22 +178,40 @@ __device__ __forceinline__ double reduce_partials16(const float* __restrict__ pa
   for (int i = 0; i < 8; ++i) s[i] = 0.0;
   if (valid) {
     int b = slice;
-    for (; b + 7 * NASSEG_RP_SLICES < nblk; b += 8 * NASSEG_RP_SLICES) {
+    for (; b + 7 * SLICES < nblk; b += 8 * SLICES) {
       float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = partial[(int64_t)(b + i * NASSEG_RP_SLICES) * per + e];
+      for (int i = 0; i < 8; ++i) v[i] = partial[(int64_t)(b + i * SLICES) * per + e];
 #pragma unroll
       for (int i = 0; i < 8; ++i) s[i] += (double)v[i];
     }
-    for (; b < nblk; b += NASSEG_RP_SLICES) s[0] += (double)partial[(int64_t)b * per + e];
+    for (; b < nblk; b += SLICES) s[0] += (double)partial[(int64_t)b * per + e];
   }
   red[slice][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
+  if (SLICES > 32) {
+    // fixed-order tree: 32 threads per element add SLICES / 32 slices each, then slice 0 adds the 32
+    double part = 0.0;
+    if (slice < 32) {
+#pragma unroll
+      for (int i = 0; i < SLICES / 32; ++i) part += red[slice * (SLICES / 32) + i][el];
+    }
+    __syncthreads();
+    if (slice < 32) red[slice][el] = part;
+    __syncthreads();
+  }
   double tot = 0.0;
   if (slice == 0) {
 #pragma unroll
-    for (int i = 0; i < NASSEG_RP_SLICES; ++i) tot += red[i][el];
+    for (int i = 0; i < 32; ++i) tot += red[i][el];
   }
   __syncthreads();
   return tot;
 }
+__device__ __forceinline__ double reduce_partials16(const float* __restrict__ partial, int nblk,
+                                                    int64_t per, int64_t e, bool valid,
+                                                    double (*red)[NASSEG_RP_ELEMS + 1]) {
+  return reduce_partials_n<NASSEG_RP_SLICES>(partial, nblk, per, e, valid, red);
+}
+#define NASSEG_RP_WIDE_SLICES 128  // (1024 threads)
+#define NASSEG_RP_WIDE_MAX_ROWS 4096

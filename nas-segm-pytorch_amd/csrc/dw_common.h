@@ -78,13 +78,15 @@ inline StripCfg strip_cfg(int stride, int dil) {
 // C4 > 256 only the groups present in the workgroup are written (caller zero-fills).
 // Lanes l, l+C4, l+2*C4, ... of a wave hold the same group: lanes < C4 gather them with
 // shuffles in a fixed order; the four waves then meet in LDS indexed by channel group.
+// ld: distance between out[t] and out[t + 1] (0 = C: the dense [NV][C] row; wider when the C channels are a
+// slice of a row over more channels - a concatenation slab's statistics).
 template <int NV, int RB>
 __device__ __forceinline__ void block_reduce_groups(float4 (&acc)[NV], float4 (*red)[4][64],
-                                                    float* __restrict__ out, int base, int C4) {
+                                                    float* __restrict__ out, int base, int C4, int ld = 0) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int C = C4 * 4;
+  const int C = ld ? ld : C4 * 4;
   const int nown = C4 < 64 ? C4 : 64;
   if (C4 < 64) {
 #pragma unroll

@@ -207,18 +207,19 @@ __global__ __launch_bounds__(256) void colred_finalize(const float* __restrict__
 
 // BatchNorm statistics finalisation (training mode).  Normalisation uses the
 // biased variance, running_var the unbiased one (torch semantics).
-// grid: ceil(C/16) workgroups of 256 threads.
-__global__ __launch_bounds__(256) void bn_stats_finalize(
+// grid: ceil(C/8) workgroups of 8 * SLICES threads (SLICES = 128: up to 4096 partial rows in one launch).
+template <int SLICES>
+__global__ __launch_bounds__(8 * SLICES) void bn_stats_finalize_t(
     const float* __restrict__ partial, int nblk, int C, double M, float eps, float momentum,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
     float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* nbt) {
-  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
+  __shared__ double red[SLICES][NASSEG_RP_ELEMS + 1];
   const int c = blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = c < C;
   const int64_t per = 2 * (int64_t)C;
-  const double s0 = reduce_partials16(partial, nblk, per, c, valid, red);
-  const double s1 = reduce_partials16(partial, nblk, per, (int64_t)C + c, valid, red);
+  const double s0 = reduce_partials_n<SLICES>(partial, nblk, per, c, valid, red);
+  const double s1 = reduce_partials_n<SLICES>(partial, nblk, per, (int64_t)C + c, valid, red);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   if (!valid || rp_slice() != 0) return;
   const double mu = s0 / M;
@@ -254,6 +255,23 @@ __global__ void bn_eval_params(int C, float eps, const float* __restrict__ gamma
   invstd[c] = is;
   scale[c] = g * is;
   shift[c] = bt - running_mean[c] * g * is;
+}
+
+// sum groups of `rows_per_group` consecutive rows of partial[nblk][per] into out[g][per]
+// (fp32 out, fp64 accumulation, fixed order): first level of a two-level finalisation
+template <int SLICES>
+__global__ __launch_bounds__(8 * SLICES) void rows_group_sum_t(const float* __restrict__ partial,
+                                                               float* __restrict__ out, int nblk, int64_t per,
+                                                               int rows_per_group) {
+  __shared__ double red[SLICES][NASSEG_RP_ELEMS + 1];
+  const int g = blockIdx.y;
+  const int r0 = g * rows_per_group;
+  int nr = nblk - r0;
+  if (nr > rows_per_group) nr = rows_per_group;
+  const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
+  const bool valid = e < per;
+  const double s = reduce_partials_n<SLICES>(partial + (int64_t)r0 * per, nr, per, e, valid, red);
+  if (valid && rp_slice() == 0) out[(int64_t)g * per + e] = (float)s;
 }
 
 struct RedPlan {
@@ -347,7 +365,7 @@ int NASSEG_FN(bn_stats)(const act_t* x, int64_t ldx, int64_t M, int C, float eps
   q.a = x; q.lda = ldx; q.S = 1; q.R = M; q.C = C; q.partial = ws;
   int rc = launch_colred<RED_SUMSQ>(q, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws, q.nblk, C,
+  hipLaunchKernelGGL(bn_stats_finalize_t<NASSEG_RP_SLICES>, dim3(cdiv(C, NASSEG_RP_ELEMS)), dim3(256), 0, s, ws, q.nblk, C,
                      (double)M, eps, momentum, gamma, beta, mean, invstd, scale, shift,
                      running_mean, running_var, num_batches_tracked);
   NASSEG_LAUNCH_CHECK("bn_stats_finalize");
@@ -355,22 +373,6 @@ int NASSEG_FN(bn_stats)(const act_t* x, int64_t ldx, int64_t M, int C, float eps
 }
 
 #if NASSEG_FP32_ONLY
-// sum groups of `rows_per_group` consecutive rows of partial[nblk][per] into out[g][per]
-// (fp32 out, fp64 accumulation, fixed order): first level of a two-level finalisation
-__global__ __launch_bounds__(256) void rows_group_sum(const float* __restrict__ partial,
-                                                      float* __restrict__ out, int nblk, int64_t per,
-                                                      int rows_per_group) {
-  __shared__ double red[NASSEG_RP_SLICES][NASSEG_RP_ELEMS + 1];
-  const int g = blockIdx.y;
-  const int r0 = g * rows_per_group;
-  int nr = nblk - r0;
-  if (nr > rows_per_group) nr = rows_per_group;
-  const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
-  const bool valid = e < per;
-  const double s = reduce_partials16(partial + (int64_t)r0 * per, nr, per, e, valid, red);
-  if (valid && rp_slice() == 0) out[(int64_t)g * per + e] = (float)s;
-}
-
 // BatchNorm statistics from per-workgroup partials [nblk][2][C] (sum, sum of squares) that a
 // producer kernel (nasseg_conv_fwd with `stats`) already wrote: same outputs as nasseg_bn_stats.
 // The buffer must have room for 64 more rows ([nblk + 64][2][C]) - scratch of the first level
@@ -382,20 +384,28 @@ int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float e
   NASSEG_REQUIRE(M > 0 && C > 0 && nblk > 0, "bn_finalize: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const float* src = partial;
+  if (nblk > 512 && nblk <= NASSEG_RP_WIDE_MAX_ROWS) {
+    // one launch of 1024-thread workgroups (1024 rows per round of loads) instead of two levels
+    hipLaunchKernelGGL(bn_stats_finalize_t<NASSEG_RP_WIDE_SLICES>, dim3(cdiv(C, NASSEG_RP_ELEMS)),
+                       dim3(8 * NASSEG_RP_WIDE_SLICES), 0, s, src, nblk, C, (double)M, eps, momentum, gamma, beta,
+                       mean, invstd, scale, shift, running_mean, running_var, num_batches_tracked);
+    NASSEG_LAUNCH_CHECK("bn_stats_finalize");
+    return NASSEG_OK;
+  }
   if (nblk > 512) {
     // two levels: 64 groups of rows first (rows [nblk, nblk+64) of the buffer are scratch)
     const int G = 64;
     const int rpg = cdiv(nblk, G);
     const int groups = cdiv(nblk, rpg);
     float* lvl = const_cast<float*>(partial) + (int64_t)nblk * 2 * C;
-    hipLaunchKernelGGL(rows_group_sum, dim3(cdiv(2 * C, NASSEG_RP_ELEMS), groups), dim3(256), 0, s,
-                       partial, lvl, nblk, (int64_t)2 * C, rpg);
+    hipLaunchKernelGGL(rows_group_sum_t<NASSEG_RP_SLICES>, dim3(cdiv(2 * C, NASSEG_RP_ELEMS), groups), dim3(256), 0,
+                       s, partial, lvl, nblk, (int64_t)2 * C, rpg);
     NASSEG_LAUNCH_CHECK("rows_group_sum");
     src = lvl;
     nblk = groups;
   }
-  hipLaunchKernelGGL(bn_stats_finalize, dim3(cdiv(C, NASSEG_RP_ELEMS)), dim3(256), 0, s, src, nblk, C,
-                     (double)M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean,
+  hipLaunchKernelGGL(bn_stats_finalize_t<NASSEG_RP_SLICES>, dim3(cdiv(C, NASSEG_RP_ELEMS)), dim3(256), 0, s, src,
+                     nblk, C, (double)M, eps, momentum, gamma, beta, mean, invstd, scale, shift, running_mean,
                      running_var, num_batches_tracked);
   NASSEG_LAUNCH_CHECK("bn_stats_finalize");
   return NASSEG_OK;
@@ -409,19 +419,25 @@ int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* 
   NASSEG_REQUIRE(nblk > 0 && cols > 0 && partial && out, "rows_sum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const float* src = partial;
+  if (nblk > 512 && nblk <= NASSEG_RP_WIDE_MAX_ROWS) {
+    hipLaunchKernelGGL(rows_group_sum_t<NASSEG_RP_WIDE_SLICES>, dim3(cdiv(cols, NASSEG_RP_ELEMS), 1),
+                       dim3(8 * NASSEG_RP_WIDE_SLICES), 0, s, src, out, nblk, (int64_t)cols, nblk);
+    NASSEG_LAUNCH_CHECK("rows_group_sum");
+    return NASSEG_OK;
+  }
   if (nblk > 512) {
     const int G = 64;
     const int rpg = cdiv(nblk, G);
     const int groups = cdiv(nblk, rpg);
     float* lvl = const_cast<float*>(partial) + (int64_t)nblk * cols;
-    hipLaunchKernelGGL(rows_group_sum, dim3(cdiv(cols, NASSEG_RP_ELEMS), groups), dim3(256), 0, s,
+    hipLaunchKernelGGL(rows_group_sum_t<NASSEG_RP_SLICES>, dim3(cdiv(cols, NASSEG_RP_ELEMS), groups), dim3(256), 0, s,
                        partial, lvl, nblk, (int64_t)cols, rpg);
     NASSEG_LAUNCH_CHECK("rows_group_sum");
     src = lvl;
     nblk = groups;
   }
-  hipLaunchKernelGGL(rows_group_sum, dim3(cdiv(cols, NASSEG_RP_ELEMS), 1), dim3(256), 0, s, src, out,
-                     nblk, (int64_t)cols, nblk);
+  hipLaunchKernelGGL(rows_group_sum_t<NASSEG_RP_SLICES>, dim3(cdiv(cols, NASSEG_RP_ELEMS), 1), dim3(256), 0, s, src,
+                     out, nblk, (int64_t)cols, nblk);
   NASSEG_LAUNCH_CHECK("rows_group_sum");
   return NASSEG_OK;
 }

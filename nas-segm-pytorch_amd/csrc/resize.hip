@@ -14,6 +14,7 @@
 // Backward is a gather over the destination footprint of each source pixel
 // (deterministic; no atomics).
 #include "common.h"
+#include "dw_common.h"
 
 namespace {
 
@@ -125,6 +126,81 @@ __device__ __forceinline__ float4 keep_if4(float4 v, bool ok) {
   v.z = __uint_as_float(__float_as_uint(v.z) & m);
   v.w = __uint_as_float(__float_as_uint(v.w) & m);
   return v;
+}
+
+// One input of a channel concatenation, written into its slice [yoff, yoff + C) of the slab y (row stride
+// ldy): bilinearly resized (align_corners=False) when RESIZE, with the producer's pending BatchNorm +
+// activation - act(scale*v + shift), scale / shift null = none - applied to the SOURCE values as they are
+// loaded (the producer never wrote its normalised output), and the per-workgroup sums of the slab's own
+// BatchNorm statistics: stats[blk][0][c] = sum y, stats[blk][1][c] = sum y*y over what this workgroup wrote
+// (rows of 2*ldy floats, columns yoff + c; null = none).
+// workgroup (bx, by): lanes = 256 consecutive (x, channel-group) positions of an output row, rows by,
+// by + gdy, ... of the flattened (image, row) axis - the layout block_reduce_groups sums over.
+template <bool RESIZE>
+__global__ __launch_bounds__(256) void cat_src_fwd_kernel(const act_t* __restrict__ x, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int act,
+                                                          act_t* __restrict__ y, int64_t ldy, int yoff,
+                                                          float* __restrict__ stats, int B, int Hi, int Wi, int C4,
+                                                          int Ho, int Wo, float sh, float sw) {
+  __shared__ float4 sred[2][4][64];
+  const int C = C4 * 4;
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 256;
+  const int pos = base + tid;
+  const bool live = pos < Wo * C4;
+  const int ox = live ? pos / C4 : 0;
+  const int c4 = live ? pos - ox * C4 : 0;
+  const float4 sc = scale ? lda4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sf = shift ? lda4(shift + c4 * 4) : f4zero();
+  const Lin lx = lin_coeff(ox, sw, Wi, Wo);
+  float4 ssum[2] = {f4zero(), f4zero()};
+  const int R = B * Ho;
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const int b = r / Ho, oy = r - b * Ho;
+    float4 o;
+    if (RESIZE) {
+      const Lin ly = lin_coeff(oy, sh, Hi, Ho);
+      const act_t* xb = x + (int64_t)b * Hi * Wi * C + c4 * 4;
+      const float4 v00 = act_apply4(fma4(lda4(xb + ((int64_t)ly.i0 * Wi + lx.i0) * C), sc, sf), act);
+      const float4 v01 = act_apply4(fma4(lda4(xb + ((int64_t)ly.i0 * Wi + lx.i1) * C), sc, sf), act);
+      const float4 v10 = act_apply4(fma4(lda4(xb + ((int64_t)ly.i1 * Wi + lx.i0) * C), sc, sf), act);
+      const float4 v11 = act_apply4(fma4(lda4(xb + ((int64_t)ly.i1 * Wi + lx.i1) * C), sc, sf), act);
+      o.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+      o.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+      o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+      o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+    } else {
+      o = act_apply4(fma4(lda4(x + ((int64_t)r * Wo + ox) * C + c4 * 4), sc, sf), act);
+    }
+    if (live) sta4(y + ((int64_t)r * Wo + ox) * ldy + yoff + c4 * 4, o);
+#ifdef NASSEG_BF16
+    o = make_float4(bf16_to_f32(f32_to_bf16(o.x)), bf16_to_f32(f32_to_bf16(o.y)), bf16_to_f32(f32_to_bf16(o.z)),
+                    bf16_to_f32(f32_to_bf16(o.w)));  // (the statistics of what a pass over the slab would read)
+#endif
+    o = keep_if4(o, live);
+    ssum[0] = add4(ssum[0], o);
+    ssum[1] = fma4(o, o, ssum[1]);
+  }
+  if (stats) {
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    block_reduce_groups<2, 2>(ssum, sred, stats + (size_t)blk * 2 * ldy + yoff, base, C4, (int)ldy);
+  }
+}
+
+struct CatGrid {
+  int gx, gy;
+};
+inline CatGrid cat_grid(int B, int Ho, int Wo, int C) {
+  CatGrid g;
+  g.gx = cdiv(Wo * (C / 4), 256);
+  const int64_t rows = (int64_t)B * Ho;
+  // ~2048 workgroups on large maps, <= 512 (one-level finalisation of the statistics rows) on small ones
+  int64_t gy = ((int64_t)g.gx * rows >= 8192 ? 2048 : 512) / g.gx;
+  if (gy > rows / 2) gy = rows / 2;
+  if (gy < 1) gy = 1;
+  if (gy > 65535) gy = 65535;
+  g.gy = (int)gy;
+  return g;
 }
 
 // conservative destination range [lo, hi] whose source footprint can touch index i
@@ -285,6 +361,40 @@ int NASSEG_FN(bilinear_ac_fwd)(const act_t* x, act_t* y, int B, int Hi, int Wi, 
   hipLaunchKernelGGL(bilinear_fwd_kernel<true>, dim3(rs_grid((int64_t)B * Ho * Wo * (C / 4))), dim3(256), 0,
                      (hipStream_t)stream, x, y, (int64_t)C, 0, B, Hi, Wi, C / 4, Ho, Wo, sh, sw, 0);
   NASSEG_LAUNCH_CHECK("bilinear_ac_fwd");
+  return NASSEG_OK;
+}
+
+#if NASSEG_FP32_ONLY
+// rows of statistics nasseg_cat_src_fwd writes for a slab of this geometry (C: channels of ONE input; every
+// input of the slab must have the same C for the rows to line up); 0: geometry not served
+int64_t nasseg_cat_src_blocks(int B, int Ho, int Wo, int C) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || C % 4 || C / 4 > 256) return 0;
+  const CatGrid g = cat_grid(B, Ho, Wo, C);
+  return (int64_t)g.gx * g.gy;
+}
+#else
+int64_t nasseg_cat_src_blocks(int B, int Ho, int Wo, int C);
+#endif
+
+// one input x [B][Hi][Wi][C] of a concatenation -> y[b,oy,ox, yoff:yoff+C] (row stride ldy), resized when
+// (Hi, Wi) != (Ho, Wo); scale / shift / act: the producer's pending BatchNorm + activation (null / 0 = none);
+// stats: null or [nasseg_cat_src_blocks(B, Ho, Wo, C) + 64][2][ldy] floats - columns yoff.. of every row are
+// written ({sum, sum of squares} of the slice, for nasseg_bn_finalize over the whole slab)
+int NASSEG_FN(cat_src_fwd)(const act_t* x, const float* scale, const float* shift, int act, act_t* y, int64_t ldy,
+                           int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo, void* stream) {
+  NASSEG_REQUIRE(x && y && nasseg_cat_src_blocks(B, Ho, Wo, C) > 0 && Hi > 0 && Wi > 0 && ldy % 4 == 0 &&
+                     yoff % 4 == 0 && yoff + C <= ldy && (!scale == !shift),
+                 "cat_src_fwd: bad arguments");
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  const CatGrid g = cat_grid(B, Ho, Wo, C);
+  hipStream_t s = (hipStream_t)stream;
+  if (Hi == Ho && Wi == Wo)
+    hipLaunchKernelGGL(cat_src_fwd_kernel<false>, dim3(g.gx, g.gy), dim3(256), 0, s, x, scale, shift, act, y, ldy, yoff,
+                       stats, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+  else
+    hipLaunchKernelGGL(cat_src_fwd_kernel<true>, dim3(g.gx, g.gy), dim3(256), 0, s, x, scale, shift, act, y, ldy, yoff,
+                       stats, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+  NASSEG_LAUNCH_CHECK("cat_src_fwd");
   return NASSEG_OK;
 }
 

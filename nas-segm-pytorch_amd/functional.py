@@ -659,6 +659,8 @@ _PW_BWD_WIDE_MIN_PIXELS = 1 << 16
 FUSE_BN_RELU_CONV = os.environ.get("NASSEG_FUSE_BN_RELU_CONV", "1") != "0"
 # Pool's 1x1 conv + BatchNorm -> 3x3 max pooling as one node (csrc/pool.hip: nasseg_maxpool_bn_fwd / _bwd)
 FUSE_POOL_BN = os.environ.get("NASSEG_FUSE_POOL_BN", "1") != "0"
+# ConcatReduce as one node fed by its producers' raw conv outputs (_CatReduce / Pending)
+FUSE_CAT_REDUCE = os.environ.get("NASSEG_FUSE_CAT_REDUCE", "1") != "0"
 # depthwise -> pointwise stages of a chain (SepConv, DilConv) as one kernel (csrc/sepconv.hip)
 FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch exists for A/B measurements)
 # which pointwise forward / backward-data calls take the persistent kernel (include/nasseg.h:
@@ -862,6 +864,8 @@ class _ConvChain(torch.autograd.Function):
             else:
                 cur, pend = z, None
         pool = cfg[3] if len(cfg) > 3 else None
+        defer = len(cfg) > 4 and cfg[4]
+        tail = None
         pool_idx = None
         pool_fused = False
         if pool is not None:
@@ -885,7 +889,12 @@ class _ConvChain(torch.autograd.Function):
                      Wc, N, Hp, Wp, ps, pp, s)
             pool_fused = pend is not None
         elif pend is not None:
-            y = _affine_act(cur, pend[0], pend[1], res, pend[2])
+            if defer and res is None and pend[0] is not None:
+                # deferred tail: the consumer applies act(scale*z + shift) as it loads (Pending below); what
+                # comes back in backward is still the gradient w.r.t. the BatchNorm's activated output
+                y, tail = cur, (pend[0], pend[1])
+            else:
+                y = _affine_act(cur, pend[0], pend[1], res, pend[2])
         elif res is not None:
             y = _axpby(cur, res, None, None)
         else:
@@ -895,10 +904,15 @@ class _ConvChain(torch.autograd.Function):
                 saved.append(pool_idx)
             ctx.save_for_backward(*[t for t in saved])
             ctx.meta = (cfg, meta, residual is not None, tuple(x.shape), pool_fused)
+        if defer:
+            if tail is None:
+                return y, None, None
+            ctx.mark_non_differentiable(tail[0], tail[1])
+            return y, tail[0], tail[1]
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_unused):
         cfg, meta, has_res, x_shape = ctx.meta[:4]
         pool_fused = ctx.meta[4] if len(ctx.meta) > 4 else False
         in_act0, ops = cfg[:2]
@@ -1109,11 +1123,57 @@ class _ConvChain(torch.autograd.Function):
         return (None, dx, dres) + tuple(grads)
 
 
-def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None):
+class Pending(object):
+    """A conv chain's raw last conv output whose BatchNorm (+ activation) is still to be applied:
+    y = act(scale[c]*z + shift[c]).  A consumer that understands it (cat_reduce) applies the tail as it loads z -
+    the normalised map is never written; anything else calls materialize().  Backward contract: the gradient
+    that flows back into ``z``'s slot is the one w.r.t. y (the chain's backward is the same either way: it has
+    always received dL/dy and redone mask and BatchNorm backward from z)."""
+
+    __slots__ = ("z", "scale", "shift", "act")
+
+    def __init__(self, z, scale, shift, act):
+        self.z, self.scale, self.shift, self.act = z, scale, shift, int(act)
+
+    shape = property(lambda self: self.z.shape)
+    dtype = property(lambda self: self.z.dtype)
+    device = property(lambda self: self.z.device)
+
+    def size(self, *a):
+        return self.z.size(*a)
+
+    def dim(self):
+        return self.z.dim()
+
+    def materialize(self):
+        return _ApplyTail.apply(self.z, self.scale, self.shift, self.act)
+
+
+class _ApplyTail(torch.autograd.Function):
+    """The pass a deferred tail avoided: y = act(scale*z + shift); the gradient goes through unchanged (see
+    Pending: z's slot carries dL/dy)."""
+
+    @staticmethod
+    def forward(ctx, z, scale, shift, act):
+        return _affine_act(_cl(z), scale, shift, None, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None, None
+
+
+def materialize(x):
+    """A plain tensor from a tensor or a Pending."""
+    return x.materialize() if isinstance(x, Pending) else x
+
+
+def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None, defer_tail=False):
     """ops: list of (weight, stride, padding, dilation, depthwise, bn, act) where ``bn`` is None
     or (gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps).
     pool = (3, stride, 1): 3x3 max pooling of the chain's output (which must end in a BatchNorm without
-    activation and without residual - the reference's Pool op), fused behind it."""
+    activation and without residual - the reference's Pool op), fused behind it.
+    defer_tail: return a Pending (raw conv output + the last BatchNorm's scale/shift + activation) instead of
+    the normalised output when the chain ends in a BatchNorm that is not folded (no residual, no pooling)."""
     cfg_ops, tensors = [], []
     for weight, stride, padding, dilation, depthwise, bn, act in ops:
         if bn is None:
@@ -1128,6 +1188,9 @@ def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None):
     cfg = (int(in_act0), tuple(cfg_ops), torch.is_grad_enabled())
     if pool is not None:
         cfg = cfg + ((int(pool[0]), int(pool[1]), int(pool[2])),)
+    elif defer_tail and residual is None and cfg_ops and cfg_ops[-1][4]:
+        y, scale, shift = _ConvChain.apply(cfg + (None, True), x, residual, *tensors)
+        return y if scale is None else Pending(y, scale, shift, cfg_ops[-1][5])
     return _ConvChain.apply(cfg, x, residual, *tensors)
 
 
@@ -1533,6 +1596,133 @@ class _BNReluConv(torch.autograd.Function):
         if ctx.needs_input_grad[6]:
             dw = _dense_wgrad(x, dout, w, scale, shift, ACT_RELU, (B, H, W, C, H, W, N, 1, 1, 1, 0, 1))
         return dx, dgamma, dbeta, None, None, None, dw, None, None, None, None
+
+
+class _CatReduce(torch.autograd.Function):
+    """ConcatReduce whole (src/nn/layer_factory.py:369-382 with Adapt's resize, :338-350) as ONE node:
+    cat(x, y) -> BatchNorm(2C) -> ReLU -> 1x1 conv.  Each input is written into its half of the slab by one
+    launch (nasseg_cat_src_fwd) that resizes it when its size differs, applies the producer's pending
+    BatchNorm + activation on load (Pending: the producers' normalised outputs are never written) and emits
+    the slab's BatchNorm statistics as partial rows - no pass over the slab for them; the conv applies the
+    slab's BatchNorm + ReLU on load (_BNReluConv).  Backward: _BNReluConv's, then the slab gradient's halves
+    go back as slices / through the resize's transpose; the gradient returned for a Pending input is the one
+    w.r.t. its activated output (the producer chain's backward takes it from there).
+
+    cfg = (Ho, Wo, act_x, act_y, training, momentum, eps, grad_mode)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, y, xsc, xsh, ysc, ysh, gamma, beta, rm, rv, nbt, weight):
+        Ho, Wo, act_x, act_y, training, momentum, eps, grad_mode = cfg
+        x, y = _cl(x), _cl(y)
+        B, C = x.shape[0], x.shape[1]
+        Ct = 2 * C
+        N = weight.shape[0]
+        w = weight.contiguous()
+        if y.shape[0] != B or y.shape[1] != C or tuple(w.shape) != (N, Ct, 1, 1):
+            raise NassegError("cat_reduce: shapes {} {} {}".format(tuple(x.shape), tuple(y.shape), tuple(w.shape)))
+        M = B * Ho * Wo
+        s = current_stream()
+        needs_grad = grad_mode and any(ctx.needs_input_grad)
+        stats = _vec(x, 4 * Ct)  # mean | invstd | scale | shift
+        mean, invstd, scale, shift = stats[0:Ct], stats[Ct:2 * Ct], stats[2 * Ct:3 * Ct], stats[3 * Ct:]
+        if training and M <= 1:
+            raise ValueError("Expected more than 1 value per channel when training, got input "
+                             "size {}".format((B, Ct, Ho, Wo)))
+        slab = _new(x, B, Ct, Ho, Wo)
+        nblk = lib.query("nasseg_cat_src_blocks", B, Ho, Wo, C)
+        part = _ws(x, (nblk + 64) * 2 * Ct) if training else None
+        for off, (t, sc, sh, act) in enumerate(((x, xsc, xsh, act_x), (y, ysc, ysh, act_y))):
+            lib.call(_k("nasseg_cat_src_fwd", t), ptr(t), ptr(sc), ptr(sh), act if sc is not None else ACT_NONE,
+                     ptr(slab), Ct, off * C, ptr(part), B, t.shape[2], t.shape[3], C, Ho, Wo, s)
+        if training:
+            lib.call("nasseg_bn_finalize", ptr(part), nblk, M, Ct, float(eps), float(momentum), ptr(gamma),
+                     ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(rm), ptr(rv), ptr(nbt), s)
+        else:
+            lib.call("nasseg_bn_eval_params", Ct, float(eps), ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+                     ptr(mean), ptr(invstd), ptr(scale), ptr(shift), s)
+        items = [(w, 0)]
+        if needs_grad:
+            items.append((w, 1))
+        packed = _pack_many(x, items)
+        out = _new(x, B, N, Ho, Wo)
+        lib.call(_k("nasseg_conv_fwd", slab), ptr(slab), Ct, ptr(packed[0]), ptr(out), N, ptr(scale), ptr(shift),
+                 ACT_RELU, None, None, ACT_NONE, None, 0, B, Ho, Wo, Ct, Ho, Wo, N, 1, 1, 1, 0, 1, 0, None, s)
+        if needs_grad:
+            ctx.save_for_backward(slab, stats, packed[1], w)
+            ctx.cfg = (bool(training), N, tuple(x.shape), tuple(y.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        slab, stats, wb, w = ctx.saved_tensors
+        training, N, x_shape, y_shape = ctx.cfg
+        dout = _cl(dout)
+        B, Ct, Ho, Wo = slab.shape
+        C = Ct // 2
+        M = B * Ho * Wo
+        s = current_stream()
+        mean, invstd, scale, shift = stats[0:Ct], stats[Ct:2 * Ct], stats[2 * Ct:3 * Ct], stats[3 * Ct:]
+        need_in = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        need_bn = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
+        dx = dy = dgamma = dbeta = dw = None
+        if need_in or need_bn:
+            nb = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, Ct, N, 2)
+            g = _new(slab, B, Ct, Ho, Wo)
+            part = _ws(slab, (nb + 64) * 2 * Ct)
+            lib.call(_k("nasseg_conv_bwd_data_bn", dout), ptr(dout), N, ptr(wb), ptr(g), Ct, ptr(slab), Ct,
+                     ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ACT_RELU, B, Ho, Wo, N, Ho, Wo, Ct, 1, 1, 1, 0,
+                     1, ptr(part), s)
+            sums = _vec(slab, 2 * Ct)
+            lib.call("nasseg_rows_sum", ptr(part), nb, 2 * Ct, ptr(sums), s)
+            if ctx.needs_input_grad[7]:
+                dgamma = sums[Ct:2 * Ct]
+            if ctx.needs_input_grad[8]:
+                dbeta = sums[0:Ct]
+            if need_in:
+                dslab = torch.empty_like(slab)
+                lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(slab), ptr(scale), ptr(shift), ptr(mean),
+                         ptr(invstd), ptr(sums), M, Ct, int(training), ACT_NONE, ptr(dslab), s)
+                grads = []
+                for off, (need, shp) in enumerate(((ctx.needs_input_grad[1], x_shape),
+                                                   (ctx.needs_input_grad[2], y_shape))):
+                    if not need:
+                        grads.append(None)
+                        continue
+                    _, _, H, W = shp
+                    d = _new(slab, B, C, H, W)
+                    if (H, W) == (Ho, Wo):
+                        lib.call(_k("nasseg_chan_copy", dslab), ptr(dslab), Ct, off * C, ptr(d), C, 0, None, 0, 0,
+                                 M, C, ACT_NONE, ACT_NONE, s)
+                    else:
+                        nws = lib.query("nasseg_bilinear_bwd_workspace", B, H, W, C, Ho, Wo)
+                        lib.call(_k("nasseg_bilinear_bwd", dslab), ptr(dslab), Ct, off * C, ptr(d), B, H, W, C, Ho,
+                                 Wo, ptr(_ws(dslab, nws)) if nws else None, s)
+                    grads.append(d)
+                dx, dy = grads
+        if ctx.needs_input_grad[12]:
+            dw = _dense_wgrad(slab, dout, w, scale, shift, ACT_RELU, (B, Ho, Wo, Ct, Ho, Wo, N, 1, 1, 1, 0, 1))
+        return None, dx, dy, None, None, None, None, dgamma, dbeta, None, None, None, dw
+
+
+def cat_reduce_ok(x, y, weight):
+    """Shapes _CatReduce serves: both inputs of the same width C (a multiple of 4; what Adapt leaves), a 1x1
+    conv over 2C channels with N % 4 == 0 outputs."""
+    C = x.shape[1]
+    return (FUSE_CAT_REDUCE and C == y.shape[1] and C % 4 == 0 and C // 4 <= 256 and weight.shape[0] % 4 == 0
+            and x.shape[0] == y.shape[0])
+
+
+def cat_reduce(x, y, size, gamma, beta, running_mean, running_var, num_batches_tracked, weight, training,
+               momentum=0.1, eps=1e-5):
+    """conv1x1(relu(batch_norm(cat(resize(x), resize(y))))) with ``size`` the common (H, W); x / y: tensors or
+    Pending outputs of conv chains (their BatchNorm + activation are then applied as the slab is written)."""
+    parts = []
+    for t in (x, y):
+        parts.append((t.z, t.scale, t.shift, t.act) if isinstance(t, Pending) else (t, None, None, ACT_NONE))
+    cfg = (int(size[0]), int(size[1]), parts[0][3], parts[1][3], bool(training), float(momentum), float(eps),
+           torch.is_grad_enabled())
+    return _CatReduce.apply(cfg, parts[0][0], parts[1][0], parts[0][1], parts[0][2], parts[1][1], parts[1][2],
+                            gamma, beta, running_mean, running_var, num_batches_tracked, weight)
 
 
 def bn_relu_conv(x, gamma, beta, running_mean, running_var, num_batches_tracked, weight, training,

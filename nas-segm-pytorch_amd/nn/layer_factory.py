@@ -147,8 +147,8 @@ class DilConv(nn.Module):
             BatchNorm2d(C_out, affine=affine),
         )
 
-    def forward(self, x):
-        return self.op(x)
+    def forward(self, x, defer_tail=False):
+        return self.op(x, defer_tail=defer_tail)
 
 
 class SepConv(nn.Module):
@@ -171,8 +171,10 @@ class SepConv(nn.Module):
             self.op.add_module("sep_{}".format(idx), stage)
             width = C_out
 
-    def forward(self, x):
-        return self.op(x)
+    def forward(self, x, defer_tail=False):
+        """defer_tail: the last BatchNorm + ReLU may come back pending (functional.Pending) for an aggregation
+        op that applies it as it loads (ConcatReduce)."""
+        return self.op(x, defer_tail=defer_tail)
 
 
 class Skip(nn.Module):
@@ -258,11 +260,23 @@ class Adapt(nn.Module):
             self.conv1 = conv_bn_relu(C_in1, C_out, 1, 1, 0)
         self.larger = larger
 
-    def forward(self, x1, x2):
+    def convs(self, x1, x2, defer_tail=False):
+        """The channel adaptation alone (ConcatReduce resizes as it writes its slab)."""
         if self.C_in0 != self.C_out:
-            x1 = self.conv0(x1)
+            x1 = self.conv0(F.materialize(x1), defer_tail=defer_tail)
         if self.C_in1 != self.C_out:
-            x2 = self.conv1(x2)
+            x2 = self.conv1(F.materialize(x2), defer_tail=defer_tail)
+        return x1, x2
+
+    def target_size(self, x1, x2):
+        """(H, W) resize() brings both maps to."""
+        s1, s2 = tuple(x1.size()[2:]), tuple(x2.size()[2:])
+        if s1 == s2:
+            return s1
+        return (s1 if s1 > s2 else s2) if self.larger else (s1 if s1 < s2 else s2)
+
+    def forward(self, x1, x2):
+        x1, x2 = self.convs(F.materialize(x1), F.materialize(x2))
         return resize(x1, x2, self.larger)
 
 
@@ -280,9 +294,10 @@ class ParamSum(nn.Module):
         return F.param_sum(x, y, self.a, self.b)
 
 
-# elements per input above which ConcatReduce skips the concatenation (F.cat_bn_relu_conv);
-# below it the slab path's fewer launches win
-_SPLIT_CAT_MIN = int(os.environ.get("NASSEG_SPLIT_CAT_MIN", 1 << 24))
+# elements per input above which ConcatReduce skips the concatenation (F.cat_bn_relu_conv: no 2C-wide slab in
+# memory); below it the one-node slab path (F.cat_reduce) wins - measured on the headline step with the
+# threshold at 2^24 / 2^25 / 2^26 elements: 251.2 / 252.6 / 254.1 img/s (its largest input has 2^25)
+_SPLIT_CAT_MIN = int(os.environ.get("NASSEG_SPLIT_CAT_MIN", 1 << 27))
 
 
 class ConcatReduce(nn.Module):
@@ -297,21 +312,31 @@ class ConcatReduce(nn.Module):
             Conv2d(2 * C_out, C_out, 1, stride=1, padding=0, bias=False),
         )
 
+    accepts_pending = True  # (inputs may be functional.Pending: a producer's BatchNorm + ReLU still to apply)
+
     def forward(self, x, y):
-        x, y = self.adapt(x, y)
-        if tuple(x.shape[2:]) != tuple(y.shape[2:]):
-            # torch.cat would refuse; same exception class so try_except scores the candidate 0
-            raise RuntimeError("Sizes of tensors must match except in dimension 1")
         bn, conv = self.conv1x1[0], self.conv1x1[2]
+        plain_bn = bn.affine and bn.momentum is not None and bn.track_running_stats
+        x, y = self.adapt.convs(x, y, defer_tail=plain_bn)
+        size = self.adapt.target_size(x, y)
         C = x.shape[1]
-        if (x.shape[0] * x.shape[2] * x.shape[3] * C >= _SPLIT_CAT_MIN and C % 4 == 0
-                and conv.weight.shape[0] % 4 == 0 and bn.affine and bn.momentum is not None
-                and bn.track_running_stats and tuple(x.shape) == tuple(y.shape)):
+        split = (x.shape[0] * size[0] * size[1] * C >= _SPLIT_CAT_MIN and C % 4 == 0
+                 and conv.weight.shape[0] % 4 == 0 and plain_bn and x.shape[1] == y.shape[1])
+        if not split and plain_bn and F.cat_reduce_ok(x, y, conv.weight):
+            # one node: both inputs written into the slab (resized, their producers' pending BatchNorm + ReLU
+            # applied on load) with the slab's statistics, then the 1x1 conv normalising as it loads
+            return F.cat_reduce(x, y, size, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn.num_batches_tracked if bn.training else None, conv.weight, bn.training,
+                                bn.momentum, bn.eps)
+        x, y = F.materialize(x), F.materialize(y)
+        if split:
             # large maps: no slab, two pointwise convs with the BatchNorm halves applied on load
+            x, y = resize(x, y, self.adapt.larger)
             return F.cat_bn_relu_conv(x, y, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                       bn.num_batches_tracked if bn.training else None, conv.weight,
                                       bn.training, bn.momentum, bn.eps)
-        z = F.concat_resize([x, y], x.shape[2:])
+        # (the input of the other size is interpolated straight into its half of the slab)
+        z = F.concat_resize([x, y], size)
         if (F.FUSE_BN_RELU_CONV and (2 * C) % 4 == 0 and conv.weight.shape[0] % 4 == 0 and bn.affine
                 and bn.momentum is not None and bn.track_running_stats):
             # the slab's BatchNorm + ReLU are applied by the 1x1 conv as it loads (no normalised slab)
@@ -319,6 +344,14 @@ class ConcatReduce(nn.Module):
                                   bn.num_batches_tracked if bn.training else None, conv.weight, bn.training,
                                   bn.momentum, bn.eps)
         return self.conv1x1(z)
+
+
+def run_op(op, x, defer_tail=False):
+    """op(x); with defer_tail the ops that end in conv + BatchNorm (+ ReLU) - SepConv, DilConv, the dense
+    conv_bn_relu ops - may return a functional.Pending for an aggregation op that ``accepts_pending``."""
+    if defer_tail and isinstance(op, (SepConv, DilConv, FusedSequential)):
+        return op(x, defer_tail=True)
+    return op(x)
 
 
 # ---------------------------------------------------------------------------

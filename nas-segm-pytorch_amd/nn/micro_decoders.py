@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from .. import functional as F
 from ..rl.genotypes import AGG_OP_NAMES, OP_NAMES, OP_NAMES_WACV
-from .layer_factory import AGG_OPS, OPS, conv3x3, conv_bn_relu
+from .layer_factory import AGG_OPS, OPS, conv3x3, conv_bn_relu, run_op
 from .modules import TREE_VERSION, FusedSequential
 
 
@@ -321,8 +321,11 @@ class TemplateDecoder(nn.Module):
             assert isinstance(pos, list), "Must be list"
             left, right = maps[pos[0]], maps[pos[1]]
             for rep in range(n_rep):
-                a = ops[rep * 3](left)
-                b = ops[rep * 3 + 1](right)
+                # (an aggregation op that applies its producers' last BatchNorm + ReLU as it loads gets their
+                #  raw conv outputs: the normalised maps are never written)
+                defer = getattr(ops[rep * 3 + 2], "accepts_pending", False)
+                a = run_op(ops[rep * 3], left, defer)
+                b = run_op(ops[rep * 3 + 1], right, defer)
                 merged = ops[rep * 3 + 2](a, b)
                 # the next repeat consumes (previous right input, previous output)
                 left, right = right, merged

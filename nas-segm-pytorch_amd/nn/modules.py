@@ -126,12 +126,14 @@ def _bn_fusable(m):
             and m.weight is not None)
 
 
-def run_fused(modules, x, residual=None, relu_in=False, pool=None):
+def run_fused(modules, x, residual=None, relu_in=False, pool=None, defer_tail=False):
     """FusedSequential.forward over an explicit list of modules - also used to run SEVERAL fused
     sequences as one (MobileNetV2 merges consecutive blocks whose boundary nobody else reads: the
     normalised activation between them is then never written).  relu_in: the input is to be passed
     through a ReLU first (the decoders' F.relu ahead of pre_clf); fused into the first conv's loads
-    when the sequence starts with a conv."""
+    when the sequence starts with a conv.  defer_tail: when the sequence ENDS in a conv chain whose last
+    BatchNorm (+ activation) is still pending, return it as a functional.Pending for a consumer that applies
+    it on load (ConcatReduce) instead of writing the normalised map."""
     mods = _flatten(modules)
     n = len(mods)
     i = 0
@@ -174,7 +176,8 @@ def run_fused(modules, x, residual=None, relu_in=False, pool=None):
             if (pool is not None and i == n and res is None and ops[-1][5] is not None and ops[-1][6] == F.ACT_NONE
                     and F.FUSE_POOL_BN):
                 tail, pool = pool, None  # (3x3 max pooling fused behind the chain's last BatchNorm)
-            x = F.conv_chain(x, ops, in_act0, res, tail)
+            x = F.conv_chain(x, ops, in_act0, res, tail,
+                             defer_tail=defer_tail and i == n and res is None and pool is None and res_used)
         elif isinstance(m, BatchNorm2d):
             act, step = F.ACT_NONE, 1
             if isinstance(nxt, nn.ReLU6):
@@ -202,9 +205,9 @@ class FusedSequential(nn.Sequential):
     between the convs, residual add in the last normalise pass).  Nested FusedSequentials
     (SepConv stages) are flattened first; anything else runs module by module."""
 
-    def forward(self, x, residual=None, relu_in=False, pool=None):
+    def forward(self, x, residual=None, relu_in=False, pool=None, defer_tail=False):
         """relu_in: the input is to be passed through a ReLU first (the decoders' F.relu ahead of
         pre_clf); fused into the first conv's loads when the sequence starts with a conv.
         pool = (3, stride, 1): 3x3 max pooling of the result (Pool), fused behind a final BatchNorm."""
-        return run_fused(self._modules.values(), x, residual, relu_in, pool)
+        return run_fused(self._modules.values(), x, residual, relu_in, pool, defer_tail)
 

@@ -287,3 +287,168 @@ def test_a_failed_capture_leaves_batchnorm_and_gradients_untouched(monkeypatch):
     next(net.decoder.parameters()).requires_grad_(False)
     s3 = _segmenter_stepper(net, other, t2, oe, od, 255, 3.0, 3.0, -1)
     assert s3 is not None and s3 is not s2
+
+
+# ---------------------------------------------------------------------------
+# ConcatReduce as one node fed by its producers' pending BatchNorm + ReLU (functional._CatReduce / Pending)
+# ---------------------------------------------------------------------------
+def _op_reference(op, x):
+    """torch.nn forward of an OPS module (src/nn/layer_factory.py:161-265)"""
+    if hasattr(op, "pool"):
+        return nn.MaxPool2d.forward(op.pool, torch_reference(op.conv1x1._modules.values(), x))
+    return torch_reference(op.op._modules.values(), x)
+
+
+def _cell_reference(cell, x1, x2):
+    """op1(x1), op2(x2) -> Adapt (1x1 conv + BN + ReLU where widths differ, then the bilinear resize to the
+    larger / smaller of the two sizes, src/nn/layer_factory.py:316-350) -> cat -> BN -> ReLU -> 1x1 conv
+    (:369-382), all through torch.nn / torch.nn.functional on the CPU"""
+    op1, op2, agg = cell
+    a, b = _op_reference(op1, x1), _op_reference(op2, x2)
+    ad = agg.adapt
+    if ad.C_in0 != ad.C_out:
+        a = torch_reference(ad.conv0._modules.values(), a)
+    if ad.C_in1 != ad.C_out:
+        b = torch_reference(ad.conv1._modules.values(), b)
+    s1, s2 = tuple(a.shape[2:]), tuple(b.shape[2:])
+    if s1 != s2:
+        first = (s1 > s2) if ad.larger else (s1 < s2)
+        if first:
+            b = torch.nn.functional.interpolate(b, size=s1, mode="bilinear", align_corners=False)
+        else:
+            a = torch.nn.functional.interpolate(a, size=s2, mode="bilinear", align_corners=False)
+    return torch_reference(agg.conv1x1._modules.values(), torch.cat([a, b], 1))
+
+
+def _build_cell(kind):
+    from nas_segm_amd.nn.layer_factory import AGG_OPS, OPS
+
+    torch.manual_seed(13)
+    if kind == "sep_sep_down":     # the headline decoder's cell: 128 x 256 and 32 x 64 maps meet at the smaller
+        return nn.ModuleList([OPS["sep_conv_3x3"](32, 32, 1, True, 2), OPS["sep_conv_5x5"](32, 32, 1, True, 2),
+                              AGG_OPS["cat"](32, 32, 32, True, 2, False)]), (32, (64, 128)), (32, (16, 32))
+    if kind == "sep_dil_up":       # ... at the larger; a DilConv (BatchNorm without ReLU) on the small map
+        return nn.ModuleList([OPS["sep_conv_3x3"](24, 24, 1, True, 1), OPS["dil_conv_3x3"](24, 24, 1, True),
+                              AGG_OPS["cat"](24, 24, 24, True, 1, True)]), (24, (33, 65)), (24, (9, 17))
+    if kind == "pool_sep_same":    # a finished tensor (Pool) next to a pending one, same size: no resize
+        return nn.ModuleList([OPS["max_pool_3x3"](32, 32, 1, True), OPS["sep_conv_3x3"](32, 32, 1, True, 1),
+                              AGG_OPS["cat"](32, 32, 32, True, 1, True)]), (32, (32, 64)), (32, (32, 64))
+    if kind == "adapt_conv":       # widths differ: Adapt's 1x1 conv + BN + ReLU is the pending producer
+        return nn.ModuleList([OPS["sep_conv_3x3"](24, 24, 1, True, 1), OPS["sep_conv_3x3"](48, 48, 1, True, 1),
+                              AGG_OPS["cat"](24, 48, 48, True, 1, True)]), (24, (32, 64)), (48, (16, 32))
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["sep_sep_down", "sep_dil_up", "pool_sep_same", "adapt_conv"])
+def test_cat_reduce_cell_against_torch_cpu_autograd(kind, monkeypatch):
+    from nas_segm_amd.nn.layer_factory import run_op
+
+    Fm = lower_thresholds(monkeypatch)
+    cell, (c1, hw1), (c2, hw2) = _build_cell(kind)
+    randomise(cell, 6)
+    ref = copy.deepcopy(cell).train()
+    ref64 = copy.deepcopy(cell).double().train()
+    cell = cell.to(DEV).train()
+    x1, x2 = rnd(2, c1, *hw1, seed=2), rnd(2, c2, *hw2, seed=4)
+    xs = [x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)]
+    yc = _cell_reference(ref, *xs)
+    cot = rnd(*yc.shape, seed=3)
+    yc.backward(cot)
+    xd = [x1.double().requires_grad_(True), x2.double().requires_grad_(True)]
+    yd = _cell_reference(ref64, *xd)
+    yd.backward(cot.double())
+
+    seen = []
+    orig = Fm.lib.call
+
+    def rec(fn, *a):
+        seen.append(fn)
+        return orig(fn, *a)
+
+    monkeypatch.setattr(Fm.lib, "call", rec)
+    xg = [dev(x1.clone()).requires_grad_(True), dev(x2.clone()).requires_grad_(True)]
+    assert cell[2].accepts_pending
+    a, b = run_op(cell[0], xg[0], True), run_op(cell[1], xg[1], True)
+    n_pending = sum(isinstance(t, Fm.Pending) for t in (a, b))
+    yg = cell[2](a, b)
+    yg.backward(dev(cot))
+    monkeypatch.setattr(Fm.lib, "call", orig)
+    assert seen.count("nasseg_cat_src_fwd") == 2, sorted(set(seen))
+    if kind != "adapt_conv":
+        assert n_pending == (1 if kind == "pool_sep_same" else 2)
+    # no pass of its own over the slab for the statistics, none over the producers' outputs to normalise them
+    assert "nasseg_bn_stats" not in seen
+    assert seen.count("nasseg_affine_act") == (1 if kind == "adapt_conv" else 0), seen.count("nasseg_affine_act")
+
+    def floor(ref32, ref64_):
+        return float((ref32.detach().double() - ref64_.detach()).abs().max())
+
+    assert_close(yg, yc, 1e-4 * float(yc.abs().max()) + 4 * floor(yc, yd), 1e-4, kind + ": output")
+    worst = {}
+    for i in range(2):
+        err = (xg[i].grad.cpu().double() - xs[i].grad.double()).abs()
+        tol = (1e-4 * float(xs[i].grad.abs().max()) + 1e-4 * xs[i].grad.abs().double()
+               + 4 * floor(xs[i].grad, xd[i].grad))
+        frac = float((err > tol).double().mean())
+        worst["dx{}_frac_off".format(i)] = frac
+        assert frac <= 2e-5, "{}: dx{}: {:.2e} of the elements off".format(kind, i, frac)
+    gp, cp, dp = dict(cell.named_parameters()), dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for k in cp:
+        fl = floor(cp[k].grad, dp[k].grad)
+        worst["d" + k] = float((gp[k].grad.cpu().double() - cp[k].grad.double()).abs().max()) / (
+            float(cp[k].grad.abs().max()) + 4 * fl + 1e-30)
+        assert_close(gp[k].grad, cp[k].grad, 1e-4 * float(cp[k].grad.abs().max()) + 4 * fl, 1e-4,
+                     "{}: gradient of {}".format(kind, k))
+    print("ANCHOR cell {:14s} ".format(kind) + " ".join("{}={:.1e}".format(k, v) for k, v in sorted(
+        worst.items(), key=lambda kv: -kv[1])[:6]))
+    gb, cb = dict(cell.named_buffers()), dict(ref.named_buffers())
+    for k in cb:
+        if cb[k].dtype == torch.int64:
+            assert int(gb[k]) == int(cb[k]), k
+        else:
+            assert_close(gb[k], cb[k], 1e-6, 2e-5, "{}: buffer {}".format(kind, k))
+    # the node and the module-by-module path (NASSEG_FUSE_CAT_REDUCE=0) agree as well
+    monkeypatch.setattr(Fm, "FUSE_CAT_REDUCE", False)
+    with torch.no_grad():
+        y_plain = cell[2](run_op(cell[0], xg[0], True), run_op(cell[1], xg[1], True))
+    assert_close(y_plain, yc, 1e-4 * float(yc.abs().max()) + 4 * floor(yc, yd), 1e-4, kind + ": unfused output")
+
+
+@pytest.mark.parametrize("nblk", [1, 37, 512, 513, 1024, 2047, 4096, 4097, 9000])
+def test_partial_row_finalisation_levels(nblk):
+    """nasseg_rows_sum / nasseg_bn_finalize over nblk partial rows: one 256-thread launch (<= 512 rows), one
+    1024-thread launch (<= 4096), two levels above - all against float64 sums of the same rows."""
+    Fm = F()
+    C = 24
+    g = torch.Generator().manual_seed(nblk)
+    rows = torch.randn(nblk, 2 * C, generator=g)
+    rows[:, C:] = rows[:, C:].abs() * 3 + rows[:, :C] ** 2  # (sum of squares >= square of sums / n)
+    part = torch.zeros(nblk + 64, 2 * C)
+    part[:nblk] = rows
+    part = part.to(DEV)
+    sums = torch.empty(2 * C, device=DEV)
+    s = Fm.current_stream()
+    Fm.lib.call("nasseg_rows_sum", Fm.ptr(part), nblk, 2 * C, Fm.ptr(sums), s)
+    want = rows.double().sum(0)
+    assert_close(sums, want, 1e-6 * float(want.abs().max()), 1e-6, "rows_sum")
+    part2 = torch.zeros(nblk + 64, 2 * C)
+    part2[:nblk] = rows
+    part2 = part2.to(DEV)
+    M = 16 * nblk
+    out = [torch.empty(C, device=DEV) for _ in range(4)]
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    Fm.lib.call("nasseg_bn_finalize", Fm.ptr(part2), nblk, M, C, 1e-5, 0.1, Fm.ptr(gd), Fm.ptr(bd),
+                Fm.ptr(out[0]), Fm.ptr(out[1]), Fm.ptr(out[2]), Fm.ptr(out[3]), Fm.ptr(rm), Fm.ptr(rv), Fm.ptr(nbt), s)
+    mu = want[:C] / M
+    var = (want[C:] / M - mu * mu).clamp_min(0)
+    istd = 1.0 / torch.sqrt(var + 1e-5)
+    assert_close(out[0], mu, 1e-6, 1e-5, "mean")
+    assert_close(out[1], istd, 1e-6, 1e-5, "invstd")
+    assert_close(out[2], gamma.double() * istd, 1e-6, 1e-5, "scale")
+    assert_close(out[3], beta.double() - mu * gamma.double() * istd, 1e-5, 1e-5, "shift")
+    assert_close(rm, 0.1 * mu, 1e-6, 1e-5, "running_mean")
+    assert_close(rv, 0.9 + 0.1 * var * M / (M - 1), 1e-6, 1e-5, "running_var")
+    assert int(nbt) == 1
