@@ -256,10 +256,16 @@ int nasseg_maxpool_bn_bwd(const float* dy, const uint8_t* idx, const float* z, c
 /* One input of ConcatReduce's torch.cat (src/nn/layer_factory.py:369-382, after Adapt's resize :316-350)
  * written into its channel slice of the slab: resized when its size differs, the producer's still pending
  * BatchNorm + activation applied as the source is loaded, and the slab's own BatchNorm statistics emitted
- * as per-workgroup rows for nasseg_bn_finalize (the slab is not read again for them). */
+ * as per-workgroup rows for nasseg_bn_finalize (the slab is not read again for them).  Backward
+ * (nasseg_cat_src_bwd): the slab BatchNorm's backward applied to one input's slice, masked with the pending
+ * activation's derivative, with the producer's BatchNorm-backward sums as per-workgroup rows. */
 int64_t nasseg_cat_src_blocks(int B, int Ho, int Wo, int C);
 int nasseg_cat_src_fwd(const float* x, const float* scale, const float* shift, int act, float* y, int64_t ldy,
                        int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo, void* stream);
+int nasseg_cat_src_bwd(const float* du, const float* slab, int64_t ld, int off, const float* sscale,
+                       const float* smean, const float* sinvstd, const float* sums, int train, const float* z,
+                       const float* tstats, int act, float* g, float* part, int B, int Ho, int Wo, int C,
+                       void* stream);
 int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream);
 /* nn.Upsample(size, mode="bilinear", align_corners=True) - src/kd/rf_lw/model_lw_v2.py:258,266,274 (the
@@ -348,6 +354,10 @@ int nasseg_bf16_maxpool_bn_bwd(const nasseg_bf16_t* dy, const uint8_t* idx, cons
 int nasseg_bf16_cat_src_fwd(const nasseg_bf16_t* x, const float* scale, const float* shift, int act, nasseg_bf16_t* y,
                             int64_t ldy, int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo,
                             void* stream);
+int nasseg_bf16_cat_src_bwd(const nasseg_bf16_t* du, const nasseg_bf16_t* slab, int64_t ld, int off, const float* sscale,
+                            const float* smean, const float* sinvstd, const float* sums, int train,
+                            const nasseg_bf16_t* z, const float* tstats, int act, nasseg_bf16_t* g, float* part, int B,
+                            int Ho, int Wo, int C, void* stream);
 int nasseg_bf16_bilinear_ac_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                 void* stream);
 int nasseg_bf16_bilinear_bwd(const nasseg_bf16_t* dy, int64_t lddy, int dyoff, nasseg_bf16_t* dx, int B, int Hi, int Wi,

@@ -187,6 +187,75 @@ __global__ __launch_bounds__(256) void cat_src_fwd_kernel(const act_t* __restric
   }
 }
 
+// Backward of one input of the concatenation: the slab BatchNorm's backward applied to this input's channel
+// slice - v = scale*(du - s0/M - xhat*s1/M) with du the ReLU-masked gradient nasseg_conv_bwd_data_bn left and
+// xhat from the slab itself (eval: v = scale*du) - written densely [rows][C] (the gradient w.r.t. this input at
+// the slab's size: final when the input had that size, the operand of nasseg_bilinear_bwd otherwise).  When the
+// input came in pending (z + the producer's BatchNorm statistics), v is multiplied by act'(tscale*z + tshift)
+// and the producer's BatchNorm-backward sums {sum g, sum g*(z - tmean)*tinvstd} are emitted per workgroup
+// (rows of 2*C floats): the producer's backward then needs no reduction pass over g and z.
+// Same workgroup layout as cat_src_fwd_kernel.
+__global__ __launch_bounds__(256) void cat_src_bwd_kernel(
+    const act_t* __restrict__ du, const act_t* __restrict__ slab, int64_t ld, int off,
+    const float* __restrict__ sscale, const float* __restrict__ smean, const float* __restrict__ sinvstd,
+    const float* __restrict__ sums, float invM, int train, const act_t* __restrict__ z,
+    const float* __restrict__ tstats, int act, act_t* __restrict__ g, float* __restrict__ part, int R, int Wo,
+    int C4) {
+  __shared__ float4 sred[2][4][64];
+  const int C = C4 * 4;
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 256;
+  const int pos = base + tid;
+  const bool live = pos < Wo * C4;
+  const int ox = live ? pos / C4 : 0;
+  const int c4 = live ? pos - ox * C4 : 0;
+  const int sc = off + c4 * 4;  // channel of the slab
+  const float4 ssc = lda4(sscale + sc), smu = lda4(smean + sc), sis = lda4(sinvstd + sc);
+  const float4 s0 = lda4(sums + sc), s1 = lda4(sums + ld + sc);
+  float4 tmu = f4zero(), tis = f4zero(), tsc = f4zero(), tsh = f4zero();
+  if (z) {
+    tmu = lda4(tstats + c4 * 4);
+    tis = lda4(tstats + C + c4 * 4);
+    tsc = lda4(tstats + 2 * C + c4 * 4);
+    tsh = lda4(tstats + 3 * C + c4 * 4);
+  }
+  float4 ssum[2] = {f4zero(), f4zero()};
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const int64_t pix = (int64_t)r * Wo + ox;
+    const float4 d = lda4(du + pix * ld + sc);
+    float4 v = d;
+    if (train) {
+      const float4 x = lda4(slab + pix * ld + sc);
+      v.x = d.x - s0.x * invM - (x.x - smu.x) * sis.x * s1.x * invM;
+      v.y = d.y - s0.y * invM - (x.y - smu.y) * sis.y * s1.y * invM;
+      v.z = d.z - s0.z * invM - (x.z - smu.z) * sis.z * s1.z * invM;
+      v.w = d.w - s0.w * invM - (x.w - smu.w) * sis.w * s1.w * invM;
+    }
+    v = mul4(v, ssc);
+    float4 xh = f4zero();
+    if (z) {
+      const float4 zv = lda4(z + pix * C + c4 * 4);
+      const float4 t = fma4(zv, tsc, tsh);
+      v = make_float4(v.x * act_mask(t.x, act), v.y * act_mask(t.y, act), v.z * act_mask(t.z, act),
+                      v.w * act_mask(t.w, act));
+      xh = make_float4((zv.x - tmu.x) * tis.x, (zv.y - tmu.y) * tis.y, (zv.z - tmu.z) * tis.z,
+                       (zv.w - tmu.w) * tis.w);
+    }
+    if (live) sta4(g + pix * C + c4 * 4, v);
+#ifdef NASSEG_BF16
+    v = make_float4(bf16_to_f32(f32_to_bf16(v.x)), bf16_to_f32(f32_to_bf16(v.y)), bf16_to_f32(f32_to_bf16(v.z)),
+                    bf16_to_f32(f32_to_bf16(v.w)));  // (what a reduction pass over g would read)
+#endif
+    v = keep_if4(v, live);
+    ssum[0] = add4(ssum[0], v);
+    ssum[1] = fma4(v, xh, ssum[1]);
+  }
+  if (part) {
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    block_reduce_groups<2, 2>(ssum, sred, part + (size_t)blk * 2 * C, base, C4);
+  }
+}
+
 struct CatGrid {
   int gx, gy;
 };
@@ -261,6 +330,89 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const act_t* __restri
       sta4(dx + i * 4, g);
     else
       sta1(dx + i, g.x);
+  }
+}
+
+// The same gather with the destination window of a source pixel made tight and walked without branches:
+// dst o contributes to source i iff src(o) in (i-1, i+1), i.e. o in ((i-0.5)/scale - 0.5, (i+1.5)/scale - 0.5)
+// - at most 4 per axis when up-sampling by <= 2 (NW = 4), at most 2 when down-sampling by >= 2 (NW = 2).
+// The window is widened by 0.01 (never narrowed: a destination dropped by rounding would be one whose weight
+// is rounding noise; one added has weight exactly 0 from lin_weight); all NW x NW loads are issued
+// unconditionally (clamped coordinates, masked values), anything beyond NW (never, for the factors the
+// launcher sends here) is walked by the tail loops.
+__device__ __forceinline__ void dst_range_tight(int i, float scale, int in_size, int out_size, int& lo, int& hi) {
+  if (in_size == out_size) {
+    lo = hi = i;
+    return;
+  }
+  const float inv = 1.0f / scale;
+  lo = (int)ceilf(((float)i - 0.5f) * inv - 0.5f - 0.01f);
+  hi = (int)floorf(((float)i + 1.5f) * inv - 0.5f + 0.01f);
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void bilinear_bwd_win_kernel(const act_t* __restrict__ dy, int64_t lddy, int dyoff,
+                                                               act_t* __restrict__ dx, int B, int Hi, int Wi, int C4,
+                                                               int Ho, int Wo, float sh, float sw) {
+  const int64_t total = (int64_t)B * Hi * Wi * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int ix = (int)(p % Wi);
+    p /= Wi;
+    const int iy = (int)(p % Hi);
+    const int b = (int)(p / Hi);
+    int ylo, yhi, xlo, xhi;
+    dst_range_tight(iy, sh, Hi, Ho, ylo, yhi);
+    dst_range_tight(ix, sw, Wi, Wo, xlo, xhi);
+    float wy[NW], wx[NW];
+    int oy[NW], ox[NW];
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      // (a source pixel no destination samples has an EMPTY window, hi < lo - down-sampling leaves most of
+      //  them so: the loads stay unconditional, at a clamped coordinate, with weight 0)
+      const int o = ylo + t;
+      const bool ok = o <= yhi;
+      oy[t] = ok ? o : (ylo < Ho ? ylo : Ho - 1);
+      wy[t] = ok ? lin_weight(oy[t], iy, sh, Hi, Ho) : 0.f;
+      const int q = xlo + t;
+      const bool okx = q <= xhi;
+      ox[t] = okx ? q : (xlo < Wo ? xlo : Wo - 1);
+      wx[t] = okx ? lin_weight(ox[t], ix, sw, Wi, Wo) : 0.f;
+    }
+    const act_t* db = dy + (int64_t)b * Ho * Wo * lddy + dyoff + c4 * 4;
+    float4 d[NW][NW];
+#pragma unroll
+    for (int ty = 0; ty < NW; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < NW; ++tx) d[ty][tx] = lda4(db + ((int64_t)oy[ty] * Wo + ox[tx]) * lddy);
+    float4 g = f4zero();
+#pragma unroll
+    for (int ty = 0; ty < NW; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < NW; ++tx) {
+        const float w = wy[ty] * wx[tx];
+        const float4 v = keep_if4(d[ty][tx], w != 0.f);
+        g.x = fmaf(w, v.x, g.x);
+        g.y = fmaf(w, v.y, g.y);
+        g.z = fmaf(w, v.z, g.z);
+        g.w = fmaf(w, v.w, g.w);
+      }
+    // (windows wider than NW: not reached for the scale factors this kernel is launched for)
+    for (int o = ylo; o <= yhi; ++o)
+      for (int q = xlo; q <= xhi; ++q) {
+        if (o < ylo + NW && q < xlo + NW) continue;
+        const float w = lin_weight(o, iy, sh, Hi, Ho) * lin_weight(q, ix, sw, Wi, Wo);
+        if (w == 0.f) continue;
+        const float4 v = lda4(db + ((int64_t)o * Wo + q) * lddy);
+        g.x = fmaf(w, v.x, g.x);
+        g.y = fmaf(w, v.y, g.y);
+        g.z = fmaf(w, v.z, g.z);
+        g.w = fmaf(w, v.w, g.w);
+      }
+    sta4(dx + i * 4, g);
   }
 }
 
@@ -398,6 +550,25 @@ int NASSEG_FN(cat_src_fwd)(const act_t* x, const float* scale, const float* shif
   return NASSEG_OK;
 }
 
+// backward of nasseg_cat_src_fwd's input w.r.t. the slab-sized tensor: see cat_src_bwd_kernel.  du / slab:
+// [B*Ho*Wo][ld], this input's channels at off; sscale / smean / sinvstd [ld], sums [2][ld]: the slab BatchNorm
+// and its backward sums; z / tstats (mean | invstd | scale | shift, C each) / act: the pending producer (null:
+// none); g [B*Ho*Wo][C]; part: null or [nasseg_cat_src_blocks(B, Ho, Wo, C) + 64][2][C] (needs z)
+int NASSEG_FN(cat_src_bwd)(const act_t* du, const act_t* slab, int64_t ld, int off, const float* sscale,
+                           const float* smean, const float* sinvstd, const float* sums, int train, const act_t* z,
+                           const float* tstats, int act, act_t* g, float* part, int B, int Ho, int Wo, int C,
+                           void* stream) {
+  NASSEG_REQUIRE(du && slab && sscale && smean && sinvstd && sums && g && nasseg_cat_src_blocks(B, Ho, Wo, C) > 0 &&
+                     ld % 4 == 0 && off % 4 == 0 && off + C <= ld && (!z == !tstats) && (!part || z),
+                 "cat_src_bwd: bad arguments");
+  const CatGrid gr = cat_grid(B, Ho, Wo, C);
+  const double M = (double)B * Ho * Wo;
+  hipLaunchKernelGGL(cat_src_bwd_kernel, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, du, slab, ld, off,
+                     sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho, Wo, C / 4);
+  NASSEG_LAUNCH_CHECK("cat_src_bwd");
+  return NASSEG_OK;
+}
+
 static int64_t bilinear_bwd_ws(int B, int Hi, int Wi, int C, int Ho, int Wo) {
   if (C % 4 != 0 || Ho < 3 * Hi || Wo < 3 * Wi) return 0;
   return (int64_t)B * Ho * Wi * C;
@@ -427,7 +598,16 @@ int NASSEG_FN(bilinear_bwd)(const act_t* dy, int64_t lddy, int dyoff, act_t* dx,
     NASSEG_LAUNCH_CHECK("bilinear_bwd_axis");
     return NASSEG_OK;
   }
-  if (vec)
+  // 1/scale = destinations per source step: <= 0.5 (down-sampling by >= 2) or <= 2 (up to 2x up-sampling) on both
+  // axes - the tight-window gathers; anything else the general one
+  const float ih = (float)Ho / (float)Hi, iw = (float)Wo / (float)Wi;
+  if (vec && ih <= 0.5f && iw <= 0.5f)
+    hipLaunchKernelGGL((bilinear_bwd_win_kernel<2>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))), dim3(256), 0, s,
+                       dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+  else if (vec && ih <= 2.f && iw <= 2.f)
+    hipLaunchKernelGGL((bilinear_bwd_win_kernel<4>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))), dim3(256), 0, s,
+                       dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+  else if (vec)
     hipLaunchKernelGGL((bilinear_bwd_kernel<4>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
                        dim3(256), 0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
   else

@@ -189,7 +189,7 @@ def _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops):
 
 
 FUSE_DW_BWD = os.environ.get("NASSEG_FUSE_DW_BWD", "1") != "0"
-_DW_BWD_MIN_BYTES = 24 << 20
+_DW_BWD_MIN_BYTES = int(os.environ.get("NASSEG_DW_BWD_MIN_BYTES", 24 << 20))
 _FLAT_WGRAD_BN_MIN_BYTES = 24 << 20  # (output map of the stem above which its BatchNorm backward rides on the wgrad loads)
 
 
@@ -647,7 +647,7 @@ def _identity_vectors(like, n):
 # for maps whose input + output exceed this many bytes (tools/kbench_pwbwd.py: 32 -> 32 at 4x128x256,
 # 33 MB, one kernel 21 us / two kernels 26 us; 64 -> 64 at 4x32x64, 4 MB, 35 / 19 us - too few slabs)
 FUSE_PW_BWD = os.environ.get("NASSEG_FUSE_PW_BWD", "1") != "0"
-_PW_BWD_MIN_BYTES = 24 << 20
+_PW_BWD_MIN_BYTES = int(os.environ.get("NASSEG_PW_BWD_MIN_BYTES", 24 << 20))
 # the wide-input variant (K > 64: the four waves split N; round 3: chunks of the input and of the
 # backward-data weight prefetched while the previous chunk is multiplied): 224 -> 64 at 4x256x512 (pre_clf,
 # whose input gradient also carries the ReLU mask) 410-425 us against 710-730 us for the two kernels
@@ -892,7 +892,7 @@ class _ConvChain(torch.autograd.Function):
             if defer and res is None and pend[0] is not None:
                 # deferred tail: the consumer applies act(scale*z + shift) as it loads (Pending below); what
                 # comes back in backward is still the gradient w.r.t. the BatchNorm's activated output
-                y, tail = cur, (pend[0], pend[1])
+                y, tail = cur, stats
             else:
                 y = _affine_act(cur, pend[0], pend[1], res, pend[2])
         elif res is not None:
@@ -906,9 +906,9 @@ class _ConvChain(torch.autograd.Function):
             ctx.meta = (cfg, meta, residual is not None, tuple(x.shape), pool_fused)
         if defer:
             if tail is None:
-                return y, None, None
-            ctx.mark_non_differentiable(tail[0], tail[1])
-            return y, tail[0], tail[1]
+                return y, None
+            ctx.mark_non_differentiable(tail)
+            return y, tail  # (mean | invstd | scale | shift of the last BatchNorm)
         return y
 
     @staticmethod
@@ -926,6 +926,12 @@ class _ConvChain(torch.autograd.Function):
         dres = g if (has_res and ctx.needs_input_grad[2]) else None
         pre = None  # BatchNorm-backward partial rows of op i that came with g (fused dgrad epilogue)
         g_masked = False  # g already carries act' of op i's activation (with or without such rows)
+        if _TAIL_ROWS and pool is None:
+            # a consumer of this chain's deferred tail (_CatReduce) has already masked the gradient and summed
+            # it against the last BatchNorm's xhat: its rows come by the side (keyed by the gradient tensor itself)
+            ent = _TAIL_ROWS.pop(dy.data_ptr(), None)
+            if ent is not None and ent[0]() is dy and ops[-1][4]:
+                pre = (ent[1], ent[2])
         if pool is not None:
             # the pooled tail: gradient w.r.t. the last BatchNorm's output by a gather over the windows -
             # together with that BatchNorm's backward sums when the pooling had applied it on load
@@ -1123,6 +1129,13 @@ class _ConvChain(torch.autograd.Function):
         return (None, dx, dres) + tuple(grads)
 
 
+# BatchNorm-backward partial rows handed from a consumer's backward to the producer chain's, by the side of
+# the gradient tensor: data_ptr -> (weakref to that tensor, rows, number of rows).  An entry is only honoured
+# for the very tensor object it was made for (a dead or different object: the chain reduces as usual).
+_TAIL_ROWS = {}
+FUSE_TAIL_ROWS = os.environ.get("NASSEG_FUSE_TAIL_ROWS", "1") != "0"
+
+
 class Pending(object):
     """A conv chain's raw last conv output whose BatchNorm (+ activation) is still to be applied:
     y = act(scale[c]*z + shift[c]).  A consumer that understands it (cat_reduce) applies the tail as it loads z -
@@ -1130,11 +1143,13 @@ class Pending(object):
     that flows back into ``z``'s slot is the one w.r.t. y (the chain's backward is the same either way: it has
     always received dL/dy and redone mask and BatchNorm backward from z)."""
 
-    __slots__ = ("z", "scale", "shift", "act")
+    __slots__ = ("z", "stats", "act")
 
-    def __init__(self, z, scale, shift, act):
-        self.z, self.scale, self.shift, self.act = z, scale, shift, int(act)
+    def __init__(self, z, stats, act):
+        self.z, self.stats, self.act = z, stats, int(act)  # stats: mean | invstd | scale | shift, C each
 
+    scale = property(lambda self: self.stats[2 * self.z.shape[1]:3 * self.z.shape[1]])
+    shift = property(lambda self: self.stats[3 * self.z.shape[1]:])
     shape = property(lambda self: self.z.shape)
     dtype = property(lambda self: self.z.dtype)
     device = property(lambda self: self.z.device)
@@ -1189,8 +1204,8 @@ def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None, defer_tail=Fa
     if pool is not None:
         cfg = cfg + ((int(pool[0]), int(pool[1]), int(pool[2])),)
     elif defer_tail and residual is None and cfg_ops and cfg_ops[-1][4]:
-        y, scale, shift = _ConvChain.apply(cfg + (None, True), x, residual, *tensors)
-        return y if scale is None else Pending(y, scale, shift, cfg_ops[-1][5])
+        y, stats = _ConvChain.apply(cfg + (None, True), x, residual, *tensors)
+        return y if stats is None else Pending(y, stats, cfg_ops[-1][5])
     return _ConvChain.apply(cfg, x, residual, *tensors)
 
 
@@ -1604,14 +1619,18 @@ class _CatReduce(torch.autograd.Function):
     launch (nasseg_cat_src_fwd) that resizes it when its size differs, applies the producer's pending
     BatchNorm + activation on load (Pending: the producers' normalised outputs are never written) and emits
     the slab's BatchNorm statistics as partial rows - no pass over the slab for them; the conv applies the
-    slab's BatchNorm + ReLU on load (_BNReluConv).  Backward: _BNReluConv's, then the slab gradient's halves
-    go back as slices / through the resize's transpose; the gradient returned for a Pending input is the one
-    w.r.t. its activated output (the producer chain's backward takes it from there).
+    slab's BatchNorm + ReLU on load (_BNReluConv).  Backward: the backward-data kernel leaves the masked
+    gradient + the slab BatchNorm's sums; nasseg_cat_src_bwd then applies that BatchNorm's backward per input
+    slice (no full-width slab gradient), and for a pending input of the slab's size also masks with its
+    activation's derivative and emits the producer's BatchNorm-backward sums (_TAIL_ROWS).  The gradient
+    returned for a Pending input is the one w.r.t. its activated output (the producer chain's backward takes
+    it from there).
 
-    cfg = (Ho, Wo, act_x, act_y, training, momentum, eps, grad_mode)."""
+    cfg = (Ho, Wo, act_x, act_y, training, momentum, eps, grad_mode); xst / yst: the producers' statistics
+    vectors (mean | invstd | scale | shift) or None."""
 
     @staticmethod
-    def forward(ctx, cfg, x, y, xsc, xsh, ysc, ysh, gamma, beta, rm, rv, nbt, weight):
+    def forward(ctx, cfg, x, y, xst, yst, gamma, beta, rm, rv, nbt, weight):
         Ho, Wo, act_x, act_y, training, momentum, eps, grad_mode = cfg
         x, y = _cl(x), _cl(y)
         B, C = x.shape[0], x.shape[1]
@@ -1631,8 +1650,9 @@ class _CatReduce(torch.autograd.Function):
         slab = _new(x, B, Ct, Ho, Wo)
         nblk = lib.query("nasseg_cat_src_blocks", B, Ho, Wo, C)
         part = _ws(x, (nblk + 64) * 2 * Ct) if training else None
-        for off, (t, sc, sh, act) in enumerate(((x, xsc, xsh, act_x), (y, ysc, ysh, act_y))):
-            lib.call(_k("nasseg_cat_src_fwd", t), ptr(t), ptr(sc), ptr(sh), act if sc is not None else ACT_NONE,
+        for off, (t, st, act) in enumerate(((x, xst, act_x), (y, yst, act_y))):
+            sc, sh = (st[2 * C:3 * C], st[3 * C:]) if st is not None else (None, None)
+            lib.call(_k("nasseg_cat_src_fwd", t), ptr(t), ptr(sc), ptr(sh), act if st is not None else ACT_NONE,
                      ptr(slab), Ct, off * C, ptr(part), B, t.shape[2], t.shape[3], C, Ho, Wo, s)
         if training:
             lib.call("nasseg_bn_finalize", ptr(part), nblk, M, Ct, float(eps), float(momentum), ptr(gamma),
@@ -1648,22 +1668,25 @@ class _CatReduce(torch.autograd.Function):
         lib.call(_k("nasseg_conv_fwd", slab), ptr(slab), Ct, ptr(packed[0]), ptr(out), N, ptr(scale), ptr(shift),
                  ACT_RELU, None, None, ACT_NONE, None, 0, B, Ho, Wo, Ct, Ho, Wo, N, 1, 1, 1, 0, 1, 0, None, s)
         if needs_grad:
-            ctx.save_for_backward(slab, stats, packed[1], w)
-            ctx.cfg = (bool(training), N, tuple(x.shape), tuple(y.shape))
+            # (x / y: the producers' raw outputs - they hold them for their own backward anyway)
+            ctx.save_for_backward(slab, stats, packed[1], w, x if xst is not None else None,
+                                  y if yst is not None else None, xst, yst)
+            ctx.cfg = (bool(training), N, tuple(x.shape), tuple(y.shape), act_x, act_y)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        slab, stats, wb, w = ctx.saved_tensors
-        training, N, x_shape, y_shape = ctx.cfg
+        for key in [k for k, e in _TAIL_ROWS.items() if e[0]() is None]:
+            del _TAIL_ROWS[key]  # (rows whose gradient tensor died unconsumed: a backward that stopped short)
+        slab, stats, wb, w, zx, zy, xst, yst = ctx.saved_tensors
+        training, N, x_shape, y_shape, act_x, act_y = ctx.cfg
         dout = _cl(dout)
         B, Ct, Ho, Wo = slab.shape
         C = Ct // 2
-        M = B * Ho * Wo
         s = current_stream()
         mean, invstd, scale, shift = stats[0:Ct], stats[Ct:2 * Ct], stats[2 * Ct:3 * Ct], stats[3 * Ct:]
         need_in = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        need_bn = ctx.needs_input_grad[7] or ctx.needs_input_grad[8]
+        need_bn = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
         dx = dy = dgamma = dbeta = dw = None
         if need_in or need_bn:
             nb = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, Ct, N, 2)
@@ -1674,34 +1697,40 @@ class _CatReduce(torch.autograd.Function):
                      1, ptr(part), s)
             sums = _vec(slab, 2 * Ct)
             lib.call("nasseg_rows_sum", ptr(part), nb, 2 * Ct, ptr(sums), s)
-            if ctx.needs_input_grad[7]:
+            if ctx.needs_input_grad[5]:
                 dgamma = sums[Ct:2 * Ct]
-            if ctx.needs_input_grad[8]:
+            if ctx.needs_input_grad[6]:
                 dbeta = sums[0:Ct]
             if need_in:
-                dslab = torch.empty_like(slab)
-                lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(slab), ptr(scale), ptr(shift), ptr(mean),
-                         ptr(invstd), ptr(sums), M, Ct, int(training), ACT_NONE, ptr(dslab), s)
+                nrows = lib.query("nasseg_cat_src_blocks", B, Ho, Wo, C)
                 grads = []
-                for off, (need, shp) in enumerate(((ctx.needs_input_grad[1], x_shape),
-                                                   (ctx.needs_input_grad[2], y_shape))):
+                for off, (need, shp, z, st, act) in enumerate(((ctx.needs_input_grad[1], x_shape, zx, xst, act_x),
+                                                               (ctx.needs_input_grad[2], y_shape, zy, yst, act_y))):
                     if not need:
                         grads.append(None)
                         continue
                     _, _, H, W = shp
-                    d = _new(slab, B, C, H, W)
-                    if (H, W) == (Ho, Wo):
-                        lib.call(_k("nasseg_chan_copy", dslab), ptr(dslab), Ct, off * C, ptr(d), C, 0, None, 0, 0,
-                                 M, C, ACT_NONE, ACT_NONE, s)
-                    else:
+                    same = (H, W) == (Ho, Wo)
+                    # the producer's mask and sums ride along when its output has the slab's size (behind a
+                    # resize the gradient w.r.t. its output only exists after nasseg_bilinear_bwd)
+                    rows = _ws(slab, (nrows + 64) * 2 * C) if (same and st is not None and FUSE_TAIL_ROWS) else None
+                    d = _new(slab, B, C, Ho, Wo)
+                    lib.call(_k("nasseg_cat_src_bwd", g), ptr(g), ptr(slab), Ct, off * C, ptr(scale), ptr(mean),
+                             ptr(invstd), ptr(sums), int(training), ptr(z) if rows is not None else None,
+                             ptr(st) if rows is not None else None, act, ptr(d), ptr(rows), B, Ho, Wo, C, s)
+                    if rows is not None:
+                        _TAIL_ROWS[d.data_ptr()] = (weakref.ref(d), rows, nrows)
+                    elif not same:
+                        full = _new(slab, B, C, H, W)
                         nws = lib.query("nasseg_bilinear_bwd_workspace", B, H, W, C, Ho, Wo)
-                        lib.call(_k("nasseg_bilinear_bwd", dslab), ptr(dslab), Ct, off * C, ptr(d), B, H, W, C, Ho,
-                                 Wo, ptr(_ws(dslab, nws)) if nws else None, s)
+                        lib.call(_k("nasseg_bilinear_bwd", d), ptr(d), C, 0, ptr(full), B, H, W, C, Ho, Wo,
+                                 ptr(_ws(d, nws)) if nws else None, s)
+                        d = full
                     grads.append(d)
                 dx, dy = grads
-        if ctx.needs_input_grad[12]:
+        if ctx.needs_input_grad[10]:
             dw = _dense_wgrad(slab, dout, w, scale, shift, ACT_RELU, (B, Ho, Wo, Ct, Ho, Wo, N, 1, 1, 1, 0, 1))
-        return None, dx, dy, None, None, None, None, dgamma, dbeta, None, None, None, dw
+        return None, dx, dy, None, None, dgamma, dbeta, None, None, None, dw
 
 
 def cat_reduce_ok(x, y, weight):
@@ -1718,11 +1747,11 @@ def cat_reduce(x, y, size, gamma, beta, running_mean, running_var, num_batches_t
     Pending outputs of conv chains (their BatchNorm + activation are then applied as the slab is written)."""
     parts = []
     for t in (x, y):
-        parts.append((t.z, t.scale, t.shift, t.act) if isinstance(t, Pending) else (t, None, None, ACT_NONE))
-    cfg = (int(size[0]), int(size[1]), parts[0][3], parts[1][3], bool(training), float(momentum), float(eps),
+        parts.append((t.z, t.stats, t.act) if isinstance(t, Pending) else (t, None, ACT_NONE))
+    cfg = (int(size[0]), int(size[1]), parts[0][2], parts[1][2], bool(training), float(momentum), float(eps),
            torch.is_grad_enabled())
-    return _CatReduce.apply(cfg, parts[0][0], parts[1][0], parts[0][1], parts[0][2], parts[1][1], parts[1][2],
-                            gamma, beta, running_mean, running_var, num_batches_tracked, weight)
+    return _CatReduce.apply(cfg, parts[0][0], parts[1][0], parts[0][1], parts[1][1], gamma, beta, running_mean,
+                            running_var, num_batches_tracked, weight)
 
 
 def bn_relu_conv(x, gamma, beta, running_mean, running_var, num_batches_tracked, weight, training,
