@@ -114,6 +114,12 @@ def algorithmic_bytes(name, a):
     if name in ("nasseg_pool_fwd", "nasseg_pool_bwd"):
         B, H, W, C, Ho, Wo = a[4], a[5], a[6], a[7], a[8], a[9]
         return 4 * B * C * (H * W + Ho * Wo) + B * C * Ho * Wo  # + uint8 winner index
+    if name == "nasseg_cat_src_fwd":  # the input read (at its own size), its slice of the slab written
+        B, Hi, Wi, C, Ho, Wo = a[8], a[9], a[10], a[11], a[12], a[13]
+        return 4 * B * C * (Hi * Wi + Ho * Wo)
+    if name == "nasseg_cat_src_bwd":  # du and slab slices (+ the pending producer's z) read, g written
+        B, Ho, Wo, C = a[14], a[15], a[16], a[17]
+        return 4 * B * Ho * Wo * C * (2 + (1 if a[8] else 0) + (1 if a[9] else 0))
     if name == "nasseg_maxpool_bn_fwd":  # z read, pooled map (+ uint8 winner index) written
         B, H, W, C, Ho, Wo = a[5], a[6], a[7], a[8], a[9], a[10]
         return 4 * B * C * (H * W + Ho * Wo) + (B * C * Ho * Wo if a[4] else 0)
