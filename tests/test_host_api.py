@@ -5,6 +5,8 @@ product path refuses to compute on the host."""
 import inspect
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -232,6 +234,23 @@ def test_install_dropin_registers_reference_module_names():
             if k in ("nn", "rl", "helpers", "engine") or k.split(".")[0] in ("nn", "rl", "helpers", "engine"):
                 if k not in saved or saved[k] is None:
                     sys.modules.pop(k, None)
+
+
+def test_install_dropin_can_also_stand_in_for_the_teacher_and_the_data_pipeline():
+    """install_dropin(kd=True, data=True): the reference's import lines for the distillation teacher
+    (src/main_search.py:456) and the loaders (:30) resolve here; in a subprocess - sys.modules stays clean."""
+    import subprocess
+    import sys
+
+    code = ("import nas_segm_amd; names = nas_segm_amd.install_dropin(kd=True, data=True);"
+            "from kd.rf_lw.model_lw_v2 import rf_lw152 as kd_model;"
+            "from data.loaders import create_loaders;"
+            "from data.datasets import PascalCustomDataset;"
+            "import nas_segm_amd.kd.rf_lw as m; assert kd_model is m.rf_lw152;"
+            "assert 'data.loaders' in names and 'kd.rf_lw.model_lw_v2' in names; print('ok')")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("taps", [[1, 2], [1, 2, 4, 6]])
