@@ -264,8 +264,13 @@ int nasseg_cat_src_fwd(const float* x, const float* scale, const float* shift, i
                        int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo, void* stream);
 int nasseg_cat_src_bwd(const float* du, const float* slab, int64_t ld, int off, const float* sscale,
                        const float* smean, const float* sinvstd, const float* sums, int train, const float* z,
-                       const float* tstats, int act, float* g, float* part, int B, int Ho, int Wo, int C,
-                       void* stream);
+                       const float* tstats, int act, float* g, float* part, int B, int Ho, int Wo, int C, int Hi,
+                       int Wi, void* stream);
+/* nasseg_bilinear_bwd with the result multiplied by act'(scale*z + shift) at the source's size: the gradient of a
+ * resized pending input, masked for its producer (its sums come from nasseg_cat_src_bwd). */
+int nasseg_bilinear_bwd_act(const float* dy, int64_t lddy, int dyoff, const float* z, const float* scale,
+                            const float* shift, int act, float* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                            float* ws, void* stream);
 int nasseg_bilinear_fwd(const float* x, float* y, int64_t ldy, int yoff, int B, int Hi, int Wi,
                         int C, int Ho, int Wo, int act, void* stream);
 /* nn.Upsample(size, mode="bilinear", align_corners=True) - src/kd/rf_lw/model_lw_v2.py:258,266,274 (the
@@ -357,7 +362,10 @@ int nasseg_bf16_cat_src_fwd(const nasseg_bf16_t* x, const float* scale, const fl
 int nasseg_bf16_cat_src_bwd(const nasseg_bf16_t* du, const nasseg_bf16_t* slab, int64_t ld, int off, const float* sscale,
                             const float* smean, const float* sinvstd, const float* sums, int train,
                             const nasseg_bf16_t* z, const float* tstats, int act, nasseg_bf16_t* g, float* part, int B,
-                            int Ho, int Wo, int C, void* stream);
+                            int Ho, int Wo, int C, int Hi, int Wi, void* stream);
+int nasseg_bf16_bilinear_bwd_act(const nasseg_bf16_t* dy, int64_t lddy, int dyoff, const nasseg_bf16_t* z,
+                                 const float* scale, const float* shift, int act, nasseg_bf16_t* dx, int B, int Hi, int Wi,
+                                 int C, int Ho, int Wo, float* ws, void* stream);
 int nasseg_bf16_bilinear_ac_fwd(const nasseg_bf16_t* x, nasseg_bf16_t* y, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                 void* stream);
 int nasseg_bf16_bilinear_bwd(const nasseg_bf16_t* dy, int64_t lddy, int dyoff, nasseg_bf16_t* dx, int B, int Hi, int Wi,

@@ -193,14 +193,17 @@ __global__ __launch_bounds__(256) void cat_src_fwd_kernel(const act_t* __restric
 // the slab's size: final when the input had that size, the operand of nasseg_bilinear_bwd otherwise).  When the
 // input came in pending (z + the producer's BatchNorm statistics), v is multiplied by act'(tscale*z + tshift)
 // and the producer's BatchNorm-backward sums {sum g, sum g*(z - tmean)*tinvstd} are emitted per workgroup
-// (rows of 2*C floats): the producer's backward then needs no reduction pass over g and z.
+// (rows of 2*C floats): the producer's backward then needs no reduction pass over g and z.  RESIZE: the pending
+// producer has ANOTHER size (z [B][Hi][Wi][C]): v is written unmasked (nasseg_bilinear_bwd_act masks what it
+// transposes), the sums are formed against the interpolated mask / mask * xhat.
 // Same workgroup layout as cat_src_fwd_kernel.
+template <bool RESIZE>
 __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
     const act_t* __restrict__ du, const act_t* __restrict__ slab, int64_t ld, int off,
     const float* __restrict__ sscale, const float* __restrict__ smean, const float* __restrict__ sinvstd,
     const float* __restrict__ sums, float invM, int train, const act_t* __restrict__ z,
     const float* __restrict__ tstats, int act, act_t* __restrict__ g, float* __restrict__ part, int R, int Wo,
-    int C4) {
+    int C4, int Ho, int Hi, int Wi, float sh, float sw) {
   __shared__ float4 sred[2][4][64];
   const int C = C4 * 4;
   const int tid = threadIdx.x;
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
     tsh = lda4(tstats + 3 * C + c4 * 4);
   }
   float4 ssum[2] = {f4zero(), f4zero()};
+  const Lin lxz = RESIZE ? lin_coeff(ox, sw, Wi, Wo) : Lin{0, 0, 1.f, 0.f};
   for (int r = blockIdx.y; r < R; r += gridDim.y) {
     const int64_t pix = (int64_t)r * Wo + ox;
     const float4 d = lda4(du + pix * ld + sc);
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
     }
     v = mul4(v, ssc);
     float4 xh = f4zero();
-    if (z) {
+    float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);  // RESIZE: interpolated mask, xh: interpolated mask * xhat
+    if (z && !RESIZE) {
       const float4 zv = lda4(z + pix * C + c4 * 4);
       const float4 t = fma4(zv, tsc, tsh);
       v = make_float4(v.x * act_mask(t.x, act), v.y * act_mask(t.y, act), v.z * act_mask(t.z, act),
@@ -241,13 +246,36 @@ __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
       xh = make_float4((zv.x - tmu.x) * tis.x, (zv.y - tmu.y) * tis.y, (zv.z - tmu.z) * tis.z,
                        (zv.w - tmu.w) * tis.w);
     }
+    if (z && RESIZE) {
+      // the producer's gradient is g(p) = m(p) * sum_o w(o, p) v(o) (nasseg_bilinear_bwd_act forms it): its sums
+      // over p are sum_o v(o) * interp[m](o) and sum_o v(o) * interp[m * xhat](o) - formed here, at the slab's size,
+      // from the 4 taps the forward read
+      const int b = r / Ho, oy = r - b * Ho;
+      const Lin ly = lin_coeff(oy, sh, Hi, Ho);
+      const act_t* zb = z + (int64_t)b * Hi * Wi * C + c4 * 4;
+      ms = f4zero();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = (k & 2) ? ly.i1 : ly.i0, xx = (k & 1) ? lxz.i1 : lxz.i0;
+        const float w = ((k & 2) ? ly.l1 : ly.l0) * ((k & 1) ? lxz.l1 : lxz.l0);
+        const float4 zv = lda4(zb + ((int64_t)yy * Wi + xx) * C);
+        const float4 t = fma4(zv, tsc, tsh);
+        const float4 m = make_float4(w * act_mask(t.x, act), w * act_mask(t.y, act), w * act_mask(t.z, act),
+                                     w * act_mask(t.w, act));
+        ms = add4(ms, m);
+        xh.x = fmaf(m.x, (zv.x - tmu.x) * tis.x, xh.x);
+        xh.y = fmaf(m.y, (zv.y - tmu.y) * tis.y, xh.y);
+        xh.z = fmaf(m.z, (zv.z - tmu.z) * tis.z, xh.z);
+        xh.w = fmaf(m.w, (zv.w - tmu.w) * tis.w, xh.w);
+      }
+    }
     if (live) sta4(g + pix * C + c4 * 4, v);
 #ifdef NASSEG_BF16
     v = make_float4(bf16_to_f32(f32_to_bf16(v.x)), bf16_to_f32(f32_to_bf16(v.y)), bf16_to_f32(f32_to_bf16(v.z)),
                     bf16_to_f32(f32_to_bf16(v.w)));  // (what a reduction pass over g would read)
 #endif
     v = keep_if4(v, live);
-    ssum[0] = add4(ssum[0], v);
+    ssum[0] = RESIZE ? fma4(v, ms, ssum[0]) : add4(ssum[0], v);
     ssum[1] = fma4(v, xh, ssum[1]);
   }
   if (part) {
@@ -289,12 +317,23 @@ __device__ __forceinline__ float lin_weight(int o, int i, float scale, int in_si
   return w;
 }
 
+// dx * act'(scale*z + shift) when a mask tensor is given (the producer's pending activation: nasseg_bilinear_bwd_act)
+__device__ __forceinline__ float4 mask_by(float4 g, const act_t* __restrict__ mz, const float* __restrict__ msc,
+                                          const float* __restrict__ msh, int mact, int64_t elem, int c) {
+  if (!mz) return g;
+  const float4 t = fma4(lda4(mz + elem), lda4(msc + c), lda4(msh + c));
+  return make_float4(g.x * act_mask(t.x, mact), g.y * act_mask(t.y, mact), g.z * act_mask(t.z, mact),
+                     g.w * act_mask(t.w, mact));
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const act_t* __restrict__ dy,
                                                            int64_t lddy, int dyoff,
                                                            act_t* __restrict__ dx, int B, int Hi,
                                                            int Wi, int CV, int Ho, int Wo, float sh,
-                                                           float sw) {
+                                                           float sw, const act_t* __restrict__ mz,
+                                                           const float* __restrict__ msc,
+                                                           const float* __restrict__ msh, int mact) {
   const int64_t total = (int64_t)B * Hi * Wi * CV;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int cv = (int)(i % CV);
@@ -327,7 +366,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const act_t* __restri
       }
     }
     if (VEC == 4)
-      sta4(dx + i * 4, g);
+      sta4(dx + i * 4, mask_by(g, mz, msc, msh, mact, i * 4, cv * 4));
     else
       sta1(dx + i, g.x);
   }
@@ -355,7 +394,10 @@ __device__ __forceinline__ void dst_range_tight(int i, float scale, int in_size,
 template <int NW>
 __global__ __launch_bounds__(256) void bilinear_bwd_win_kernel(const act_t* __restrict__ dy, int64_t lddy, int dyoff,
                                                                act_t* __restrict__ dx, int B, int Hi, int Wi, int C4,
-                                                               int Ho, int Wo, float sh, float sw) {
+                                                               int Ho, int Wo, float sh, float sw,
+                                                               const act_t* __restrict__ mz,
+                                                               const float* __restrict__ msc,
+                                                               const float* __restrict__ msh, int mact) {
   const int64_t total = (int64_t)B * Hi * Wi * C4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
@@ -412,7 +454,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_win_kernel(const act_t* __re
         g.z = fmaf(w, v.z, g.z);
         g.w = fmaf(w, v.w, g.w);
       }
-    sta4(dx + i * 4, g);
+    sta4(dx + i * 4, mask_by(g, mz, msc, msh, mact, i * 4, c4 * 4));
   }
 }
 
@@ -428,7 +470,10 @@ __global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const TS* __rest
                                                                 int64_t lds, int soff,
                                                                 TD* __restrict__ dst, int B,
                                                                 int H, int Wsrc, int Wdst, int C4,
-                                                                int Hdst, float scale) {
+                                                                int Hdst, float scale,
+                                                                const act_t* __restrict__ mz,
+                                                                const float* __restrict__ msc,
+                                                                const float* __restrict__ msh, int mact) {
   // AXIS 1: src [B][H][Wsrc][lds], dst [B][H][Wdst][C] (reduce along x: Wsrc = Wo, Wdst = Wi)
   // AXIS 0: src [B][H][Wsrc][C] with H = Ho, dst [B][Hdst][Wsrc][C]   (reduce along y)
   const int rows_out = AXIS == 1 ? H : Hdst;
@@ -456,7 +501,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_axis_kernel(const TS* __rest
       g.z = fmaf(w, d.z, g.z);
       g.w = fmaf(w, d.w, g.w);
     }
-    sta4(dst + i * 4, g);
+    sta4(dst + i * 4, mask_by(g, mz, msc, msh, mact, i * 4, c4 * 4));  // (mz: second pass only)
   }
 }
 
@@ -553,18 +598,28 @@ int NASSEG_FN(cat_src_fwd)(const act_t* x, const float* scale, const float* shif
 // backward of nasseg_cat_src_fwd's input w.r.t. the slab-sized tensor: see cat_src_bwd_kernel.  du / slab:
 // [B*Ho*Wo][ld], this input's channels at off; sscale / smean / sinvstd [ld], sums [2][ld]: the slab BatchNorm
 // and its backward sums; z / tstats (mean | invstd | scale | shift, C each) / act: the pending producer (null:
-// none); g [B*Ho*Wo][C]; part: null or [nasseg_cat_src_blocks(B, Ho, Wo, C) + 64][2][C] (needs z)
+// none), z of size (Hi, Wi) - when that is not the slab's size g is left UNMASKED for nasseg_bilinear_bwd_act and
+// only the sums see the mask; g [B*Ho*Wo][C]; part: null or [nasseg_cat_src_blocks(B, Ho, Wo, C) + 64][2][C]
+// (needs z)
 int NASSEG_FN(cat_src_bwd)(const act_t* du, const act_t* slab, int64_t ld, int off, const float* sscale,
                            const float* smean, const float* sinvstd, const float* sums, int train, const act_t* z,
-                           const float* tstats, int act, act_t* g, float* part, int B, int Ho, int Wo, int C,
-                           void* stream) {
+                           const float* tstats, int act, act_t* g, float* part, int B, int Ho, int Wo, int C, int Hi,
+                           int Wi, void* stream) {
   NASSEG_REQUIRE(du && slab && sscale && smean && sinvstd && sums && g && nasseg_cat_src_blocks(B, Ho, Wo, C) > 0 &&
-                     ld % 4 == 0 && off % 4 == 0 && off + C <= ld && (!z == !tstats) && (!part || z),
+                     ld % 4 == 0 && off % 4 == 0 && off + C <= ld && (!z == !tstats) && (!part || z) && Hi > 0 &&
+                     Wi > 0,
                  "cat_src_bwd: bad arguments");
   const CatGrid gr = cat_grid(B, Ho, Wo, C);
   const double M = (double)B * Ho * Wo;
-  hipLaunchKernelGGL(cat_src_bwd_kernel, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, du, slab, ld, off,
-                     sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho, Wo, C / 4);
+  const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+  if (Hi == Ho && Wi == Wo)
+    hipLaunchKernelGGL(cat_src_bwd_kernel<false>, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, du, slab, ld,
+                       off, sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho, Wo,
+                       C / 4, Ho, Hi, Wi, sh, sw);
+  else
+    hipLaunchKernelGGL(cat_src_bwd_kernel<true>, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, du, slab, ld,
+                       off, sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho, Wo,
+                       C / 4, Ho, Hi, Wi, sh, sw);
   NASSEG_LAUNCH_CHECK("cat_src_bwd");
   return NASSEG_OK;
 }
@@ -583,18 +638,20 @@ int64_t nasseg_bilinear_bwd_workspace(int B, int Hi, int Wi, int C, int Ho, int 
 
 // dx [B][Hi][Wi][C] = transpose of the forward map applied to dy[..., dyoff:dyoff+C].
 // ws: nasseg_bilinear_bwd_workspace() floats, or null (then always the single-pass gather).
-int NASSEG_FN(bilinear_bwd)(const act_t* dy, int64_t lddy, int dyoff, act_t* dx, int B, int Hi, int Wi,
-                        int C, int Ho, int Wo, float* ws, void* stream) {
+static int bilinear_bwd_launch(const act_t* dy, int64_t lddy, int dyoff, act_t* dx, int B, int Hi, int Wi, int C,
+                               int Ho, int Wo, float* ws, const act_t* mz, const float* msc, const float* msh,
+                               int mact, void* stream) {
   NASSEG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0, "bilinear_bwd: bad shape");
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = C % 4 == 0 && lddy % 4 == 0 && dyoff % 4 == 0;
+  NASSEG_REQUIRE(vec || !mz, "bilinear_bwd_act: channels must be multiples of 4");
   if (ws && vec && bilinear_bwd_ws(B, Hi, Wi, C, Ho, Wo) > 0) {
     // up-sampling by >= 3 in both directions: separable two-pass form
     hipLaunchKernelGGL((bilinear_bwd_axis_kernel<1, act_t, float>), dim3(rs_grid((int64_t)B * Ho * Wi * (C / 4))),
-                       dim3(256), 0, s, dy, lddy, dyoff, ws, B, Ho, Wo, Wi, C / 4, 0, sw);
+                       dim3(256), 0, s, dy, lddy, dyoff, ws, B, Ho, Wo, Wi, C / 4, 0, sw, nullptr, nullptr, nullptr, 0);
     hipLaunchKernelGGL((bilinear_bwd_axis_kernel<0, float, act_t>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
-                       dim3(256), 0, s, ws, (int64_t)C, 0, dx, B, Ho, Wi, Wi, C / 4, Hi, sh);
+                       dim3(256), 0, s, ws, (int64_t)C, 0, dx, B, Ho, Wi, Wi, C / 4, Hi, sh, mz, msc, msh, mact);
     NASSEG_LAUNCH_CHECK("bilinear_bwd_axis");
     return NASSEG_OK;
   }
@@ -603,18 +660,33 @@ int NASSEG_FN(bilinear_bwd)(const act_t* dy, int64_t lddy, int dyoff, act_t* dx,
   const float ih = (float)Ho / (float)Hi, iw = (float)Wo / (float)Wi;
   if (vec && ih <= 0.5f && iw <= 0.5f)
     hipLaunchKernelGGL((bilinear_bwd_win_kernel<2>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))), dim3(256), 0, s,
-                       dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+                       dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw, mz, msc, msh, mact);
   else if (vec && ih <= 2.f && iw <= 2.f)
     hipLaunchKernelGGL((bilinear_bwd_win_kernel<4>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))), dim3(256), 0, s,
-                       dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+                       dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw, mz, msc, msh, mact);
   else if (vec)
     hipLaunchKernelGGL((bilinear_bwd_kernel<4>), dim3(rs_grid((int64_t)B * Hi * Wi * (C / 4))),
-                       dim3(256), 0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw);
+                       dim3(256), 0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C / 4, Ho, Wo, sh, sw, mz, msc, msh, mact);
   else
     hipLaunchKernelGGL((bilinear_bwd_kernel<1>), dim3(rs_grid((int64_t)B * Hi * Wi * C)), dim3(256),
-                       0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C, Ho, Wo, sh, sw);
+                       0, s, dy, lddy, dyoff, dx, B, Hi, Wi, C, Ho, Wo, sh, sw, nullptr, nullptr, nullptr, 0);
   NASSEG_LAUNCH_CHECK("bilinear_bwd");
   return NASSEG_OK;
+}
+
+int NASSEG_FN(bilinear_bwd)(const act_t* dy, int64_t lddy, int dyoff, act_t* dx, int B, int Hi, int Wi,
+                        int C, int Ho, int Wo, float* ws, void* stream) {
+  return bilinear_bwd_launch(dy, lddy, dyoff, dx, B, Hi, Wi, C, Ho, Wo, ws, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// the same, the result multiplied by act'(scale*z + shift) of a pending activation at the SOURCE's size
+// (z [B][Hi][Wi][C]; C %% 4 == 0): the gradient w.r.t. a resized Pending input of ConcatReduce, masked for its
+// producer (whose BatchNorm-backward sums nasseg_cat_src_bwd has formed at the slab's size)
+int NASSEG_FN(bilinear_bwd_act)(const act_t* dy, int64_t lddy, int dyoff, const act_t* z, const float* scale,
+                                const float* shift, int act, act_t* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                float* ws, void* stream) {
+  NASSEG_REQUIRE(z && scale && shift, "bilinear_bwd_act: null argument");
+  return bilinear_bwd_launch(dy, lddy, dyoff, dx, B, Hi, Wi, C, Ho, Wo, ws, z, scale, shift, act, stream);
 }
 
 #if NASSEG_FP32_ONLY

@@ -1711,21 +1711,27 @@ class _CatReduce(torch.autograd.Function):
                         continue
                     _, _, H, W = shp
                     same = (H, W) == (Ho, Wo)
-                    # the producer's mask and sums ride along when its output has the slab's size (behind a
-                    # resize the gradient w.r.t. its output only exists after nasseg_bilinear_bwd)
-                    rows = _ws(slab, (nrows + 64) * 2 * C) if (same and st is not None and FUSE_TAIL_ROWS) else None
+                    # the producer's mask and BatchNorm-backward sums ride along: directly when its output has the
+                    # slab's size; behind a resize the sums are formed at the slab's size against the interpolated
+                    # mask and nasseg_bilinear_bwd_act masks the gradient it transposes
+                    rows = _ws(slab, (nrows + 64) * 2 * C) if (st is not None and FUSE_TAIL_ROWS) else None
                     d = _new(slab, B, C, Ho, Wo)
                     lib.call(_k("nasseg_cat_src_bwd", g), ptr(g), ptr(slab), Ct, off * C, ptr(scale), ptr(mean),
                              ptr(invstd), ptr(sums), int(training), ptr(z) if rows is not None else None,
-                             ptr(st) if rows is not None else None, act, ptr(d), ptr(rows), B, Ho, Wo, C, s)
-                    if rows is not None:
-                        _TAIL_ROWS[d.data_ptr()] = (weakref.ref(d), rows, nrows)
-                    elif not same:
+                             ptr(st) if rows is not None else None, act, ptr(d), ptr(rows), B, Ho, Wo, C,
+                             H if rows is not None else Ho, W if rows is not None else Wo, s)
+                    if not same:
                         full = _new(slab, B, C, H, W)
                         nws = lib.query("nasseg_bilinear_bwd_workspace", B, H, W, C, Ho, Wo)
-                        lib.call(_k("nasseg_bilinear_bwd", d), ptr(d), C, 0, ptr(full), B, H, W, C, Ho, Wo,
-                                 ptr(_ws(d, nws)) if nws else None, s)
+                        ws = ptr(_ws(d, nws)) if nws else None
+                        if rows is not None:
+                            lib.call(_k("nasseg_bilinear_bwd_act", d), ptr(d), C, 0, ptr(z), ptr(st[2 * C:3 * C]),
+                                     ptr(st[3 * C:]), act, ptr(full), B, H, W, C, Ho, Wo, ws, s)
+                        else:
+                            lib.call(_k("nasseg_bilinear_bwd", d), ptr(d), C, 0, ptr(full), B, H, W, C, Ho, Wo, ws, s)
                         d = full
+                    if rows is not None:
+                        _TAIL_ROWS[d.data_ptr()] = (weakref.ref(d), rows, nrows)
                     grads.append(d)
                 dx, dy = grads
         if ctx.needs_input_grad[10]:

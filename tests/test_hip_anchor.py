@@ -374,11 +374,11 @@ def test_cat_reduce_cell_against_torch_cpu_autograd(kind, monkeypatch):
     yg.backward(dev(cot))
     monkeypatch.setattr(Fm.lib, "call", orig)
     assert seen.count("nasseg_cat_src_fwd") == 2 and seen.count("nasseg_cat_src_bwd") == 2, sorted(set(seen))
-    # a pending producer of the slab's size gets its BatchNorm-backward sums from nasseg_cat_src_bwd: the only
-    # reduction passes left are those behind a resize (none in pool_sep_same, one in each of the others)
-    # (adapt_conv: one more, the SepConv whose output Adapt's conv needed materialised)
-    want_reduce = {"pool_sep_same": 0, "adapt_conv": 2}.get(kind, 1)
-    assert seen.count("nasseg_bn_bwd_reduce") == want_reduce, seen.count("nasseg_bn_bwd_reduce")
+    # every pending producer gets its BatchNorm-backward sums from nasseg_cat_src_bwd (behind a resize they are
+    # formed at the slab's size and nasseg_bilinear_bwd_act masks the transposed gradient): the one reduction
+    # pass left is adapt_conv's SepConv whose output Adapt's conv needed materialised
+    assert seen.count("nasseg_bn_bwd_reduce") == (1 if kind == "adapt_conv" else 0), seen.count("nasseg_bn_bwd_reduce")
+    assert ("nasseg_bilinear_bwd_act" in seen) == (kind != "pool_sep_same")
     assert "nasseg_chan_copy" not in seen
     if kind != "adapt_conv":
         assert n_pending == (1 if kind == "pool_sep_same" else 2)
