@@ -290,3 +290,84 @@ def test_encoder_groups_units_into_chains_without_crossing_a_skip_or_a_returned_
                         u[1] == len(getattr(enc, enc._stage_name(u[0]))) - 1 and u[0] in taps]
         assert not stages_ended, r  # no run continues past a returned map
     assert runs[0][0] == "stem" and len(runs[0]) == 3  # stem + stage 1 + the first block of stage 2
+
+
+def _dry_run(monkeypatch, build, inputs):
+    """Run forward + backward of a module tree on the CPU with every kernel launch replaced by a recorder
+    (tensors stay uninitialised host memory; the workspace / plan queries are pure host functions): the
+    HOST graph - which entry points run, in what order, with which shapes - without a GPU."""
+    import nas_segm_amd.functional as F
+
+    calls = []
+    monkeypatch.setattr(F.lib, "call", lambda name, *a: (calls.append((name, a)), 0)[1])
+    monkeypatch.setattr(F, "require_device", lambda *a: None)
+    monkeypatch.setattr(F, "current_stream", lambda: 0)
+    torch.manual_seed(0)
+    net = build().train()
+    xs = [torch.empty(*shape).contiguous(memory_format=torch.channels_last).requires_grad_(True) for shape in inputs]
+    out = net(xs)
+    n_fwd = len(calls)
+    out.backward(torch.empty_like(out))
+    return F, calls[:n_fwd], calls[n_fwd:], xs
+
+
+def test_template_decoder_hands_pending_batchnorms_to_concat_reduce(monkeypatch):
+    """TemplateDecoder asks the two ops of a block for PENDING outputs (functional.Pending: raw conv output +
+    the last BatchNorm's statistics) when its aggregation op is ConcatReduce, which then runs as one node:
+    no normalise pass (nasseg_affine_act) over an op's output, no statistics pass over the slab, one
+    nasseg_cat_src_fwd / _bwd per input, and - backward - the producers' BatchNorm sums arrive with the
+    gradient (functional._TAIL_ROWS, keyed by the gradient tensor ITSELF: this checks that autograd hands the
+    very tensor object on), so no producer runs a reduction pass; nothing is left in the side table."""
+    from nas_segm_amd.nn.micro_decoders import TemplateDecoder
+
+    # two blocks, both [sep_conv_3x3, sep_conv_5x5, cat]: maps of two sizes meet at the smaller / the larger
+    genotype = [[[0, 1, 1]], [[0, 1, 0, 0, 0], [1, 2, 0, 1, 0]]]
+    F, fwd, bwd, xs = _dry_run(monkeypatch, lambda: TemplateDecoder([24, 32], 19, genotype, agg_size=32, repeats=1),
+                               [(2, 24, 32, 64), (2, 32, 16, 32)])
+    f_names, b_names = [n for n, _ in fwd], [n for n, _ in bwd]
+    n_cat = f_names.count("nasseg_cat_src_fwd") // 2
+    assert n_cat >= 2 and f_names.count("nasseg_cat_src_fwd") == 2 * n_cat
+    assert "nasseg_bn_stats" not in f_names or f_names.count("nasseg_bn_stats") <= 1  # (pre_clf's slab only)
+    # the only normalise passes are pre_clf's output and inputs Adapt's 1x1 convs needed materialised
+    cells = sum(1 for n in f_names if n == "nasseg_sepconv_fwd" or n == "nasseg_dwconv")
+    assert cells > 0
+    assert f_names.count("nasseg_affine_act") <= 1 + f_names.count("nasseg_cat_src_fwd") // 2
+    assert b_names.count("nasseg_cat_src_bwd") == 2 * n_cat
+    pending_inputs = sum(1 for n, a in bwd if n == "nasseg_cat_src_bwd" and a[9] is not None)
+    assert pending_inputs >= n_cat  # at least one pending producer per ConcatReduce here
+    # every pending producer got its sums by the side: what still reduces is pre_clf's tail and materialised inputs
+    assert b_names.count("nasseg_bn_bwd_reduce") <= 1 + f_names.count("nasseg_affine_act")
+    assert b_names.count("nasseg_rows_sum") >= pending_inputs
+    assert not F._TAIL_ROWS, "rows left behind: {}".format(len(F._TAIL_ROWS))
+    assert all(x.grad is not None for x in xs)
+
+
+def test_pending_tail_is_materialised_for_consumers_that_do_not_take_it(monkeypatch):
+    """A Pending handed to anything but ConcatReduce's node costs exactly the pass it had deferred
+    (functional.materialize -> nasseg_affine_act), and the no-concatenation form of ConcatReduce
+    (NASSEG_SPLIT_CAT_MIN) and NASSEG_FUSE_CAT_REDUCE=0 both take that route."""
+    import nas_segm_amd.nn.layer_factory as LF
+    from nas_segm_amd.nn.layer_factory import AGG_OPS, OPS, run_op
+
+    class Cell(torch.nn.Module):
+        def __init__(self, agg):
+            super(Cell, self).__init__()
+            self.a, self.b = OPS["sep_conv_3x3"](32, 32, 1, True, 1), OPS["dil_conv_3x3"](32, 32, 1, True)
+            self.agg = AGG_OPS[agg](32, 32, 32, True, 1, True)
+
+        def forward(self, xs):
+            return self.agg(run_op(self.a, xs[0], True), run_op(self.b, xs[1], True))
+
+    shapes = [(2, 32, 16, 32), (2, 32, 16, 32)]
+    F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("cat"), shapes)
+    assert [n for n, _ in fwd].count("nasseg_affine_act") == 0
+    monkeypatch.setattr(F, "FUSE_CAT_REDUCE", False)
+    F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("cat"), shapes)
+    assert [n for n, _ in fwd].count("nasseg_affine_act") == 2 and "nasseg_cat_src_fwd" not in [n for n, _ in fwd]
+    monkeypatch.setattr(F, "FUSE_CAT_REDUCE", True)
+    monkeypatch.setattr(LF, "_SPLIT_CAT_MIN", 0)
+    F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("cat"), shapes)
+    assert [n for n, _ in fwd].count("nasseg_affine_act") == 2 and "nasseg_cat_src_fwd" not in [n for n, _ in fwd]
+    F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("psum"), shapes)  # ParamSum does not accept pending inputs
+    assert [n for n, _ in fwd].count("nasseg_affine_act") == 2
+    assert not F._TAIL_ROWS
