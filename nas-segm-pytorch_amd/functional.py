@@ -1134,6 +1134,7 @@ class _ConvChain(torch.autograd.Function):
 # for the very tensor object it was made for (a dead or different object: the chain reduces as usual).
 _TAIL_ROWS = {}
 FUSE_TAIL_ROWS = os.environ.get("NASSEG_FUSE_TAIL_ROWS", "1") != "0"
+_TAIL_ROWS_UP = os.environ.get("NASSEG_TAIL_ROWS_UP", "0") == "1"  # (A/B switch: also for up-sampled producers)
 
 
 class Pending(object):
@@ -1714,7 +1715,10 @@ class _CatReduce(torch.autograd.Function):
                     # the producer's mask and BatchNorm-backward sums ride along: directly when its output has the
                     # slab's size; behind a resize the sums are formed at the slab's size against the interpolated
                     # mask and nasseg_bilinear_bwd_act masks the gradient it transposes
-                    rows = _ws(slab, (nrows + 64) * 2 * C) if (st is not None and FUSE_TAIL_ROWS) else None
+                    # (a producer SMALLER than the slab keeps its own reduction pass: over its few pixels that is
+                    #  cheaper than four taps of z per slab pixel - 3 launches of the headline step, +15 us each)
+                    rows = (_ws(slab, (nrows + 64) * 2 * C)
+                            if (st is not None and FUSE_TAIL_ROWS and (H * W >= Ho * Wo or _TAIL_ROWS_UP)) else None)
                     d = _new(slab, B, C, Ho, Wo)
                     lib.call(_k("nasseg_cat_src_bwd", g), ptr(g), ptr(slab), Ct, off * C, ptr(scale), ptr(mean),
                              ptr(invstd), ptr(sums), int(training), ptr(z) if rows is not None else None,

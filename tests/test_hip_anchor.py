@@ -374,11 +374,14 @@ def test_cat_reduce_cell_against_torch_cpu_autograd(kind, monkeypatch):
     yg.backward(dev(cot))
     monkeypatch.setattr(Fm.lib, "call", orig)
     assert seen.count("nasseg_cat_src_fwd") == 2 and seen.count("nasseg_cat_src_bwd") == 2, sorted(set(seen))
-    # every pending producer gets its BatchNorm-backward sums from nasseg_cat_src_bwd (behind a resize they are
-    # formed at the slab's size and nasseg_bilinear_bwd_act masks the transposed gradient): the one reduction
-    # pass left is adapt_conv's SepConv whose output Adapt's conv needed materialised
-    assert seen.count("nasseg_bn_bwd_reduce") == (1 if kind == "adapt_conv" else 0), seen.count("nasseg_bn_bwd_reduce")
-    assert ("nasseg_bilinear_bwd_act" in seen) == (kind != "pool_sep_same")
+    # a pending producer at least as large as the slab gets its BatchNorm-backward sums from nasseg_cat_src_bwd
+    # (behind a down-sampling they are formed at the slab's size and nasseg_bilinear_bwd_act masks the transposed
+    # gradient); what still reduces: adapt_conv's SepConv whose output Adapt's conv needed materialised
+    # (... and producers SMALLER than the slab, which keep their own, cheap, reduction: sep_dil_up's DilConv and
+    #  adapt_conv's second SepConv)
+    want_reduce = {"sep_sep_down": 0, "sep_dil_up": 1, "pool_sep_same": 0, "adapt_conv": 2}[kind]
+    assert seen.count("nasseg_bn_bwd_reduce") == want_reduce, seen.count("nasseg_bn_bwd_reduce")
+    assert ("nasseg_bilinear_bwd_act" in seen) == (kind == "sep_sep_down")
     assert "nasseg_chan_copy" not in seen
     if kind != "adapt_conv":
         assert n_pending == (1 if kind == "pool_sep_same" else 2)
