@@ -11,7 +11,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnasseg_hip.so")
+# (NASSEG_LIB: another build of the same ABI, for A/B measurements of two libraries on one box)
+LIB_PATH = os.environ.get("NASSEG_LIB") or os.path.join(_HERE, "libnasseg_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nasseg.h")
 
 _CTYPE = {

@@ -339,16 +339,19 @@ def _build_cell(kind):
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("kind", ["sep_sep_down", "sep_dil_up", "pool_sep_same", "adapt_conv"])
-def test_cat_reduce_cell_against_torch_cpu_autograd(kind, monkeypatch):
+@pytest.mark.parametrize("kind,mode", [("sep_sep_down", "train"), ("sep_dil_up", "train"), ("pool_sep_same", "train"),
+                                       ("adapt_conv", "train"), ("sep_sep_down", "eval"), ("pool_sep_same", "eval")])
+def test_cat_reduce_cell_against_torch_cpu_autograd(kind, mode, monkeypatch):
+    """mode eval: every BatchNorm on its running statistics WITH gradients (the engine's freeze_bn mode,
+    src/engine/trainer.py:124-127,219-222) - nothing folds, the same pending-tail path with statistics from the buffers"""
     from nas_segm_amd.nn.layer_factory import run_op
 
     Fm = lower_thresholds(monkeypatch)
     cell, (c1, hw1), (c2, hw2) = _build_cell(kind)
     randomise(cell, 6)
-    ref = copy.deepcopy(cell).train()
-    ref64 = copy.deepcopy(cell).double().train()
-    cell = cell.to(DEV).train()
+    ref = copy.deepcopy(cell).train(mode == "train")
+    ref64 = copy.deepcopy(cell).double().train(mode == "train")
+    cell = cell.to(DEV).train(mode == "train")
     x1, x2 = rnd(2, c1, *hw1, seed=2), rnd(2, c2, *hw2, seed=4)
     xs = [x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)]
     yc = _cell_reference(ref, *xs)
