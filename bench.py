@@ -540,6 +540,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     if args.same_device:
         local_rank = 0
+        if args.backend == "nccl":
+            # (RCCL refuses two ranks on one device - "Duplicate GPU detected": the debug mode stages through gloo)
+            if rank == 0:
+                sys.stderr.write("bench.py: --same-device: RCCL needs a device per rank, using --backend gloo\n")
+            args.backend = "gloo"
     elif local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank {} has no GPU of its own ({} visible)".format(
             local_rank, torch.cuda.device_count()))
