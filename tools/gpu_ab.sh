@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B on ONE box: the headline bench of this tree against the round-2 tree (_ab_r2, built in the container)
+# A/B on ONE box: the headline bench of this tree against the round-2 tree (_ab_r2, built in the container:
+#   git worktree add _ab_r2 33418a2 && (cd _ab_r2 && python -c 'import __graft_entry__ as g; g.build()');
+#   _ab_r2/ is git-ignored and removed again after the measurement - it would travel with every gpurun call)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/r3ab; mkdir -p $OUT
 for i in 1 2; do
