@@ -1364,3 +1364,127 @@ def test_pointwise_backward_emits_the_sums_of_the_batchnorm_in_front(case, in_ac
     lib.call("nasseg_rows_sum", ptr(part), nsl, 2 * K, ptr(got), s)
     tol = 1e-5 * float(M) ** 0.5 * float(dx_ref.abs().max()) * (float(pis.max()) * 4 + 1)
     assert_close(got, sums_ref, tol, 1e-4, "sums of the BatchNorm in front")
+
+
+# ---------------------------------------------------------------------------
+# nasseg_cat_src_fwd / _bwd / nasseg_bilinear_bwd_act: one input of ConcatReduce's slab, directly
+# (reference ops: Adapt's resize + torch.cat + BatchNorm backward, src/nn/layer_factory.py:316-382)
+# ---------------------------------------------------------------------------
+CAT_SRC_CASES = [
+    # B, C, (Hi, Wi), (Ho, Wo), pending tail's activation (None: a finished tensor), train
+    (1, 20, (7, 9), (7, 9), 1, 1),          # same size; Wo * C/4 < 256 and C/4 = 5 does not divide 64
+    (2, 64, (32, 64), (32, 64), 1, 1),      # two workgroups per row
+    (2, 24, (13, 17), (13, 17), 0, 0),      # BatchNorm-only tail (DilConv), slab BatchNorm on running statistics
+    (2, 32, (32, 48), (8, 12), 1, 1),       # 4x down-sampling: the sums are formed at the slab's size
+    (2, 12, (13, 17), (7, 9), 1, 1),        # non-integer down-sampling
+    (2, 16, (7, 9), (13, 17), 1, 1),        # up-sampling: the producer reduces for itself (no rows)
+    (3, 8, (9, 9), (9, 9), None, 1),        # finished input: a slice of the slab BatchNorm's backward
+    (2, 16, (4, 5), (32, 40), None, 1),     # finished input, x8 up (the separable transpose behind it)
+]
+
+
+@pytest.mark.parametrize("case", CAT_SRC_CASES, ids=lambda c: "B{}C{}_{}x{}_to_{}x{}_act{}_train{}".format(
+    c[0], c[1], *c[2], *c[3], c[4], c[5]))
+def test_cat_src_kernels_against_torch(case):
+    B, C, (Hi, Wi), (Ho, Wo), act, train = case
+    f = F()
+    s = f.current_stream()
+    Ct, off = 2 * C + 16, C + 8  # (this input's slice sits behind 8 + C other channels, 8 more follow)
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    z = torch.randn(B, C, Hi, Wi, generator=g)
+    pending = act is not None
+    tmean, tinv = torch.randn(C, generator=g) * 0.3, torch.rand(C, generator=g) + 0.5
+    tgamma, tbeta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    tscale, tshift = tgamma * tinv, tbeta - tmean * tgamma * tinv
+    tstats = torch.cat([tmean, tinv, tscale, tshift])
+
+    def tail(t):
+        if not pending:
+            return t
+        u = t * tscale.view(1, C, 1, 1) + tshift.view(1, C, 1, 1)
+        return TF.relu(u) if act == 1 else u
+
+    def resized(t):
+        return t if (Hi, Wi) == (Ho, Wo) else TF.interpolate(t, size=(Ho, Wo), mode="bilinear", align_corners=False)
+
+    # ---- forward: slice of the slab + its statistics rows
+    want = resized(tail(z))
+    slab = dev(torch.zeros(B, Ct, Ho, Wo))
+    nblk = f.lib.query("nasseg_cat_src_blocks", B, Ho, Wo, C)
+    assert nblk > 0
+    rows = torch.zeros((nblk + 64) * 2 * Ct, device=DEV)
+    zd, td = dev(z), tstats.to(DEV)
+    f.lib.call("nasseg_cat_src_fwd", f.ptr(zd), f.ptr(td[2 * C:3 * C]) if pending else None,
+               f.ptr(td[3 * C:]) if pending else None, act if pending else 0, f.ptr(slab), Ct, off, f.ptr(rows),
+               B, Hi, Wi, C, Ho, Wo, s)
+    got = slab[:, off:off + C]
+    assert_close(got, want, 1e-5, 1e-5, "slab slice")
+    assert float(slab[:, :off].abs().max()) == 0.0 and float(slab[:, off + C:].abs().max()) == 0.0
+    r = rows[:nblk * 2 * Ct].view(nblk, 2, Ct).double().sum(0).cpu()
+    wd = want.double()
+    assert_close(r[0, off:off + C], wd.sum(dim=(0, 2, 3)), 1e-4 * float(wd.abs().sum(dim=(0, 2, 3)).max()), 1e-5, "sum")
+    assert_close(r[1, off:off + C], (wd * wd).sum(dim=(0, 2, 3)), 1e-4 * float((wd * wd).sum(dim=(0, 2, 3)).max()), 1e-5,
+                 "sum of squares")
+
+    # ---- backward: slab BatchNorm backward of the slice (+ the pending producer's mask and sums)
+    M = B * Ho * Wo
+    du = torch.randn(B, Ct, Ho, Wo, generator=g)
+    sl = torch.randn(B, Ct, Ho, Wo, generator=g)
+    sscale, smean, sinv = torch.rand(Ct, generator=g) + 0.5, torch.randn(Ct, generator=g) * 0.2, torch.rand(Ct, generator=g) + 0.5
+    sums = torch.randn(2 * Ct, generator=g) * (M ** 0.5)
+    c = slice(off, off + C)
+    v = du[:, c].double()
+    if train:
+        xh = (sl[:, c].double() - smean[c].double().view(1, C, 1, 1)) * sinv[c].double().view(1, C, 1, 1)
+        v = v - sums[:Ct][c].double().view(1, C, 1, 1) / M - xh * sums[Ct:][c].double().view(1, C, 1, 1) / M
+    v = v * sscale[c].double().view(1, C, 1, 1)
+    # the producer's view: u = scale*z + shift, y = act(u), slab slice = resize(y); dL/du = mask * dL/dy
+    zz = z.double().requires_grad_(True)
+    if pending:
+        u = zz * tscale.double().view(1, C, 1, 1) + tshift.double().view(1, C, 1, 1)
+        u.retain_grad()
+        y = TF.relu(u) if act == 1 else u
+    else:
+        u = y = zz
+    rr = y if (Hi, Wi) == (Ho, Wo) else TF.interpolate(y, size=(Ho, Wo), mode="bilinear", align_corners=False)
+    (rr * v).sum().backward()
+    g_want = u.grad if pending else zz.grad  # gradient w.r.t. the producer's output, masked when pending
+    same = (Hi, Wi) == (Ho, Wo)
+    want_rows = pending and Hi * Wi >= Ho * Wo  # (functional._CatReduce.backward's rule)
+    part = torch.zeros((nblk + 64) * 2 * C, device=DEV) if want_rows else None
+    d = dev(torch.empty(B, C, Ho, Wo))
+    dud, sld = dev(du), dev(sl)
+    vec = [t.to(DEV) for t in (sscale, smean, sinv, sums)]
+    f.lib.call("nasseg_cat_src_bwd", f.ptr(dud), f.ptr(sld), Ct, off, f.ptr(vec[0]), f.ptr(vec[1]), f.ptr(vec[2]),
+               f.ptr(vec[3]), train, f.ptr(zd) if want_rows else None, f.ptr(td) if want_rows else None,
+               act if pending else 0, f.ptr(d), f.ptr(part), B, Ho, Wo, C, Hi if want_rows else Ho,
+               Wi if want_rows else Wo, s)
+    if same:
+        full = d
+        # (without rows the kernel leaves the mask to the producer's own backward)
+        ref_same = g_want if want_rows or not pending else v
+        assert_close(full, ref_same, 1e-4 * float(ref_same.abs().max()), 1e-4, "gradient at the slab's size")
+    else:
+        assert_close(d, v, 1e-4 * float(v.abs().max()), 1e-4, "slab-size gradient ahead of the transpose")
+        full = dev(torch.empty(B, C, Hi, Wi))
+        nws = f.lib.query("nasseg_bilinear_bwd_workspace", B, Hi, Wi, C, Ho, Wo)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        if want_rows:
+            f.lib.call("nasseg_bilinear_bwd_act", f.ptr(d), C, 0, f.ptr(zd), f.ptr(td[2 * C:3 * C]), f.ptr(td[3 * C:]),
+                       act, f.ptr(full), B, Hi, Wi, C, Ho, Wo, f.ptr(ws) if nws else None, s)
+            assert_close(full, g_want, 1e-4 * float(g_want.abs().max()), 1e-4, "masked transposed gradient")
+        else:
+            f.lib.call("nasseg_bilinear_bwd", f.ptr(d), C, 0, f.ptr(full), B, Hi, Wi, C, Ho, Wo,
+                       f.ptr(ws) if nws else None, s)
+            # unmasked: what the producer's own reduction / mask starts from
+            vv = v.clone().requires_grad_(False)
+            yy = z.double().requires_grad_(True)
+            (TF.interpolate(yy, size=(Ho, Wo), mode="bilinear", align_corners=False) * vv).sum().backward()
+            assert_close(full, yy.grad, 1e-4 * float(yy.grad.abs().max()), 1e-4, "transposed gradient")
+    if want_rows:
+        pr = part[:nblk * 2 * C].view(nblk, 2, C).double().sum(0).cpu()
+        xhat = (z.double() - tmean.double().view(1, C, 1, 1)) * tinv.double().view(1, C, 1, 1)
+        s0, s1 = g_want.sum(dim=(0, 2, 3)), (g_want * xhat).sum(dim=(0, 2, 3))
+        scale0 = float(g_want.abs().sum(dim=(0, 2, 3)).max())
+        assert_close(pr[0], s0, 2e-5 * scale0, 1e-4, "sum g")
+        assert_close(pr[1], s1, 2e-5 * float((g_want * xhat).abs().sum(dim=(0, 2, 3)).max()), 1e-4, "sum g*xhat")
