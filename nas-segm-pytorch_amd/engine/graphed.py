@@ -22,8 +22,9 @@ bucket (one multi-tensor copy) and all-reduced with one collective after the rep
 (``auto_graph``): at most ``AUTO_GRAPH_MAX_PIXELS`` image pixels per step and rank (one process,
 independent candidates per rank, or data-parallel replicas whose gradient all-reduce follows the
 replay) - above that the step is GPU-bound and a
-replay runs at the speed of host launches (measured: 4x1024x2048 195.9 eager / 195.7 replayed
-images/s, 8x713x713 467 / 610, 8x480x640 445 / 590, 16x321x321 682 / 1062).
+replay runs at the speed of host launches (measured, round 3: 4x1024x2048 262.1 eager / 261.0 replayed
+images/s, 8x713x713 518-586 / 732, 8x480x640 438 / 675 (bf16), 16x321x321 711 / 1116; with bf16 storage the
+4x1024x2048 step is at the edge - 13.3 ms of host work against 13.9 ms of GPU time: 265-287 eager, 287.7 replayed).
 """
 import gc
 import logging
