@@ -45,6 +45,21 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
+def _address_of(obj):
+    """Address behind a ctypes array / pointer / c_void_p (the call shim's slow path; ints and None never get
+    here)."""
+    if isinstance(obj, ctypes.Array):
+        return ctypes.addressof(obj)
+    if not isinstance(obj, (ctypes._SimpleCData, ctypes._Pointer)):
+        raise TypeError("address must be an int, None or a ctypes array / pointer, not {}".format(type(obj).__name__))
+    value = getattr(obj, "value", None)  # c_void_p and friends
+    if isinstance(value, int):
+        return value
+    if value is None and isinstance(obj, ctypes.c_void_p):
+        return 0
+    return ctypes.cast(obj, ctypes.c_void_p).value or 0
+
+
 class NassegError(RuntimeError):
     """A nasseg C-ABI call failed (bad arguments, HIP launch failure, ...)."""
 
@@ -95,6 +110,8 @@ class _Library(object):
     def __init__(self):
         self._dll = None
         self._fn = {}
+        self._ctypes_fn = {}
+        self.ffi = None  # "native" | "ctypes" once loaded
         self._memo = {}
         self.profiler = None
 
@@ -107,13 +124,35 @@ class _Library(object):
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.".format(LIB_PATH)
             )
         dll = ctypes.CDLL(LIB_PATH)
+        ffi = self._shim()
         for name, (restype, argtypes) in parse_header().items():
             fn = getattr(dll, name)  # AttributeError if the symbol is not exported
             fn.restype = restype
             fn.argtypes = argtypes
+            self._ctypes_fn[name] = fn
+            fast = getattr(ffi, name, None) if ffi is not None else None
+            if fast is not None and ffi.bind(name, ctypes.cast(fn, ctypes.c_void_p).value):
+                fn = fast
             self._fn[name] = fn
+        self.ffi = "native" if ffi is not None else "ctypes"
         self._dll = dll
         return self
+
+    @staticmethod
+    def _shim():
+        """The generated CPython call shim (ffi_gen.py; built by build.py next to the library): same library,
+        same symbols - resolved above with ctypes and handed over by address - a fifth of the host time per
+        call.  NASSEG_FFI=ctypes keeps ctypes; a shim that is missing or older than the header does too."""
+        if os.environ.get("NASSEG_FFI", "native") == "ctypes":
+            return None
+        try:
+            from . import _nasseg_ffi as ffi
+        except ImportError:
+            return None
+        if os.path.getmtime(ffi.__file__) < os.path.getmtime(HEADER_PATH):
+            return None  # (generated from an older header: its argument lists may not match)
+        ffi.set_addr_of(_address_of)
+        return ffi
 
     def symbols(self):
         self.load()
@@ -122,7 +161,7 @@ class _Library(object):
     def last_error(self):
         self.load()
         msg = self._fn["nasseg_last_error"]()
-        return msg.decode("utf-8", "replace") if msg else ""
+        return msg.decode("utf-8", "replace") if msg else ""  # (bytes from either call path)
 
     def call(self, name, *args):
         """Call a status-returning entry point; raise RuntimeError on failure."""

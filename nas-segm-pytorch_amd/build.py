@@ -69,9 +69,29 @@ def build_library(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n{}\n{}".format(r.stdout, r.stderr))
+    build_ffi(force=force, verbose=verbose)
     if verbose:
         print("built", LIB_PATH)
     return LIB_PATH
+
+
+def build_ffi(force=False, verbose=False):
+    """The native call shim (ffi_gen.py): generated from include/nasseg.h, compiled with the host C compiler.
+    Optional - without it the calls go through ctypes (same library, same kernels, ~4 us more host time each)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_nasseg_ffi_gen", os.path.join(HERE, "ffi_gen.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    header = os.path.join(os.path.dirname(HERE), "include", "nasseg.h")
+    try:
+        path = gen.build(header, HERE, OBJ_DIR, force=force)
+    except (RuntimeError, OSError) as e:  # (no compiler / headers: ctypes stays)
+        sys.stderr.write("nasseg: call shim not built ({}); using ctypes\n".format(str(e).splitlines()[0]))
+        return None
+    if verbose and path:
+        print("built", path)
+    return path
 
 
 if __name__ == "__main__":

@@ -371,3 +371,36 @@ def test_pending_tail_is_materialised_for_consumers_that_do_not_take_it(monkeypa
     F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("psum"), shapes)  # ParamSum does not accept pending inputs
     assert [n for n, _ in fwd].count("nasseg_affine_act") == 2
     assert not F._TAIL_ROWS
+
+
+def test_native_call_shim_agrees_with_ctypes():
+    """The generated CPython shim (ffi_gen.py -> _nasseg_ffi) is the default call path once built: same symbols
+    (bound by address from the ctypes handle), same results and error convention as ctypes; NASSEG_FFI=ctypes
+    switches it off."""
+    import subprocess
+    import sys
+
+    from nas_segm_amd._lib import NassegError, lib, parse_header
+
+    lib.load()
+    assert lib.ffi == "native", "build() did not produce the call shim"
+    protos = parse_header()
+    for name in protos:
+        assert lib._fn[name] is not lib._ctypes_fn[name], name  # every prototype has a native entry
+    for args in ((4, 128, 256, 64, 64, 1), (1, 7, 9, 20, 32, 0), (2, 512, 1024, 96, 16, 2)):
+        assert lib._fn["nasseg_conv_fwd_stats_blocks"](*args) == lib._ctypes_fn["nasseg_conv_fwd_stats_blocks"](*args)
+    assert lib._fn["nasseg_colred_workspace"](1, 1 << 33, 64) == lib._ctypes_fn["nasseg_colred_workspace"](1, 1 << 33, 64)
+    # a refused call: negative status, message through nasseg_last_error() (bytes from either path)
+    with pytest.raises(NassegError, match="rows_sum"):
+        lib.call("nasseg_rows_sum", None, 0, 0, None, None)
+    with pytest.raises(TypeError):
+        lib._fn["nasseg_rows_sum"](None, 0, 0, None)  # arity is checked
+    with pytest.raises(TypeError):
+        lib._fn["nasseg_rows_sum"]("not an address", 1, 1, None, None)
+    code = ("import nas_segm_amd; from nas_segm_amd._lib import lib; lib.load(); "
+            "assert lib.ffi == 'ctypes'; print(lib.query('nasseg_cat_src_blocks', 4, 32, 64, 64))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, NASSEG_FFI="ctypes"),
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert int(out.stdout.strip()) == lib.query("nasseg_cat_src_blocks", 4, 32, 64, 64)
