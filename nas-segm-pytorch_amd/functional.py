@@ -723,6 +723,14 @@ class _ConvChain(torch.autograd.Function):
         cur, pend = x, ((None, None, in_act0) if in_act0 else None)
         saved, meta = [], []
         n_ops = len(ops)
+        in_pending = len(cfg) > 5 and cfg[5] is not None
+        if in_pending:
+            # the input is another chain's Pending: its BatchNorm + activation are op 0's prologue (tensors[-1]: the
+            # producer's statistics vector); what backward returns for x is the gradient w.r.t. the ACTIVATED
+            # input - exactly what a plain backward-data of op 0 computes
+            K0 = x.shape[1]
+            in_st = tensors[6 * n_ops]
+            pend = (in_st[2 * K0:3 * K0], in_st[3 * K0:], cfg[5])
         # every layout of every weight of the chain (forward now, backward-data later) is
         # produced by one launch
         weights = [tensors[6 * i].contiguous() for i in range(n_ops)]
@@ -1126,7 +1134,7 @@ class _ConvChain(torch.autograd.Function):
                 # the chain started with an activation applied on load and the backward-data
                 # kernel had no fused mask for this geometry
                 dx = _act_bwd(dx, sv[0], in_act0)
-        return (None, dx, dres) + tuple(grads)
+        return (None, dx, dres) + tuple(grads) + ((None,) if (len(cfg) > 5 and cfg[5] is not None) else ())
 
 
 # BatchNorm-backward partial rows handed from a consumer's backward to the producer chain's, by the side of
@@ -1135,6 +1143,7 @@ class _ConvChain(torch.autograd.Function):
 _TAIL_ROWS = {}
 FUSE_TAIL_ROWS = os.environ.get("NASSEG_FUSE_TAIL_ROWS", "1") != "0"
 _TAIL_ROWS_UP = os.environ.get("NASSEG_TAIL_ROWS_UP", "0") == "1"  # (A/B switch: also for up-sampled producers)
+_PENDING_IN = os.environ.get("NASSEG_PENDING_IN", "1") != "0"  # (A/B switch: chains take a Pending as their prologue)
 
 
 class Pending(object):
@@ -1202,6 +1211,19 @@ def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None, defer_tail=Fa
                             True, int(act), bool(training), float(momentum), float(eps)))
             tensors.extend([weight, gamma, beta, rm, rv, nbt if training else None])
     cfg = (int(in_act0), tuple(cfg_ops), torch.is_grad_enabled())
+    if isinstance(x, Pending):
+        if in_act0 != ACT_NONE or not cfg_ops or not _PENDING_IN:
+            x = x.materialize()  # (an activation on top of a pending one: not fused)
+        else:
+            # cfg[3] pool, cfg[4] deferred tail, cfg[5] the pending input's activation (its statistics vector
+            # rides behind the per-op tensors)
+            defer = bool(defer_tail and residual is None and pool is None and cfg_ops[-1][4])
+            full = cfg + ((int(pool[0]), int(pool[1]), int(pool[2])) if pool is not None else None, defer, x.act)
+            out = _ConvChain.apply(full, x.z, residual, *(tensors + [x.stats]))
+            if not defer:
+                return out
+            y, stats = out
+            return y if stats is None else Pending(y, stats, cfg_ops[-1][5])
     if pool is not None:
         cfg = cfg + ((int(pool[0]), int(pool[1]), int(pool[2])),)
     elif defer_tail and residual is None and cfg_ops and cfg_ops[-1][4]:

@@ -262,10 +262,11 @@ class Adapt(nn.Module):
 
     def convs(self, x1, x2, defer_tail=False):
         """The channel adaptation alone (ConcatReduce resizes as it writes its slab)."""
+        # (a pending input is the 1x1 conv's prologue: conv_chain takes it)
         if self.C_in0 != self.C_out:
-            x1 = self.conv0(F.materialize(x1), defer_tail=defer_tail)
+            x1 = self.conv0(x1, defer_tail=defer_tail)
         if self.C_in1 != self.C_out:
-            x2 = self.conv1(F.materialize(x2), defer_tail=defer_tail)
+            x2 = self.conv1(x2, defer_tail=defer_tail)
         return x1, x2
 
     def target_size(self, x1, x2):

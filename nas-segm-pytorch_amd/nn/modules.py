@@ -137,6 +137,8 @@ def run_fused(modules, x, residual=None, relu_in=False, pool=None, defer_tail=Fa
     mods = _flatten(modules)
     n = len(mods)
     i = 0
+    if isinstance(x, F.Pending) and not (n and _chainable(mods[0]) and not relu_in):
+        x = x.materialize()  # (only a conv at the head of the sequence applies a pending input as its prologue)
     res_used = residual is None
     if relu_in and not (n and _chainable(mods[0])):
         x, relu_in = F.relu(x), False
