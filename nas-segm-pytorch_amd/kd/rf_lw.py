@@ -24,183 +24,138 @@ from ..nn.modules import BatchNorm2d, Conv2d, FusedSequential, MaxPool2d, ReLU, 
 
 num_classes = 21
 
+# ResNet stages: (bottleneck width, stride of the first block); depths come with the variant
+_RESNET_STAGES = ((64, 1), (128, 2), (256, 2), (512, 2))
+_EXPANSION = 4
+# The RefineNet decoder, deepest encoder map first: (encoder channels, width of the stage, channels handed to
+# the next stage or None for the last one).  Attribute names follow the reference checkpoint
+# (model_lw_v2.py:191-211): p_ims1d2_outl{g}_dimred, adapt_stage{g}_b2_joint_varout_dimred (g > 1),
+# mflow_conv_g{g}_pool, mflow_conv_g{g}_b3_joint_varout_dimred (g < 4) - created in exactly this order, which
+# is also the order a seeded initialisation visits them in.
+_DECODER_STAGES = ((2048, 512, 256), (1024, 256, 256), (512, 256, 256), (256, 256, None))
+_CRP_STAGES = 4
 
-def conv3x3(in_planes, out_planes, stride=1, bias=False):
-    return Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=bias)
 
-
-def conv1x1(in_planes, out_planes, stride=1, bias=False):
-    return Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, padding=0, bias=bias)
+def _pointwise(cin, cout):
+    return Conv2d(cin, cout, kernel_size=1, stride=1, padding=0, bias=False)
 
 
 class CRPBlock(nn.Module):
-    """Chained residual pooling (model_lw_v2.py:76-100): n x [5x5 max-pool (stride 1) -> 1x1 conv], each
-    stage's output added to the running sum."""
+    """Chained residual pooling (model_lw_v2.py:76-100): a running sum of n x [5x5 max-pool, stride 1 -> 1x1
+    conv] applied to the block's input.  Keys ``{i}_outvar_dimred.weight``, i = 1..n."""
 
     def __init__(self, in_planes, out_planes, n_stages):
-        super(CRPBlock, self).__init__()
-        for i in range(n_stages):
-            setattr(self, "{}_{}".format(i + 1, "outvar_dimred"),
-                    conv1x1(in_planes if (i == 0) else out_planes, out_planes, stride=1, bias=False))
-        self.stride = 1
+        super().__init__()
         self.n_stages = n_stages
+        self.stride = 1
+        widths = [in_planes] + [out_planes] * n_stages
+        for i in range(n_stages):
+            self.add_module("{}_outvar_dimred".format(i + 1), _pointwise(widths[i], widths[i + 1]))
         self.maxpool = MaxPool2d(kernel_size=5, stride=1, padding=2)
 
     def forward(self, x):
-        top = x
+        acc, path = x, x
         for i in range(self.n_stages):
-            top = self.maxpool(top)
-            top = getattr(self, "{}_{}".format(i + 1, "outvar_dimred"))(top)
-            x = F.add(top, x)
-        return x
-
-
-class BasicBlock(nn.Module):
-    expansion = 1
-
-    def __init__(self, inplanes, planes, stride=1, downsample=None):
-        super(BasicBlock, self).__init__()
-        self.conv1 = conv3x3(inplanes, planes, stride)
-        self.bn1 = BatchNorm2d(planes, momentum=0.95)
-        self.relu = ReLU(inplace=True)
-        self.conv2 = conv3x3(planes, planes)
-        self.bn2 = BatchNorm2d(planes, momentum=0.95)
-        self.downsample = downsample
-        self.stride = stride
-
-    def forward(self, x):
-        residual = x if self.downsample is None else self.downsample(x)
-        # conv1 -> bn1 -> relu -> conv2 -> bn2 (+ residual) as one fused sequence, then the ReLU
-        out = run_fused([self.conv1, self.bn1, self.relu, self.conv2, self.bn2], x, residual=residual)
-        return F.relu(out)
+            path = self._modules["{}_outvar_dimred".format(i + 1)](self.maxpool(path))
+            acc = F.add(path, acc)
+        return acc
 
 
 class Bottleneck(nn.Module):
-    expansion = 4
+    """1x1 -> 3x3 (stride) -> 1x1 (x4) with BatchNorms, skip connection, ReLU (model_lw_v2.py:131-169); the whole
+    body is one fused conv chain with the skip as its residual."""
+    expansion = _EXPANSION
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
-        super(Bottleneck, self).__init__()
+        super().__init__()
         self.conv1 = Conv2d(inplanes, planes, kernel_size=1, bias=False)
         self.bn1 = BatchNorm2d(planes, momentum=0.95)
         self.conv2 = Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
         self.bn2 = BatchNorm2d(planes, momentum=0.95)
-        self.conv3 = Conv2d(planes, planes * 4, kernel_size=1, bias=False)
-        self.bn3 = BatchNorm2d(planes * 4, momentum=0.95)
+        self.conv3 = Conv2d(planes, planes * _EXPANSION, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm2d(planes * _EXPANSION, momentum=0.95)
         self.relu = ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x):
-        residual = x if self.downsample is None else self.downsample(x)
-        out = run_fused([self.conv1, self.bn1, self.relu, self.conv2, self.bn2, self.relu, self.conv3, self.bn3],
-                        x, residual=residual)
-        return F.relu(out)
+        skip = x if self.downsample is None else self.downsample(x)
+        body = [self.conv1, self.bn1, self.relu, self.conv2, self.bn2, self.relu, self.conv3, self.bn3]
+        return F.relu(run_fused(body, x, residual=skip))
 
 
 class ResNetLW(nn.Module):
+    """Encoder (ResNet) + Light-Weight RefineNet decoder, both generated from the tables above."""
+
     def __init__(self, block, layers, num_classes=21):
+        super().__init__()
         self.inplanes = 64
-        super(ResNetLW, self).__init__()
         self.do = nn.Dropout(p=0.5)
         self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = BatchNorm2d(64)
         self.relu = ReLU(inplace=True)
         self.maxpool = MaxPool2d(kernel_size=3, stride=2, padding=1)
-        self.layer1 = self._make_layer(block, 64, layers[0])
-        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
-        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
-        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
-        self.p_ims1d2_outl1_dimred = conv1x1(2048, 512, bias=False)
-        self.mflow_conv_g1_pool = self._make_crp(512, 512, 4)
-        self.mflow_conv_g1_b3_joint_varout_dimred = conv1x1(512, 256, bias=False)
-        self.p_ims1d2_outl2_dimred = conv1x1(1024, 256, bias=False)
-        self.adapt_stage2_b2_joint_varout_dimred = conv1x1(256, 256, bias=False)
-        self.mflow_conv_g2_pool = self._make_crp(256, 256, 4)
-        self.mflow_conv_g2_b3_joint_varout_dimred = conv1x1(256, 256, bias=False)
-
-        self.p_ims1d2_outl3_dimred = conv1x1(512, 256, bias=False)
-        self.adapt_stage3_b2_joint_varout_dimred = conv1x1(256, 256, bias=False)
-        self.mflow_conv_g3_pool = self._make_crp(256, 256, 4)
-        self.mflow_conv_g3_b3_joint_varout_dimred = conv1x1(256, 256, bias=False)
-
-        self.p_ims1d2_outl4_dimred = conv1x1(256, 256, bias=False)
-        self.adapt_stage4_b2_joint_varout_dimred = conv1x1(256, 256, bias=False)
-        self.mflow_conv_g4_pool = self._make_crp(256, 256, 4)
-
-        self.clf_conv = Conv2d(256, num_classes, kernel_size=3, stride=1, padding=1, bias=True)
-
-    def _make_crp(self, in_planes, out_planes, stages):
-        return nn.Sequential(CRPBlock(in_planes, out_planes, stages))
+        for i, ((planes, stride), depth) in enumerate(zip(_RESNET_STAGES, layers)):
+            self.add_module("layer{}".format(i + 1), self._make_layer(block, planes, depth, stride))
+        for g, (enc, width, out) in enumerate(_DECODER_STAGES, start=1):
+            self.add_module("p_ims1d2_outl{}_dimred".format(g), _pointwise(enc, width))
+            if g > 1:
+                self.add_module("adapt_stage{}_b2_joint_varout_dimred".format(g), _pointwise(width, width))
+            self.add_module("mflow_conv_g{}_pool".format(g), nn.Sequential(CRPBlock(width, width, _CRP_STAGES)))
+            if out is not None:
+                self.add_module("mflow_conv_g{}_b3_joint_varout_dimred".format(g), _pointwise(width, out))
+        self.clf_conv = Conv2d(_DECODER_STAGES[-1][1], num_classes, kernel_size=3, stride=1, padding=1, bias=True)
 
     def _make_layer(self, block, planes, blocks, stride=1):
-        downsample = None
-        if stride != 1 or self.inplanes != planes * block.expansion:
-            downsample = FusedSequential(
-                Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
-                BatchNorm2d(planes * block.expansion),
-            )
-        layers = [block(self.inplanes, planes, stride, downsample)]
-        self.inplanes = planes * block.expansion
-        for _ in range(1, blocks):
-            layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
-
-    def _dropout(self, x):
-        if self.training:
-            raise NassegError("the distillation teacher is inference-only here (no dropout kernel): call .eval()")
-        return x
+        width = planes * block.expansion
+        project = None
+        if stride != 1 or self.inplanes != width:
+            project = FusedSequential(Conv2d(self.inplanes, width, kernel_size=1, stride=stride, bias=False),
+                                      BatchNorm2d(width))
+        units = [block(self.inplanes, planes, stride, project)]
+        units += [block(width, planes) for _ in range(blocks - 1)]
+        self.inplanes = width
+        return nn.Sequential(*units)
 
     def forward(self, x):
-        x = run_fused([self.conv1, self.bn1, self.relu], x)
-        x = self.maxpool(x)
+        if self.training:
+            raise NassegError("the distillation teacher is inference-only here (no dropout kernel): call .eval()")
+        x = self.maxpool(run_fused([self.conv1, self.bn1, self.relu], x))
+        pyramid = []
+        for i in range(len(_RESNET_STAGES)):
+            x = self._modules["layer{}".format(i + 1)](x)
+            pyramid.append(x)
+        pyramid.reverse()  # deepest first; (dropout on the two deepest maps is the identity in eval mode)
+        m = self._modules
+        carried = None
+        for g, feat in enumerate(pyramid, start=1):
+            y = m["p_ims1d2_outl{}_dimred".format(g)](feat)
+            if carried is not None:
+                y = F.add(m["adapt_stage{}_b2_joint_varout_dimred".format(g)](y), carried)
+            y = m["mflow_conv_g{}_pool".format(g)](F.relu(y))
+            if g < len(pyramid):
+                y = m["mflow_conv_g{}_b3_joint_varout_dimred".format(g)](y)
+                carried = F.bilinear_resize(y, pyramid[g].size()[2:], align_corners=True)
+        return self.clf_conv(y)
 
-        l1 = self.layer1(x)
-        l2 = self.layer2(l1)
-        l3 = self.layer3(l2)
-        l4 = self.layer4(l3)
 
-        l4 = self._dropout(l4)
-        l3 = self._dropout(l3)
-
-        x4 = F.relu(self.p_ims1d2_outl1_dimred(l4))
-        x4 = self.mflow_conv_g1_pool(x4)
-        x4 = self.mflow_conv_g1_b3_joint_varout_dimred(x4)
-        x4 = F.bilinear_resize(x4, l3.size()[2:], align_corners=True)
-
-        x3 = self.p_ims1d2_outl2_dimred(l3)
-        x3 = self.adapt_stage2_b2_joint_varout_dimred(x3)
-        x3 = F.relu(F.add(x3, x4))
-        x3 = self.mflow_conv_g2_pool(x3)
-        x3 = self.mflow_conv_g2_b3_joint_varout_dimred(x3)
-        x3 = F.bilinear_resize(x3, l2.size()[2:], align_corners=True)
-
-        x2 = self.p_ims1d2_outl3_dimred(l2)
-        x2 = self.adapt_stage3_b2_joint_varout_dimred(x2)
-        x2 = F.relu(F.add(x2, x3))
-        x2 = self.mflow_conv_g3_pool(x2)
-        x2 = self.mflow_conv_g3_b3_joint_varout_dimred(x2)
-        x2 = F.bilinear_resize(x2, l1.size()[2:], align_corners=True)
-
-        x1 = self.p_ims1d2_outl4_dimred(l1)
-        x1 = self.adapt_stage4_b2_joint_varout_dimred(x1)
-        x1 = F.relu(F.add(x1, x2))
-        x1 = self.mflow_conv_g4_pool(x1)
-
-        return self.clf_conv(x1)
+def _checkpoint_path(name):
+    """Where the reference's loader caches its download (model_lw_v2.py:283-289 -> utils/helpers.maybe_download)."""
+    torch_home = os.path.expanduser(os.getenv("TORCH_HOME", "~/.torch"))
+    return os.path.join(os.getenv("TORCH_MODEL_ZOO", os.path.join(torch_home, "models")), name)
 
 
 def rf_lw152(pretrained=False, num_classes=num_classes, **kwargs):
-    """ResNet-152 Light-Weight RefineNet (model_lw_v2.py:280-297)."""
+    """ResNet-152 Light-Weight RefineNet (model_lw_v2.py:280-297).  ``pretrained=True`` loads the reference's
+    checkpoint from its cache location (entries whose key this model lacks are ignored, as there); there is no
+    network here, so a missing file is an error."""
     model = ResNetLW(Bottleneck, [3, 8, 36, 3], num_classes=num_classes, **kwargs)
     if pretrained:
-        torch_home = os.path.expanduser(os.getenv("TORCH_HOME", "~/.torch"))
-        model_dir = os.getenv("TORCH_MODEL_ZOO", os.path.join(torch_home, "models"))
-        cached = os.path.join(model_dir, "rf_lw152.pth.tar")  # (where the reference caches its download)
-        if not os.path.exists(cached):
+        path = _checkpoint_path("rf_lw152.pth.tar")
+        if not os.path.exists(path):
             raise NassegError("rf_lw152(pretrained=True): {} not found and there is no network here; fetch the "
-                              "reference's checkpoint to that path".format(cached))
-        pretrained_dict = torch.load(cached, map_location="cpu")
-        model_dict = model.state_dict()
-        model_dict.update({k: v for k, v in pretrained_dict.items() if k in model_dict})
-        model.load_state_dict(model_dict)
+                              "reference's checkpoint to that path".format(path))
+        known = model.state_dict()
+        loaded = {k: v for k, v in torch.load(path, map_location="cpu").items() if k in known}
+        model.load_state_dict(loaded, strict=False)
     return model
