@@ -142,15 +142,18 @@ class _Library(object):
     def _shim():
         """The generated CPython call shim (ffi_gen.py; built by build.py next to the library): same library,
         same symbols - resolved above with ctypes and handed over by address - a fifth of the host time per
-        call.  NASSEG_FFI=ctypes keeps ctypes; a shim that is missing or older than the header does too."""
+        call.  NASSEG_FFI=ctypes keeps ctypes; so does a missing shim, or one generated from other prototypes
+        than include/nasseg.h declares now (ffi_gen.abi_hash - not file times)."""
         if os.environ.get("NASSEG_FFI", "native") == "ctypes":
             return None
         try:
             from . import _nasseg_ffi as ffi
         except ImportError:
             return None
-        if os.path.getmtime(ffi.__file__) < os.path.getmtime(HEADER_PATH):
-            return None  # (generated from an older header: its argument lists may not match)
+        from . import ffi_gen
+
+        if not hasattr(ffi, "abi") or ffi.abi() != ffi_gen.abi_hash(HEADER_PATH):
+            return None  # (generated from another header: its argument lists may not match the library's)
         ffi.set_addr_of(_address_of)
         return ffi
 

@@ -15,8 +15,9 @@ the static input buffers, the RCCL gradient all-reduce, and (unless
 
 Gradients are cleared (``grad = None``) before the capture, so backward writes them as
 fresh tensors of the graph's private pool: every replay refills the same addresses and no
-accumulation kernels are recorded.  When data parallel they are packed into one flat fp32
-bucket (one multi-tensor copy) and all-reduced with one collective after the replay.
+accumulation kernels are recorded.  When data parallel they go to ``RankParallel.sync_gradients()``
+after the replay - the same flat fp32 bucket, status element and step count as a host-launched step,
+so replaying and host-launching ranks (and a failing one) pair their collectives.
 
 ``train_segmenter`` / ``train_task0`` use these steppers by themselves where they win
 (``auto_graph``): at most ``AUTO_GRAPH_MAX_PIXELS`` image pixels per step and rank (one process,
@@ -29,9 +30,9 @@ images/s, 8x713x713 518-586 / 732, 8x480x640 438 / 675 (bf16), 16x321x321 711 / 
 import gc
 import logging
 import os
+import weakref
 
 import torch
-import torch.distributed as dist
 from torch import nn
 
 from .. import functional as F
@@ -81,28 +82,19 @@ class _GraphedStep(object):
         self.capture_optimisers = bool(capture_optimisers and self.world == 1
                                        and all(_capturable(o) for o in optimisers))
         self._optimisers = [o for o in optimisers if o is not None]
-        self.flat = self._views = None
         self._params = [p for m in self._trained for p in m.parameters()]
         self._pack_memo = F.PackMemo()  # (owns the packed-weight buffers the graph reads)
-        # A capture that fails on ONE rank (HIP out of memory, say) must fail on all of them: the
-        # others would otherwise wait for it in the first gradient all-reduce.
-        error = None
-        try:
-            self._capture(warmup)
-        except RuntimeError as e:
-            error = e
-        if self.world > 1:
-            flag = torch.tensor([1.0 if error is not None else 0.0], device=self._params[0].device)
-            dist.all_reduce(flag, group=getattr(segmenter, "process_group", None))
-            if error is None and float(flag) > 0:
-                error = RuntimeError("graphed step: the capture failed on a peer rank")
-        if error is not None:
-            raise error
+        # Data parallel, the replayed region ends where the eager step's does: the gradients are handed to
+        # RankParallel.sync_gradients() - ONE bucket layout (every trainable parameter + the status element)
+        # for replayed steps, host-launched steps and a failing rank's farewell alike.  A capture therefore
+        # needs no agreement between the ranks: one that fails here (HIP out of memory, say) leaves THIS rank
+        # launching from the host while its peers replay, and their collectives still pair.
+        self._rank_parallel = weakref.ref(segmenter) if self.world > 1 else None
+        self._capture(warmup)
         # The modules were needed to RECORD the step; replaying needs parameters, optimisers and
         # static tensors only.  Dropping them here means a stepper cached on its model (engine/
         # trainer.py) forms no reference cycle: the candidate's graph and its memory pool go away
         # with the candidate, by reference counting, not at some later garbage collection.
-        self._process_group = getattr(segmenter, "process_group", None)
         self.segmenter = self.model = self._trained = None
         if hasattr(self, "decoder"):
             self.decoder = None
@@ -196,21 +188,15 @@ class _GraphedStep(object):
         # capturing executes nothing: state is exactly as restored above.  The gradients the
         # capture left in ``param.grad`` are the static tensors every replay refills.
         self._static_grads = [(p, p.grad) for p in self._params if p.grad is not None]
-        if self.world > 1:
-            used = [p for p, _ in self._static_grads]
-            self.flat = torch.zeros(sum(p.numel() for p in used), device=used[0].device,
-                                    dtype=used[0].dtype)
-            self._views, off = [], 0
-            for p in used:
-                self._views.append(self.flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
 
-    def _all_reduce(self):
-        torch._foreach_copy_(self._views, [g for _, g in self._static_grads])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self._process_group)
-        self.flat.div_(self.world)
-        for (p, _), v in zip(self._static_grads, self._views):
-            p.grad = v
+    def _sync_gradients(self):
+        """the step's gradient collective - RankParallel's, so that the failure protocol (status element,
+        ``sync_count``) covers replayed steps: a peer that left its step loop is seen by ``check_peers`` right
+        after this step, and a failure AFTER this point (clipping, the optimisers) is told in the next one"""
+        owner = self._rank_parallel() if self._rank_parallel is not None else None
+        if owner is None:
+            raise F.NassegError("graphed step: the data-parallel segmenter it was captured for is gone")
+        owner.sync_gradients()
 
     def _replay(self):
         self.graph.replay()
@@ -218,7 +204,7 @@ class _GraphedStep(object):
             p.grad = g
         if not self.capture_optimisers:
             if self.world > 1:
-                self._all_reduce()
+                self._sync_gradients()
             clip_and_step(self.groups)
         return self.loss
 

@@ -24,6 +24,14 @@ class PeerFailure(RuntimeError):
     0 - abandons the candidate on ALL ranks together and the collectives stay paired."""
 
 
+class RankFailure(RuntimeError):
+    """A data-parallel rank's step loop ended with an exception that is not a RuntimeError (an
+    IndexError from the feature cache, a ValueError from a loader ...).  In ONE process the reference lets
+    those escape ``try_except`` (helpers/utils.py:172-187); with one process per GPU that would end this
+    rank's process while its peers wait in the next collective, so the engine re-raises them as this
+    RuntimeError (``__cause__`` = the original): every rank then scores the candidate 0 and moves on."""
+
+
 class RankParallel(nn.Module):
     """Data parallelism with one process per GPU over RCCL.
 
@@ -164,6 +172,20 @@ class RankParallel(nn.Module):
         if not ok:
             raise PeerFailure("a data-parallel peer failed in this step: candidate abandoned on all ranks")
         return value
+
+    def epoch_status(self, failed=False):
+        """The end-of-epoch handshake of a training epoch: one single-element all-reduce that every rank
+        which reached the end of its step loop takes part in - and a rank whose LAST step failed after that
+        step's gradient collective (clipping, the optimisers), with ``failed``: there is no next step whose
+        collective could carry its status.  Raises PeerFailure on the healthy ranks."""
+        if self.world_size == 1:
+            return
+        if self._flat is None:
+            self._build_bucket()
+        flag = torch.full((1,), 1.0 if failed else 0.0, device=self._flat.device, dtype=torch.float32)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=self.process_group)
+        if not failed and float(flag) != 0.0:
+            raise PeerFailure("a data-parallel peer failed in the epoch's last step: candidate abandoned on all ranks")
 
     def reduce_confusion(self, cm, failed=False):
         """Sum the int64 confusion matrix over ranks at the end of validation; one extra element

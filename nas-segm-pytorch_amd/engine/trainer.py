@@ -106,8 +106,8 @@ def _tell_peers(segmenter, exc, syncs_before=None, last_step=False):
     protocol).  ``syncs_before``: segmenter.sync_count at the start of the step - if this rank
     has already joined the step's collective (the failure came later: clipping, the optimiser)
     the flag reaches the peers in the NEXT step's collective and they all stop there; after the
-    epoch's last step there is no such collective and nothing is sent (the peers have finished
-    the epoch; every rank goes on to validation).  A PeerFailure needs no telling: every healthy
+    epoch's last step there is no such collective and the flag goes into the end-of-epoch handshake the
+    peers are about to make (RankParallel.epoch_status).  A PeerFailure needs no telling: every healthy
     rank raised it at the same point."""
     from .segmenter import PeerFailure
 
@@ -118,8 +118,28 @@ def _tell_peers(segmenter, exc, syncs_before=None, last_step=False):
     except AttributeError:
         pass
     if last_step and syncs_before is not None and _syncs(segmenter) > syncs_before:
+        segmenter.epoch_status(failed=True)  # (the peers are on their way to the end-of-epoch handshake)
         return
     segmenter.sync_gradients(failed=True)
+
+
+def _as_rank_failure(segmenter, exc):
+    """what the step loop re-raises: data parallel, an exception that ``try_except`` would let through (not
+    a RuntimeError) becomes a RankFailure, so that this rank scores the candidate 0 like the peers it just
+    told - instead of ending its process while they go on to the next collective"""
+    from .segmenter import RankFailure
+
+    if not _distributed(segmenter) or isinstance(exc, RuntimeError):
+        return exc
+    wrapped = RankFailure("{}: {}".format(type(exc).__name__, exc))
+    wrapped.__cause__ = exc
+    return wrapped
+
+
+def _epoch_handshake(segmenter):
+    """after the last step of a training epoch (data parallel only): see RankParallel.epoch_status"""
+    if _distributed(segmenter):
+        segmenter.epoch_status()
 
 
 def _agreed_count(segmenter, n):
@@ -140,6 +160,11 @@ def _graphed():
     from . import graphed  # (graphed imports this module's helpers)
 
     return graphed
+
+
+def _replays(segmenter, device, n_pixels):
+    """does this step run as a hipGraph replay?  (device memory only; engine/graphed.py: auto_graph)"""
+    return device.type == "cuda" and _graphed().auto_graph(segmenter, n_pixels)
 
 
 def _bn_modes(module):
@@ -279,7 +304,7 @@ def make_task0_step(Xy_train, segmenter, optim_dec, batch_size, ignore_index=255
     pack_memo = F.PackMemo()
     n_rows = int(Xy_train["y"].shape[0])
     n_pixels = batch_size * int(Xy_train[feat_keys[0]].shape[2]) * int(Xy_train[feat_keys[0]].shape[3]) * 16
-    if not do_kd and device.type == "cuda" and _graphed().auto_graph(segmenter, n_pixels):
+    if not do_kd and _replays(segmenter, device, n_pixels):
         stepper = _task0_stepper(Xy_train, segmenter, optim_dec, batch_size, ignore_index, dec_grad_clip,
                                  aux_weight, freeze_bn)
         if stepper is not None:
@@ -350,11 +375,12 @@ def train_task0(Xy_train, segmenter, optim_dec, epoch, segm_crit, kd_crit, batch
             loss = step(indices[i * batch_size:(i + 1) * batch_size])
         except Exception as e:
             _tell_peers(segmenter, e, syncs, i == n_passes - 1)
-            raise
+            raise _as_rank_failure(segmenter, e)
         losses.update(_loss_value(segmenter, loss))
         batch_time.update(time.time() - start)
         if do_polyak:
             _polyak_update(decoder.parameters(), avg_param, polyak_decay)
+    _epoch_handshake(segmenter)
     logger.info(" Train epoch: {}\tAvg. Loss: {:.3f}\tAvg. Time: {:.3f}".format(
         epoch, losses.avg, batch_time.avg))
 
@@ -443,8 +469,7 @@ def train_segmenter(segmenter, train_loader, optim_enc, optim_dec, epoch, segm_c
             image = _to_device_image(sample["image"], device)
             target = _labels(sample["mask"], device)
             stepper = None
-            if device.type == "cuda" and _graphed().auto_graph(segmenter,
-                                                               image.shape[0] * image.shape[2] * image.shape[3]):
+            if _replays(segmenter, device, image.shape[0] * image.shape[2] * image.shape[3]):
                 # launch-bound sizes: forward + loss + backward replayed from a hipGraph captured on
                 # this candidate's first batch (bit-identical to the eager step)
                 stepper = _segmenter_stepper(segmenter, image, target, optim_enc, optim_dec, ignore,
@@ -458,10 +483,11 @@ def train_segmenter(segmenter, train_loader, optim_enc, optim_dec, epoch, segm_c
                 _polyak_update(segmenter.parameters(), avg_param, polyak_decay)
         except Exception as e:
             _tell_peers(segmenter, e, syncs, n_steps is not None and i == n_steps - 1)
-            raise
+            raise _as_rank_failure(segmenter, e)
         losses.update(_loss_value(segmenter, loss))
         batch_time.update(time.time() - start)
         if i % print_every == 0:
             logger.info(" Train epoch: {} [{}/{}]\tAvg. Loss: {:.3f}\tAvg. Time: {:.3f}".format(
                 epoch, i, len(train_loader), losses.avg, batch_time.avg))
         i += 1
+    _epoch_handshake(segmenter)

@@ -938,7 +938,10 @@ class _ConvChain(torch.autograd.Function):
             # a consumer of this chain's deferred tail (_CatReduce) has already masked the gradient and summed
             # it against the last BatchNorm's xhat: its rows come by the side (keyed by the gradient tensor itself)
             ent = _TAIL_ROWS.pop(dy.data_ptr(), None)
-            if ent is not None and ent[0]() is dy and ops[-1][4]:
+            # ... AND still holding what that consumer wrote: with a second consumer of the same Pending autograd may
+            # have accumulated another gradient INTO this tensor (same object, same address) - the version
+            # counter tells, and the chain then runs its own reduction over the summed gradient
+            if ent is not None and ent[0]() is dy and dy._version == ent[3] and ops[-1][4]:
                 pre = (ent[1], ent[2])
         if pool is not None:
             # the pooled tail: gradient w.r.t. the last BatchNorm's output by a gather over the windows -
@@ -1757,7 +1760,7 @@ class _CatReduce(torch.autograd.Function):
                             lib.call(_k("nasseg_bilinear_bwd", d), ptr(d), C, 0, ptr(full), B, H, W, C, Ho, Wo, ws, s)
                         d = full
                     if rows is not None:
-                        _TAIL_ROWS[d.data_ptr()] = (weakref.ref(d), rows, nrows)
+                        _TAIL_ROWS[d.data_ptr()] = (weakref.ref(d), rows, nrows, d._version)
                     grads.append(d)
                 dx, dy = grads
         if ctx.needs_input_grad[10]:

@@ -365,6 +365,76 @@ def _engine_worker(rank, world, port, q):
         probe = torch.tensor([float(rank + 1)])
         dist.all_reduce(probe)
         out["uneven_shards"] = (ret, int(Xy[0].shape[0]), same_on_all_ranks(net.decoder), float(probe))
+
+        # (6) round 4.  (a) a failure that is NOT a RuntimeError, in the epoch's LAST step, AFTER that step's
+        # gradient collective (rank 0's optimiser raises IndexError in step 3 of 3): rank 0 re-raises it as
+        # RankFailure (try_except scores 0 instead of letting the process die), tells its peers through the
+        # end-of-epoch handshake, and they score 0 too - nobody goes on to validation alone
+        net, dp, oe, od = candidate()
+        if rank == 0:
+            real_step, n_calls = od.step, [0]
+
+            def late_step(*a, **k):
+                n_calls[0] += 1
+                if n_calls[0] == 3:
+                    raise IndexError("index out of range in optimiser state (simulated)")
+                return real_step(*a, **k)
+
+            od.step = late_step
+        ret = train_segmenter(dp, _toy_batches(rank, 3), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+        probe = torch.tensor([float(rank + 1)])
+        dist.all_reduce(probe)
+        out["last_step_failure"] = (ret, net.encoder.calls, float(probe))
+
+        # (b) replayed steps take part in the SAME protocol as host-launched ones.  The CPU has no hipGraph:
+        # the stepper's graph is replaced by an object whose replay() runs forward + backward on the host -
+        # everything after the replay (RankParallel.sync_gradients with its status element and step count,
+        # clipping, the optimisers) is the product's code.  Rank 1's loader dies before its second step while
+        # rank 0 replays: both leave with 0 at that step.
+        from nas_segm_amd.engine import graphed, trainer
+
+        class HostReplayStep(graphed.GraphedSegmenterStep):
+            built = 0
+
+            def _capture(self, warmup):
+                HostReplayStep.built += 1
+                if getattr(self.segmenter, "_refuse_capture", False):
+                    raise RuntimeError("HIP out of memory while capturing (simulated)")
+                stepper, seg, model = self, self.segmenter, self.model
+
+                class Graph(object):
+                    def replay(self):
+                        stepper.segmenter, stepper.model = seg, model
+                        try:
+                            stepper.loss = stepper._fwd_bwd(False)
+                        finally:
+                            stepper.segmenter = stepper.model = None
+                        stepper._static_grads = [(p, p.grad) for p in stepper._params if p.grad is not None]
+
+                self.graph = Graph()
+                self._static_grads = []
+
+        real_replays, real_step_cls = trainer._replays, graphed.GraphedSegmenterStep
+        trainer._replays = lambda segmenter, device, n_pixels: True
+        graphed.GraphedSegmenterStep = HostReplayStep
+        try:
+            net, dp, oe, od = candidate()
+            ret = train_segmenter(dp, _toy_batches(rank, 3), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+            out["replayed_healthy"] = (ret, HostReplayStep.built, dp.sync_count, same_on_all_ranks(net))
+            net, dp, oe, od = candidate()
+            ret = train_segmenter(dp, FlakyLoader(_toy_batches(rank, 3)), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+            probe = torch.tensor([float(rank + 1)])
+            dist.all_reduce(probe)
+            out["replayed_loader_failure"] = (ret, net.encoder.calls, dp.sync_count, float(probe))
+            # (c) the capture fails on rank 1 only: it launches from the host while rank 0 replays - one bucket
+            # layout, so the collectives pair and the replicas stay identical
+            net, dp, oe, od = candidate()
+            dp._refuse_capture = rank == 1
+            built = HostReplayStep.built
+            ret = train_segmenter(dp, _toy_batches(rank, 3), oe, od, 0, _Crit(), False, 3.0, 3.0, False)
+            out["mixed_replay_and_host"] = (ret, HostReplayStep.built - built, dp.sync_count, same_on_all_ranks(net))
+        finally:
+            trainer._replays, graphed.GraphedSegmenterStep = real_replays, real_step_cls
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
@@ -403,6 +473,11 @@ def test_engine_entry_points_two_ranks_gloo():
         assert ret == 0 and probe == 3.0 and calls <= 2, out["optimiser_failure"]
         ret, n, same, probe = out["uneven_shards"]
         assert ret is None and n == (4 if rank == 0 else 2) and same and probe == 3.0, out["uneven_shards"]
+        assert out["last_step_failure"] == (0, 3, 3.0), out["last_step_failure"]
+        assert out["replayed_healthy"] == (None, 1, 3, True), out["replayed_healthy"]
+        ret, calls, syncs, probe = out["replayed_loader_failure"]
+        assert ret == 0 and probe == 3.0 and calls in (1, 2) and syncs == 2, out["replayed_loader_failure"]
+        assert out["mixed_replay_and_host"] == (None, 1, 3, True), out["mixed_replay_and_host"]
 
 
 def _ctrl_search_worker(rank, world, port, q, log_path):
