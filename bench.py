@@ -233,6 +233,10 @@ def cpu_baseline(height, width):
 
     med, n_fb = timed(fwd_bwd, 30.0)
     fmed, n_f = timed(fwd_eval, 10.0)
+    # BASELINE config 1 / BASELINE.md section 4: the eval forward at 1x3x321x321 (reference tests/test_inference.py path)
+    x_full, x = x, torch.randn(1, 3, 321, 321, generator=g)
+    c1med, n_c1 = timed(fwd_eval, 5.0, max_n=9)
+    x = x_full
     cpu_name = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -245,7 +249,9 @@ def cpu_baseline(height, width):
             "sample": "median of {} train-mode fwd+bwd passes of WACV arch0 at 1x3x{}x{} fp32 after 1 warm-up "
                       "({} eval-forward passes for fwd_only), torch CPU threads = cores".format(
                           n_fb, height, width, n_f),
-            "fwd_only_images_per_sec": 1.0 / fmed, "cpu_model": cpu_name}
+            "fwd_only_images_per_sec": 1.0 / fmed, "cpu_model": cpu_name,
+            "config1_321x321_fwd_images_per_sec": 1.0 / c1med,
+            "config1_sample": "median of {} eval-forward passes of WACV arch0 at 1x3x321x321 (BASELINE config 1)".format(n_c1)}
 
 
 def lib_hash():
@@ -789,6 +795,17 @@ def main():
                 segmenter(one)
             torch.cuda.synchronize()
             cpu["gpu_fwd_only_images_per_sec"] = 10.0 / (time.perf_counter() - t0)
+            # ... and BASELINE config 1's shape, 1x3x321x321 (host-launch-bound at this size)
+            small = torch.randn(1, 3, 321, 321, device=device).to(image.dtype).contiguous(
+                memory_format=torch.channels_last)
+            for _ in range(3):
+                segmenter(small)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                segmenter(small)
+            torch.cuda.synchronize()
+            cpu["config1_321x321_gpu_fwd_images_per_sec"] = 20.0 / (time.perf_counter() - t0)
         segmenter.train()
 
     if rank == 0:

@@ -371,3 +371,29 @@ def test_config2_shape_properties_at_full_size():
     assert l0 == l1, (l0, l1)
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
+
+
+@pytest.mark.parametrize("net_name", ["wacv_arch0", "cvpr_arch0"])
+def test_config1_inference_at_1x3x321x321_matches_the_oracle(net_name):
+    """BASELINE config 1 (the reference's tests/test_inference.py:147-169 path: arch0 decoder + MobileNetV2
+    encoder, ONE 3x321x321 image, eval forward) for both readings of "arch0" (WACV TemplateDecoder,
+    19 classes / CVPR MicroDecoder, 21 classes): the product's inference path - every BatchNorm folded into its
+    conv's epilogue, odd map sizes 161 / 81 / 41 / 21 / 11 - against the CPU oracle, logits within 1e-4
+    (north_star's bound), argmax identical wherever the oracle's top-2 margin exceeds that bound."""
+    from _util import oracle_forward
+
+    rec = load_json("nets_meta.json")[net_name]
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).eval()
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    x = torch.randn(1, 3, 321, 321, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        want = oracle_forward(sd, x, rec, training=False)
+        want = want[0] if isinstance(want, tuple) else want
+        got = net.to(DEV)(_cl(x))
+        got = (got[0] if isinstance(got, tuple) else got).float().cpu()
+    assert tuple(got.shape) == tuple(want.shape) == (1, rec["classes"], 81, 81)
+    err = float((got - want).abs().max())
+    assert err <= 1e-4, "logits differ by {:.3e}".format(err)
+    top2 = want.topk(2, dim=1).values
+    sure = (top2[:, 0] - top2[:, 1]) > 2e-4
+    assert bool((got.argmax(1) == want.argmax(1))[sure].all())
