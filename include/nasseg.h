@@ -118,6 +118,14 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int po
  * statistics differ in the rounding of their partial sums.  Row counts from nasseg_conv_fwd_stats_blocks are
  * valid for the setting they were asked under. */
 int64_t nasseg_conv_pw_min_pixels(int64_t v);
+/* tuning / testing knob: which pointwise calls take the N-split persistent kernel (csrc/conv_pwn.hip: input streamed
+ * through an LDS ring with four 16-channel blocks in flight per workgroup, the waves of a workgroup split the output
+ * channels, statistics reduced across lanes once per kernel).  0: none; 1 (initial): where it measured faster;
+ * 2: every call it supports (N, K multiples of 4, N <= 256, K <= 512); v < 0 only queries.  Returns the previous
+ * setting.  It is asked BEFORE nasseg_conv_pw_min_pixels' kernel.  Outputs are bit-identical either way; BatchNorm
+ * statistics differ in the rounding of their partial sums; row counts from nasseg_conv_fwd_stats_blocks are valid
+ * for the setting they were asked under. */
+int nasseg_conv_pwn_mode(int v);
 /* dense twin of nasseg_dwconv_bwd_data_bn (arguments as nasseg_conv_fwd, transposed) */
 int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
                             const float* z, int ldz, const float* scale, const float* shift,

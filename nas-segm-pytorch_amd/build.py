@@ -34,6 +34,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers_of(path, seen=None):
+    """the csrc/*.h files a source includes, directly or through another header"""
+    import re
+
+    seen = set() if seen is None else seen
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        h = os.path.join(CSRC, name)
+        if os.path.exists(h) and h not in seen:
+            seen.add(h)
+            _headers_of(h, seen)
+    return seen
+
+
 # sources whose entry points never touch activations: compiled once (fp32 build only)
 FP32_ONLY_SOURCES = ("capi.cpp", "miou.hip")
 
@@ -43,8 +56,7 @@ def _compile(job):
     (nasseg_<op>) and as bfloat16 (-DNASSEG_BF16, nasseg_bf16_<op>); see csrc/common.h."""
     src, bf16 = job
     obj = os.path.join(OBJ_DIR, os.path.basename(src) + (".bf16.o" if bf16 else ".o"))
-    deps = [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"),
-            os.path.join(CSRC, "dw_common.h"), os.path.abspath(__file__)]
+    deps = [src, os.path.abspath(__file__)] + sorted(_headers_of(src))
     if _stale(obj, deps):
         cmd = [HIPCC] + FLAGS + (["-DNASSEG_BF16"] if bf16 else []) + ["-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -27,7 +27,7 @@
 //   mode 0 forward       : wp[tap][N][K]    from OIHW (N,K,kh,kw)
 //   mode 1 backward-data : wp[tap][K][N]    (roles of N and K swapped)
 //   mode 2 flat forward  : wp[N][tap*K + k]
-#include "conv_common.h"
+#include "conv_args.h"
 
 #include <atomic>
 
@@ -38,34 +38,6 @@
 extern "C" int64_t nasseg_conv_pw_min_pixels(int64_t v);
 
 namespace {
-
-struct FwdArgs {
-  const act_t* x;  // activations: fp32 or bf16 storage (common.h)
-  int ldx;
-  const float* w;
-  act_t* y;
-  int ldy;
-  const float* in_scale;
-  const float* in_shift;
-  int in_act;
-  const float* out_scale;
-  const float* out_shift;
-  int out_act;
-  const act_t* res;
-  int ldres;
-  float* stats;  // optional [gridDim.x][2][N]: per-workgroup partial sums (see STATS)
-  // STATS == 2: the BatchNorm whose backward statistics are gathered (y is the gradient
-  // w.r.t. act(b_scale*bz + b_shift))
-  const act_t* bz;
-  int ldbz;
-  const float* b_scale;
-  const float* b_shift;
-  const float* b_mean;
-  const float* b_invstd;
-  int b_act;
-  int K, N;
-  ConvGeom g;
-};
 
 enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
 
@@ -1073,6 +1045,14 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
                  "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
   const int tiles = cdiv(N, 16);
   if (!md.gather && md.km != KM_FLAT) {
+    // the N-split persistent kernel (conv_pwn.hip) where its plan says so
+    const PwnPlan pn = nasseg_internal_pwn_plan((int64_t)g.B * g.Ho * g.Wo, N, K, stats_mode >= 2 ? 2 : 1);
+    if (pn.ok) {
+      const bool aligned = md.km == KM_VEC && md.vecn && (stats_mode < 2 || (a.ldbz & 3) == 0);
+      NASSEG_REQUIRE(aligned || (md.stats != 1 && md.stats != 2),
+                     "conv_fwd: the pointwise statistics path needs channel strides that are multiples of 4");
+      if (aligned) return NASSEG_INTERNAL(pwn_launch)(a, pn, md.stats, s);
+    }
     const PwFwdPlan pw = pw_fwd_plan((int64_t)g.B * g.Ho * g.Wo, N, K, stats_mode >= 2 ? 2 : 1);
     if (pw.ok) {
       const bool aligned = md.km == KM_VEC && md.vecn;
@@ -1175,6 +1155,8 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int po
   const int64_t Mtot = (int64_t)B * Ho * Wo;
   const int tiles = cdiv(N, 16);
   if (pointwise) {
+    const PwnPlan pn = nasseg_internal_pwn_plan(Mtot, N, K, pointwise);
+    if (pn.ok) return pn.grid;
     const PwFwdPlan pw = pw_fwd_plan(Mtot, N, K, pointwise);
     if (pw.ok) return pw.grid;
   }

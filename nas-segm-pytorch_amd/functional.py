@@ -666,6 +666,9 @@ FUSE_SEPCONV = os.environ.get("NASSEG_FUSE_SEPCONV", "1") != "0"  # (the switch 
 # which pointwise forward / backward-data calls take the persistent kernel (include/nasseg.h:
 # nasseg_conv_pw_min_pixels): unset = where it measured faster, 0 = wherever it can, a huge number = nowhere
 _PW_MIN_PIXELS = os.environ.get("NASSEG_PW_MIN_PIXELS")
+# ... and which take the N-split persistent kernel (nasseg_conv_pwn_mode): unset / 1 = where it measured faster,
+# 0 = nowhere, 2 = wherever it can
+_PWN_MODE = os.environ.get("NASSEG_PWN_MODE")
 
 
 # elements of the stage's depthwise output above which a 5x5 stage runs as two kernels when the
@@ -2148,6 +2151,9 @@ def argmax_confusion(logits, gt, n_classes, cm=None, out_size=None, return_preds
 def _apply_library_knobs():
     if _PW_MIN_PIXELS is not None:
         lib.query("nasseg_conv_pw_min_pixels", int(_PW_MIN_PIXELS))
+        lib._memo.clear()
+    if _PWN_MODE is not None:
+        lib.query("nasseg_conv_pwn_mode", int(_PWN_MODE))
         lib._memo.clear()
 
 

@@ -1248,6 +1248,106 @@ def test_persistent_pointwise_kernel_equals_the_general_one(case, mode):
         assert_close(got[1], ref[1], tol, 1e-4, "statistics")
 
 
+class _pwn_mode(object):
+    """inside: nasseg_conv_pwn_mode(mode) - 0 = the N-split persistent kernel (conv_pwn_kernel) nowhere, 2 = wherever
+    it is supported"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        f = F()
+        f.lib._memo.clear()
+        self.old = f.lib._fn["nasseg_conv_pwn_mode"](self.mode)
+        f.lib._memo.clear()
+
+    def __exit__(self, *exc):
+        f = F()
+        f.lib._fn["nasseg_conv_pwn_mode"](self.old)
+        f.lib._memo.clear()
+
+
+PWN_CASES = PW_FAST_CASES + [
+    # every split of the four waves: N < 32 (4 x 1 pixels x channels), 32 <= N < 64 (2 x 2), N >= 64 (1 x 4 with
+    # 1..4 channel tiles per wave, incl. tile counts that are no multiple of 4); K of one to 20 k-blocks; fewer
+    # tiles than workgroups and more; one pixel
+    (1, 1, 1, 16, 16), (1, 7, 9, 8, 12), (2, 50, 60, 32, 48), (1, 64, 64, 64, 128), (1, 40, 40, 320, 64),
+    (1, 33, 33, 24, 256), (3, 90, 91, 16, 64), (1, 128, 260, 32, 64), (1, 20, 21, 40, 80),
+]
+
+
+@pytest.mark.parametrize("case", PWN_CASES)
+@pytest.mark.parametrize("mode", ["plain", "prologue", "epilogue", "stats", "prologue_stats", "bwd_bn", "bwd_mask"])
+def test_nsplit_pointwise_kernel_equals_the_general_one(case, mode):
+    """conv_pwn_kernel (csrc/conv_pwn.hip) against conv_fwd_kernel on the same calls: outputs bit-identical (same
+    MFMA order per accumulator), statistics rows summing to the same totals up to fp32 rounding."""
+    f = F()
+    B, H, W, K, N = case
+    M = B * H * W
+    x = dev(rnd(B, K, H, W, seed=1))
+    w = rnd(N, K, 1, 1, seed=2, scale=0.3).to(DEV)
+    res = dev(rnd(B, N, H, W, seed=3))
+    z = dev(rnd(B, N, H, W, seed=4))
+    isc, ish = _bn_vectors(K, 5)[:2]
+    osc, osh, omu, ois = _bn_vectors(N, 6)
+    s = f.current_stream()
+
+    def run():
+        y = dev(torch.full((B, N, H, W), float("nan")))
+        out = [y]
+        nb = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, N, K, 2 if mode.startswith("bwd") else 1)
+        part = torch.full(((nb + 64) * 2 * N,), float("nan"), device=DEV)
+        sums = torch.empty(2 * N, device=DEV)
+        pro = (f.ptr(isc), f.ptr(ish), 2) if mode.startswith("prologue") else (None, None, 0)
+        if mode in ("plain", "prologue", "epilogue", "stats", "prologue_stats"):
+            epi = (f.ptr(osc), f.ptr(osh), 1, f.ptr(res), N) if mode == "epilogue" else (None, None, 0, None, 0)
+            st = f.ptr(part) if mode.endswith("stats") else None
+            f.lib.call("nasseg_conv_fwd", f.ptr(x), K, f.ptr(w), f.ptr(y), N, *pro, *epi, B, H, W, K, H, W, N, 1, 1,
+                       1, 0, 1, 0, st, s)
+        else:
+            st = f.ptr(part) if mode == "bwd_bn" else None
+            f.lib.call("nasseg_conv_bwd_data_bn", f.ptr(x), K, f.ptr(w), f.ptr(y), N, f.ptr(z), N, f.ptr(osc),
+                       f.ptr(osh), f.ptr(omu), f.ptr(ois), 2, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, st, s)
+        if st is not None:
+            f.lib.call("nasseg_rows_sum", f.ptr(part), nb, 2 * N, f.ptr(sums), s)
+            out.append(sums)
+        return out, nb
+
+    with _pwn_mode(0), _pw_threshold(1 << 40):
+        ref, nb_ref = run()
+    with _pwn_mode(2):
+        got, nb_new = run()
+    assert nb_new == min((M + 63) // 64, nb_new) and nb_new <= 256 * 3, "not the persistent kernel's grid"
+    if M > 64 * 256 * 3:
+        assert nb_new != nb_ref
+    assert not torch.isnan(got[0]).any()
+    assert torch.equal(got[0], ref[0]), "outputs differ by {}".format(float((got[0] - ref[0]).abs().max()))
+    if len(ref) > 1:
+        tol = 1e-5 * float(M) ** 0.5 * (float(ref[1].abs().max()) / float(M) ** 0.5 + 1.0)
+        assert_close(got[1], ref[1], tol, 1e-4, "statistics")
+
+
+def test_nsplit_pointwise_kernel_on_a_channel_slice_and_in_bf16():
+    """the same kernel reading a channel slice of a wider slab (ldx > K), writing into one (ldy > N), and its
+    bfloat16-storage twin: equal to the general kernel bit for bit"""
+    f = F()
+    B, H, W, K, N = 2, 37, 45, 32, 80
+    s = f.current_stream()
+    for dtype, fn in ((torch.float32, "nasseg_conv_fwd"), (torch.bfloat16, "nasseg_bf16_conv_fwd")):
+        xs = dev(rnd(B, K + 16, H, W, seed=11)).to(dtype)
+        w = rnd(N, K, 1, 1, seed=12, scale=0.3).to(DEV)
+        outs = []
+        for md in (0, 2):
+            with _pwn_mode(md), _pw_threshold(1 << 40):
+                ys = dev(torch.zeros(B, N + 8, H, W)).to(dtype)
+                esz = xs.element_size()
+                f.lib.call(fn, xs.data_ptr() + 8 * esz, K + 16, f.ptr(w), ys.data_ptr() + 4 * esz, N + 8,
+                           None, None, 0, None, None, 0, None, 0, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, 0, None, s)
+                outs.append(ys)
+        assert torch.equal(outs[0], outs[1])
+        assert float(outs[1][:, 4:4 + N].float().abs().max()) > 0 and float(outs[1][:, :4].float().abs().max()) == 0
+
+
 @pytest.mark.parametrize("taps", [[1, 2], [1, 2, 4, 6]])
 def test_encoder_units_merged_into_one_chain_equal_the_separate_chains(taps):
     """MobileNetV2 runs consecutive units without a skip connection or a returned map in between as one
