@@ -355,13 +355,12 @@ def kernel_family(name, a):
     the PMC traffic of the same name under profiles/"""
     base = name.replace("nasseg_bf16_", "nasseg_")
 
-    def persistent_pointwise(B, Ho, Wo, N, K, mode):
-        # (conv_fwd.hip:pw_fwd_plan) the library's own answer: the statistics-row query returns the
-        # persistent kernel's grid for the calls that take it
+    def pointwise_kernel(B, Ho, Wo, N, K, mode):
+        # (conv_fwd.hip:conv_dispatch) the library's own answer for a 1x1, stride-1 call
         from nas_segm_amd import functional as NF
 
-        return (NF.lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N, K, mode)
-                != NF.lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N, K, 0))
+        return ("conv_fwd_kernel", "conv_pw_kernel", "conv_pwn_kernel")[
+            NF.lib.query("nasseg_conv_pointwise_kernel", B, Ho, Wo, N, K, mode)]
 
     if base == "nasseg_conv_fwd":
         # (conv_fwd.hip:conv_dispatch) 3x3, stride 1, dilation <= 2, plain forward form, at least one
@@ -371,15 +370,13 @@ def kernel_family(name, a):
         if (not transposed and kh == 3 and kw == 3 and stride == 1 and dil <= 2 and kh * kw * K > 64 and not pro
                 and not a[26] and N <= 64 and Wo >= 32 and Ho >= 8 and 0 <= pad <= 2 * dil):
             return "conv3x3_lds_kernel"
-        if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and (Hs, Ws) == (Ho, Wo)
-                and persistent_pointwise(B, Ho, Wo, N, K, 1)):
-            return "conv_pw_kernel"
+        if kh == 1 and kw == 1 and stride == 1 and pad == 0 and (Hs, Ws) == (Ho, Wo) and K % 4 == 0 and N % 4 == 0:
+            return pointwise_kernel(B, Ho, Wo, N, K, 1)
         return "conv_fwd_kernel"
     if base == "nasseg_conv_bwd_data_bn":
         B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil = a[12:24]
-        if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and (Hs, Ws) == (Ho, Wo)
-                and persistent_pointwise(B, Ho, Wo, N, K, 2)):
-            return "conv_pw_kernel"
+        if kh == 1 and kw == 1 and stride == 1 and pad == 0 and (Hs, Ws) == (Ho, Wo) and K % 4 == 0 and N % 4 == 0:
+            return pointwise_kernel(B, Ho, Wo, N, K, 2)
         return "conv_fwd_kernel"
     if base == "nasseg_conv_pw_bwd_bn" and a[21] > 64:
         return "conv_pw_bwd_wide_kernel"

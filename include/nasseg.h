@@ -126,6 +126,11 @@ int64_t nasseg_conv_pw_min_pixels(int64_t v);
  * statistics differ in the rounding of their partial sums; row counts from nasseg_conv_fwd_stats_blocks are valid
  * for the setting they were asked under. */
 int nasseg_conv_pwn_mode(int v);
+/* which kernel a 1x1, stride-1, unpadded call with these sizes takes under the current settings: 0 the general MFMA
+ * kernel, 1 the persistent kernel whose waves own all output channels, 2 the N-split persistent kernel.  pointwise
+ * as for nasseg_conv_fwd_stats_blocks (1 forward, 2 backward-data).  For measurement tools (bench.py names kernel
+ * families by it). */
+int64_t nasseg_conv_pointwise_kernel(int B, int Ho, int Wo, int N, int K, int pointwise);
 /* dense twin of nasseg_dwconv_bwd_data_bn (arguments as nasseg_conv_fwd, transposed) */
 int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
                             const float* z, int ldz, const float* scale, const float* shift,

@@ -75,6 +75,11 @@ __device__ __forceinline__ float act_mask(float z, int act) {
   if (act == NASSEG_ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
   return 1.f;
 }
+// ... the same with the activation as loop-invariant scalars (no branch per element)
+__device__ __forceinline__ float act_mask(float z, const ActSel& s) {
+  const bool inside = z > 0.f && z < s.hi;
+  return (s.on && !inside) ? 0.f : 1.f;
+}
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -1165,6 +1165,19 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int po
 #endif  // NASSEG_FP32_ONLY
 
 #if NASSEG_FP32_ONLY
+// which kernel a pointwise call over B*Ho*Wo pixels takes (measurement tools name kernels by it):
+// 0 conv_fwd_kernel, 1 conv_pw_kernel, 2 conv_pwn_kernel.  pointwise: 1 = nasseg_conv_fwd, 2 = nasseg_conv_bwd_data_bn.
+int64_t nasseg_conv_pointwise_kernel(int B, int Ho, int Wo, int N, int K, int pointwise) {
+  const int64_t Mtot = (int64_t)B * Ho * Wo;
+  if (pointwise) {
+    if (nasseg_internal_pwn_plan(Mtot, N, K, pointwise).ok) return 2;
+    if (pw_fwd_plan(Mtot, N, K, pointwise).ok) return 1;
+  }
+  return 0;
+}
+#endif  // NASSEG_FP32_ONLY
+
+#if NASSEG_FP32_ONLY
 // which packing nasseg_conv_fwd expects for a forward (non-transposed) convolution
 int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) { return fwd_pack_mode(K, kh, kw); }
 #endif  // NASSEG_FP32_ONLY

@@ -19,15 +19,22 @@
 //     whatever K is; a landed k-block is written to an LDS ring of eight slots, chunk-major
 //     ([k-chunk][pixel], 66 slots per row: conflict-free ds_write_b128, near conflict-free
 //     ds_read_b128) and multiplied from there by ALL waves - one workgroup barrier per four k-blocks;
-//   * the waves split N (and, for N < 64, the pixels too): wave w owns channel tiles w, w+4, w+8 ...
-//     of all 64 pixels (N >= 64), or a 2 x 2 / 4 x 1 (pixels x channels) split for narrower outputs - at
-//     most four channel tiles per wave however wide the output, weights from LDS ([N][K+4]);
+//   * the waves split N (and, for N <= 64, the pixels too): wave w owns the 32-channel units w, w+4 of all
+//     64 pixels (N > 64), or a 2 x 2 / 4 x 1 (pixels x units) split for narrower outputs - at most four
+//     channel tiles per wave however wide the output, weights from LDS ([N][K+4]);
 //   * the per-channel statistics (BatchNorm batch statistics of the layer that follows, or the
 //     BatchNorm-backward sums of the layer in front, conv_fwd.hip STATS 1 / 2) stay in PER-LANE registers
 //     for the whole kernel and are reduced across lanes ONCE, at its end: no shuffles per tile, one row
 //     per workgroup;
 //   * the input prologue (scale * x + shift, activation) is applied once per element as a k-block is
-//     written to LDS, not once per wave that multiplies it.
+//     written to LDS, not once per wave that multiplies it;
+//   * stores cover FULL 128-byte lines.  The MFMA result layout gives a lane 4 channels of one pixel, so a
+//     store instruction of one 16-channel tile writes 64-byte segments (16 pixels x 64 B) - and 64-byte
+//     segments are what caps the write-heavy calls: measured on this part, 2.6 TB/s of such writes against
+//     5.2-5.6 TB/s for whole lines (tools/membench.hip; 16->96 ran at 3.0 TB/s with 86 % writes while its
+//     backward, 46 % writes, reached 4.5).  A wave therefore owns channel tiles in adjacent PAIRS (a "unit"
+//     = 32 channels = 128 B of a pixel row); lanes j and j + 8 of a 16-lane row exchange one tile each
+//     (row_ror:8, four v_mov_dpp per subtile and unit) and every store instruction writes 8 pixels x 128 B.
 // Per accumulator the MFMA order (k-blocks ascending, the four components of a lane's float4 in turn) is
 // that of conv_fwd_kernel: convolution outputs are bit-identical to it; statistics differ in the rounding
 // of their partial sums only.
@@ -58,12 +65,25 @@ __device__ __forceinline__ raw4_t ld_raw(const float* p) { return ld4(p); }
 __device__ __forceinline__ float4 cvt_raw(raw4_t u) { return u; }
 #endif
 
-// PS: how many ways the four waves split the 64 pixels of a tile (1, 2, 4); they split N 4 / PS ways.
-// MTW = 4 / PS subtiles of 16 pixels per wave, NTW channel tiles per wave.
-template <int PS, int NTW, int STATS>
-__global__ __launch_bounds__(256) void conv_pwn_kernel(FwdArgs a) {
+__device__ __forceinline__ float4 row_swap8(float4 v) {  // lanes j <-> j ^ 8 of every 16-lane row
+  v.x = dpp_mov<0x128>(v.x);  // row_ror:8
+  v.y = dpp_mov<0x128>(v.y);
+  v.z = dpp_mov<0x128>(v.z);
+  v.w = dpp_mov<0x128>(v.w);
+  return v;
+}
+__device__ __forceinline__ float4 sel4(bool c, float4 a, float4 b) {
+  return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+
+// PS: how many ways the four waves split the 64 pixels of a tile (1, 2, 4); they split the 32-channel units of
+// N 4 / PS ways.  MTW = 4 / PS subtiles of 16 pixels per wave, NTU units (NTW = 2 NTU channel tiles) per wave:
+// tile nt of a wave is channel tile 2 * (nw + NS * (nt / 2)) + nt % 2.
+template <int PS, int NTU, int STATS>
+__global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a) {
   constexpr int MTW = 4 / PS;
   constexpr int NS = 4 / PS;
+  constexpr int NTW = 2 * NTU;
   constexpr bool kSums = STATS == 1 || STATS == 2;
   extern __shared__ float smem[];
   const int K = a.K, N = a.N;
@@ -94,6 +114,7 @@ __global__ __launch_bounds__(256) void conv_pwn_kernel(FwdArgs a) {
   }
   __syncthreads();
   const ActSel pact = act_sel(a.in_act);
+  const ActSel bact = act_sel(a.b_act);
 
   // ---- the loader: thread -> (pixel lp of the tile, 4-channel chunk lq of the k-block) ----
   const int lp = tid >> 2, lq = tid & 3;
@@ -142,12 +163,12 @@ __global__ __launch_bounds__(256) void conv_pwn_kernel(FwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) sx[nt][r] = sq[nt][r] = 0.f;
 
-  // this wave's channel tiles: tn(nt) = nw + NS * nt; its operand offsets
+  // this wave's channel tiles and its operand offsets
   int woff[NTW];
   bool tvalid[NTW];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
-    const int tn = nw + NS * nt;
+    const int tn = 2 * (nw + NS * (nt >> 1)) + (nt & 1);
     tvalid[nt] = tn < tiles_n;  // wave-uniform
     woff[nt] = ((tvalid[nt] ? tn : 0) * 16 + j) * LSK + kg * 4;
   }
@@ -201,57 +222,79 @@ __global__ __launch_bounds__(256) void conv_pwn_kernel(FwdArgs a) {
       const float* e_mu = a.b_mean;
       const float* e_is = a.b_invstd;
       asm volatile("" : "+s"(e_sc), "+s"(e_sh), "+s"(e_mu), "+s"(e_is));
+      const bool lo = j < 8;
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        if (!tvalid[nt]) continue;
-        const int n = (nw + NS * nt) * 16 + kg * 4;
-        const bool nok = n < N;
-        const int nc = nok ? n : 0;
-        if (STATS == 0) {
-          float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
-          if (e_sc) sc = ld4(e_sc + nc);
-          if (e_sh) sh = ld4(e_sh + nc);
+      for (int u2 = 0; u2 < NTU; ++u2) {
+        if (!tvalid[2 * u2]) continue;  // (wave-uniform: the unit lies beyond N)
+        // per-channel vectors of the unit's two tiles (this lane's channels 4*kg .. 4*kg+3 of each)
+        int nch[2];
+        bool nok[2];
+        float4 v_sc[2], v_sh[2], v_mu[2], v_is[2];
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
-            const f32x4 c = acc[mt][nt];
-            float4 o = make_float4(c[0], c[1], c[2], c[3]);
-            if (e_sc || e_sh) o = fma4(o, sc, sh);
-            if (a.out_act) o = act_apply4(o, a.out_act);
-            if (a.res) o = add4(o, lda4(a.res + (int64_t)pm[mt] * a.ldres + nc));
-            if (nok && pok[mt]) sta4(a.y + (int64_t)pm[mt] * a.ldy + n, o);
-          }
-        } else {
-          float bsc[4] = {1.f, 1.f, 1.f, 1.f}, bsh[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f},
-                bis[4] = {0.f, 0.f, 0.f, 0.f};
-          if (STATS >= 2) {
-            if (e_sc) { const float4 t = ld4(e_sc + nc); bsc[0] = t.x; bsc[1] = t.y; bsc[2] = t.z; bsc[3] = t.w; }
-            if (e_sh) { const float4 t = ld4(e_sh + nc); bsh[0] = t.x; bsh[1] = t.y; bsh[2] = t.z; bsh[3] = t.w; }
+        for (int h = 0; h < 2; ++h) {
+          nch[h] = (2 * (nw + NS * u2) + h) * 16 + kg * 4;
+          nok[h] = nch[h] < N;
+          const int nc = nok[h] ? nch[h] : 0;
+          v_sc[h] = make_float4(1.f, 1.f, 1.f, 1.f);
+          v_sh[h] = v_mu[h] = v_is[h] = f4zero();
+          if (STATS == 0 || STATS >= 2) {
+            if (e_sc) v_sc[h] = ld4(e_sc + nc);
+            if (e_sh) v_sh[h] = ld4(e_sh + nc);
           }
           if (STATS == 2) {
-            const float4 t2 = ld4(e_mu + nc), t3 = ld4(e_is + nc);
-            bmu[0] = t2.x; bmu[1] = t2.y; bmu[2] = t2.z; bmu[3] = t2.w;
-            bis[0] = t3.x; bis[1] = t3.y; bis[2] = t3.z; bis[3] = t3.w;
+            v_mu[h] = ld4(e_mu + nc);
+            v_is[h] = ld4(e_is + nc);
           }
-          float4 zv[MTW];
-          if (STATS >= 2) {
+        }
+        // lanes j < 8 keep tile 0 of their pixel and take tile 0 of pixel j + 8; lanes j >= 8 keep tile 1 of
+        // their pixel and take tile 1 of pixel j - 8: every store below covers 8 pixels x 128 contiguous bytes
+        const int ns = lo ? nch[0] : nch[1];
+        const bool nsok = ns < N;
+        // everything the unit reads besides the accumulators is requested before the first use (one round trip
+        // for the unit instead of one per subtile and tile)
+        float4 zv[2][MTW];
+        if (STATS >= 2 || STATS == 0) {
+          const act_t* zsrc = STATS == 0 ? a.res : a.bz;
+          const int zld = STATS == 0 ? a.ldres : a.ldbz;
+          if (STATS >= 2 || zsrc) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) zv[mt] = lda4(a.bz + (int64_t)pm[mt] * a.ldbz + nc);
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int mt = 0; mt < MTW; ++mt)
+                zv[h][mt] = lda4(zsrc + (int64_t)pm[mt] * zld + (nok[h] ? nch[h] : 0));
           }
+        }
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt) {
+          float4 fin[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int nt = 2 * u2 + h;
             f32x4 c = acc[mt][nt];
-            if (STATS >= 2) {
-              const float zz[4] = {zv[mt].x, zv[mt].y, zv[mt].z, zv[mt].w};
+            acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (STATS == 0) {
+              float4 o = make_float4(c[0], c[1], c[2], c[3]);
+              if (e_sc || e_sh) o = fma4(o, v_sc[h], v_sh[h]);
+              if (a.out_act) o = act_apply4(o, a.out_act);
+              if (a.res) o = add4(o, zv[h][mt]);
+              fin[h] = o;
+            } else if (STATS >= 2) {
+              const float zz[4] = {zv[h][mt].x, zv[h][mt].y, zv[h][mt].z, zv[h][mt].w};
+              const float bsc[4] = {v_sc[h].x, v_sc[h].y, v_sc[h].z, v_sc[h].w};
+              const float bsh[4] = {v_sh[h].x, v_sh[h].y, v_sh[h].z, v_sh[h].w};
+              const float bmu[4] = {v_mu[h].x, v_mu[h].y, v_mu[h].z, v_mu[h].w};
+              const float bis[4] = {v_is[h].x, v_is[h].y, v_is[h].z, v_is[h].w};
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float g = c[r] * act_mask(fmaf(zz[r], bsc[r], bsh[r]), a.b_act);
+                const float g = c[r] * act_mask(fmaf(zz[r], bsc[r], bsh[r]), bact);
                 c[r] = g;
                 if (STATS == 2) {
-                  const float v = keep_if(g, pok[mt]);
+                  const float v = keep_if(g, pok[mt] && nok[h]);
                   sx[nt][r] += v;
                   sq[nt][r] = fmaf(v, (zz[r] - bmu[r]) * bis[r], sq[nt][r]);
                 }
               }
+              fin[h] = make_float4(c[0], c[1], c[2], c[3]);
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -259,12 +302,16 @@ __global__ __launch_bounds__(256) void conv_pwn_kernel(FwdArgs a) {
                 sx[nt][r] += v;
                 sq[nt][r] = fmaf(v, v, sq[nt][r]);
               }
+              fin[h] = make_float4(c[0], c[1], c[2], c[3]);
             }
-            if (nok && pok[mt]) sta4(a.y + (int64_t)pm[mt] * a.ldy + n, make_float4(c[0], c[1], c[2], c[3]));
           }
+          const float4 got = row_swap8(sel4(lo, fin[1], fin[0]));
+          const float4 d0 = sel4(lo, fin[0], got);  // pixel (j & 7)
+          const float4 d1 = sel4(lo, got, fin[1]);  // pixel (j & 7) + 8
+          const int m0 = m_base + mt * 16 + (j & 7);
+          if (nsok && m0 < Mtot) sta4(a.y + (int64_t)m0 * a.ldy + ns, d0);
+          if (nsok && m0 + 8 < Mtot) sta4(a.y + (int64_t)(m0 + 8) * a.ldy + ns, d1);
         }
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     }
     group ^= 1;
@@ -287,11 +334,11 @@ __global__ __launch_bounds__(256) void conv_pwn_kernel(FwdArgs a) {
       }
     }
     __syncthreads();
-    // thread t < NS * NTW * 16 writes channel c of channel part q: tile tn = q + NS * nt
+    // thread t < NS * NTW * 16 writes channel c of tile nt of channel part q
     for (int t = tid; t < NS * NTW * 16; t += 256) {
       const int q = t / (NTW * 16), rem = t - q * (NTW * 16);
       const int nt = rem >> 4, c = rem & 15;
-      const int n = (q + NS * nt) * 16 + c;
+      const int n = (2 * (q + NS * (nt >> 1)) + (nt & 1)) * 16 + c;
       if (n < N) {
         float vx = 0.f, vq = 0.f;
 #pragma unroll
@@ -309,29 +356,29 @@ __global__ __launch_bounds__(256) void conv_pwn_kernel(FwdArgs a) {
 }
 
 // more dynamic LDS than the 64 KB a kernel may use by default (wide weights): raised once per instantiation
-template <int PS, int NTW, int STATS>
+template <int PS, int NTU, int STATS>
 int launch_one(const FwdArgs& a, const PwnPlan& p, hipStream_t s) {
   static std::atomic<int> raised{0};
   if (p.lds > (size_t)(64 << 10) && !raised.load()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pwn_kernel<PS, NTW, STATS>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pwn_kernel<PS, NTU, STATS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) != hipSuccess) {
       (void)hipGetLastError();
       return nasseg_fail(NASSEG_ERR_LAUNCH, "conv_pwn_kernel: cannot raise the dynamic LDS limit");
     }
     raised.store(1);
   }
-  hipLaunchKernelGGL((conv_pwn_kernel<PS, NTW, STATS>), dim3(p.grid), dim3(256), p.lds, s, a);
+  hipLaunchKernelGGL((conv_pwn_kernel<PS, NTU, STATS>), dim3(p.grid), dim3(256), p.lds, s, a);
   NASSEG_LAUNCH_CHECK("conv_pwn_kernel");
   return NASSEG_OK;
 }
 
-template <int PS, int NTW>
+template <int PS, int NTU>
 int launch_stats(const FwdArgs& a, const PwnPlan& p, int stats, hipStream_t s) {
   switch (stats) {
-    case 0: return launch_one<PS, NTW, 0>(a, p, s);
-    case 1: return launch_one<PS, NTW, 1>(a, p, s);
-    case 2: return launch_one<PS, NTW, 2>(a, p, s);
-    default: return launch_one<PS, NTW, 3>(a, p, s);
+    case 0: return launch_one<PS, NTU, 0>(a, p, s);
+    case 1: return launch_one<PS, NTU, 1>(a, p, s);
+    case 2: return launch_one<PS, NTU, 2>(a, p, s);
+    default: return launch_one<PS, NTU, 3>(a, p, s);
   }
 }
 
@@ -346,36 +393,39 @@ std::atomic<int> g_pwn_mode{NASSEG_PWN_MODE};
 }  // namespace
 
 #if NASSEG_FP32_ONLY
-// which calls take this kernel when the mode is "auto" (measured on the headline step, tools/kbench_pwn.py)
-static bool pwn_auto(int64_t M, int N, int K, int mode) {
-  (void)mode;
-  return M >= 32768 && N > K;
-}
+// which calls take this kernel when the mode is "auto": tools/kbench_pwn.py on MI355X, us today -> here.  Forward:
+// 16->96 @4x512x1024 264 -> 197, 24->144 @256x512 117 -> 92, 32->192 @128x256 41 -> 36, 32->32 @512x1024 121 -> 102,
+// 64->64 @256x512 70 -> 58, 64->32 49 -> 42, 128->64 122 -> 114; backward-data (with the BatchNorm-backward sums):
+// 16->96 466 -> 322, 64->128 @256x512 213 -> 151, 32->64 102 -> 66, 24->96 136 -> 92, 24->144 186 -> 164, 64->224
+// 426 -> 348, 32->192 @128x256 76 -> 57.  It loses where its weight leaves room for ONE workgroup per CU only and the
+// call is a forward one (224->64 @256x512: 201 -> 239 against conv_pw_kernel's 192; 144->24 is a tie at 86).
+static bool pwn_auto(const PwnPlan& p, int resident, int mode) { return resident >= 2 || mode == 2; }
 
 PwnPlan nasseg_internal_pwn_plan(int64_t M, int N, int K, int mode) {
   PwnPlan p = {};
   const int md = nasseg_conv_pwn_mode(-1);
   if (md == 0 || N <= 0 || K <= 0 || (N & 3) || (K & 3) || N > 256 || K > 512) return p;
-  if (md == 1 && !pwn_auto(M, N, K, mode)) return p;
   const int tiles = cdiv(N, 16);
-  if (tiles >= 4) {
+  const int units = cdiv(N, 32);  // pairs of channel tiles: 128 bytes of a pixel row
+  if (units >= 3) {
     p.ps = 1;
-    p.ntw = cdiv(tiles, 4);
-  } else if (tiles >= 2) {
+    p.ntw = cdiv(units, 4);  // (units per wave)
+  } else if (units == 2) {
     p.ps = 2;
-    p.ntw = cdiv(tiles, 2);
+    p.ntw = 1;
   } else {
     p.ps = 4;
     p.ntw = 1;
   }
   p.mtw = 4 / p.ps;
   const int KP = (K + 15) & ~15;
-  p.lds = ((size_t)kSlots * kSlotF + (size_t)tiles * 16 * (KP + 4) + 2 * KP + 4 * 2 * p.ntw * 16) * sizeof(float);
+  p.lds = ((size_t)kSlots * kSlotF + (size_t)tiles * 16 * (KP + 4) + 2 * KP + 4 * 2 * 2 * p.ntw * 16) * sizeof(float);
   if (p.lds > (size_t)(128 << 10)) return p;
-  int r = p.ntw <= 2 ? 3 : 2;  // resident workgroups per CU by registers
+  int r = p.ntw <= 1 ? 3 : 2;  // resident workgroups per CU by registers
   const int by_lds = (int)((size_t)(160 << 10) / p.lds);
   if (r > by_lds) r = by_lds;
   if (r < 1) return p;
+  if (md == 1 && !pwn_auto(p, r, mode)) return p;
   const int64_t ntiles = cdiv64(M, kTP);
   p.grid = (int)(ntiles < 256LL * r ? ntiles : 256LL * r);
   p.ok = 1;
@@ -389,14 +439,7 @@ extern "C" int nasseg_conv_pwn_mode(int v) {
 #endif  // NASSEG_FP32_ONLY
 
 int NASSEG_INTERNAL(pwn_launch)(const FwdArgs& a, const PwnPlan& p, int stats, hipStream_t s) {
-  if (p.ps == 1) {
-    switch (p.ntw) {
-      case 1: return launch_stats<1, 1>(a, p, stats, s);
-      case 2: return launch_stats<1, 2>(a, p, stats, s);
-      case 3: return launch_stats<1, 3>(a, p, stats, s);
-      default: return launch_stats<1, 4>(a, p, stats, s);
-    }
-  }
-  if (p.ps == 2) return p.ntw == 1 ? launch_stats<2, 1>(a, p, stats, s) : launch_stats<2, 2>(a, p, stats, s);
+  if (p.ps == 1) return p.ntw == 1 ? launch_stats<1, 1>(a, p, stats, s) : launch_stats<1, 2>(a, p, stats, s);
+  if (p.ps == 2) return launch_stats<2, 1>(a, p, stats, s);
   return launch_stats<4, 1>(a, p, stats, s);
 }

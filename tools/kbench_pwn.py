@@ -42,6 +42,7 @@ def timeit(fn, n):
 
 
 def set_mode(pwn, pw):
+    F.lib.load()
     F.lib._memo.clear()
     F.lib._fn["nasseg_conv_pwn_mode"](pwn)
     F.lib._fn["nasseg_conv_pw_min_pixels"](pw)

@@ -22,6 +22,47 @@ __global__ __launch_bounds__(256) void mix_kernel(const float4* __restrict__ src
   if (W == 0 && acc.x == 12345.678f) dst[0] = acc;
 }
 
+// The store patterns of an MFMA epilogue over rows of ROWB bytes (one pixel = ROWB bytes, pixels contiguous):
+// SEG = 64: an instruction writes 16 pixels x 64 B (lane = 16 pixel lanes x 4 chunks - a 16-channel tile);
+// SEG = 128: 8 pixels x 128 B (two adjacent tiles after the row_ror:8 exchange).  Every wave writes whole rows
+// in the end (all segments of its 16 pixels, one after the other), as a conv epilogue does.
+template <int SEG, int ROWB>
+__global__ __launch_bounds__(256) void seg_write_kernel(char* __restrict__ dst, size_t n_px16) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t t = (size_t)blockIdx.x * 4 + wave; t < n_px16; t += (size_t)gridDim.x * 4) {
+    char* base = dst + t * 16 * ROWB;
+    if (SEG == 64) {
+#pragma unroll
+      for (int sgm = 0; sgm < ROWB / 64; ++sgm)
+        *reinterpret_cast<float4*>(base + (size_t)(lane & 15) * ROWB + sgm * 64 + (lane >> 4) * 16) =
+            make_float4(1.f, 2.f, 3.f, (float)sgm);
+    } else {
+#pragma unroll
+      for (int sgm = 0; sgm < ROWB / 128; ++sgm) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+          *reinterpret_cast<float4*>(base + (size_t)((lane & 7) + 8 * half) * ROWB + sgm * 128 + (lane >> 3) * 16) =
+              make_float4(1.f, 2.f, 3.f, (float)sgm);
+      }
+    }
+  }
+}
+template <int SEG, int ROWB>
+void run_seg(const char* name, char* dst, size_t bytes, int grid) {
+  const size_t n = bytes / (16 * ROWB);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((seg_write_kernel<SEG, ROWB>), dim3(grid), dim3(256), 0, 0, dst, n);
+  CK(hipEventRecord(e0, 0));
+  const int reps = 5;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((seg_write_kernel<SEG, ROWB>), dim3(grid), dim3(256), 0, 0, dst, n);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double moved = (double)n * 16 * ROWB * reps;
+  printf("%-28s grid %5d: %8.1f GB/s  (%.1f us per launch)\n", name, grid, moved / (ms * 1e-3) / 1e9, ms * 1e3 / reps);
+}
+
 template <int R, int W>
 void run(const char* name, const float4* src, float4* dst, size_t bytes, int grid) {
   const size_t per_unit = (size_t)(R > W ? R : W) * 4096;  // the larger side bounds the unit count
@@ -53,6 +94,10 @@ int main() {
     run<6, 1>("contract 6:1 (96->16)", a, b, bytes, grid);
     run<2, 4>("1:2 (32->64)", a, b, bytes, grid);
     run<4, 2>("2:1 (64->32)", a, b, bytes, grid);
+    run_seg<64, 384>("write 64 B segs, 384 B rows", (char*)b, bytes, grid);
+    run_seg<128, 384>("write 128 B segs, 384 B rows", (char*)b, bytes, grid);
+    run_seg<64, 256>("write 64 B segs, 256 B rows", (char*)b, bytes, grid);
+    run_seg<128, 256>("write 128 B segs, 256 B rows", (char*)b, bytes, grid);
   }
   return 0;
 }
