@@ -120,6 +120,20 @@ __device__ __forceinline__ float row16_allsum(float v) {
   return v;
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_allsum(double v) {  // (same pairing as the float form)
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  return v;
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ uint32_t f32_to_bf16(float f) {
   const uint32_t u = __float_as_uint(f);

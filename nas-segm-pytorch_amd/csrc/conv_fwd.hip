@@ -1155,8 +1155,9 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int po
   const int64_t Mtot = (int64_t)B * Ho * Wo;
   const int tiles = cdiv(N, 16);
   if (pointwise) {
+    // (forward statistics of conv_pwn_kernel: two rows per workgroup - value and fp32 rounding residue)
     const PwnPlan pn = nasseg_internal_pwn_plan(Mtot, N, K, pointwise);
-    if (pn.ok) return pn.grid;
+    if (pn.ok) return pointwise == 1 ? 2 * pn.grid : pn.grid;
     const PwFwdPlan pw = pw_fwd_plan(Mtot, N, K, pointwise);
     if (pw.ok) return pw.grid;
   }

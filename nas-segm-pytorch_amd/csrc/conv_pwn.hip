@@ -41,6 +41,7 @@
 #include "conv_args.h"
 
 #include <atomic>
+#include <type_traits>
 
 extern "C" int nasseg_conv_pwn_mode(int v);
 
@@ -157,11 +158,17 @@ __global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a) {
   for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float sx[NTW][4], sq[NTW][4];
+  // Forward statistics (sum y, sum y^2) run in DOUBLE: the variance comes out of E[y^2] - E[y]^2, and a channel
+  // whose |mean| is hundreds of standard deviations (a 1x1 conv over a nearly constant map: seen at 471 in a
+  // controller-sampled cell) loses every digit of it to fp32 sums - two fp32 evaluation orders differed by 21 % in
+  // the variance there.  The adds hide behind the MFMAs (half-rate VALU, 3 per output element).  The
+  // BatchNorm-backward sums (STATS 2) have no such cancellation and stay fp32.
+  typedef typename std::conditional<STATS == 1, double, float>::type sum_t;
+  sum_t sx[NTW][4], sq[NTW][4];
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sx[nt][r] = sq[nt][r] = 0.f;
+    for (int r = 0; r < 4; ++r) sx[nt][r] = sq[nt][r] = (sum_t)0;
 
   // this wave's channel tiles and its operand offsets
   int woff[NTW];
@@ -290,17 +297,17 @@ __global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a) {
                 c[r] = g;
                 if (STATS == 2) {
                   const float v = keep_if(g, pok[mt] && nok[h]);
-                  sx[nt][r] += v;
-                  sq[nt][r] = fmaf(v, (zz[r] - bmu[r]) * bis[r], sq[nt][r]);
+                  sx[nt][r] += (sum_t)v;
+                  sq[nt][r] += (sum_t)(v * ((zz[r] - bmu[r]) * bis[r]));
                 }
               }
               fin[h] = make_float4(c[0], c[1], c[2], c[3]);
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float v = keep_if(c[r], pok[mt]);
+                const sum_t v = (sum_t)keep_if(c[r], pok[mt]);
                 sx[nt][r] += v;
-                sq[nt][r] = fmaf(v, v, sq[nt][r]);
+                sq[nt][r] += v * v;
               }
               fin[h] = make_float4(c[0], c[1], c[2], c[3]);
             }
@@ -319,14 +326,17 @@ __global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a) {
 
   if (kSums) {
     // one cross-lane reduction per kernel: over the 16 pixel lanes of a k-group with DPP adds, over the pixel
-    // parts of the workgroup (PS > 1) through LDS in a fixed order
-    float* my_red = sred + wave * 2 * NTW * 16;
+    // parts of the workgroup (PS > 1) through LDS in a fixed order.  STATS 1 (double sums) leaves TWO rows per
+    // workgroup - the sum rounded to fp32 and what the rounding dropped - which the finaliser adds in fp64 like any
+    // other rows: the fp32 row format costs the statistics nothing.
+    sum_t* red = reinterpret_cast<sum_t*>(sred);
+    sum_t* my_red = red + wave * 2 * NTW * 16;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float tx = row16_allsum(sx[nt][r]);
-        const float tq = row16_allsum(sq[nt][r]);
+        const sum_t tx = row16_allsum(sx[nt][r]);
+        const sum_t tq = row16_allsum(sq[nt][r]);
         if (j == 0) {
           my_red[nt * 16 + kg * 4 + r] = tx;
           my_red[NTW * 16 + nt * 16 + kg * 4 + r] = tq;
@@ -340,22 +350,30 @@ __global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a) {
       const int nt = rem >> 4, c = rem & 15;
       const int n = (2 * (q + NS * (nt >> 1)) + (nt & 1)) * 16 + c;
       if (n < N) {
-        float vx = 0.f, vq = 0.f;
+        sum_t vx = (sum_t)0, vq = (sum_t)0;
 #pragma unroll
         for (int p = 0; p < PS; ++p) {
           const int wv = PS == 1 ? q : (PS == 2 ? (p * 2 + q) : p);
-          vx += sred[wv * 2 * NTW * 16 + rem];
-          vq += sred[wv * 2 * NTW * 16 + NTW * 16 + rem];
+          vx += red[wv * 2 * NTW * 16 + rem];
+          vq += red[wv * 2 * NTW * 16 + NTW * 16 + rem];
         }
-        float* po = a.stats + (int64_t)blockIdx.x * 2 * N + n;
-        po[0] = vx;
-        po[N] = vq;
+        if (STATS == 1) {
+          float* po = a.stats + (int64_t)blockIdx.x * 4 * N + n;
+          const float hx = (float)vx, hq = (float)vq;
+          po[0] = hx;
+          po[N] = hq;
+          po[2 * N] = (float)((double)vx - (double)hx);
+          po[3 * N] = (float)((double)vq - (double)hq);
+        } else {
+          float* po = a.stats + (int64_t)blockIdx.x * 2 * N + n;
+          po[0] = (float)vx;
+          po[N] = (float)vq;
+        }
       }
     }
   }
 }
 
-// more dynamic LDS than the 64 KB a kernel may use by default (wide weights): raised once per instantiation
 template <int PS, int NTU, int STATS>
 int launch_one(const FwdArgs& a, const PwnPlan& p, hipStream_t s) {
   static std::atomic<int> raised{0};
@@ -419,7 +437,7 @@ PwnPlan nasseg_internal_pwn_plan(int64_t M, int N, int K, int mode) {
   }
   p.mtw = 4 / p.ps;
   const int KP = (K + 15) & ~15;
-  p.lds = ((size_t)kSlots * kSlotF + (size_t)tiles * 16 * (KP + 4) + 2 * KP + 4 * 2 * 2 * p.ntw * 16) * sizeof(float);
+  p.lds = ((size_t)kSlots * kSlotF + (size_t)tiles * 16 * (KP + 4) + 2 * KP + 2 * 4 * 2 * 2 * p.ntw * 16) * sizeof(float);
   if (p.lds > (size_t)(128 << 10)) return p;
   int r = p.ntw <= 1 ? 3 : 2;  // resident workgroups per CU by registers
   const int by_lds = (int)((size_t)(160 << 10) / p.lds);

@@ -1235,9 +1235,9 @@ def test_persistent_pointwise_kernel_equals_the_general_one(case, mode):
             out.append(sums)
         return out, nb
 
-    with _pw_threshold(1 << 40):
+    with _pwn_mode(0), _pw_threshold(1 << 40):
         ref, nb_ref = run()
-    with _pw_threshold(0):
+    with _pwn_mode(0), _pw_threshold(0):
         got, nb_new = run()
     if N * (((K + 15) & ~15) + 4) * 4 <= 56 << 10:  # (its weight fits the 64 KB of LDS next to the rest)
         assert nb_new != nb_ref, "the persistent kernel was not selected"
@@ -1318,14 +1318,48 @@ def test_nsplit_pointwise_kernel_equals_the_general_one(case, mode):
         ref, nb_ref = run()
     with _pwn_mode(2):
         got, nb_new = run()
+        kern = f.lib.query("nasseg_conv_pointwise_kernel", B, H, W, N, K, 2 if mode.startswith("bwd") else 1)
     # (its weight [N][K+4] next to the 34 KB input ring must fit 128 KB of LDS - else the call stays where it was)
     if 4 * ((N + 15) // 16 * 16) * (((K + 15) & ~15) + 4) <= 90 << 10:
-        assert nb_new == min((M + 63) // 64, nb_new) and nb_new <= 256 * 3, "not the persistent kernel's grid"
+        # (forward calls write two rows per workgroup: the double sums as an fp32 value and its rounding residue)
+        grid = nb_new if mode.startswith("bwd") else nb_new // 2
+        assert grid == min((M + 63) // 64, grid) and grid <= 256 * 3 and kern == 2
     assert not torch.isnan(got[0]).any()
     assert torch.equal(got[0], ref[0]), "outputs differ by {}".format(float((got[0] - ref[0]).abs().max()))
     if len(ref) > 1:
         tol = 1e-5 * float(M) ** 0.5 * (float(ref[1].abs().max()) / float(M) ** 0.5 + 1.0)
         assert_close(got[1], ref[1], tol, 1e-4, "statistics")
+
+
+def test_nsplit_pointwise_statistics_of_nearly_constant_channels():
+    """BatchNorm statistics from the conv epilogue when |mean| is hundreds of standard deviations (a 1x1 conv over
+    a nearly constant map - a controller-sampled cell had 471): E[y^2] - E[y]^2 in fp32 partial sums loses the
+    variance there; conv_pwn_kernel sums in double and hands value + rounding residue to the fp64 finaliser.
+    Against the float64 statistics of its own output: variance to 1e-4 relative."""
+    f = F()
+    B, H, W, K, N = 2, 61, 67, 16, 48
+    M = B * H * W
+    g = torch.Generator().manual_seed(5)
+    x = dev(1.0 + 8e-3 * torch.randn(B, K, H, W, generator=g))
+    w = (torch.rand(N, K, 1, 1, generator=g) + 0.5).to(DEV)
+    s = f.current_stream()
+    with _pwn_mode(2):
+        y = dev(torch.empty(B, N, H, W))
+        nb = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, N, K, 1)
+        part = torch.empty((nb + 64) * 2 * N, device=DEV)
+        f.lib.call("nasseg_conv_fwd", f.ptr(x), K, f.ptr(w), f.ptr(y), N, None, None, 0, None, None, 0, None, 0, B, H,
+                   W, K, H, W, N, 1, 1, 1, 0, 1, 0, f.ptr(part), s)
+        assert f.lib.query("nasseg_conv_pointwise_kernel", B, H, W, N, K, 1) == 2
+    st = torch.empty(4 * N, device=DEV)
+    f.lib.call("nasseg_bn_finalize", f.ptr(part), nb, M, N, 0.0, 0.1, None, None, f.ptr(st[0:N]), f.ptr(st[N:2 * N]),
+               f.ptr(st[2 * N:3 * N]), f.ptr(st[3 * N:]), None, None, None, s)
+    yd = y.permute(1, 0, 2, 3).reshape(N, -1).double()
+    mean, var = yd.mean(1), yd.var(1, unbiased=False)
+    assert float((mean.abs() / var.sqrt()).min()) > 100  # (the regime under test)
+    got_var = 1.0 / st[N:2 * N].double() ** 2
+    # (the mean is an fp32 number: at 500 standard deviations from zero its last bit is 3e-5 of one)
+    assert float(((st[0:N].double() - mean).abs() / var.sqrt()).max()) < 2e-4
+    assert float(((got_var - var).abs() / var).max()) < 1e-4, float(((got_var - var).abs() / var).max())
 
 
 def test_nsplit_pointwise_kernel_on_a_channel_slice_and_in_bf16():
