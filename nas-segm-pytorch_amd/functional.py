@@ -56,6 +56,26 @@ def _vec(like, n):
     return torch.empty((int(n),), device=like.device, dtype=torch.float32)
 
 
+# Finalising per-channel reductions inside the kernel that produced their rows (csrc/tail.h) needs a few counters that
+# are zero between launches: one set per (device, stream) - launches on one stream run one after the other.
+# OFF by default - measured on MI355X (tools/gpu_r4_ab_env.sh NASSEG_FUSE_TAIL "0 1"): it removes 37 of the 452 launches
+# of a headline step, 35 of CVPR 321x321's 885, 25 of task0's 680, and the steps get SLOWER by 0.5-0.8 % (267.0 -> 265.6,
+# 1105 -> 1097, 5482 -> 5446 img/s): the last workgroup's drain -> ticket -> row loads -> group row -> ticket -> loads
+# -> finish is a chain of six or seven memory round trips at the end of the producing kernel, as long as the
+# boundary + 5-8 us finaliser it replaces.  The entry points stay (tested, bit-reproducible) for parts where a kernel
+# boundary costs more.
+FUSE_TAIL = os.environ.get("NASSEG_FUSE_TAIL", "0") != "0"
+_TICKETS = {}
+
+
+def _tickets(like, stream):
+    key = (like.device.index, stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(64, device=like.device, dtype=torch.int32)
+    return t
+
+
 # ---------------------------------------------------------------------------
 # deferred finalisation of weight gradients
 # ---------------------------------------------------------------------------
@@ -847,6 +867,14 @@ class _ConvChain(torch.autograd.Function):
             elif kind == "dw":
                 lib.call(_k("nasseg_dwconv", cur), ptr(cur), ptr(wp), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
                          ptr(o_sh), o_act, B, H, W, K, Ho, Wo, kh, stride, pad, dil, 0, ptr(part), s)
+            elif part is not None and FUSE_TAIL and pointwise and not fold:
+                # conv + statistics + the BatchNorm's finalisation in one launch where the kernel can (returns 1)
+                finalised = lib.call(_k("nasseg_conv_fwd_bn", cur), ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh),
+                                     pact, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, ptr(part),
+                                     ptr(_tickets(cur, s)), float(eps), float(momentum), ptr(gamma), ptr(beta),
+                                     ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(rm), ptr(rv), ptr(nbt), s)
+                if finalised:
+                    part = False  # (statistics done: no nasseg_bn_finalize below)
             else:
                 lib.call(_k("nasseg_conv_fwd", cur), ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh), pact,
                          ptr(o_sc), ptr(o_sh), o_act, ptr(o_res), N, B, H, W, K, Ho, Wo, N, kh, kw,
@@ -862,7 +890,9 @@ class _ConvChain(torch.autograd.Function):
                 continue
             if has_bn:
                 if training:
-                    if part is not None:
+                    if part is False:
+                        pass  # (finalised by the producing kernel)
+                    elif part is not None:
                         lib.call("nasseg_bn_finalize", ptr(part), nblk, M, N, float(eps), float(momentum),
                                  ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                  ptr(rm), ptr(rv), ptr(nbt), s)
@@ -977,8 +1007,10 @@ class _ConvChain(torch.autograd.Function):
             fused_bn = None  # BatchNorm backward applied by the weight-gradient kernel on load
             if has_bn:
                 mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
-                sums = _vec(z, 2 * N)
-                if pre is not None:
+                sums = _vec(z, 2 * N) if (pre is None or len(pre) < 3 or pre[2] is None) else pre[2]
+                if pre is not None and sums is (pre[2] if len(pre) > 2 else None):
+                    pass  # g arrived masked and its sums were finished by the kernel that produced it
+                elif pre is not None:
                     # g arrived masked, with its per-workgroup {sum g, sum g*xhat} rows
                     lib.call("nasseg_rows_sum", ptr(pre[0]), pre[1], 2 * N, ptr(sums), s)
                 else:
@@ -1122,14 +1154,24 @@ class _ConvChain(torch.autograd.Function):
                     if bn_prev is not None:
                         g = _new(cur, Bc, K, H, W)
                         zp, psc_, psh_, pmu_, pis_, pact_ = bn_prev
-                        nb = (lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K, N,
-                                        2 * int(kh == 1 and kw == 1 and stride == 1 and pad == 0))
+                        pw1 = kh == 1 and kw == 1 and stride == 1 and pad == 0
+                        nb = (lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K, N, 2 * int(pw1))
                               if pmu_ is not None else 0)
                         part = _ws(cur, (nb + 64) * 2 * K) if nb else None
-                        lib.call(_k("nasseg_conv_bwd_data_bn", dz), ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
-                                 ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
-                                 K, kh, kw, stride, pad, dil, ptr(part), s)
-                        pre = (part, nb)
+                        summed = None
+                        if nb and pw1 and FUSE_TAIL:
+                            # ... with the rows summed by the same launch where the kernel can (returns 1)
+                            summed = _vec(cur, 2 * K)
+                            if not lib.call(_k("nasseg_conv_bwd_data_bn_sums", dz), ptr(dz), N, ptr(wb), ptr(g), K,
+                                            ptr(zp), K, ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo,
+                                            N, H, W, K, kh, kw, stride, pad, dil, ptr(part), ptr(_tickets(cur, s)),
+                                            ptr(summed), s):
+                                summed = None
+                        else:
+                            lib.call(_k("nasseg_conv_bwd_data_bn", dz), ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
+                                     ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
+                                     K, kh, kw, stride, pad, dil, ptr(part), s)
+                        pre = (part, nb, summed)
                     else:
                         g = _dense_backward_data(dz, wb, _dense_dgrad_form(w, stride, pad, dil),
                                                  (Bc, K, H, W), N, kh, kw, stride, pad, dil)
