@@ -527,6 +527,59 @@ def test_depthwise_backward_data_with_bn_backward_statistics(case, act):
     assert_close(sums, sums_ref, tol, 1e-4, "bn backward sums")
 
 
+@pytest.mark.parametrize("rows", [1, 255, 1936, 4096, 4097, 8192, 8193, 16384, 16385])
+@pytest.mark.parametrize("C", [8, 64, 100])
+def test_column_reductions_against_float64(rows, C):
+    """nasseg_bn_stats, nasseg_bn_bwd_reduce and nasseg_colred from one row to a few workgroups' worth, vector and
+    scalar channel counts: against float64 sums of the same data.  (A one-launch form for small maps - a workgroup
+    per 4-16 channels over ALL rows, result finished in the kernel - was measured in round 4 and dropped: one
+    workgroup streams ~20 GB/s, so even a 1 MB map lost to the two launches of the two-stage form; CVPR 321x321
+    1105 -> 1076 images/s, task0 5450 -> 5415.)"""
+    f = F()
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * 1.5 + 0.7).to(DEV)
+    dy = torch.randn(rows, C, generator=g).to(DEV)
+    s = f.current_stream()
+    ws = torch.empty(f.lib.query("nasseg_colred_workspace", 1, rows, C), device=DEV)
+    # BatchNorm statistics
+    gamma, beta = _bn_vectors(C, 1)[:2]
+    st = torch.empty(4 * C, device=DEV)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    if rows > 1:
+        f.lib.call("nasseg_bn_stats", f.ptr(x), C, rows, C, 1e-5, 0.1, f.ptr(gamma), f.ptr(beta), f.ptr(st[0:C]),
+                   f.ptr(st[C:2 * C]), f.ptr(st[2 * C:3 * C]), f.ptr(st[3 * C:]), f.ptr(rm), f.ptr(rv), f.ptr(nbt),
+                   f.ptr(ws), s)
+        xd = x.double()
+        mean, var = xd.mean(0), xd.var(0, unbiased=False)
+        invstd = 1.0 / (var + 1e-5).sqrt()
+        assert_close(st[0:C], mean, 1e-6, 1e-6, "mean")
+        assert_close(st[C:2 * C], invstd, 1e-6, 1e-5, "invstd")
+        assert_close(st[2 * C:3 * C], gamma.double() * invstd, 1e-6, 1e-5, "scale")
+        assert_close(st[3 * C:], beta.double() - mean * gamma.double() * invstd, 1e-5, 1e-5, "shift")
+        assert_close(rm, 0.1 * mean, 1e-6, 1e-5, "running_mean")
+        assert_close(rv, 0.9 + 0.1 * xd.var(0, unbiased=True), 1e-6, 1e-5, "running_var")
+        assert int(nbt) == 1
+    # BatchNorm-backward sums with the ReLU6 mask recomputed
+    scale, shift, mu, istd = _bn_vectors(C, 2)
+    sums = torch.empty(2 * C, device=DEV)
+    f.lib.call("nasseg_bn_bwd_reduce", f.ptr(dy), C, f.ptr(x), C, rows, C, f.ptr(scale), f.ptr(shift), f.ptr(mu),
+               f.ptr(istd), 2, f.ptr(sums), f.ptr(ws), s)
+    y = x.double() * scale.double() + shift.double()
+    gm = dy.double() * ((y > 0) & (y < 6)).double()
+    xh = (x.double() - mu.double()) * istd.double()
+    tol = 2e-6 * float(rows) ** 0.5 * 4
+    assert_close(sums[0:C], gm.sum(0), tol, 1e-5, "sum g")
+    assert_close(sums[C:], (gm * xh).sum(0), tol * 4, 1e-5, "sum g*xhat")
+    # plain column sums (global average pooling: mode 0 with a multiplier) and the two-dot form (mode 3)
+    out = torch.empty(2 * C, device=DEV)
+    f.lib.call("nasseg_colred", 0, f.ptr(x), C, None, 0, None, 0, f.ptr(out), f.ptr(ws), 1, rows, C, 1.0 / rows, s)
+    assert_close(out[0:C], x.double().mean(0), 1e-6, 1e-5, "mean over rows")
+    f.lib.call("nasseg_colred", 3, f.ptr(dy), C, f.ptr(x), C, f.ptr(x), C, f.ptr(out), f.ptr(ws), 1, rows, C, 1.0, s)
+    assert_close(out[0:C], (dy.double() * x.double()).sum(0), tol * 4, 1e-5, "sum a*b")
+    assert_close(out[C:], out[0:C], 0.0, 0.0, "sum a*c (c = b)")
+
+
 def _bn_bwd_reference(f, g, z, vecs, train, act=0):
     """sums {sum g', sum g'*xhat} and dz of nasseg_bn_bwd_reduce / nasseg_bn_bwd_apply"""
     scale, shift, mean, invstd = vecs
