@@ -50,6 +50,9 @@ WORKLOADS = {
     # cells), 256x256 crops, batch 64 (default_args.py:5,24), cache of 1024 samples per GPU (sharded)
     "task0": ("micro_search", CVPR_ARCH0, 21, 64, 256, 256, "train_task0 step on the cached encoder features, "
               "CVPR search decoder, 256x256 crops bs64"),
+    # the distillation teacher (Light-Weight RefineNet on ResNet-152, 62 M parameters), the
+    # inference forward populate_task0 runs per training crop (src/engine/trainer.py:17-74); forward only
+    "teacher": ("teacher", None, 21, 16, 256, 256, "KD teacher rf_lw152 inference forward, 256x256 crops bs16"),
 }
 NUM_CLASSES = 19
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -139,6 +142,73 @@ def algorithmic_bytes(name, a):
         P, C = (a[3], a[4]) if name == "nasseg_ce_fwd" else (a[5], a[6])
         return P * (4 * C * (2 if name == "nasseg_ce_bwd" else 1) + 8)
     return 0
+
+
+def algorithmic_flops(name, a):
+    """multiply-add FLOPs (2 per MAC) of one launch of a dense-convolution entry point"""
+    base = name.replace("nasseg_bf16_", "nasseg_")
+    if base == "nasseg_conv_fwd":
+        B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[13], a[14], a[15], a[16], a[17], a[18], a[19], a[20], a[21]
+        return 2 * B * Ho * Wo * N * K * kh * kw
+    return 0
+
+
+def bench_teacher(args, device):
+    """--workload teacher: images/s of the teacher's inference forward and, for the kernel family with the largest
+    share of its time, the achieved fp32 MFMA rate against the 157.3 TFLOP/s peak (MI355X_MICROARCH.md): the
+    teacher's 256-2048-channel 1x1 / 3x3 convs are the one place on this path where the matrix pipe is the roofline."""
+    from nas_segm_amd._lib import LaunchProfiler, lib
+    from nas_segm_amd.kd.rf_lw import rf_lw152
+
+    torch.manual_seed(0)
+    net = rf_lw152(pretrained=False, num_classes=21).to(device).eval()
+    x = torch.randn(args.batch, 3, args.height, args.width, device=device).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net(x)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        lib.profiler = LaunchProfiler()
+        net(x)
+        net(x)
+        torch.cuda.synchronize()
+        records, lib.profiler = lib.profiler.records, None
+    fam = {}
+    per = len(records) // 2
+    for i in range(per):
+        name, a = records[i][0], records[i][1]
+        ms = min(records[i][2].elapsed_time(records[i][3]), records[per + i][2].elapsed_time(records[per + i][3]))
+        ent = fam.setdefault(kernel_family(name, a), [0, 0.0, 0, 0])
+        ent[0] += 1
+        ent[1] += ms
+        ent[2] += algorithmic_flops(name, a)
+        ent[3] += algorithmic_bytes(name, a)
+    total_ms = sum(v[1] for v in fam.values())
+    top, (n, ms, fl, nb) = max(fam.items(), key=lambda kv: kv[1][1])
+    peak = 157.3
+    tf = fl / 1e12 / (ms / 1e3) if ms > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": top, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+            "traffic": None, "algorithmic_flops_per_launch": fl / max(n, 1), "avg_launch_ms": ms / max(n, 1),
+            "launches_per_step": n, "share_of_kernel_time": ms / total_ms if total_ms else None,
+            "hbm_gbs_of_that_family": nb / 1e9 / (ms / 1e3) if ms > 0 else None,
+            "launch_duration": "HIP events on the launch stream, minimum of 2 samples per launch",
+            "families": sorted(((k, v[0], round(v[1], 3), round(v[2] / 1e12 / (v[1] / 1e3), 1) if v[1] > 0 else 0.0)
+                                for k, v in fam.items()), key=lambda r: -r[2])[:6],
+            "nasseg_calls_per_step": per}
+    return {"metric": "images/sec (inference forward) KD teacher rf_lw152 {}x{} bs={}".format(
+                args.width, args.height, args.batch),
+            "value": args.batch * args.steps / elapsed, "unit": "images/sec", "n_gpus": 1, "rccl_ranks": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (randn images; random-init weights of the published architecture)",
+            "config": {"workload": "teacher: {} - {}x3x{}x{}".format(WORKLOADS["teacher"][6], args.batch,
+                                                                  args.height, args.width),
+                       "logits_shape": list(out.shape)},
+            "roofline": roof, "cpu_baseline": None}
 
 
 def build_model(device, workload="headline"):
@@ -568,6 +638,11 @@ def main():
     args.batch = args.batch or wl[3]
     args.height = args.height or wl[4]
     args.width = args.width or wl[5]
+    if args.workload == "teacher":
+        if world > 1:
+            raise SystemExit("bench.py: the teacher workload is a one-GPU inference measurement")
+        print(json.dumps(bench_teacher(args, device)))
+        return
     segmenter, net = build_model(device, args.workload)
     segmenter.train()
     # default_args.py:57-66: SGD(lr 1e-3, mom 0.9, wd 1e-5) encoder, Adam(lr 3e-3, wd 1e-5) decoder
