@@ -256,6 +256,13 @@ int nasseg_affine_act(const float* x, const float* scale, const float* shift, co
                       float* y, int64_t n, int C, int act, void* stream);
 int nasseg_axpby(const float* a, const float* b, const float* alpha, const float* beta, float* y,
                  int64_t n, int C, int act, void* stream);
+/* y = ca[c] * act_a(xa*sa[c] + ha[c]) + cb[c] * act_b(xb*sb[c] + hb[c]): the sum of two op outputs (cell sums,
+ * micro_decoders.py:48-51,110-121; ParamSum's coefficients, layer_factory.py:353-366) whose last BatchNorm +
+ * activation is applied as they are loaded - the normalised maps are never written.  Null vectors: scale /
+ * coefficient 1, shift 0. */
+int nasseg_add_act2(const float* xa, const float* sa, const float* ha, int act_a, const float* ca, const float* xb,
+                    const float* sb, const float* hb, int act_b, const float* cb, float* y, int64_t n, int C,
+                    void* stream);
 int nasseg_act_bwd(const float* dy, const float* ref, float* dx, int64_t n, int act, void* stream);
 int nasseg_fill(float* y, int64_t n, float v, void* stream);
 int nasseg_chan_copy(const float* x, int64_t ldx, int xoff, float* y, int64_t ldy, int yoff,
@@ -366,6 +373,9 @@ int nasseg_bf16_sepconv_fwd(const nasseg_bf16_t* x, const float* wdw, const floa
                             int Ho, int Wo, int N, int K, int stride, int pad, int dil, float* stats, void* stream);
 int nasseg_bf16_affine_act(const nasseg_bf16_t* x, const float* scale, const float* shift, const nasseg_bf16_t* res,
                       nasseg_bf16_t* y, int64_t n, int C, int act, void* stream);
+int nasseg_bf16_add_act2(const nasseg_bf16_t* xa, const float* sa, const float* ha, int act_a, const float* ca,
+                         const nasseg_bf16_t* xb, const float* sb, const float* hb, int act_b, const float* cb,
+                         nasseg_bf16_t* y, int64_t n, int C, void* stream);
 int nasseg_bf16_bn_bwd_apply(const nasseg_bf16_t* dy, const nasseg_bf16_t* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
                         int C, int train, int act, nasseg_bf16_t* dx, void* stream);

@@ -32,6 +32,28 @@ __global__ __launch_bounds__(256) void affine_act_kernel(
   }
 }
 
+// y = ca[c] * act_a(xa*sa[c] + ha[c]) + cb[c] * act_b(xb*sb[c] + hb[c]): the sum of two op outputs whose last
+// BatchNorm (+ activation) is still pending (functional.Pending), with ParamSum's per-channel coefficients; any of
+// the per-channel vectors may be null (scale / coefficient 1, shift 0)
+__global__ __launch_bounds__(256) void add_act2_kernel(
+    const act_t* __restrict__ xa, const float* __restrict__ sa, const float* __restrict__ ha, int act_a,
+    const float* __restrict__ ca, const act_t* __restrict__ xb, const float* __restrict__ sb,
+    const float* __restrict__ hb, int act_b, const float* __restrict__ cb, act_t* __restrict__ y, int64_t n4,
+    int C4) {
+  const ActSel fa = act_sel(act_a), fb = act_sel(act_b);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    float4 u = lda4(xa + i * 4), v = lda4(xb + i * 4);
+    if (sa || ha) u = fma4(u, sa ? lda4(sa + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f), ha ? lda4(ha + c4 * 4) : f4zero());
+    if (sb || hb) v = fma4(v, sb ? lda4(sb + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f), hb ? lda4(hb + c4 * 4) : f4zero());
+    u = act_apply4(u, fa);
+    v = act_apply4(v, fb);
+    if (ca) u = mul4(u, lda4(ca + c4 * 4));
+    if (cb) v = mul4(v, lda4(cb + c4 * 4));
+    sta4(y + i * 4, add4(u, v));
+  }
+}
+
 // BatchNorm (+activation) backward apply:
 //   g = dy * act'(x*scale+shift);  xhat = (x-mean)*invstd
 //   train: dx = scale * (g - sums0/M - xhat*sums1/M)     eval: dx = scale * g
@@ -164,6 +186,20 @@ int NASSEG_FN(affine_act)(const act_t* x, const float* scale, const float* shift
   hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, x,
                      scale, shift, res, y, n / 4, C / 4, act);
   NASSEG_LAUNCH_CHECK("affine_act");
+  return NASSEG_OK;
+}
+
+// y = ca[c] * act_a(xa*sa[c] + ha[c]) + cb[c] * act_b(xb*sb[c] + hb[c]); xa, xb, y dense [n/C][C]; every
+// per-channel vector may be null
+int NASSEG_FN(add_act2)(const act_t* xa, const float* sa, const float* ha, int act_a, const float* ca,
+                        const act_t* xb, const float* sb, const float* hb, int act_b, const float* cb, act_t* y,
+                        int64_t n, int C, void* stream) {
+  NASSEG_REQUIRE(C > 0 && C % 4 == 0 && n % C == 0 && xa && xb && y, "add_act2: bad shape n=%lld C=%d",
+                 (long long)n, C);
+  if (n == 0) return NASSEG_OK;
+  hipLaunchKernelGGL(add_act2_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, (hipStream_t)stream, xa, sa, ha, act_a,
+                     ca, xb, sb, hb, act_b, cb, y, n / 4, C / 4);
+  NASSEG_LAUNCH_CHECK("add_act2");
   return NASSEG_OK;
 }
 

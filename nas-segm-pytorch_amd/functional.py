@@ -1201,10 +1201,11 @@ class Pending(object):
     that flows back into ``z``'s slot is the one w.r.t. y (the chain's backward is the same either way: it has
     always received dL/dy and redone mask and BatchNorm backward from z)."""
 
-    __slots__ = ("z", "stats", "act")
+    __slots__ = ("z", "stats", "act", "_mat")
 
     def __init__(self, z, stats, act):
         self.z, self.stats, self.act = z, stats, int(act)  # stats: mean | invstd | scale | shift, C each
+        self._mat = None
 
     scale = property(lambda self: self.stats[2 * self.z.shape[1]:3 * self.z.shape[1]])
     shift = property(lambda self: self.stats[3 * self.z.shape[1]:])
@@ -1219,7 +1220,10 @@ class Pending(object):
         return self.z.dim()
 
     def materialize(self):
-        return _ApplyTail.apply(self.z, self.scale, self.shift, self.act)
+        # (memoised: a node with several consumers that cannot apply the tail themselves is normalised once)
+        if self._mat is None:
+            self._mat = _ApplyTail.apply(self.z, self.scale, self.shift, self.act)
+        return self._mat
 
 
 class _ApplyTail(torch.autograd.Function):
@@ -1857,8 +1861,43 @@ class _Add(torch.autograd.Function):
         return dy, dy
 
 
+class _AddPending(torch.autograd.Function):
+    """a + b where one or both are conv-chain outputs with a pending BatchNorm + activation (Pending): the tails
+    are applied as the raw conv outputs are loaded (nasseg_add_act2) - one launch and three tensor passes instead
+    of up to three launches and seven passes.  Backward: the gradient w.r.t. a sum's operands is the incoming one -
+    and a Pending's slot carries the gradient w.r.t. its NORMALISED value (see Pending), so nothing is computed."""
+
+    @staticmethod
+    def forward(ctx, za, zb, sta, stb, act_a, act_b):
+        za, zb = _cl(za), _cl(zb)
+        if za.shape != zb.shape:
+            raise NassegError("add: shapes {} and {} differ".format(tuple(za.shape), tuple(zb.shape)))
+        C = za.shape[1]
+        y = torch.empty_like(za)
+
+        def vecs(st):
+            return (None, None) if st is None else (st[2 * C:3 * C], st[3 * C:])
+
+        (sa, ha), (sb, hb) = vecs(sta), vecs(stb)
+        lib.call(_k("nasseg_add_act2", za), ptr(za), ptr(sa), ptr(ha), act_a, None, ptr(zb), ptr(sb), ptr(hb), act_b,
+                 None, ptr(y), za.numel(), C, current_stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy, None, None, None, None
+
+
+FUSE_PENDING_ADD = os.environ.get("NASSEG_PENDING_ADD", "1") != "0"
+
+
 def add(a, b):
-    return _Add.apply(a, b)
+    """a + b; operands may be Pending (applied on load) where their width allows the vector kernel"""
+    pa, pb = isinstance(a, Pending), isinstance(b, Pending)
+    if (pa or pb) and FUSE_PENDING_ADD and a.shape[1] % 4 == 0:
+        return _AddPending.apply(a.z if pa else a, b.z if pb else b, a.stats if pa else None, b.stats if pb else None,
+                                 a.act if pa else ACT_NONE, b.act if pb else ACT_NONE)
+    return _Add.apply(materialize(a), materialize(b))
 
 
 class _ReLU(torch.autograd.Function):

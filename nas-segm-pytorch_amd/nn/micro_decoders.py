@@ -20,6 +20,15 @@ from .layer_factory import AGG_OPS, OPS, conv3x3, conv_bn_relu, run_op
 from .modules import TREE_VERSION, FusedSequential
 
 
+def _takes_pending_types():
+    from .layer_factory import DilConv, SepConv
+
+    return (SepConv, DilConv, FusedSequential)
+
+
+_TAKES_PENDING = _takes_pending_types()  # ops whose first layer is a conv chain (it applies a pending input itself)
+
+
 def _hw(t):
     return (int(t.size(2)), int(t.size(3)))
 
@@ -63,12 +72,13 @@ def collect_all(feats, collect_indices, relu=False):
 
 
 def _sum_to_larger(x1, x2):
-    """Bilinearly up-sample the (lexicographically) smaller map and add."""
+    """Bilinearly up-sample the (lexicographically) smaller map and add.  (Operands may be functional.Pending:
+    F.add applies a pending BatchNorm + ReLU as it loads; a resize needs the finished map.)"""
     s1, s2 = _hw(x1), _hw(x2)
     if s1 > s2:
-        x2 = F.bilinear_resize(x2, s1)
+        x2 = F.bilinear_resize(F.materialize(x2), s1)
     elif s1 < s2:
-        x1 = F.bilinear_resize(x1, s2)
+        x1 = F.bilinear_resize(F.materialize(x1), s2)
     return F.add(x1, x2)
 
 
@@ -141,17 +151,23 @@ class ContextualCell(nn.Module):
             self._pools.append("sum({},{})".format(self._pools[node_a], self._pools[node_b]))
 
     def forward(self, x):
+        # Ops that end in conv + BatchNorm + ReLU hand their raw conv output over with the tail pending
+        # (functional.Pending): the sums of a step and of the loose ends apply it as they load, an op that starts
+        # with a conv takes it as its prologue, anything else gets the normalised map (computed once per node).
         nodes = [x]
         for src, op in zip(self._pos, self._ops):
             if isinstance(src, list):
                 assert len(src) == 2, "Two ops must be provided"
                 nodes.append(op(nodes[src[0]], nodes[src[1]]))
             else:
-                nodes.append(op(nodes[src]))
+                inp = nodes[src]
+                if not isinstance(op, _TAKES_PENDING):
+                    inp = F.materialize(inp)
+                nodes.append(run_op(op, inp, defer_tail=True))
         out = None
         for i in self._collect_inds:
             out = nodes[i] if out is None else F.add(out, nodes[i])
-        return out
+        return F.materialize(out)
 
     def prettify(self):
         return " + ".join(self._pools[i] for i in self._collect_inds)
