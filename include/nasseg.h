@@ -299,6 +299,14 @@ int nasseg_maxpool_bn_bwd(const float* dy, const uint8_t* idx, const float* z, c
  * (nasseg_cat_src_bwd): the slab BatchNorm's backward applied to one input's slice, masked with the pending
  * activation's derivative, with the producer's BatchNorm-backward sums as per-workgroup rows. */
 int64_t nasseg_cat_src_blocks(int B, int Ho, int Wo, int C);
+/* Backward of ParamSum (a[c]*x + b[c]*y, layer_factory.py:353-366) for both operands from one read of the gradient:
+ * an operand may be a conv chain's raw output with its BatchNorm + activation pending (ts*: mean | invstd | scale |
+ * shift; null: a finished map).  g* = c* dy act'(...) - masked, with the producer's BatchNorm-backward sums as rows
+ * part* [nasseg_cat_src_blocks(B, H, W, C) + 64][2][C] - and cpart [blocks + 64][2][C]: rows of the coefficient
+ * gradients {sum dy*x, sum dy*y} (nasseg_rows_sum finishes them). */
+int nasseg_psum_bwd(const float* dy, const float* za, const float* tsa, int act_a, const float* ca, float* ga,
+                    float* part_a, const float* zb, const float* tsb, int act_b, const float* cb, float* gb,
+                    float* part_b, float* cpart, int B, int H, int W, int C, void* stream);
 int nasseg_cat_src_fwd(const float* x, const float* scale, const float* shift, int act, float* y, int64_t ldy,
                        int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo, void* stream);
 int nasseg_cat_src_bwd(const float* du, const float* slab, int64_t ld, int off, const float* sscale,
@@ -373,6 +381,10 @@ int nasseg_bf16_sepconv_fwd(const nasseg_bf16_t* x, const float* wdw, const floa
                             int Ho, int Wo, int N, int K, int stride, int pad, int dil, float* stats, void* stream);
 int nasseg_bf16_affine_act(const nasseg_bf16_t* x, const float* scale, const float* shift, const nasseg_bf16_t* res,
                       nasseg_bf16_t* y, int64_t n, int C, int act, void* stream);
+int nasseg_bf16_psum_bwd(const nasseg_bf16_t* dy, const nasseg_bf16_t* za, const float* tsa, int act_a, const float* ca,
+                         nasseg_bf16_t* ga, float* part_a, const nasseg_bf16_t* zb, const float* tsb, int act_b,
+                         const float* cb, nasseg_bf16_t* gb, float* part_b, float* cpart, int B, int H, int W, int C,
+                         void* stream);
 int nasseg_bf16_add_act2(const nasseg_bf16_t* xa, const float* sa, const float* ha, int act_a, const float* ca,
                          const nasseg_bf16_t* xb, const float* sb, const float* hb, int act_b, const float* cb,
                          nasseg_bf16_t* y, int64_t n, int C, void* stream);

@@ -284,6 +284,75 @@ __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
   }
 }
 
+// Backward of ParamSum, out = ca[c] * ya + cb[c] * yb (src/nn/layer_factory.py:353-366), for BOTH operands from one
+// read of the gradient: y_s = act_s(scale_s * z_s + shift_s) where operand s is a conv chain's raw output with its
+// BatchNorm + activation pending (tstats_s: mean | invstd | scale | shift), else y_s = z_s.  Writes
+// g_s = c_s * dy * act_s'(...) (the gradient the producer's chain takes: masked, with its BatchNorm-backward sums
+// {sum g, sum g * xhat} as per-workgroup rows part_s) and the coefficient gradients' rows cpart [blk][2][C] =
+// {sum dy * ya, sum dy * yb}.  Same workgroup layout as cat_src_fwd_kernel.  Replaces two scaling passes, a two-dot
+// reduction and the producers' two mask-and-reduce passes: 5 tensor passes instead of 11, 1 launch instead of 8.
+__global__ __launch_bounds__(256) void psum_bwd_kernel(
+    const act_t* __restrict__ dy, const act_t* __restrict__ za, const float* __restrict__ tsa, int act_a,
+    const float* __restrict__ ca, act_t* __restrict__ ga, float* __restrict__ part_a, const act_t* __restrict__ zb,
+    const float* __restrict__ tsb, int act_b, const float* __restrict__ cb, act_t* __restrict__ gb,
+    float* __restrict__ part_b, float* __restrict__ cpart, int R, int Wo, int C4) {
+  __shared__ float4 sred[2][4][64];
+  const int C = C4 * 4;
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 256;
+  const int pos = base + tid;
+  const bool live = pos < Wo * C4;
+  const int ox = live ? pos / C4 : 0;
+  const int c4 = live ? pos - ox * C4 : 0;
+  const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 mu[2] = {f4zero(), f4zero()}, is[2] = {f4zero(), f4zero()}, sc[2] = {one, one}, sh[2] = {f4zero(), f4zero()};
+  const float* ts[2] = {tsa, tsb};
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    if (ts[s]) {
+      mu[s] = lda4(ts[s] + c4 * 4);
+      is[s] = lda4(ts[s] + C + c4 * 4);
+      sc[s] = lda4(ts[s] + 2 * C + c4 * 4);
+      sh[s] = lda4(ts[s] + 3 * C + c4 * 4);
+    }
+  const float4 cf[2] = {ca ? lda4(ca + c4 * 4) : one, cb ? lda4(cb + c4 * 4) : one};
+  const ActSel as[2] = {act_sel(tsa ? act_a : NASSEG_ACT_NONE), act_sel(tsb ? act_b : NASSEG_ACT_NONE)};
+  const act_t* zz[2] = {za, zb};
+  act_t* gg[2] = {ga, gb};
+  float4 sa[2] = {f4zero(), f4zero()}, sb[2] = {f4zero(), f4zero()}, scf[2] = {f4zero(), f4zero()};
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const int64_t e = ((int64_t)r * Wo + ox) * C + c4 * 4;
+    const float4 d = keep_if4(lda4(dy + e), live);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float4 zv = lda4(zz[s] + e);
+      const float4 t = fma4(zv, sc[s], sh[s]);
+      scf[s] = fma4(d, act_apply4(t, as[s]), scf[s]);
+      float4 g = mul4(d, cf[s]);
+      g = make_float4(g.x * act_mask(t.x, as[s]), g.y * act_mask(t.y, as[s]), g.z * act_mask(t.z, as[s]),
+                      g.w * act_mask(t.w, as[s]));
+      if (live && gg[s]) sta4(gg[s] + e, g);
+#ifdef NASSEG_BF16
+      g = make_float4(bf16_to_f32(f32_to_bf16(g.x)), bf16_to_f32(f32_to_bf16(g.y)), bf16_to_f32(f32_to_bf16(g.z)),
+                      bf16_to_f32(f32_to_bf16(g.w)));  // (what a reduction pass over g would read)
+#endif
+      const float4 xh = make_float4((zv.x - mu[s].x) * is[s].x, (zv.y - mu[s].y) * is[s].y, (zv.z - mu[s].z) * is[s].z,
+                                    (zv.w - mu[s].w) * is[s].w);
+      float4(&acc)[2] = s == 0 ? sa : sb;
+      acc[0] = add4(acc[0], g);
+      acc[1] = fma4(g, xh, acc[1]);
+    }
+  }
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  if (part_a) block_reduce_groups<2, 2>(sa, sred, part_a + (size_t)blk * 2 * C, base, C4);
+  if (part_b) {
+    __syncthreads();
+    block_reduce_groups<2, 2>(sb, sred, part_b + (size_t)blk * 2 * C, base, C4);
+  }
+  __syncthreads();
+  block_reduce_groups<2, 2>(scf, sred, cpart + (size_t)blk * 2 * C, base, C4);
+}
+
 struct CatGrid {
   int gx, gy;
 };
@@ -621,6 +690,23 @@ int NASSEG_FN(cat_src_bwd)(const act_t* du, const act_t* slab, int64_t ld, int o
                        off, sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho, Wo,
                        C / 4, Ho, Hi, Wi, sh, sw);
   NASSEG_LAUNCH_CHECK("cat_src_bwd");
+  return NASSEG_OK;
+}
+
+// ParamSum backward (psum_bwd_kernel): dy, za, zb, ga, gb dense [B*H*W][C]; tsa / tsb: null (operand is a finished
+// map) or its pending BatchNorm's mean | invstd | scale | shift; ca / cb: the coefficients (null: 1); ga / gb: null
+// when that operand needs no gradient; part_a / part_b: null or [nasseg_cat_src_blocks(B, H, W, C) + 64][2][C]
+// (pending operands only); cpart: [blocks + 64][2][C] rows of {sum dy * ya, sum dy * yb}.
+int NASSEG_FN(psum_bwd)(const act_t* dy, const act_t* za, const float* tsa, int act_a, const float* ca, act_t* ga,
+                        float* part_a, const act_t* zb, const float* tsb, int act_b, const float* cb, act_t* gb,
+                        float* part_b, float* cpart, int B, int H, int W, int C, void* stream) {
+  NASSEG_REQUIRE(dy && za && zb && cpart && nasseg_cat_src_blocks(B, H, W, C) > 0 && (!part_a || tsa) &&
+                     (!part_b || tsb),
+                 "psum_bwd: bad arguments");
+  const CatGrid gr = cat_grid(B, H, W, C);
+  hipLaunchKernelGGL(psum_bwd_kernel, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, dy, za, tsa, act_a, ca, ga,
+                     part_a, zb, tsb, act_b, cb, gb, part_b, cpart, B * H, W, C / 4);
+  NASSEG_LAUNCH_CHECK("psum_bwd");
   return NASSEG_OK;
 }
 

@@ -1945,8 +1945,72 @@ class _ParamSum(torch.autograd.Function):
         return dx, dyy, da, db
 
 
+class _ParamSumPending(torch.autograd.Function):
+    """a[c]*x + b[c]*y where x and / or y are conv-chain outputs whose last BatchNorm + activation is pending
+    (Pending): forward applies the tails as it loads the raw conv outputs (nasseg_add_act2); backward is ONE kernel
+    over the gradient (nasseg_psum_bwd) that leaves, per operand, the masked gradient its chain takes together
+    with that chain's BatchNorm-backward sums (handed over by the side of the gradient, _TAIL_ROWS), and the rows of
+    the coefficient gradients - instead of two scaling passes, a two-dot reduction and two mask-and-reduce passes."""
+
+    @staticmethod
+    def forward(ctx, za, zb, sta, stb, a, b, act_a, act_b):
+        za, zb = _cl(za), _cl(zb)
+        if za.shape != zb.shape:
+            raise NassegError("psum: shapes {} and {} differ".format(tuple(za.shape), tuple(zb.shape)))
+        C = za.shape[1]
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(za)
+
+        def vecs(st):
+            return (None, None) if st is None else (st[2 * C:3 * C], st[3 * C:])
+
+        (sa, ha), (sb, hb) = vecs(sta), vecs(stb)
+        lib.call(_k("nasseg_add_act2", za), ptr(za), ptr(sa), ptr(ha), act_a, ptr(a), ptr(zb), ptr(sb), ptr(hb), act_b,
+                 ptr(b), ptr(y), za.numel(), C, current_stream())
+        ctx.save_for_backward(za, zb, sta, stb, a, b)
+        ctx.acts = (act_a, act_b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        for key in [k for k, e in _TAIL_ROWS.items() if e[0]() is None]:
+            del _TAIL_ROWS[key]
+        za, zb, sta, stb, a, b = ctx.saved_tensors
+        act_a, act_b = ctx.acts
+        dy = _cl(dy)
+        B, C, H, W = za.shape
+        s = current_stream()
+        nrows = lib.query("nasseg_cat_src_blocks", B, H, W, C)
+        ga = torch.empty_like(za) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(zb) if ctx.needs_input_grad[1] else None
+        rows_a = _ws(za, (nrows + 64) * 2 * C) if (sta is not None and ga is not None and FUSE_TAIL_ROWS) else None
+        rows_b = _ws(zb, (nrows + 64) * 2 * C) if (stb is not None and gb is not None and FUSE_TAIL_ROWS) else None
+        cpart = _ws(za, (nrows + 64) * 2 * C)
+        if (sta is not None and rows_a is None and ga is not None) or (stb is not None and rows_b is None and gb is not None):
+            raise NassegError("psum: pending operands need NASSEG_FUSE_TAIL_ROWS")
+        lib.call(_k("nasseg_psum_bwd", dy), ptr(dy), ptr(za), ptr(sta), act_a, ptr(a), ptr(ga), ptr(rows_a), ptr(zb),
+                 ptr(stb), act_b, ptr(b), ptr(gb), ptr(rows_b), ptr(cpart), B, H, W, C, s)
+        da = db = None
+        if ctx.needs_input_grad[4] or ctx.needs_input_grad[5]:
+            sums = _vec(za, 2 * C)
+            lib.call("nasseg_rows_sum", ptr(cpart), nrows, 2 * C, ptr(sums), s)
+            da, db = sums[0:C], sums[C:2 * C]
+        for g, rows in ((ga, rows_a), (gb, rows_b)):
+            if rows is not None:
+                _TAIL_ROWS[g.data_ptr()] = (weakref.ref(g), rows, nrows, g._version)
+        return ga, gb, None, None, da, db, None, None
+
+
+FUSE_PENDING_PSUM = os.environ.get("NASSEG_PENDING_PSUM", "1") != "0"
+
+
 def param_sum(x, y, a, b):
-    return _ParamSum.apply(x, y, a, b)
+    """a[c]*x + b[c]*y (ParamSum); x / y may be Pending (same size, C % 4 == 0: applied on load)"""
+    px, py = isinstance(x, Pending), isinstance(y, Pending)
+    if (px or py) and FUSE_PENDING_PSUM and FUSE_TAIL_ROWS and x.shape[1] % 4 == 0 and torch.is_grad_enabled():
+        return _ParamSumPending.apply(x.z if px else x, y.z if py else y, x.stats if px else None,
+                                      y.stats if py else None, a, b, x.act if px else ACT_NONE, y.act if py else ACT_NONE)
+    return _ParamSum.apply(materialize(x), materialize(y), a, b)
 
 
 class _ChannelRepeat(torch.autograd.Function):

@@ -290,8 +290,17 @@ class ParamSum(nn.Module):
         self.a = nn.Parameter(torch.ones(C_out))
         self.b = nn.Parameter(torch.ones(C_out))
 
+    accepts_pending = True  # (inputs may be functional.Pending: a producer's BatchNorm + ReLU still to apply)
+
     def forward(self, x, y):
-        x, y = self.adapt(x, y)
+        # Adapt's 1x1 convs take pending inputs as their prologue and may leave their own tail pending; an operand
+        # that has to be resized needs the finished map, the other one stays pending: F.param_sum applies it
+        x, y = self.adapt.convs(x, y, defer_tail=True)
+        size = self.adapt.target_size(x, y)
+        if tuple(x.size()[2:]) != size:
+            x = F.bilinear_resize(F.materialize(x), size)
+        if tuple(y.size()[2:]) != size:
+            y = F.bilinear_resize(F.materialize(y), size)
         return F.param_sum(x, y, self.a, self.b)
 
 

@@ -1758,3 +1758,76 @@ def test_cat_src_kernels_against_torch(case):
         scale0 = float(g_want.abs().sum(dim=(0, 2, 3)).max())
         assert_close(pr[0], s0, 2e-5 * scale0, 1e-4, "sum g")
         assert_close(pr[1], s1, 2e-5 * float((g_want * xhat).abs().sum(dim=(0, 2, 3)).max()), 1e-4, "sum g*xhat")
+
+
+@pytest.mark.parametrize("case", [(2, 13, 17, 32), (1, 40, 64, 64), (3, 9, 5, 8), (2, 64, 96, 24)],
+                         ids=lambda c: "B{}_{}x{}_C{}".format(*c))
+@pytest.mark.parametrize("pend", [(True, True), (True, False), (False, True)], ids=["both", "first", "second"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pending_sum_kernels_against_torch(case, pend, dtype):
+    """nasseg_add_act2 (sums of op outputs whose BatchNorm + activation is pending: cell sums, ParamSum) and
+    nasseg_psum_bwd (ParamSum's whole backward from one read of the gradient) against float64 torch: output, both
+    masked gradients, both producers' BatchNorm-backward sums, both coefficient gradients."""
+    f = F()
+    B, H, W, C = case
+    M = B * H * W
+    pre = "nasseg_bf16_" if dtype == torch.bfloat16 else "nasseg_"
+    s = f.current_stream()
+    za, zb, dy = (dev(rnd(B, C, H, W, seed=i) * 1.5).to(dtype) for i in (1, 2, 3))
+    sta = torch.cat(_bn_vectors(C, 4)[2:] + _bn_vectors(C, 4)[:2]).contiguous()  # mean | invstd | scale | shift
+    stb = torch.cat(_bn_vectors(C, 5)[2:] + _bn_vectors(C, 5)[:2]).contiguous()
+    ca, cb = (torch.rand(C, generator=torch.Generator().manual_seed(9 + i)) + 0.5 for i in (0, 1))
+    ca, cb = ca.to(DEV), cb.to(DEV)
+    acts = (2 if pend[0] else 0, 1 if pend[1] else 0)  # ReLU6 on the first operand, ReLU on the second (when pending)
+
+    def parts(st):
+        return st[0:C], st[C:2 * C], st[2 * C:3 * C], st[3 * C:]
+
+    def ref_side(z, st, act, on):
+        z = z.double().permute(0, 2, 3, 1)
+        if not on:
+            return z, torch.ones_like(z), torch.zeros_like(z)
+        mu, istd, sc, sh = (v.double() for v in parts(st))
+        t = z * sc + sh
+        y = t.clamp(0, 6) if act == 2 else t.clamp_min(0)
+        mask = ((t > 0) & (t < 6)).double() if act == 2 else (t > 0).double()
+        return y, mask, (z - mu) * istd
+
+    ya, ma, xha = ref_side(za, sta, acts[0], pend[0])
+    yb, mb, xhb = ref_side(zb, stb, acts[1], pend[1])
+    want = ca.double() * ya + cb.double() * yb
+    y = torch.empty_like(za)
+    tsa, tsb = (sta if pend[0] else None), (stb if pend[1] else None)
+
+    def vec(st, k):
+        return None if st is None else f.ptr(parts(st)[k])
+
+    f.lib.call(pre + "add_act2", f.ptr(za), vec(tsa, 2), vec(tsa, 3), acts[0], f.ptr(ca), f.ptr(zb), vec(tsb, 2),
+               vec(tsb, 3), acts[1], f.ptr(cb), f.ptr(y), za.numel(), C, s)
+    tol = 2.0 ** -7 * float(want.abs().max()) if dtype == torch.bfloat16 else 1e-5
+    assert_close(y.float().permute(0, 2, 3, 1), want, tol, 1e-5, "ca*ya + cb*yb")
+    # ---- backward ----
+    nrows = f.lib.query("nasseg_cat_src_blocks", B, H, W, C)
+    ga, gb = torch.empty_like(za), torch.empty_like(zb)
+    ra = torch.full(((nrows + 64) * 2 * C,), float("nan"), device=DEV) if pend[0] else None
+    rb = torch.full(((nrows + 64) * 2 * C,), float("nan"), device=DEV) if pend[1] else None
+    rc = torch.full(((nrows + 64) * 2 * C,), float("nan"), device=DEV)
+    f.lib.call(pre + "psum_bwd", f.ptr(dy), f.ptr(za), f.ptr(tsa), acts[0], f.ptr(ca), f.ptr(ga), f.ptr(ra), f.ptr(zb),
+               f.ptr(tsb), acts[1], f.ptr(cb), f.ptr(gb), f.ptr(rb), f.ptr(rc), B, H, W, C, s)
+    d = dy.double().permute(0, 2, 3, 1)
+    gtol = 2.0 ** -7 * float(d.abs().max()) * 1.5 if dtype == torch.bfloat16 else 1e-5
+    for got, coef, mask, xh, rows, what in ((ga, ca, ma, xha, ra, "first"), (gb, cb, mb, xhb, rb, "second")):
+        g_ref = coef.double() * d * mask
+        assert_close(got.float().permute(0, 2, 3, 1), g_ref, gtol, 1e-5, "masked gradient of the {} operand".format(what))
+        if rows is not None:
+            sums = torch.empty(2 * C, device=DEV)
+            f.lib.call("nasseg_rows_sum", f.ptr(rows), nrows, 2 * C, f.ptr(sums), s)
+            g_seen = got.double().permute(0, 2, 3, 1)  # (the sums are over the gradient as stored)
+            stol = 2e-6 * float(M) ** 0.5 * (float(g_seen.abs().max()) + 1.0) * 8
+            assert_close(sums[0:C], g_seen.reshape(-1, C).sum(0), stol, 1e-4, "sum g ({})".format(what))
+            assert_close(sums[C:], (g_seen * xh).reshape(-1, C).sum(0), stol * 4, 1e-4, "sum g*xhat ({})".format(what))
+    csum = torch.empty(2 * C, device=DEV)
+    f.lib.call("nasseg_rows_sum", f.ptr(rc), nrows, 2 * C, f.ptr(csum), s)
+    ctol = 2e-6 * float(M) ** 0.5 * (float((d * ya).abs().max()) + 1.0) * 8
+    assert_close(csum[0:C], (d * ya).reshape(-1, C).sum(0), ctol, 1e-4, "coefficient gradient a")
+    assert_close(csum[C:], (d * yb).reshape(-1, C).sum(0), ctol, 1e-4, "coefficient gradient b")

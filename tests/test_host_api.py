@@ -368,8 +368,17 @@ def test_pending_tail_is_materialised_for_consumers_that_do_not_take_it(monkeypa
     monkeypatch.setattr(LF, "_SPLIT_CAT_MIN", 0)
     F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("cat"), shapes)
     assert [n for n, _ in fwd].count("nasseg_affine_act") == 2 and "nasseg_cat_src_fwd" not in [n for n, _ in fwd]
-    F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("psum"), shapes)  # ParamSum does not accept pending inputs
-    assert [n for n, _ in fwd].count("nasseg_affine_act") == 2
+    # ParamSum takes pending operands too (round 4): one forward kernel applies both tails, one backward kernel
+    # leaves both masked gradients with their producers' sums and the coefficient gradients' rows
+    F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("psum"), shapes)
+    f_names, b_names = [n for n, _ in fwd], [n for n, _ in bwd]
+    assert f_names.count("nasseg_affine_act") == 0 and f_names.count("nasseg_add_act2") == 1
+    assert b_names.count("nasseg_psum_bwd") == 1 and b_names.count("nasseg_bn_bwd_reduce") == 0
+    assert b_names.count("nasseg_axpby") == 0 and b_names.count("nasseg_colred") == 0
+    assert not F._TAIL_ROWS
+    monkeypatch.setattr(F, "FUSE_PENDING_PSUM", False)
+    F, fwd, bwd, _ = _dry_run(monkeypatch, lambda: Cell("psum"), shapes)
+    assert [n for n, _ in fwd].count("nasseg_affine_act") == 2 and "nasseg_psum_bwd" not in [n for n, _ in bwd]
     assert not F._TAIL_ROWS
 
 
