@@ -46,6 +46,8 @@ if [[ "$WHAT" == "all" || "$WHAT" == "graph" ]]; then
   echo "bench task0 (auto graph) exit $?" >> $OUT/summary.log; cat $OUT/bench_task0_auto.json >> $OUT/summary.log
   timeout 300 python bench.py --workload task0 --graph 0 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_task0_g0.json 2> $OUT/bench_task0_g0.err
   echo "bench task0 --graph 0 exit $?" >> $OUT/summary.log; cat $OUT/bench_task0_g0.json >> $OUT/summary.log
+  timeout 300 python bench.py --workload teacher --steps 8 --warmup 2 > $OUT/bench_teacher.json 2> $OUT/bench_teacher.err
+  echo "bench teacher exit $?" >> $OUT/summary.log; cat $OUT/bench_teacher.json >> $OUT/summary.log
   for wl in arch1 cvpr321 search713; do
     for g in 0 2; do
       timeout 300 python bench.py --workload $wl --steps 8 --warmup 2 --graph $g --no-cpu-baseline > $OUT/bench_${wl}_g$g.json 2> $OUT/bench_${wl}_g$g.err
