@@ -116,15 +116,22 @@ EXPECT = {  # entry points the case is there for (fp32 names)
 }
 
 
+@pytest.mark.parametrize("batch", [1, 3])
 @pytest.mark.parametrize("kind", sorted(EXPECT))
-def test_fused_chain_kernels_against_torch_cpu_autograd(kind, monkeypatch):
+def test_fused_chain_kernels_against_torch_cpu_autograd(kind, batch, monkeypatch):
+    """batch 3: several images per slab of the one-kernel backwards, tiles of the persistent pointwise kernel that
+    straddle image boundaries"""
+    if batch > 1 and kind in ("stem", "stem_stage1_2"):
+        pytest.skip("the 128 x 256 image cases stay at one image (the float64 reference of three takes a minute)")
     Fm = lower_thresholds(monkeypatch)
     mods, cin, (H, W), residual, relu_in = build(kind)
     randomise(mods, 5)
     ref = copy.deepcopy(mods).train()
     ref64 = copy.deepcopy(mods).double().train()
     mods = mods.to(DEV).train()
-    x0 = rnd(1, cin, H, W, seed=2)
+    # (seed 2 at three images puts ONE pre-activation of ir_24_24 within rounding of the ReLU6 kink: the gradient then
+    # differs in the 3 x 3 neighbourhood of that pixel and nowhere else - tools/diag_anchor_b3.py)
+    x0 = rnd(batch, cin, H, W, seed=2 if batch == 1 else 7)
     xc = x0.clone().requires_grad_(cin > 3)  # (the image needs no gradient: the stem's flat weight-gradient path)
     is_pool = kind.startswith("pool")
 
@@ -426,6 +433,102 @@ def test_cat_reduce_cell_against_torch_cpu_autograd(kind, mode, monkeypatch):
     with torch.no_grad():
         y_plain = cell[2](run_op(cell[0], xg[0], True), run_op(cell[1], xg[1], True))
     assert_close(y_plain, yc, 1e-4 * float(yc.abs().max()) + 4 * floor(yc, yd), 1e-4, kind + ": unfused output")
+
+
+@pytest.mark.parametrize("kind", ["sep_sep_same", "sep_pool_same", "adapt_resize"])
+def test_param_sum_cell_against_torch_cpu_autograd(kind, monkeypatch):
+    """ParamSum (src/nn/layer_factory.py:353-366) fed by its producers' pending BatchNorm + ReLU (round 4:
+    nasseg_add_act2 forward, nasseg_psum_bwd backward, the producers' sums handed over by the side): output, both
+    input gradients, every parameter gradient (the coefficients a, b included) and the BatchNorm buffers against
+    torch.nn on the CPU, floors from the same graph in float64."""
+    from nas_segm_amd.nn.layer_factory import AGG_OPS, OPS, run_op
+
+    Fm = lower_thresholds(monkeypatch)
+    torch.manual_seed(17)
+    if kind == "sep_sep_same":      # two pending operands of one size
+        cell = nn.ModuleList([OPS["sep_conv_3x3"](32, 32, 1, True, 2), OPS["sep_conv_5x5"](32, 32, 1, True, 1),
+                              AGG_OPS["psum"](32, 32, 32, True, 1, True)])
+        (c1, hw1), (c2, hw2) = (32, (33, 64)), (32, (33, 64))
+    elif kind == "sep_pool_same":   # a pending operand next to a finished one (Pool)
+        cell = nn.ModuleList([OPS["sep_conv_3x3"](24, 24, 1, True, 1), OPS["max_pool_3x3"](24, 24, 1, True),
+                              AGG_OPS["psum"](24, 24, 24, True, 1, True)])
+        (c1, hw1), (c2, hw2) = (24, (32, 48)), (24, (32, 48))
+    else:                           # widths and sizes differ: Adapt's 1x1 conv is the pending producer, the other
+        cell = nn.ModuleList([OPS["sep_conv_3x3"](24, 24, 1, True, 1), OPS["sep_conv_3x3"](48, 48, 1, True, 1),
+                              AGG_OPS["psum"](24, 48, 48, True, 1, True)])  # operand is resized (finished map)
+        (c1, hw1), (c2, hw2) = (24, (16, 32)), (48, (32, 64))
+    randomise(cell, 8)
+    with torch.no_grad():
+        cell[2].a.copy_(torch.rand(cell[2].a.shape) + 0.5)
+        cell[2].b.copy_(torch.rand(cell[2].b.shape) + 0.5)
+    ref = copy.deepcopy(cell).train()
+    ref64 = copy.deepcopy(cell).double().train()
+    cell = cell.to(DEV).train()
+
+    def reference(c, x1, x2):
+        a, b = _op_reference(c[0], x1), _op_reference(c[1], x2)
+        ad = c[2].adapt
+        if ad.C_in0 != ad.C_out:
+            a = torch_reference(ad.conv0._modules.values(), a)
+        if ad.C_in1 != ad.C_out:
+            b = torch_reference(ad.conv1._modules.values(), b)
+        s1, s2 = tuple(a.shape[2:]), tuple(b.shape[2:])
+        if s1 != s2:
+            if (s1 > s2) if ad.larger else (s1 < s2):
+                b = torch.nn.functional.interpolate(b, size=s1, mode="bilinear", align_corners=False)
+            else:
+                a = torch.nn.functional.interpolate(a, size=s2, mode="bilinear", align_corners=False)
+        return a * c[2].a.view(1, -1, 1, 1) + b * c[2].b.view(1, -1, 1, 1)
+
+    x1, x2 = rnd(2, c1, *hw1, seed=2), rnd(2, c2, *hw2, seed=4)
+    xs = [x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)]
+    yc = reference(ref, *xs)
+    cot = rnd(*yc.shape, seed=3)
+    yc.backward(cot)
+    xd = [x1.double().requires_grad_(True), x2.double().requires_grad_(True)]
+    yd = reference(ref64, *xd)
+    yd.backward(cot.double())
+
+    seen = []
+    orig = Fm.lib.call
+
+    def rec(fn, *a):
+        seen.append(fn)
+        return orig(fn, *a)
+
+    monkeypatch.setattr(Fm.lib, "call", rec)
+    xg = [dev(x1.clone()).requires_grad_(True), dev(x2.clone()).requires_grad_(True)]
+    assert cell[2].accepts_pending
+    yg = cell[2](run_op(cell[0], xg[0], True), run_op(cell[1], xg[1], True))
+    yg.backward(dev(cot))
+    monkeypatch.setattr(Fm.lib, "call", orig)
+    assert seen.count("nasseg_add_act2") == 1 and seen.count("nasseg_psum_bwd") == 1, sorted(set(seen))
+    assert "nasseg_axpby" not in seen and "nasseg_colred" not in seen
+    # producers whose pending output went straight into the sum need no reduction pass of their own
+    assert seen.count("nasseg_bn_bwd_reduce") == {"sep_sep_same": 0, "sep_pool_same": 0, "adapt_resize": 2}[kind]
+    assert not Fm._TAIL_ROWS
+
+    def floor(ref32, ref64_):
+        return float((ref32.detach().double() - ref64_.detach()).abs().max())
+
+    assert_close(yg, yc, 1e-4 * float(yc.abs().max()) + 4 * floor(yc, yd), 1e-4, kind + ": output")
+    for i in range(2):
+        err = (xg[i].grad.cpu().double() - xs[i].grad.double()).abs()
+        tol = (1e-4 * float(xs[i].grad.abs().max()) + 1e-4 * xs[i].grad.abs().double()
+               + 4 * floor(xs[i].grad, xd[i].grad))
+        frac = float((err > tol).double().mean())
+        assert frac <= 2e-5, "{}: dx{}: {:.2e} of the elements off".format(kind, i, frac)
+    gp, cp, dp = dict(cell.named_parameters()), dict(ref.named_parameters()), dict(ref64.named_parameters())
+    for k in cp:
+        fl = floor(cp[k].grad, dp[k].grad)
+        assert_close(gp[k].grad, cp[k].grad, 1e-4 * float(cp[k].grad.abs().max()) + 4 * fl, 1e-4,
+                     "{}: gradient of {}".format(kind, k))
+    gb, cb = dict(cell.named_buffers()), dict(ref.named_buffers())
+    for k in cb:
+        if cb[k].dtype == torch.int64:
+            assert int(gb[k]) == int(cb[k]), k
+        else:
+            assert_close(gb[k], cb[k], 1e-6, 2e-5, "{}: buffer {}".format(kind, k))
 
 
 @pytest.mark.parametrize("nblk", [1, 37, 512, 513, 1024, 2047, 4096, 4097, 9000])
