@@ -649,9 +649,12 @@ def main():
     # (torch.optim is the reference's optimiser too - SURVEY section 8a O1; `fused` selects its
     # single-kernel multi-tensor implementation instead of the foreach one)
     fused = dict(fused=True) if args.fused_optim else {}
+    # (plain objects, as src/utils/solvers.py makes them: the engine steps those with nasseg_optim_step, also inside a
+    # hipGraph; torch's own implementations - NASSEG_NATIVE_OPTIM=0 or --fused-optim 1 - need capturable=True there)
+    torch_steps = bool(args.fused_optim) or os.environ.get("NASSEG_NATIVE_OPTIM", "1") == "0"
     optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5, **fused)
     optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5,
-                                 capturable=args.graph == 2, **fused)
+                                 capturable=args.graph == 2 and torch_steps, **fused)
     image, mask = synthetic_batch(args.batch, args.height, args.width, rank, device, wl[2])
     if args.dtype == "bf16":
         image = image.to(torch.bfloat16)

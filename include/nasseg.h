@@ -355,6 +355,26 @@ int nasseg_argmax_cm(const float* logits, const uint8_t* gt, uint8_t* preds, int
 int nasseg_compute_ius_accs(const int64_t* cm, int n, double* iu, int64_t* n_pixels, double* accs);
 
 
+/* ---- clip_grad_norm_ + optimiser steps: src/engine/trainer.py:163-166,258-268 on the torch.optim.SGD /
+ * torch.optim.Adam objects of src/utils/solvers.py:6-52 - two launches for every parameter of the step.
+ *   tensors  DEVICE int64 [n_tensors][8]: parameter, gradient, state 1 (SGD momentum_buffer | Adam exp_avg; 0: SGD
+ *            without momentum), state 2 (Adam exp_avg_sq; else 0) addresses, numel, clip set (-1: none), hyper
+ *            group, flags (bit 0: all four addresses are 16-byte aligned).  fp32, dense, gradient laid out like
+ *            the parameter.
+ *   chunks   DEVICE int32 [n_chunks][2] = {tensor, first element}: nasseg_optim_chunk() elements each; the chunks of
+ *            one clip set are consecutive.
+ *   hyper    HOST double [n_hyper][6] = {kind (0 SGD, 1 Adam), lr, weight_decay, momentum | beta1, beta2, eps};
+ *            SGD: no nesterov, no dampening; Adam: no amsgrad; neither maximises.  n_hyper <= 8.
+ *   clips    HOST double [n_clip][3] = {max_norm, first chunk, chunk count}, n_clip <= 8: L2 norm over the set,
+ *            gradients scaled in place by min(1, max_norm / (norm + 1e-6)); norms[n_clip] receives the norms.
+ *   dstep    DEVICE float [n_tensors]: steps taken per tensor, advanced by the call (Adam's bias correction reads
+ *            it on the device: the call can be replayed from a hipGraph).
+ *   partial  DEVICE double [n_chunks] workspace. */
+int64_t nasseg_optim_chunk(void);
+int nasseg_optim_step(const int64_t* tensors, int n_tensors, const int* chunks, int n_chunks, const double* hyper,
+                      int n_hyper, const double* clips, int n_clip, float* dstep, double* partial, float* norms,
+                      void* stream);
+
 /* ---- bfloat16 activation storage --------------------------------------------
  * Every entry point above that reads or writes ACTIVATIONS (feature maps and their gradients)
  * has a twin nasseg_bf16_<op> with the same arguments in which those tensors are stored as

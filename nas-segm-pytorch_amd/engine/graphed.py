@@ -79,8 +79,16 @@ class _GraphedStep(object):
         self.segmenter = segmenter
         self.model = inner(segmenter)
         self.world = int(getattr(segmenter, "world_size", 1))
+        # optimisers inside the graph: plain SGD / Adam through nasseg_optim_step (step counters on the device;
+        # an object of this stepper's own - its tables are re-uploaded by the graph at every replay), others only
+        # when torch can record them (``_capturable``)
+        self._native = None
+        if capture_optimisers and self.world == 1:
+            from .optim_native import NativeStep
+
+            self._native = NativeStep.build(self.groups)
         self.capture_optimisers = bool(capture_optimisers and self.world == 1
-                                       and all(_capturable(o) for o in optimisers))
+                                       and (self._native is not None or all(_capturable(o) for o in optimisers)))
         self._optimisers = [o for o in optimisers if o is not None]
         self._params = [p for m in self._trained for p in m.parameters()]
         self._pack_memo = F.PackMemo()  # (owns the packed-weight buffers the graph reads)
@@ -108,7 +116,7 @@ class _GraphedStep(object):
             with F.deferred_wgrad(params=self._params):  # (gradients were cleared above)
                 loss.backward()
         if with_optimisers:
-            clip_and_step(self.groups)
+            clip_and_step(self.groups, self._native)
         return loss.detach()
 
     def _bn_buffers(self):
@@ -149,6 +157,8 @@ class _GraphedStep(object):
                                     v.zero_()
                 for b, s in zip(buffers, saved):
                     b.copy_(s)
+                if self._native is not None:
+                    self._native.sync_steps()  # (device step counters := the restored state["step"])
 
         done = False
         try:
@@ -164,6 +174,8 @@ class _GraphedStep(object):
             # process (torch >= 2.9 no longer collects before a capture by itself).  Collect now,
             # hold the collector off for the capture.
             self.graph = torch.cuda.CUDAGraph()
+            if self._native is not None:
+                self._native.prepare_capture()
             gc.collect()
             gc_was_enabled = gc.isenabled()
             gc.disable()
@@ -199,7 +211,12 @@ class _GraphedStep(object):
         owner.sync_gradients()
 
     def _replay(self):
+        native = self._native if self.capture_optimisers else None
+        if native is not None and not native.host_steps_match():
+            native.sync_steps()  # (the optimisers were stepped or reloaded outside this graph)
         self.graph.replay()
+        if native is not None:
+            native.bump_host_steps()
         for p, g in self._static_grads:  # (an eager step in between may have re-pointed them)
             p.grad = g
         if not self.capture_optimisers:

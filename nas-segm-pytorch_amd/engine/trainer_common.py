@@ -6,9 +6,19 @@ def inner(segmenter):
     return segmenter.module if hasattr(segmenter, "module") else segmenter
 
 
-def clip_and_step(groups):
+def clip_and_step(groups, native=None):
     """groups: [(parameters, max_norm, optimiser)] - per-sub-module gradient-norm clipping, then
-    the optimiser steps (src/engine/trainer.py:163-166,258-268)"""
+    the optimiser steps (src/engine/trainer.py:163-166,258-268).  Plain torch.optim.SGD / Adam objects on a HIP
+    device are stepped by nasseg_optim_step (engine/optim_native.py: two launches, the optimisers' own state);
+    anything else by torch.  ``native``: the NativeStep to use (a hipGraph stepper's own) instead of the one
+    cached on the optimisers."""
+    if native is not None:
+        native.step()
+        return
+    from .optim_native import native_clip_and_step
+
+    if native_clip_and_step(groups):
+        return
     for params, max_norm, _ in groups:
         if max_norm > 0:
             nn.utils.clip_grad_norm_(params, max_norm)

@@ -350,12 +350,15 @@ def test_candidate_evaluation_with_controller_samples():
     assert len(r2) == 1 and np.isfinite(r2[0]) and 0.0 <= r2[0] <= 1.0
 
 
-@pytest.mark.parametrize("net_name,capture_opt", [("wacv_arch0", False), ("wacv_arch0", True),
-                                                    ("cvpr_arch0", False)])
-def test_graphed_step_equals_eager_step(net_name, capture_opt):
+@pytest.mark.parametrize("net_name,capture_opt,plain", [("wacv_arch0", False, False), ("wacv_arch0", True, False),
+                                                          ("cvpr_arch0", False, False), ("wacv_arch0", True, True),
+                                                          ("cvpr_arch0", True, True), ("cvpr_arch0", False, True)])
+def test_graphed_step_equals_eager_step(net_name, capture_opt, plain):
     """hipGraph replay of forward+loss+backward (optionally clip+optimisers) leaves exactly the
     parameters, running statistics and losses the eager step sequence leaves (bit for bit:
-    same kernels, same order, no float atomics), over changing batches."""
+    same kernels, same order, no float atomics), over changing batches.  plain: the optimisers as the
+    reference's create_optimisers makes them (no ``capturable``) - stepped by nasseg_optim_step, inside the graph
+    too, with Adam's step count on the device; otherwise torch's capturable implementations."""
     from nas_segm_amd.engine.graphed import GraphedSegmenterStep
     from nas_segm_amd.engine.trainer import segmenter_step
 
@@ -368,17 +371,22 @@ def test_graphed_step_equals_eager_step(net_name, capture_opt):
     def run(graphed):
         net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
         oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
-        od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5, capturable=True)
+        od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5, capturable=not plain)
         losses = []
         if graphed:
             stepper = GraphedSegmenterStep(net, batches[0][0], batches[0][1], oe, od, 255, 3.0, 3.0, aux_w,
                                            capture_optimisers=capture_opt)
             assert stepper.capture_optimisers == capture_opt
+            assert (stepper._native is not None) == (plain and capture_opt)
             for x, t in batches:
                 losses.append(float(stepper.step(x, t)))
         else:
             for x, t in batches:
                 losses.append(float(segmenter_step(net, x, t, oe, od, 255, 3.0, 3.0, aux_w)))
+        if plain:  # the optimisers' state is torch's: CPU step counts that followed the device's
+            steps = set(float(st["step"]) for st in od.state.values())
+            assert steps == {float(len(batches))} and not any(st["step"].is_cuda for st in od.state.values())
+            assert all(torch.is_tensor(st.get("momentum_buffer")) for st in oe.state.values())
         return losses, _cpu_sd(net)
 
     l0, sd0 = run(False)

@@ -4,9 +4,11 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/${1:-r4trace}
+shift || true
+EXTRA="$*"   # e.g. --workload cvpr321 --graph 2
 mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --pmc 0 > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o run -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --pmc 0 $EXTRA > $OUT/bench.json 2> $OUT/bench.err
 cd $OLDPWD
 python - <<'PY' $OUT
 import csv, glob, sys, re, collections
