@@ -77,6 +77,13 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
                         const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
                         int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream);
 
+/* XCD-aware tile order of the depthwise strip kernels: workgroups reach the 8 XCDs (one L2 each) round-robin in
+ * dispatch order; with 1 (initial) XCD k works through the k-th eighth of the tiles, ordered so that tiles sharing
+ * input rows and halo columns follow each other in one L2 (what a 5x5 conv at dilation 6 shares with its neighbours
+ * is 4 times the tile).  0: the identity mapping; v < 0 only queries.  Returns the previous setting.  Outputs are
+ * bit-identical either way. */
+int nasseg_dw_swizzle(int v);
+
 /* ---- one SepConv stage in one kernel: depthwise k x k -> pointwise 1x1 (+ BN statistics) -----
  * replaces the Conv2d(C, C, k, groups=C) -> Conv2d(C, N, 1) pair of SepConv / DilConv
  * (layer_factory.py:207-218,241-262): the depthwise output tile stays in LDS and feeds the

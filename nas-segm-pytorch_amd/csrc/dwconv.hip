@@ -20,6 +20,7 @@
 // affine+act epilogue (inference); and a *statistics* epilogue (per-workgroup sum and sum
 // of squares per channel of y), i.e. the batch statistics of a following BatchNorm.
 #include <math.h>
+#include <atomic>
 
 #include <vector>
 
@@ -33,7 +34,24 @@
 #define NASSEG_DW_P3 8
 #endif
 // (maps of fewer than 128 rows keep 4: the launch is short of workgroups there, not of bandwidth)
+// output columns per thread of the forward strip kernel (dw_fwd_strip's PX): dilated 5x5 at stride 1 on maps at least
+// four column groups wide (tools/kbench_dwswz.py, us PX 1 -> 4: 64 channels 256x512 dilation 6 124 -> 98, 32 channels
+// 128x256 dilation 6 21.5 -> 20; at dilation 1 the taps of a row share cache lines anyway: 17.8 -> 18.7)
+static inline int dw_fwd_px(int K, int stride, int dil, int Wo) {
+  return (K == 5 && stride == 1 && dil > 1 && Wo >= 16 * dil) ? 4 : 1;
+}
+// threads along x (times C/4) of the forward strip kernel
+static inline int dw_fwd_xgroups(int K, int stride, int dil, int Wo) {
+  const int px = dw_fwd_px(K, stride, dil, Wo);
+  return px == 1 ? Wo : ((Wo + px * dil - 1) / (px * dil)) * dil;
+}
 static inline int dw_fwd_rows(int K, int e, int Ho) { return (K == 3 && e == 1 && Ho >= 128) ? NASSEG_DW_P3 : 4; }
+
+#if NASSEG_FP32_ONLY
+std::atomic<int> g_dw_swizzle{1};
+#else
+extern std::atomic<int> g_dw_swizzle;
+#endif
 
 namespace {
 
@@ -95,13 +113,18 @@ __global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // difference between 1 and 4+ resident waves per SIMD.
 // PRO: input prologue; STATS == 1: per-workgroup channel sums of y and y^2 to
 // stats[blk][2][C]; STATS == 2: BatchNorm-backward statistics of `bn` (y is a gradient).
-template <int K, int P, int E, bool WLDS, bool PRO, int STATS>
+// PX > 1 (stride 1 only): a thread owns PX output COLUMNS as well, `dil` pixels apart, so that they share input
+// columns the way its P rows share input rows: (P - 1 + K) x (PX - 1 + K) loads for P x PX outputs - 4 per output
+// for 5x5 with P = PX = 4 instead of 10 - each prologue applied once per load, and one weight read from LDS serves PX
+// multiplies.  The 5x5 kernels of the decoders (dilation 1 ... 12) were bound by exactly those three: 40 L1 loads,
+// 120 prologue operations and 100 LDS reads per four outputs (64 channels 256x512 dilation 6: 124 us = 2.2 TB/s).
+template <int K, int P, int E, bool WLDS, bool PRO, int STATS, int PX = 1>
 __global__ __launch_bounds__(256) void dw_fwd_strip(
     const act_t* __restrict__ x, const float* __restrict__ wt, act_t* __restrict__ y,
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ scale, const float* __restrict__ shift, int H, int W, int C4, int Ho,
     int Wo, int stride, int pad, int dil, int g, int nchunk, int act, float* __restrict__ stats,
-    BnBwd bn) {
+    BnBwd bn, int swz) {
   __shared__ float4 lw[WLDS ? K * K : 1][WLDS ? 64 : 1];
   __shared__ float4 sred[STATS ? 2 : 1][STATS ? 4 : 1][STATS ? 64 : 1];
   const int C = C4 * 4;
@@ -112,19 +135,41 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     }
     __syncthreads();
   }
-  const int base = blockIdx.x * 256;
+  // Which tile this workgroup takes.  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest),
+  // each XCD with an L2 of its own: with the identity mapping the 2 * dil columns of halo a tile shares with
+  // its horizontal neighbours and the (K - E) of Q input rows it shares with the next chunk of its row class
+  // are fetched by several L2s - 2.5 x 2 times the tensor for 5x5 at dilation 6.  swz: XCD k takes the k-th
+  // eighth of the tiles in order, and the order is (image, row class r, chunk, x): the tiles that share input
+  // rows - same class, consecutive chunks - follow each other in ONE L2 (rows of different classes are disjoint).
+  int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z, r, chunk;
+  if (swz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned T8 = (gx * gy * gridDim.z) & ~7u;
+    unsigned L = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    if (L < T8) L = (L & 7u) * (T8 >> 3) + (L >> 3);
+    bx = L % gx;
+    const unsigned q = L / gx;
+    by = q % gy;
+    b = q / gy;
+    r = by / nchunk;
+    chunk = by - r * nchunk;
+  } else {
+    r = by % g;
+    chunk = by / g;
+  }
+  const int base = bx * 256;
   const int idx = base + threadIdx.x;
-  const int b = blockIdx.z;
-  const int r = blockIdx.y % g;
-  const int chunk = blockIdx.y / g;
   const int oy0 = chunk * (P * g) + r;
-  const bool live = (idx < Wo * C4) && (oy0 < Ho);
+  // column groups: PX == 1: one per output column; else group xg owns columns ox + i * dil, i < PX
+  const int XG = PX == 1 ? Wo : ((Wo + PX * dil - 1) / (PX * dil)) * dil;
+  const int idc = idx < XG * C4 ? idx : 0;
+  const int xg = idc / C4;
+  const int c4 = idc - xg * C4;
+  const int ox = PX == 1 ? xg : (xg / dil) * (PX * dil) + xg % dil;
+  const bool live = (idx < XG * C4) && (oy0 < Ho) && (ox < Wo);
   if (!STATS && !live) return;
   // (with STATS every thread stays for the workgroup reduction; dead threads work on a
   //  clamped, valid position and contribute zeros)
-  const int idc = idx < Wo * C4 ? idx : 0;
-  const int ox = idc / C4;
-  const int c4 = idc - ox * C4;
 
   float4 w[WLDS ? 1 : K * K];
   if (!WLDS) {
@@ -137,17 +182,20 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   // Out-of-range taps load from a clamped (always valid) address and are zeroed by a
   // mask afterwards: a load under a branch would be followed by its own
   // s_waitcnt vmcnt(0) and serialise the whole strip on memory latency.
-  int xoff[K];
-  bool xok[K];
+  constexpr int KX = K + PX - 1;  // input columns a thread visits per row
+  int xoff[KX];
+  bool xok[KX];
 #pragma unroll
-  for (int tx = 0; tx < K; ++tx) {
+  for (int tx = 0; tx < KX; ++tx) {
     const int ix = ox * stride - pad + tx * dil;
     xok[tx] = (ix >= 0) && (ix < W);
     xoff[tx] = (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;
   }
-  float4 acc[P];
+  float4 acc[P][PX];
 #pragma unroll
-  for (int j = 0; j < P; ++j) acc[j] = f4zero();
+  for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int i = 0; i < PX; ++i) acc[j][i] = f4zero();
 
   const act_t* xb = x + (size_t)b * H * W * C + c4 * 4;
   const int iy0 = oy0 * stride - pad;
@@ -160,13 +208,13 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     const bool yok = (iy >= 0) && (iy < H);
     const act_t* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
-    for (int tx = 0; tx < K; ++tx) {
+    for (int tx = 0; tx < KX; ++tx) {
       float4 t = lda4(xr + xoff[tx]);
       if (PRO) t = apply_prologue(t, pro);
       v[tx] = keep_if(t, yok && xok[tx]);  // zero padding applies to the prologue's output
     }
   };
-  float4 vcur[K], vnext[K];
+  float4 vcur[KX], vnext[KX];
   load_row(0, vcur);
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
@@ -176,15 +224,20 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
       const int ty = q - j * E;
       if (ty >= 0 && ty < K) {
 #pragma unroll
-        for (int tx = 0; tx < K; ++tx)
-          acc[j] = fma4(WLDS ? lw[ty * K + tx][c4] : w[WLDS ? 0 : ty * K + tx], vcur[tx], acc[j]);
+        for (int tx = 0; tx < K; ++tx) {
+          const float4 wv = WLDS ? lw[ty * K + tx][c4] : w[WLDS ? 0 : ty * K + tx];
+#pragma unroll
+          for (int i = 0; i < PX; ++i) acc[j][i] = fma4(wv, vcur[tx + i], acc[j][i]);
+        }
       }
     }
 #pragma unroll
-    for (int j = 0; j < P; ++j) pin(acc[j]);
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+      for (int i = 0; i < PX; ++i) pin(acc[j][i]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int tx = 0; tx < K; ++tx) vcur[tx] = vnext[tx];
+    for (int tx = 0; tx < KX; ++tx) vcur[tx] = vnext[tx];
   }
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
   if (scale) sc = lda4(scale + c4 * 4);
@@ -195,20 +248,25 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
 #pragma unroll
   for (int j = 0; j < P; ++j) {
     const int oy = oy0 + j * g;
-    const bool ok = live && oy < Ho;
-    float4 o = fma4(acc[j], sc, sh);
-    if (act) o = act_apply4(o, act);
-    if (STATS == 1) {
-      const float4 m = keep_if(o, ok);
-      ssum[0] = add4(ssum[0], m);
-      ssum[1] = fma4(m, m, ssum[1]);
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+      const int oxi = ox + i * dil;
+      const bool ok = live && oy < Ho && (PX == 1 || oxi < Wo);
+      float4 o = fma4(acc[j][i], sc, sh);
+      if (act) o = act_apply4(o, act);
+      if (STATS == 1) {
+        const float4 m = keep_if(o, ok);
+        ssum[0] = add4(ssum[0], m);
+        ssum[1] = fma4(m, m, ssum[1]);
+      }
+      if (STATS == 2) {
+        const int oyc = oy < Ho ? oy : Ho - 1;  // (unconditional load from a valid address)
+        const int oxc = (PX == 1 || oxi < Wo) ? oxi : Wo - 1;
+        const float4 z = lda4(bn.z + (((size_t)b * Ho + oyc) * Wo + oxc) * C + c4 * 4);
+        bnbwd_accumulate(o, z, bl, bn.act, ok, ssum);
+      }
+      if (ok) sta4(y + (((size_t)b * Ho + oy) * Wo + oxi) * C + c4 * 4, o);
     }
-    if (STATS == 2) {
-      const int oyc = oy < Ho ? oy : Ho - 1;  // (unconditional load from a valid address)
-      const float4 z = lda4(bn.z + (((size_t)b * Ho + oyc) * Wo + ox) * C + c4 * 4);
-      bnbwd_accumulate(o, z, bl, bn.act, ok, ssum);
-    }
-    if (ok) sta4(y + (((size_t)b * Ho + oy) * Wo + ox) * C + c4 * 4, o);
   }
   if constexpr (STATS != 0) {
     const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -879,8 +937,10 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
   const bool strip_ok = !transposed && (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2) && B <= 65535;
   if (strip_ok) {
     constexpr int P = 4, P3 = NASSEG_DW_P3;  // output rows per thread (see dw_fwd_rows)
+    const int swz = g_dw_swizzle.load();
     const int nchunk = cdiv(Ho, dw_fwd_rows(K, sc.e, Ho) * sc.g);
-    dim3 grid(cdiv(Wo * C4, 256), nchunk * sc.g, B);
+    const int px = dw_fwd_px(K, stride, dil, Wo);
+    dim3 grid(cdiv(dw_fwd_xgroups(K, stride, dil, Wo) * C4, 256), nchunk * sc.g, B);
     NASSEG_REQUIRE(grid.y <= 65535, "dwconv: too many row chunks");
     NASSEG_REQUIRE(stats_mode != 2 || !pro, "dwconv_bwd_data_bn: no input prologue on this path");
     if (stats && C4 > 256) {
@@ -890,7 +950,7 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                             \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, \
-                     act, stats, bn)
+                     act, stats, bn, swz)
 #define LAUNCH_FWD(KK, EE, WL)                                    \
   do {                                                            \
     if (stats_mode == 2) LAUNCH_FWD3(KK, EE, WL, false, 2);       \
@@ -900,19 +960,25 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
     else LAUNCH_FWD3(KK, EE, WL, false, 0);                       \
   } while (0)
     const bool wl = C4 <= 64;
-    if (K == 5 && sc.e == 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
-    else if (K == 5) { if (wl) LAUNCH_FWD(5, 2, true); else LAUNCH_FWD(5, 2, false); }
+    if (K == 5 && sc.e == 1 && px == 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
+    else if (K == 5 && px == 1) { if (wl) LAUNCH_FWD(5, 2, true); else LAUNCH_FWD(5, 2, false); }
+#undef LAUNCH_FWD3
+#define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                                   \
+  hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST, 4>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
+                     in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk,    \
+                     act, stats, bn, swz)
+    if (K == 5 && px == 4) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
 #undef LAUNCH_FWD3
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                              \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P3, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk,  \
-                     act, stats, bn)
+                     act, stats, bn, swz)
     if (K == 3 && sc.e == 1 && dw_fwd_rows(K, sc.e, Ho) == P3) LAUNCH_FWD(3, 1, false);
 #undef LAUNCH_FWD3
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                             \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, \
-                     act, stats, bn)
+                     act, stats, bn, swz)
     if (K == 3 && sc.e == 1 && dw_fwd_rows(K, sc.e, Ho) == P) LAUNCH_FWD(3, 1, false);
     else if (K == 3 && sc.e == 2) LAUNCH_FWD(3, 2, false);
 #undef LAUNCH_FWD3
@@ -999,7 +1065,8 @@ int nasseg_dwconv_strip_ok(int K, int stride, int dil) {
 int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil) {
   if (!nasseg_dwconv_strip_ok(K, stride, dil)) return 0;
   StripCfg sc = strip_cfg(stride, dil);
-  return (int64_t)cdiv(Wo * (C / 4), 256) * cdiv(Ho, dw_fwd_rows(K, sc.e, Ho) * sc.g) * sc.g * B;
+  return (int64_t)cdiv(dw_fwd_xgroups(K, stride, dil, Wo) * (C / 4), 256) * cdiv(Ho, dw_fwd_rows(K, sc.e, Ho) * sc.g) *
+         sc.g * B;
 }
 #endif  // NASSEG_FP32_ONLY
 
@@ -1277,5 +1344,15 @@ int NASSEG_FN(dwconv_bwd_bn)(const act_t* xz, const act_t* g, const act_t* z, co
   NASSEG_LAUNCH_CHECK("dw_wgrad_finalize");
   return NASSEG_OK;
 }
+
+#if NASSEG_FP32_ONLY
+// XCD-aware tile order of the depthwise strip kernels (dw_fwd_strip): 1 (initial) on, 0 the identity mapping;
+// v < 0 only queries.  Returns the previous setting.  Outputs are bit-identical either way; statistics rows hold
+// other tiles' sums (their total differs in rounding only).
+int nasseg_dw_swizzle(int v) {
+  if (v < 0) return g_dw_swizzle.load();
+  return g_dw_swizzle.exchange(v ? 1 : 0);
+}
+#endif
 
 }  // extern "C"

@@ -281,7 +281,9 @@ struct RedPlan {
 inline RedPlan red_plan(int S, int64_t R, int C, int vec) {
   const int CV = C / vec;
   const int rpi = 256 / CV;
-  int64_t nb = R / ((int64_t)rpi * 16);
+  // at least 4 rounds of loads per workgroup (16 until round 4: the 16 x 11 x 11 maps of the CVPR cells ran on 7
+  // workgroups - 19 us for 1 MB; one workgroup streams ~20 GB/s whatever the size of the part)
+  int64_t nb = R / ((int64_t)rpi * 4);
   int64_t cap = 768 / S;
   if (cap < 1) cap = 1;
   if (nb > cap) nb = cap;
