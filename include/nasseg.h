@@ -78,9 +78,9 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
                         int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream);
 
 /* XCD-aware tile order of the depthwise strip kernels: workgroups reach the 8 XCDs (one L2 each) round-robin in
- * dispatch order; with 1 (initial) XCD k works through the k-th eighth of the tiles, ordered so that tiles sharing
- * input rows and halo columns follow each other in one L2 (what a 5x5 conv at dilation 6 shares with its neighbours
- * is 4 times the tile).  0: the identity mapping; v < 0 only queries.  Returns the previous setting.  Outputs are
+ * dispatch order; with 1 XCD k works through the k-th eighth of the tiles, ordered so that tiles sharing input rows
+ * and halo columns follow each other in one L2.  0 (initial): the identity mapping - the experiment measured neutral
+ * to 3 % slower (tools/kbench_dwswz.py).  v < 0 only queries.  Returns the previous setting.  Outputs are
  * bit-identical either way. */
 int nasseg_dw_swizzle(int v);
 

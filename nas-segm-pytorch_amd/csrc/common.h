@@ -158,12 +158,14 @@ __device__ __forceinline__ void sta4(bf16_t* p, float4 v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two v_pk_fma_f32 (two fp32 fused multiply-adds per lane and instruction) instead of four v_fma_f32: the depthwise
+// and elementwise kernels issue a third fewer vector instructions (dilated 5x5 depthwise: 3440 -> 2000 per wave,
+// 99.8 -> 91.9 us; every other kernel within 1 %).  Same fused operation per element: results are bit-identical.
 __device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
-  c.x = fmaf(a.x, b.x, c.x);
-  c.y = fmaf(a.y, b.y, c.y);
-  c.z = fmaf(a.z, b.z, c.z);
-  c.w = fmaf(a.w, b.w, c.w);
-  return c;
+  const f32x2 lo = __builtin_elementwise_fma((f32x2){a.x, a.y}, (f32x2){b.x, b.y}, (f32x2){c.x, c.y});
+  const f32x2 hi = __builtin_elementwise_fma((f32x2){a.z, a.w}, (f32x2){b.z, b.w}, (f32x2){c.z, c.w});
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);

@@ -47,10 +47,11 @@ __device__ __forceinline__ Prologue make_prologue(const float* scale, const floa
 }
 __device__ __forceinline__ float4 apply_prologue(float4 v, const Prologue& p) {
   v = fma4(v, p.sc, p.sh);
-  v.x = fminf(fmaxf(v.x, p.lo), p.hi);
-  v.y = fminf(fmaxf(v.y, p.lo), p.hi);
-  v.z = fminf(fmaxf(v.z, p.lo), p.hi);
-  v.w = fminf(fmaxf(v.w, p.lo), p.hi);
+  // v_med3_f32 = the clamp in one instruction (a NaN comes out as lo, as fminf(fmaxf(v, lo), hi) gives)
+  v.x = __builtin_amdgcn_fmed3f(v.x, p.lo, p.hi);
+  v.y = __builtin_amdgcn_fmed3f(v.y, p.lo, p.hi);
+  v.z = __builtin_amdgcn_fmed3f(v.z, p.lo, p.hi);
+  v.w = __builtin_amdgcn_fmed3f(v.w, p.lo, p.hi);
   return v;
 }
 

@@ -37,18 +37,30 @@
 // output columns per thread of the forward strip kernel (dw_fwd_strip's PX): dilated 5x5 at stride 1 on maps at least
 // four column groups wide (tools/kbench_dwswz.py, us PX 1 -> 4: 64 channels 256x512 dilation 6 124 -> 98, 32 channels
 // 128x256 dilation 6 21.5 -> 20; at dilation 1 the taps of a row share cache lines anyway: 17.8 -> 18.7)
-static inline int dw_fwd_px(int K, int stride, int dil, int Wo) {
-  return (K == 5 && stride == 1 && dil > 1 && Wo >= 16 * dil) ? 4 : 1;
+#ifndef NASSEG_DW5_P
+#define NASSEG_DW5_P 4
+#endif
+#ifndef NASSEG_DW5_PX
+#define NASSEG_DW5_PX 4
+#endif
+#ifndef NASSEG_DW5_WPX  // ... of the backward-weight kernels (25 accumulators of their own: 4 columns leave one wave per SIMD)
+#define NASSEG_DW5_WPX 2
+#endif
+static inline int dw_fwd_px(int K, int stride, int dil, int Wo, int px_max = NASSEG_DW5_PX) {
+  return (K == 5 && stride == 1 && dil > 1 && Wo >= 4 * px_max * dil) ? px_max : 1;
 }
 // threads along x (times C/4) of the forward strip kernel
-static inline int dw_fwd_xgroups(int K, int stride, int dil, int Wo) {
-  const int px = dw_fwd_px(K, stride, dil, Wo);
+static inline int dw_fwd_xgroups(int K, int stride, int dil, int Wo, int px_max = NASSEG_DW5_PX) {
+  const int px = dw_fwd_px(K, stride, dil, Wo, px_max);
   return px == 1 ? Wo : ((Wo + px * dil - 1) / (px * dil)) * dil;
 }
-static inline int dw_fwd_rows(int K, int e, int Ho) { return (K == 3 && e == 1 && Ho >= 128) ? NASSEG_DW_P3 : 4; }
+static inline int dw_fwd_rows(int K, int e, int Ho, int px = 1) {
+  if (px > 1) return NASSEG_DW5_P;
+  return (K == 3 && e == 1 && Ho >= 128) ? NASSEG_DW_P3 : 4;
+}
 
 #if NASSEG_FP32_ONLY
-std::atomic<int> g_dw_swizzle{1};
+std::atomic<int> g_dw_swizzle{0};
 #else
 extern std::atomic<int> g_dw_swizzle;
 #endif
@@ -138,7 +150,8 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
   // Which tile this workgroup takes.  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest),
   // each XCD with an L2 of its own: with the identity mapping the 2 * dil columns of halo a tile shares with
   // its horizontal neighbours and the (K - E) of Q input rows it shares with the next chunk of its row class
-  // are fetched by several L2s - 2.5 x 2 times the tensor for 5x5 at dilation 6.  swz: XCD k takes the k-th
+  // are fetched by several L2s - 2.5 x 2 times the tensor for 5x5 at dilation 6.  swz (off by default: it measured
+  // neutral - the Infinity Cache behind the L2s already serves those re-reads): XCD k takes the k-th
   // eighth of the tiles in order, and the order is (image, row class r, chunk, x): the tiles that share input
   // rows - same class, consecutive chunks - follow each other in ONE L2 (rows of different classes are disjoint).
   int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z, r, chunk;
@@ -423,6 +436,7 @@ struct DwWgArgs {
   const float* in_scale;
   const float* in_shift;
   int in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, g, nchunk;
+  int lgx, lgy;  // PX > 1: the logical grid (lgx * lgy <= workgroups launched; the others zero their partial rows)
   // BN variant (nasseg_dwconv_wgrad_bn): dy is the masked gradient w.r.t. the BatchNorm output, z
   // the conv's raw output; dz = second half of the BatchNorm backward, computed on load and stored
   const act_t* z;
@@ -438,7 +452,9 @@ struct DwWgArgs {
 
 // (bx, by) of (gdx, gdy): the workgroup's coordinates in the layer's own grid - the grouped
 // launch below runs several layers' grids side by side in one kernel
-template <int K, int P, int E, bool PRO, bool BN = false>
+// PX > 1 (stride 1): PX columns a dilation apart per thread, as in dw_fwd_strip - (P - 1 + K) x (PX - 1 + K) loads of
+// x and P x PX of dy for P x PX pixels instead of ((P - 1 + K) x K + P) x PX.
+template <int K, int P, int E, bool PRO, bool BN = false, int PX = 1>
 __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, const int by,
                                               const int gdx, const int gdy) {
   const act_t* __restrict__ x = q.x;
@@ -450,9 +466,12 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
   const int tid = threadIdx.x;
   const int base = bx * 256;
   const int idx = base + tid;
-  const bool live = idx < Wo * C4;
-  const int ox = live ? idx / C4 : 0;
-  const int c4 = live ? idx - ox * C4 : 0;
+  const int XG = PX == 1 ? Wo : ((Wo + PX * dil - 1) / (PX * dil)) * dil;
+  const int idc = idx < XG * C4 ? idx : 0;
+  const int xg = idc / C4;
+  const int c4 = idc - xg * C4;
+  const int ox = PX == 1 ? xg : (xg / dil) * (PX * dil) + xg % dil;
+  const bool live = idx < XG * C4 && ox < Wo;
   const int C = C4 * 4;
 
   float4 acc[K * K];
@@ -476,10 +495,11 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
     }
   }
 
-  int xoff[K];
-  bool xok[K];
+  constexpr int KX = K + PX - 1;
+  int xoff[KX];
+  bool xok[KX];
 #pragma unroll
-  for (int tx = 0; tx < K; ++tx) {
+  for (int tx = 0; tx < KX; ++tx) {
     const int ix = ox * stride - pad + tx * dil;
     xok[tx] = live && (ix >= 0) && (ix < W);
     xoff[tx] = (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;  // clamped: loads are unconditional
@@ -493,11 +513,16 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
     const int b = t2 / nchunk;
     const int oy0 = chunk * (P * g) + r;
     if (oy0 >= Ho || !live) continue;  // (wave-divergent only in the last x-block)
-    float4 d[P];
+    float4 d[P][PX];
 #pragma unroll
-    for (int j = 0; j < P; ++j) {
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
       const int oy = oy0 + j * g;
-      const size_t off = (((size_t)b * Ho + (oy < Ho ? oy : Ho - 1)) * Wo + ox) * C + c4 * 4;
+      const int oxi = ox + i * dil;
+      const bool pok = oy < Ho && (PX == 1 || oxi < Wo);
+      const size_t off = (((size_t)b * Ho + (oy < Ho ? oy : Ho - 1)) * Wo + ((PX == 1 || oxi < Wo) ? oxi : Wo - 1)) * C +
+                         c4 * 4;
       float4 gv = lda4(dy + off);
       if (BN) {
         const float4 zv = lda4(q.z + off);
@@ -511,9 +536,9 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
         gv = make_float4(bf16_to_f32(f32_to_bf16(gv.x)), bf16_to_f32(f32_to_bf16(gv.y)),
                          bf16_to_f32(f32_to_bf16(gv.z)), bf16_to_f32(f32_to_bf16(gv.w)));
 #endif
-        if (oy < Ho) sta4(q.dz + off, gv);  // (every dy element is loaded by exactly one lane)
+        if (pok) sta4(q.dz + off, gv);  // (every dy element is loaded by exactly one lane)
       }
-      d[j] = keep_if(gv, oy < Ho);
+      d[j][i] = keep_if(gv, pok);
     }
     const act_t* xb = x + (size_t)b * H * W * C + c4 * 4;
     const int iy0 = oy0 * stride - pad;
@@ -522,13 +547,13 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
       const bool yok = (iy >= 0) && (iy < H);
       const act_t* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
 #pragma unroll
-      for (int tx = 0; tx < K; ++tx) {
+      for (int tx = 0; tx < KX; ++tx) {
         float4 t = lda4(xr + xoff[tx]);
         if (PRO) t = apply_prologue(t, pro);
         v[tx] = keep_if(t, yok && xok[tx]);
       }
     };
-    float4 vcur[K], vnext[K];
+    float4 vcur[KX], vnext[KX];
     load_row(0, vcur);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -538,12 +563,14 @@ __device__ __forceinline__ void dw_wgrad_tile(const DwWgArgs& q, const int bx, c
         const int ty = q - j * E;
         if (ty >= 0 && ty < K) {
 #pragma unroll
-          for (int tx = 0; tx < K; ++tx) acc[ty * K + tx] = fma4(d[j], vcur[tx], acc[ty * K + tx]);
+          for (int tx = 0; tx < K; ++tx)
+#pragma unroll
+            for (int i = 0; i < PX; ++i) acc[ty * K + tx] = fma4(d[j][i], vcur[tx + i], acc[ty * K + tx]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tx = 0; tx < K; ++tx) vcur[tx] = vnext[tx];
+      for (int tx = 0; tx < KX; ++tx) vcur[tx] = vnext[tx];
     }
   }
   // Block reduction without a serial tail.  Lanes l, l+C4, l+2*C4, ... of a wave hold
@@ -560,6 +587,19 @@ __global__ __launch_bounds__(256) void dw_wgrad_strip(DwWgArgs q) {
   dw_wgrad_tile<K, P, E, PRO, BN>(q, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y);
 }
 
+// a workgroup without a tile (PX > 1: the partial buffer was sized for the one-column grid) zeroes its row
+__device__ __forceinline__ void dw_wgrad_zero_row(float* partial, int row, int n) {
+  float* po = partial + (size_t)row * n;
+  for (int i = threadIdx.x; i < n; i += 256) po[i] = 0.f;
+}
+// the PX = NASSEG_DW5_PX form: a 1-D launch of as many workgroups as the partial buffer has rows
+template <int K, int P, int E, bool PRO, bool BN, int PX>
+__global__ __launch_bounds__(256, 2) void dw_wgrad_strip_px(DwWgArgs q) {
+  const int id = blockIdx.x;
+  if (id < q.lgx * q.lgy) dw_wgrad_tile<K, P, E, PRO, BN, PX>(q, id % q.lgx, id / q.lgx, q.lgx, q.lgy);
+  else dw_wgrad_zero_row(q.partial, id, K * K * q.C4 * 4);
+}
+
 // several depthwise layers of one specialisation in one launch (see conv_wgrad_group_kernel)
 constexpr int kDwGroup = 8;
 struct DwWgGroup {
@@ -568,12 +608,15 @@ struct DwWgGroup {
   int gx[kDwGroup], gy[kDwGroup];
   DwWgArgs a[kDwGroup];
 };
-template <int K, int P, int E, bool PRO>
-__global__ __launch_bounds__(256) void dw_wgrad_group_kernel(DwWgGroup t) {
+template <int K, int P, int E, bool PRO, int PX = 1>
+__global__ __launch_bounds__(256, 2) void dw_wgrad_group_kernel(DwWgGroup t) {
   int d = 0;
   while (d + 1 < t.n && (int)blockIdx.x >= t.start[d + 1]) ++d;
   const int local = blockIdx.x - t.start[d];
-  dw_wgrad_tile<K, P, E, PRO>(t.a[d], local % t.gx[d], local / t.gx[d], t.gx[d], t.gy[d]);
+  if (PX == 1 || local < t.gx[d] * t.gy[d])
+    dw_wgrad_tile<K, P, E, PRO, false, PX>(t.a[d], local % t.gx[d], local / t.gx[d], t.gx[d], t.gy[d]);
+  else
+    dw_wgrad_zero_row(t.a[d].partial, local, K * K * t.a[d].C4 * 4);
 }
 
 // generic backward-weight (any K): same block reduction, one tap at a time.
@@ -938,8 +981,8 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
   if (strip_ok) {
     constexpr int P = 4, P3 = NASSEG_DW_P3;  // output rows per thread (see dw_fwd_rows)
     const int swz = g_dw_swizzle.load();
-    const int nchunk = cdiv(Ho, dw_fwd_rows(K, sc.e, Ho) * sc.g);
     const int px = dw_fwd_px(K, stride, dil, Wo);
+    const int nchunk = cdiv(Ho, dw_fwd_rows(K, sc.e, Ho, px) * sc.g);
     dim3 grid(cdiv(dw_fwd_xgroups(K, stride, dil, Wo) * C4, 256), nchunk * sc.g, B);
     NASSEG_REQUIRE(grid.y <= 65535, "dwconv: too many row chunks");
     NASSEG_REQUIRE(stats_mode != 2 || !pro, "dwconv_bwd_data_bn: no input prologue on this path");
@@ -964,10 +1007,10 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
     else if (K == 5 && px == 1) { if (wl) LAUNCH_FWD(5, 2, true); else LAUNCH_FWD(5, 2, false); }
 #undef LAUNCH_FWD3
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                                   \
-  hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST, 4>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
+  hipLaunchKernelGGL((dw_fwd_strip<KK, NASSEG_DW5_P, EE, WL, PR, ST, NASSEG_DW5_PX>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk,    \
                      act, stats, bn, swz)
-    if (K == 5 && px == 4) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
+    if (K == 5 && px > 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
 #undef LAUNCH_FWD3
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                              \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P3, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
@@ -1065,7 +1108,7 @@ int nasseg_dwconv_strip_ok(int K, int stride, int dil) {
 int64_t nasseg_dwconv_stats_blocks(int B, int C, int Ho, int Wo, int K, int stride, int dil) {
   if (!nasseg_dwconv_strip_ok(K, stride, dil)) return 0;
   StripCfg sc = strip_cfg(stride, dil);
-  return (int64_t)cdiv(dw_fwd_xgroups(K, stride, dil, Wo) * (C / 4), 256) * cdiv(Ho, dw_fwd_rows(K, sc.e, Ho) * sc.g) *
+  return (int64_t)cdiv(dw_fwd_xgroups(K, stride, dil, Wo) * (C / 4), 256) * cdiv(Ho, dw_fwd_rows(K, sc.e, Ho, dw_fwd_px(K, stride, dil, Wo)) * sc.g) *
          sc.g * B;
 }
 #endif  // NASSEG_FP32_ONLY
@@ -1093,6 +1136,14 @@ static int64_t wgrad_rows(int B, int C, int Ho, int Wo) {
   if (gy > rows / 8) gy = rows / 8;
   if (gy < 1) gy = 1;
   return gy;
+}
+
+// logical grid of the PX-column backward-weight kernel inside the gx * gy workgroups (= partial rows) of the
+// one-column form: a quarter of the columns, as many row workers as fit
+static void dw_wgrad_px_grid(int K, int stride, int dil, int Wo, int C4, int gx, int gy, int* lgx, int* lgy) {
+  *lgx = cdiv(dw_fwd_xgroups(K, stride, dil, Wo, NASSEG_DW5_WPX) * C4, 256);
+  *lgy = (gx * gy) / *lgx;
+  if (*lgy < 1) *lgy = 1;  // (lgx <= gx: never reached)
 }
 
 #if NASSEG_FP32_ONLY
@@ -1126,6 +1177,8 @@ static int dw_wgrad_impl(const act_t* x, const act_t* dy, float* dw, float* ws, 
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(gx, gy, 1);
     DwWgArgs q = {x, dy, ws, in_scale, in_shift, in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk};
+    const int px = dw_fwd_px(K, stride, dil, Wo, NASSEG_DW5_WPX);
+    if (px > 1) dw_wgrad_px_grid(K, stride, dil, Wo, C4, gx, gy, &q.lgx, &q.lgy);
     if (bn) {
       q.z = bn->z; q.dz = bn->dz; q.bn_scale = bn->bn_scale; q.bn_shift = bn->bn_shift; q.bn_mean = bn->bn_mean;
       q.bn_invstd = bn->bn_invstd; q.bn_sums = bn->bn_sums; q.invM = bn->invM; q.bn_train = bn->bn_train;
@@ -1142,8 +1195,12 @@ static int dw_wgrad_impl(const act_t* x, const act_t* dy, float* dw, float* ws, 
   } while (0)
     if (K == 3 && sc.e == 1) LAUNCH_WG(3, 1);
     else if (K == 3 && sc.e == 2) LAUNCH_WG(3, 2);
-    else if (K == 5 && sc.e == 1) LAUNCH_WG(5, 1);
-    else LAUNCH_WG(5, 2);
+    else if (K == 5 && sc.e == 1 && px == 1) LAUNCH_WG(5, 1);
+    else if (K == 5 && px == 1) LAUNCH_WG(5, 2);
+#undef LAUNCH_WG2
+#define LAUNCH_WG2(KK, EE, PR, BB) \
+  hipLaunchKernelGGL((dw_wgrad_strip_px<KK, P, EE, PR, BB, NASSEG_DW5_WPX>), dim3(gx * gy), dim3(256), 0, s, q)
+    if (K == 5 && px > 1) LAUNCH_WG(5, 1);
 #undef LAUNCH_WG2
 #undef LAUNCH_WG
     NASSEG_LAUNCH_CHECK("dw_wgrad_strip");
@@ -1206,7 +1263,8 @@ int NASSEG_FN(dwconv_wgrad_many)(int count, const int64_t* desc, void* stream) {
     const bool strip_ok = (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2) && C % 4 == 0 && C / 4 <= 256;
     if (!strip_ok) return -1;
     const bool pro = d[3] || d[4] || d[5];
-    return K * 100 + sc.e * 10 + (pro ? 1 : 0);
+    const int px = dw_fwd_px(K, (int)d[13], (int)d[15], (int)d[11], NASSEG_DW5_WPX);
+    return (px > 1 ? 1000 : 0) + K * 100 + sc.e * 10 + (pro ? 1 : 0);
   };
   for (int i = 0; i < count; ++i) {
     if (done[i]) continue;
@@ -1241,13 +1299,20 @@ int NASSEG_FN(dwconv_wgrad_many)(int count, const int64_t* desc, void* stream) {
       t.a[t.n] = q;
       t.gx[t.n] = gx;
       t.gy[t.n] = gy;
+      if (key >= 1000) dw_wgrad_px_grid((int)d[12], (int)d[13], (int)d[15], Wo, C4, gx, gy, &t.gx[t.n], &t.gy[t.n]);
       t.start[t.n + 1] = t.start[t.n] + gx * gy;
       ++t.n;
       done[j] = 1;
     }
     const dim3 grid(t.start[t.n]);
-    const int K = key / 100, e = (key / 10) % 10;
+    const int K = (key % 1000) / 100, e = (key / 10) % 10;
     const bool pro = key % 10;
+    if (key >= 1000) {
+      if (pro) hipLaunchKernelGGL((dw_wgrad_group_kernel<5, P, 1, true, NASSEG_DW5_WPX>), grid, dim3(256), 0, s, t);
+      else hipLaunchKernelGGL((dw_wgrad_group_kernel<5, P, 1, false, NASSEG_DW5_WPX>), grid, dim3(256), 0, s, t);
+      NASSEG_LAUNCH_CHECK("dw_wgrad_group_kernel");
+      continue;
+    }
 #define GO_DW(KK, EE)                                                                              \
   do {                                                                                             \
     if (pro) hipLaunchKernelGGL((dw_wgrad_group_kernel<KK, P, EE, true>), grid, dim3(256), 0, s, t); \
@@ -1346,8 +1411,9 @@ int NASSEG_FN(dwconv_bwd_bn)(const act_t* xz, const act_t* g, const act_t* z, co
 }
 
 #if NASSEG_FP32_ONLY
-// XCD-aware tile order of the depthwise strip kernels (dw_fwd_strip): 1 (initial) on, 0 the identity mapping;
-// v < 0 only queries.  Returns the previous setting.  Outputs are bit-identical either way; statistics rows hold
+// XCD-aware tile order of the depthwise strip kernels (dw_fwd_strip): 1 on, 0 (initial) the identity mapping;
+// v < 0 only queries.  Measured neutral to -3 % (tools/kbench_dwswz.py): these kernels are bound by their loads'
+// issue rate, not by what their L2s share.  Returns the previous setting.  Outputs are bit-identical either way; statistics rows hold
 // other tiles' sums (their total differs in rounding only).
 int nasseg_dw_swizzle(int v) {
   if (v < 0) return g_dw_swizzle.load();

@@ -65,6 +65,12 @@ DW_CASES = [
     (3, 96, 10, 12, 3, 2, 1, 1),
     (1, 144, 8, 8, 3, 1, 1, 1),
     (1, 4, 3, 3, 5, 1, 12, 6),
+    # dilated 5x5 on maps at least 16 (8) dilations wide: four (two) output columns per thread in the forward
+    # / backward-data (backward-weight) kernels, ragged last column group, C / 4 not a divisor of 256
+    (1, 32, 20, 100, 5, 1, 12, 6),
+    (2, 24, 9, 50, 5, 1, 4, 2),
+    (1, 16, 14, 97, 5, 1, 6, 3),
+    (1, 64, 30, 200, 5, 1, 24, 12),
 ]
 
 
@@ -492,7 +498,8 @@ def test_dense_backward_data_with_bn_backward_statistics(case, act):
     # B, C, H, W (dims of the conv INPUT = of g / z), K, stride, pad, dil
     (2, 24, 13, 17, 3, 1, 1, 1), (2, 32, 16, 20, 5, 1, 2, 1), (2, 16, 21, 19, 3, 1, 3, 3),
     (2, 32, 30, 33, 5, 1, 12, 6), (2, 24, 17, 23, 3, 2, 1, 1), (2, 16, 18, 22, 5, 2, 2, 1),
-    (1, 96, 32, 64, 3, 2, 1, 1), (2, 144, 9, 8, 3, 2, 1, 1), (1, 8, 9, 11, 7, 1, 3, 1)])
+    (1, 96, 32, 64, 3, 2, 1, 1), (2, 144, 9, 8, 3, 2, 1, 1), (1, 8, 9, 11, 7, 1, 3, 1),
+    (1, 32, 20, 100, 5, 1, 12, 6), (2, 24, 9, 50, 5, 1, 4, 2), (1, 16, 14, 97, 5, 1, 6, 3)])
 @pytest.mark.parametrize("act", [0, 2])
 def test_depthwise_backward_data_with_bn_backward_statistics(case, act):
     f = F()
@@ -636,7 +643,8 @@ def test_dense_weight_gradient_with_fused_bn_backward(case, dtype, act):
     (2, 24, 13, 17, 3, 1, 1, 1, True, True), (2, 32, 16, 20, 5, 1, 2, 1, False, True),
     (2, 96, 18, 22, 3, 2, 1, 1, True, True), (2, 16, 21, 19, 3, 1, 3, 3, True, True),
     (1, 32, 30, 33, 5, 1, 12, 6, False, False), (2, 16, 18, 22, 5, 2, 2, 1, True, True),
-    (1, 960, 6, 7, 3, 1, 1, 1, True, True)])
+    (1, 960, 6, 7, 3, 1, 1, 1, True, True), (1, 32, 20, 100, 5, 1, 12, 6, True, True),
+    (2, 24, 9, 50, 5, 1, 4, 2, False, True), (1, 16, 14, 97, 5, 1, 6, 3, True, False)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", [0, 2])
 def test_depthwise_weight_gradient_with_fused_bn_backward(case, dtype, act):
