@@ -83,6 +83,11 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
  * to 3 % slower (tools/kbench_dwswz.py).  v < 0 only queries.  Returns the previous setting.  Outputs are
  * bit-identical either way. */
 int nasseg_dw_swizzle(int v);
+/* backward-weight of stride-1 5x5 depthwise layers (any dilation that divides the padding): 1 (initial) a kernel that
+ * stages its tiles in LDS - the prologue applied once per element, the 5x8 window of a thread read from LDS, a dilated
+ * conv cut into its dil^2 pixel classes; 0: the strip kernel of the other geometries.  v < 0 only queries.  Returns
+ * the previous setting.  Partial rows (nasseg_dwconv_wgrad_workspace) have the same count and layout either way. */
+int nasseg_dw_wgrad_lds(int v);
 
 /* ---- one SepConv stage in one kernel: depthwise k x k -> pointwise 1x1 (+ BN statistics) -----
  * replaces the Conv2d(C, C, k, groups=C) -> Conv2d(C, N, 1) pair of SepConv / DilConv

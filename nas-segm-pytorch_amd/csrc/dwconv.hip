@@ -61,8 +61,10 @@ static inline int dw_fwd_rows(int K, int e, int Ho, int px = 1) {
 
 #if NASSEG_FP32_ONLY
 std::atomic<int> g_dw_swizzle{0};
+std::atomic<int> g_dw_wgrad_lds{1};
 #else
 extern std::atomic<int> g_dw_swizzle;
+extern std::atomic<int> g_dw_wgrad_lds;
 #endif
 
 namespace {
@@ -619,6 +621,205 @@ __global__ __launch_bounds__(256, 2) void dw_wgrad_group_kernel(DwWgGroup t) {
     dw_wgrad_zero_row(t.a[d].partial, local, K * K * t.a[d].C4 * 4);
 }
 
+// ---------------------------------------------------------------------------
+// backward-weight of a stride-1 K x K depthwise conv with the tiles staged in LDS.
+// The strip kernel above keeps K*K float4 accumulators AND a (P - 1 + K) x K window of loads per thread: 200-250
+// registers for 5x5, two waves per SIMD, every load normalised K times over and a dependent chain of P - 1 + K
+// global-memory round trips per work item - 0.8-1.3 TB/s on the 5x5 layers of the decoders (3x3: 3.3-5.7).
+// Here a workgroup stages a (TH + K - 1) x (16 + K - 1) patch of x - prologue applied ONCE per element, zero padding
+// in place - and the TH x 16 tile of dy for CG channel groups in LDS, and a thread (one channel group, four
+// consecutive pixels of a tile row) reads its K x (K + 3) window and four dy values from there: K + 3 + ... LDS reads
+// per row of taps, no global latency inside the arithmetic.  A dilated conv is dil^2 independent dense convs on the
+// pixel classes (y mod dil, x mod dil): tiles are cut in the subsampled coordinates of one class, so the patch is
+// (TH + K - 1) x (16 + K - 1) pixels whatever the dilation (pad must be a multiple of it).
+// Workgroup = (worker, channel chunk): a worker walks its share of the (image, class, tile) items with the
+// accumulators in registers and leaves ONE partial row [K*K][C] (its chunks' workgroups each write their channels):
+// the row count and layout of the strip kernel's partial buffer, so the callers' second stage is unchanged.
+// ---------------------------------------------------------------------------
+constexpr int kWlTW = 16;  // tile width (pixels of one class)
+struct DwWlArgs {
+  DwWgArgs a;       // tensors and geometry (stride 1)
+  int CG, TH;       // channel groups per workgroup (<= 8, divides C4), tile rows = (256 / CG) / 4
+  int nchunkC;      // C4 / CG
+  int workers;      // partial rows
+  int pd;           // pad / dil
+  int Hs, Ws;       // rows / columns of a pixel class (upper bound over the classes)
+  int ty_n, tx_n;   // tiles per class
+};
+
+template <int K, bool PRO, bool BN>
+__global__ __launch_bounds__(256, 2) void dw_wgrad_lds_kernel(DwWlArgs w) {
+  extern __shared__ float4 wl_lds[];
+  const DwWgArgs& q = w.a;
+  const int tid = threadIdx.x;
+  const int CG = w.CG, TH = w.TH, dil = q.dil;
+  const int C4 = q.C4, C = C4 * 4;
+  const int PS = CG + 1;                   // pixel stride in LDS (float4): one group of padding against bank conflicts
+  const int XW = kWlTW + K - 1;            // patch width
+  float4* xs = wl_lds;                     // [(TH + K - 1) * XW][PS]
+  float4* ds = wl_lds + (TH + K - 1) * XW * PS;  // [TH * kWlTW][PS]
+  const int chunk = blockIdx.x % w.nchunkC;
+  const int worker = blockIdx.x / w.nchunkC;
+  const int c0 = chunk * CG;               // first channel group of this workgroup
+  // compute role: channel group cc, tile row tr, pixels 4 * seg .. + 3
+  const int cc = tid % CG;
+  const int slot = tid / CG;
+  const bool worker_thread = slot < TH * 4;
+  const int tr = slot >> 2, seg = slot & 3;
+
+  float4 acc[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) acc[t] = f4zero();
+
+  // staging role: consecutive threads take consecutive channel groups of consecutive pixels
+  Prologue pro;
+  // (the prologue depends on the channel group a staging thread handles: groups repeat with period CG)
+  const int sc_ = tid % CG;
+  if (PRO) pro = make_prologue(q.in_scale, q.in_shift, q.in_act, c0 + sc_);
+  float4 ca = f4zero(), cb = f4zero(), cd = f4zero(), cs = f4zero();
+  if (BN) {
+    const int c4 = c0 + sc_;
+    ca = lda4(q.bn_scale + c4 * 4);
+    if (q.bn_act) cs = lda4(q.bn_shift + c4 * 4);
+    if (q.bn_train) {
+      const float4 is = lda4(q.bn_invstd + c4 * 4), mu = lda4(q.bn_mean + c4 * 4);
+      const float4 s0 = lda4(q.bn_sums + c4 * 4), s1 = lda4(q.bn_sums + C + c4 * 4);
+      const float m = q.invM;
+      cb = make_float4(-ca.x * is.x * (s1.x * m), -ca.y * is.y * (s1.y * m), -ca.z * is.z * (s1.z * m),
+                       -ca.w * is.w * (s1.w * m));
+      cd = make_float4(ca.x * (mu.x * is.x * (s1.x * m) - s0.x * m), ca.y * (mu.y * is.y * (s1.y * m) - s0.y * m),
+                       ca.z * (mu.z * is.z * (s1.z * m) - s0.z * m), ca.w * (mu.w * is.w * (s1.w * m) - s0.w * m));
+    }
+  }
+  const int npx_x = (TH + K - 1) * XW, npx_d = TH * kWlTW;
+  const int stagers = (256 / CG) * CG;     // threads that stage (a whole number of pixels per pass)
+  const int ppp = 256 / CG;                // pixels per staging pass
+  const int spx = tid / CG;                // this thread's pixel within a pass
+
+  const int per_img = dil * dil * w.ty_n * w.tx_n;
+  const int nitems = q.B * per_img;
+  for (int it = worker; it < nitems; it += w.workers) {
+    const int b = it / per_img;
+    int r = it - b * per_img;
+    const int cls = r / (w.ty_n * w.tx_n);
+    r -= cls * (w.ty_n * w.tx_n);
+    const int tyi = r / w.tx_n, txi = r - tyi * w.tx_n;
+    const int ry = cls / dil, rx = cls - ry * dil;
+    const int Y0 = tyi * TH, X0 = txi * kWlTW;   // tile origin, class coordinates
+    __syncthreads();                              // (the previous item's reads of xs / ds are done)
+    if (tid < stagers) {
+      // all loads of the item first (clamped addresses, no branches), then the arithmetic and the LDS stores: one
+      // global-memory round trip per item instead of one per pass
+      const act_t* xb = q.x + (size_t)b * q.H * q.W * C + (c0 + sc_) * 4;
+      constexpr int NX = 8, ND = 4;  // passes: ceil((TH + K - 1) * XW / ppp) <= 8, TH * 16 / ppp <= 4 for every CG
+      float4 xv[NX], gv[ND], zv[BN ? ND : 1];
+      bool xo[NX], go[ND];
+      int goff[ND];  // (element offsets inside image b: < 2^31)
+      const size_t ib = (size_t)b * q.Ho * q.Wo * C + (c0 + sc_) * 4;
+      auto load_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const int p = spx + i * ppp;
+          const int pc = p < npx_x ? p : 0;
+          const int pj = pc / XW, pi = pc - pj * XW;
+          const int iy = (Y0 + pj - w.pd) * dil + ry, ix = (X0 + pi - w.pd) * dil + rx;
+          xo[i] = p < npx_x && iy >= 0 && iy < q.H && ix >= 0 && ix < q.W;
+          xv[i] = lda4(xb + ((size_t)(xo[i] ? iy : 0) * q.W + (xo[i] ? ix : 0)) * C);
+        }
+      };
+      auto load_d = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const int p = spx + i * ppp;
+          const int pc = p < npx_d ? p : 0;
+          const int pj = pc / kWlTW, pi = pc - pj * kWlTW;
+          const int oy = (Y0 + pj) * dil + ry, ox = (X0 + pi) * dil + rx;
+          go[i] = p < npx_d && oy < q.Ho && ox < q.Wo;
+          goff[i] = ((go[i] ? oy : 0) * q.Wo + (go[i] ? ox : 0)) * C;
+          gv[i] = lda4(q.dy + ib + goff[i]);
+          if (BN) zv[i] = lda4(q.z + ib + goff[i]);
+        }
+      };
+      auto store_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          const int p = spx + i * ppp;
+          float4 v = xv[i];
+          if (PRO) v = apply_prologue(v, pro);
+          if (p < npx_x) xs[p * PS + sc_] = keep_if(v, xo[i]);
+        }
+      };
+      auto store_d = [&]() {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const int p = spx + i * ppp;
+          float4 g = gv[i];
+          if (BN) {
+            if (q.bn_act) {
+              const float4 y = fma4(zv[i], ca, cs);
+              g = make_float4(g.x * act_mask(y.x, q.bn_act), g.y * act_mask(y.y, q.bn_act),
+                              g.z * act_mask(y.z, q.bn_act), g.w * act_mask(y.w, q.bn_act));
+            }
+            g = fma4(g, ca, fma4(zv[i], cb, cd));
+#ifdef NASSEG_BF16
+            g = make_float4(bf16_to_f32(f32_to_bf16(g.x)), bf16_to_f32(f32_to_bf16(g.y)),
+                            bf16_to_f32(f32_to_bf16(g.z)), bf16_to_f32(f32_to_bf16(g.w)));
+#endif
+            if (go[i]) sta4(q.dz + ib + goff[i], g);
+          }
+          if (p < npx_d) ds[p * PS + sc_] = keep_if(g, go[i]);
+        }
+      };
+      if (BN) {  // (25 accumulators + both batches do not fit two waves per SIMD: two round trips)
+        load_x();
+        store_x();
+        __builtin_amdgcn_sched_barrier(0);
+        load_d();
+        store_d();
+      } else {
+        load_x();
+        load_d();
+        store_x();
+        store_d();
+      }
+    }
+    __syncthreads();
+    if (worker_thread) {
+      float4 d[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = ds[(tr * kWlTW + seg * 4 + i) * PS + cc];
+#pragma unroll
+      for (int ty = 0; ty < K; ++ty) {
+        float4 v[K + 3];
+#pragma unroll
+        for (int u = 0; u < K + 3; ++u) v[u] = xs[((tr + ty) * XW + seg * 4 + u) * PS + cc];
+#pragma unroll
+        for (int tx = 0; tx < K; ++tx)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[ty * K + tx] = fma4(d[i], v[tx + i], acc[ty * K + tx]);
+      }
+    }
+  }
+  // the slots of a channel group meet in LDS, K taps at a time, and are added in slot order
+  float* pout = q.partial + (size_t)worker * (K * K) * C;
+  const int nslot = TH * 4;
+#pragma unroll
+  for (int r = 0; r < K; ++r) {
+    __syncthreads();
+    if (worker_thread) {
+#pragma unroll
+      for (int u = 0; u < K; ++u) wl_lds[(u * nslot + slot) * CG + cc] = acc[r * K + u];
+    }
+    __syncthreads();
+    if (tid < K * CG) {
+      const int u = tid / CG, c = tid - u * CG;
+      float4 s4 = f4zero();
+      for (int sl = 0; sl < nslot; ++sl) s4 = add4(s4, wl_lds[(u * nslot + sl) * CG + c]);
+      sta4(pout + (size_t)(r * K + u) * C + (c0 + c) * 4, s4);
+    }
+  }
+}
+
 // generic backward-weight (any K): same block reduction, one tap at a time.
 __global__ __launch_bounds__(256) void dw_wgrad_generic(
     const act_t* __restrict__ x, const act_t* __restrict__ dy, float* __restrict__ partial, int B,
@@ -1153,6 +1354,44 @@ int64_t nasseg_dwconv_wgrad_workspace(int B, int C, int Ho, int Wo, int K) {
 }
 #endif  // NASSEG_FP32_ONLY
 
+// the LDS-tiled backward-weight kernel's plan for a layer (ok == 0: the strip kernel)
+struct DwWlPlan {
+  int ok, CG, TH, Hs, Ws, ty_n, tx_n;
+  size_t lds;
+};
+static DwWlPlan dw_wgrad_lds_plan(int K, int stride, int pad, int dil, int C4, int Ho, int Wo) {
+  DwWlPlan p = {};
+  if (!g_dw_wgrad_lds.load() || K != 5 || stride != 1 || pad % dil != 0 || C4 > 256) return p;
+  for (int cg = 8; cg >= 2; --cg)
+    if (C4 % cg == 0) { p.CG = cg; break; }
+  if (!p.CG) return p;
+  p.TH = (256 / p.CG) / 4;
+  p.Hs = cdiv(Ho, dil);
+  p.Ws = cdiv(Wo, dil);
+  if (p.Hs < 4 || p.Ws < 8) return p;  // (a class smaller than a quarter tile: the strip kernel)
+  p.ty_n = cdiv(p.Hs, p.TH);
+  p.tx_n = cdiv(p.Ws, kWlTW);
+  p.lds = (size_t)((p.TH + K - 1) * (kWlTW + K - 1) + p.TH * kWlTW) * (p.CG + 1) * sizeof(float4);
+  p.ok = 1;
+  return p;
+}
+static int dw_wgrad_lds_launch5(const DwWgArgs& q, const DwWlPlan& p, int workers, bool pro, bool bn, hipStream_t s) {
+  constexpr int K = 5;
+  DwWlArgs w = {};
+  w.a = q;
+  w.CG = p.CG; w.TH = p.TH; w.nchunkC = q.C4 / p.CG; w.workers = workers; w.pd = q.pad / q.dil;
+  w.Hs = p.Hs; w.Ws = p.Ws; w.ty_n = p.ty_n; w.tx_n = p.tx_n;
+  const dim3 grid((unsigned)(workers * w.nchunkC));
+#define GO_WL(PR, BB) hipLaunchKernelGGL((dw_wgrad_lds_kernel<K, PR, BB>), grid, dim3(256), p.lds, s, w)
+  if (bn && pro) GO_WL(true, true);
+  else if (bn) GO_WL(false, true);
+  else if (pro) GO_WL(true, false);
+  else GO_WL(false, false);
+#undef GO_WL
+  NASSEG_LAUNCH_CHECK("dw_wgrad_lds_kernel");
+  return NASSEG_OK;
+}
+
 // dw (C,1,K,K) = sum over pixels of dy * in_act(in_scale*x_tap + in_shift); ws must hold
 // nasseg_dwconv_wgrad_workspace() floats.  dw == null: only the partial rows [rows][K*K][C] are
 // produced (rows = workspace floats / (K*K*C)) for nasseg_wgrad_finalize_many.
@@ -1172,7 +1411,17 @@ static int dw_wgrad_impl(const act_t* x, const act_t* dy, float* dw, float* ws, 
   const bool pro = in_scale || in_shift || in_act;
   const bool strip_ok = (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2);
   NASSEG_REQUIRE(!bn || strip_ok, "dwconv_wgrad_bn: needs a strip geometry (nasseg_dwconv_strip_ok)");
-  if (strip_ok) {
+  const DwWlPlan wl = dw_wgrad_lds_plan(K, stride, pad, dil, C4, Ho, Wo);
+  if (wl.ok) {
+    DwWgArgs q = {x, dy, ws, in_scale, in_shift, in_act, B, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, 0};
+    if (bn) {
+      q.z = bn->z; q.dz = bn->dz; q.bn_scale = bn->bn_scale; q.bn_shift = bn->bn_shift; q.bn_mean = bn->bn_mean;
+      q.bn_invstd = bn->bn_invstd; q.bn_sums = bn->bn_sums; q.invM = bn->invM; q.bn_train = bn->bn_train;
+      q.bn_act = bn->bn_act;
+    }
+    int rc = dw_wgrad_lds_launch5(q, wl, gx * gy, pro, bn != nullptr, s);
+    if (rc) return rc;
+  } else if (strip_ok) {
     constexpr int P = 4;
     const int nchunk = cdiv(Ho, P * sc.g);
     dim3 grid(gx, gy, 1);
@@ -1262,6 +1511,8 @@ int NASSEG_FN(dwconv_wgrad_many)(int count, const int64_t* desc, void* stream) {
     sc = strip_cfg((int)d[13], (int)d[15]);
     const bool strip_ok = (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2) && C % 4 == 0 && C / 4 <= 256;
     if (!strip_ok) return -1;
+    if (dw_wgrad_lds_plan(K, (int)d[13], (int)d[14], (int)d[15], C / 4, (int)d[10], (int)d[11]).ok)
+      return -1;  // (the LDS-tiled kernel: launched by itself through the ordinary entry point)
     const bool pro = d[3] || d[4] || d[5];
     const int px = dw_fwd_px(K, (int)d[13], (int)d[15], (int)d[11], NASSEG_DW5_WPX);
     return (px > 1 ? 1000 : 0) + K * 100 + sc.e * 10 + (pro ? 1 : 0);
@@ -1418,6 +1669,12 @@ int NASSEG_FN(dwconv_bwd_bn)(const act_t* xz, const act_t* g, const act_t* z, co
 int nasseg_dw_swizzle(int v) {
   if (v < 0) return g_dw_swizzle.load();
   return g_dw_swizzle.exchange(v ? 1 : 0);
+}
+// backward-weight of stride-1 5x5 depthwise layers: 1 (initial) the LDS-tiled kernel where its plan applies, 0 the
+// strip kernel; v < 0 only queries.  Returns the previous setting.  Same partial-row layout either way.
+int nasseg_dw_wgrad_lds(int v) {
+  if (v < 0) return g_dw_wgrad_lds.load();
+  return g_dw_wgrad_lds.exchange(v ? 1 : 0);
 }
 #endif
 

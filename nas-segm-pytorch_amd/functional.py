@@ -2300,6 +2300,12 @@ def _apply_library_knobs():
     if _PWN_MODE is not None:
         lib.query("nasseg_conv_pwn_mode", int(_PWN_MODE))
         lib._memo.clear()
+    # NASSEG_DW_WGRAD_LDS=0: the strip kernel for 5x5 depthwise weight gradients too; NASSEG_DW_SWIZZLE=1: XCD-aware
+    # tile order of the depthwise strips (A/B switches, include/nasseg.h)
+    for env, fn in (("NASSEG_DW_WGRAD_LDS", "nasseg_dw_wgrad_lds"), ("NASSEG_DW_SWIZZLE", "nasseg_dw_swizzle")):
+        if os.environ.get(env) is not None:
+            lib.query(fn, int(os.environ[env]))
+            lib._memo.clear()
 
 
 try:

@@ -15,7 +15,8 @@ SHAPES = [  # B, C, H, W, K, stride, pad, dil
     (4, 32, 128, 256, 5, 1, 2, 1), (4, 64, 128, 256, 5, 1, 2, 1), (4, 32, 128, 256, 5, 1, 12, 6),
     (4, 24, 256, 512, 5, 1, 2, 1), (4, 64, 32, 64, 5, 1, 2, 1), (4, 32, 256, 512, 3, 1, 1, 1),
     (4, 32, 64, 128, 3, 1, 1, 1), (4, 64, 64, 128, 5, 1, 2, 1), (4, 144, 256, 512, 3, 1, 1, 1),
-    (4, 96, 512, 1024, 3, 2, 1, 1),
+    (4, 96, 512, 1024, 3, 2, 1, 1), (4, 64, 256, 512, 5, 1, 12, 6), (4, 24, 256, 512, 5, 1, 12, 6),
+    (4, 48, 128, 256, 5, 1, 2, 1), (16, 64, 11, 11, 5, 1, 2, 1), (16, 64, 41, 41, 5, 1, 12, 6),
 ]
 
 
@@ -32,23 +33,27 @@ def main():
         def run():
             F.lib.call("nasseg_dwconv_wgrad", F.ptr(x), F.ptr(dy), F.ptr(dw), F.ptr(ws), None, None, 0,
                        B, H, W, C, Ho, Wo, K, st, pad, dil, s)
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n = 40
-        e0.record()
-        for _ in range(n):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / n
+        times = []
+        for mode in ((0, 1) if K == 5 else (1,)):
+            F.lib.call("nasseg_dw_wgrad_lds", mode)
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 40
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) / n)
+        t = times[-1]
         ref = torch.nn.grad.conv2d_weight(x.cpu(), (C, 1, K, K), dy.cpu(), stride=st, padding=pad, dilation=dil,
                                           groups=C) if H * W <= 128 * 256 else None
         err = float((dw.cpu() - ref).abs().max() / ref.abs().max()) if ref is not None else float("nan")
         by = 4 * (x.numel() + dy.numel())
-        print("dw_wgrad C{:4d} {:4d}x{:4d} k{} s{} d{}: {:8.1f} us {:8.1f} GB/s  rel err {:.1e}".format(
-            C, H, W, K, st, dil, t * 1e3, by / t / 1e6, err))
+        print("dw_wgrad C{:4d} B{:2d} {:4d}x{:4d} k{} s{} d{}: {} us (strip, LDS) {:8.1f} GB/s  rel err {:.1e}".format(
+            C, B, H, W, K, st, dil, " ".join("{:7.1f}".format(v * 1e3) for v in times), by / t / 1e6, err))
 
 
 if __name__ == "__main__":
