@@ -274,6 +274,12 @@ __global__ __launch_bounds__(8 * SLICES) void rows_group_sum_t(const float* __re
   if (valid && rp_slice() == 0) out[(int64_t)g * per + e] = (float)s;
 }
 
+// partial rows from which the 1024-thread second stage is used (one round of loads per thread instead of
+// several): 512 until round 4; 32 measured +1 % on the replayed CVPR 321x321 step, neutral on the headline
+#ifndef NASSEG_RP_WIDE_FROM
+#define NASSEG_RP_WIDE_FROM 32
+#endif
+
 struct RedPlan {
   int nblk;
   int64_t rows_per_blk;
@@ -386,7 +392,7 @@ int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float e
   NASSEG_REQUIRE(M > 0 && C > 0 && nblk > 0, "bn_finalize: bad shape");
   hipStream_t s = (hipStream_t)stream;
   const float* src = partial;
-  if (nblk > 512 && nblk <= NASSEG_RP_WIDE_MAX_ROWS) {
+  if (nblk > NASSEG_RP_WIDE_FROM && nblk <= NASSEG_RP_WIDE_MAX_ROWS) {
     // one launch of 1024-thread workgroups (1024 rows per round of loads) instead of two levels
     hipLaunchKernelGGL(bn_stats_finalize_t<NASSEG_RP_WIDE_SLICES>, dim3(cdiv(C, NASSEG_RP_ELEMS)),
                        dim3(8 * NASSEG_RP_WIDE_SLICES), 0, s, src, nblk, C, (double)M, eps, momentum, gamma, beta,
@@ -421,7 +427,7 @@ int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* 
   NASSEG_REQUIRE(nblk > 0 && cols > 0 && partial && out, "rows_sum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const float* src = partial;
-  if (nblk > 512 && nblk <= NASSEG_RP_WIDE_MAX_ROWS) {
+  if (nblk > NASSEG_RP_WIDE_FROM && nblk <= NASSEG_RP_WIDE_MAX_ROWS) {
     hipLaunchKernelGGL(rows_group_sum_t<NASSEG_RP_WIDE_SLICES>, dim3(cdiv(cols, NASSEG_RP_ELEMS), 1),
                        dim3(8 * NASSEG_RP_WIDE_SLICES), 0, s, src, out, nblk, (int64_t)cols, nblk);
     NASSEG_LAUNCH_CHECK("rows_group_sum");
