@@ -259,6 +259,15 @@ int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* 
 int nasseg_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
                         int C, int train, int act, float* dx, void* stream);
+/* nasseg_bn_bwd_reduce and (dx not NULL) nasseg_bn_bwd_apply of a small map as ONE launch: a workgroup per four
+ * channels walks the M <= nasseg_bn_bwd_small_max_pixels() pixels twice (the second time out of registers or L2).
+ * sums[2][C] out; dx = scale * (g - sums0/M - xhat * sums1/M) (train) or scale * g (eval), g = dy * act'(x*scale+shift).
+ * The 16 x 11 x 11 ... 16 x 21 x 21 maps of the CVPR cells (micro_decoders.py:54-121) spend three launches of 5-13 us
+ * on this otherwise. */
+int64_t nasseg_bn_bwd_small_max_pixels(void);
+int nasseg_bn_bwd_small(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t M, int C,
+                        const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                        int train, float* sums, float* dx, int64_t lddx, void* stream);
 
 /* ---- elementwise / copies ----------------------------------------------------
  * BN apply + ReLU/ReLU6 + residual (layer_factory.py:94-158), cell sums
@@ -423,6 +432,9 @@ int nasseg_bf16_add_act2(const nasseg_bf16_t* xa, const float* sa, const float* 
 int nasseg_bf16_bn_bwd_apply(const nasseg_bf16_t* dy, const nasseg_bf16_t* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
                         int C, int train, int act, nasseg_bf16_t* dx, void* stream);
+int nasseg_bf16_bn_bwd_small(const nasseg_bf16_t* dy, int64_t lddy, const nasseg_bf16_t* x, int64_t ldx, int64_t M, int C,
+                             const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                             int train, float* sums, nasseg_bf16_t* dx, int64_t lddx, void* stream);
 int nasseg_bf16_axpby(const nasseg_bf16_t* a, const nasseg_bf16_t* b, const float* alpha, const float* beta, nasseg_bf16_t* y,
                  int64_t n, int C, int act, void* stream);
 int nasseg_bf16_act_bwd(const nasseg_bf16_t* dy, const nasseg_bf16_t* ref, nasseg_bf16_t* dx, int64_t n, int act, void* stream);

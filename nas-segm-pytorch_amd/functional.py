@@ -65,6 +65,18 @@ def _vec(like, n):
 # boundary + 5-8 us finaliser it replaces.  The entry points stay (tested, bit-reproducible) for parts where a kernel
 # boundary costs more.
 FUSE_TAIL = os.environ.get("NASSEG_FUSE_TAIL", "0") != "0"
+# BatchNorm backward of a small map (<= 2048 pixels: the 16 x 11 x 11 maps of the CVPR cells) as one launch instead
+# of three (nasseg_bn_bwd_small).  OFF by default: measured neutral on the replayed CVPR 321x321 step (1348 vs 1346
+# img/s with 39 launches fewer - back to back in one stream the three launches cost 10 us, the one 7.7; above 2048
+# pixels the one-workgroup-per-channel-group walk loses outright, tools/kbench_bnsmall.py).  NASSEG_BN_BWD_SMALL=1
+# switches it on.
+BN_BWD_SMALL = os.environ.get("NASSEG_BN_BWD_SMALL", "0") != "0"
+
+
+def _bn_small_ok(M, C):
+    return BN_BWD_SMALL and C % 4 == 0 and M <= lib.query("nasseg_bn_bwd_small_max_pixels")
+
+
 _TICKETS = {}
 
 
@@ -223,6 +235,14 @@ def _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops):
         return 0
     B, C, H, W = cur.shape
     return lib.query("nasseg_dwconv_bwd_bn_rows", B, C, H, W, w.shape[-1], stride, pad, dil)
+
+
+def _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z):
+    """the stem's weight gradient with the BatchNorm backward on its loads (nasseg_conv_wgrad_bn_flat)"""
+    return (kind == "dense" and need_dw and not need_dx and psc is None and psh is None and not pact
+            and w.shape[2] * w.shape[3] > 1 and N % 4 == 0
+            and lib.query("nasseg_conv_fwd_pack_mode", w.shape[1], w.shape[2], w.shape[3]) == 2
+            and z.numel() * z.element_size() > _FLAT_WGRAD_BN_MIN_BYTES)
 
 
 def _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
@@ -1008,35 +1028,49 @@ class _ConvChain(torch.autograd.Function):
             if has_bn:
                 mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
                 sums = _vec(z, 2 * N) if (pre is None or len(pre) < 3 or pre[2] is None) else pre[2]
+                reduce_here = False
                 if pre is not None and sums is (pre[2] if len(pre) > 2 else None):
                     pass  # g arrived masked and its sums were finished by the kernel that produced it
                 elif pre is not None:
                     # g arrived masked, with its per-workgroup {sum g, sum g*xhat} rows
                     lib.call("nasseg_rows_sum", ptr(pre[0]), pre[1], 2 * N, ptr(sums), s)
                 else:
-                    ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
-                    lib.call(_k("nasseg_bn_bwd_reduce", g), ptr(g), N, ptr(z), N, M, N, ptr(scale),
-                             ptr(shift), ptr(mean), ptr(invstd), ACT_NONE if g_masked else act, ptr(sums),
-                             ptr(ws), s)
+                    reduce_here = True
                 if ctx.needs_input_grad[3 + 6 * i + 1]:
                     grads[6 * i + 1] = sums[N:2 * N]
                 if ctx.needs_input_grad[3 + 6 * i + 2]:
                     grads[6 * i + 2] = sums[0:N]
-                if not (need_dw or need_dx):
-                    g = None
-                    break
                 act_left = ACT_NONE if (pre is not None or g_masked) else act  # (the mask still to be applied to g)
                 pw_bact = act_left
-                pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops)
-                dw_rows = _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops)
+                go_on = need_dw or need_dx
+                pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops) if go_on else 0
+                dw_rows = _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops) if go_on else 0
+                small_dz = None
+                if reduce_here and _bn_small_ok(M, N):
+                    # a small map: the sums and - where no kernel below applies the BatchNorm backward on load -
+                    # dz by ONE launch
+                    wants_dz = (go_on and not (pw_nsl > 0 or dw_rows > 0)
+                                and not _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z)
+                                and not (need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil)))
+                    if wants_dz:
+                        small_dz = torch.empty_like(z)
+                    lib.call(_k("nasseg_bn_bwd_small", g), ptr(g), N, ptr(z), N, M, N, ptr(scale), ptr(shift),
+                             ptr(mean), ptr(invstd), act_left, int(training), ptr(sums), ptr(small_dz), N, s)
+                elif reduce_here:
+                    ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
+                    lib.call(_k("nasseg_bn_bwd_reduce", g), ptr(g), N, ptr(z), N, M, N, ptr(scale),
+                             ptr(shift), ptr(mean), ptr(invstd), ACT_NONE if g_masked else act, ptr(sums),
+                             ptr(ws), s)
+                if not go_on:
+                    g = None
+                    break
                 # the stem (small-K k x k conv, no gradient for the image): BatchNorm backward on load in the
                 # weight-gradient kernel, dz never written (nasseg_conv_wgrad_bn_flat)
-                flat_bn = (kind == "dense" and need_dw and not need_dx and psc is None and psh is None and not pact
-                           and w.shape[2] * w.shape[3] > 1 and N % 4 == 0
-                           and lib.query("nasseg_conv_fwd_pack_mode", w.shape[1], w.shape[2], w.shape[3]) == 2
-                           and z.numel() * z.element_size() > _FLAT_WGRAD_BN_MIN_BYTES)
+                flat_bn = _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z)
                 if pw_nsl > 0 or dw_rows > 0 or flat_bn:
                     dz = None  # (the one-kernel pointwise backward below applies the BatchNorm backward on load)
+                elif small_dz is not None:
+                    dz = small_dz
                 elif need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
                     # the weight-gradient kernel below computes dz while it loads g and z (masking
                     # g first if it did not arrive masked) and leaves it behind for the
@@ -1335,14 +1369,17 @@ class _BatchNormAct(torch.autograd.Function):
         mean, invstd, scale, shift = stats[0:C], stats[C:2 * C], stats[2 * C:3 * C], stats[3 * C:]
         s = current_stream()
         sums = _vec(x, 2 * C)
-        ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
-        lib.call(_k("nasseg_bn_bwd_reduce", dy), ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift),
-                 ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            lib.call(_k("nasseg_bn_bwd_apply", dy), ptr(dy), ptr(x), ptr(scale), ptr(shift), ptr(mean),
-                     ptr(invstd), ptr(sums), M, C, int(training), act, ptr(dx), s)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        if _bn_small_ok(M, C):
+            lib.call(_k("nasseg_bn_bwd_small", dy), ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift), ptr(mean),
+                     ptr(invstd), act, int(training), ptr(sums), ptr(dx), C, s)
+        else:
+            ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
+            lib.call(_k("nasseg_bn_bwd_reduce", dy), ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift),
+                     ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
+            if dx is not None:
+                lib.call(_k("nasseg_bn_bwd_apply", dy), ptr(dy), ptr(x), ptr(scale), ptr(shift), ptr(mean),
+                         ptr(invstd), ptr(sums), M, C, int(training), act, ptr(dx), s)
         dgamma = sums[C:2 * C] if (affine and ctx.needs_input_grad[1]) else None
         dbeta = sums[0:C] if (affine and ctx.needs_input_grad[2]) else None
         dres = dy if (has_res and ctx.needs_input_grad[10]) else None

@@ -1839,3 +1839,42 @@ def test_pending_sum_kernels_against_torch(case, pend, dtype):
     ctol = 2e-6 * float(M) ** 0.5 * (float((d * ya).abs().max()) + 1.0) * 8
     assert_close(csum[0:C], (d * ya).reshape(-1, C).sum(0), ctol, 1e-4, "coefficient gradient a")
     assert_close(csum[C:], (d * yb).reshape(-1, C).sum(0), ctol, 1e-4, "coefficient gradient b")
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 11, 11), (4, 64, 21, 21), (2, 24, 13, 17), (1, 8, 1, 1), (3, 144, 5, 7),
+                                   (2, 32, 32, 32)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("with_dx", [True, False])
+def test_small_map_bn_backward_in_one_launch(shape, act, training, with_dx):
+    """nasseg_bn_bwd_small == nasseg_bn_bwd_reduce + nasseg_bn_bwd_apply (the sums to rounding of their order, dx
+    computed from its own sums with the same arithmetic)"""
+    f = F()
+    B, C, H, W = shape
+    M = B * H * W
+    assert M <= f.lib.query("nasseg_bn_bwd_small_max_pixels")
+    dy, x = dev(rnd(B, C, H, W, seed=1)), dev(rnd(B, C, H, W, seed=2, scale=2.0))
+    scale, shift, mean, invstd = _bn_vectors(C, 3)
+    s = f.current_stream()
+    sums_ref = torch.empty(2 * C, device=DEV)
+    ws = torch.empty(f.lib.query("nasseg_colred_workspace", 1, M, C), device=DEV)
+    f.lib.call("nasseg_bn_bwd_reduce", f.ptr(dy), C, f.ptr(x), C, M, C, f.ptr(scale), f.ptr(shift), f.ptr(mean),
+               f.ptr(invstd), act, f.ptr(sums_ref), f.ptr(ws), s)
+    dx_ref = torch.empty_like(x)
+    f.lib.call("nasseg_bn_bwd_apply", f.ptr(dy), f.ptr(x), f.ptr(scale), f.ptr(shift), f.ptr(mean), f.ptr(invstd),
+               f.ptr(sums_ref), M, C, int(training), act, f.ptr(dx_ref), s)
+    sums = torch.full((2 * C,), float("nan"), device=DEV)
+    dx = torch.full_like(x, float("nan")) if with_dx else None
+    f.lib.call("nasseg_bn_bwd_small", f.ptr(dy), C, f.ptr(x), C, M, C, f.ptr(scale), f.ptr(shift), f.ptr(mean),
+               f.ptr(invstd), act, int(training), f.ptr(sums), f.ptr(dx), C, s)
+    # float64 reference of the sums
+    yv = x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    mask = torch.ones_like(yv) if act == 0 else ((yv > 0) if act == 1 else ((yv > 0) & (yv < 6))).double()
+    g = dy.double() * mask
+    xh = (x.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+    want = torch.cat([g.sum((0, 2, 3)), (g * xh).sum((0, 2, 3))])
+    tol = 2e-6 * float(M) ** 0.5 * float(g.abs().max()) * float(xh.abs().max() + 1)
+    assert_close(sums.double(), want, tol, 1e-5, "sums against float64")
+    assert float((sums.double() - want).abs().max()) <= float((sums_ref.double() - want).abs().max()) + tol * 0.1
+    if with_dx:
+        assert_close(dx, dx_ref, 2e-5 * float(dx_ref.abs().max()) + 1e-6, 1e-4, "dx")
