@@ -37,6 +37,12 @@
 // Process-wide; outputs do not depend on it, BatchNorm statistics only in the rounding of their partial sums.
 extern "C" int64_t nasseg_conv_pw_min_pixels(int64_t v);
 
+#if NASSEG_FP32_ONLY
+std::atomic<int> g_conv_deep_k{1};
+#else
+extern std::atomic<int> g_conv_deep_k;
+#endif
+
 namespace {
 
 enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
@@ -95,7 +101,11 @@ __device__ __forceinline__ float4 load4(const bf16_t* row, int k, int K) {
 // the price of one read of z instead of a separate pass over g and z.
 // STATS == 3: only the act' mask of STATS == 2 (b_scale / b_shift may be null = identity): the
 // backward of an activation that was applied on load, without a pass over dx and x.
-template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, int STATS, bool WS>
+// KU_: k-steps of X requested per iteration (see NASSEG_CONV_KU): 1 on large maps, where other waves hide a round
+// trip; 4 on SMALL maps (launch_one: at most kDeepKMaxPixels pixels), where a workgroup per CU or fewer runs and the
+// reduction is a chain of round trips - 960 -> 160 at 16 x 11 x 11: 60 of them, 78 us for 0.6 GFLOP.
+template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, int STATS, bool WS,
+          int KU_ = NASSEG_CONV_KU>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
   constexpr bool kSums = STATS == 1 || STATS == 2;
   __shared__ float sred[(kSums && !WS) ? 4 : 1][2][(kSums && !WS) ? NT * 16 : 1];
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int ntaps = a.g.kh * a.g.kw;
-  constexpr int KU = (KM == KM_VEC) ? NASSEG_CONV_KU : 1;
+  constexpr int KU = (KM == KM_VEC) ? KU_ : 1;
   const ActSel pact = act_sel(a.in_act);
   const int Kq = (KM == KM_FLAT) ? ntaps * a.K : a.K;  // reduction length of one pass
   const int nk = (Kq + 15) >> 4;
@@ -225,16 +235,31 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
             bv[u][mt] = keep_if(v, xok[mt] && kok);
           }
         }
+        if constexpr (KU > 1) {
+          // small maps: the weights of the KU steps are requested with the X operands - with a workgroup or two per
+          // CU they come from L2, not L1, and a round trip per step is what the kernel would spend its time on
+          float4 av[KU][NT];
 #pragma unroll
-        for (int u = 0; u < KU; ++u) {
-          const int k = (it + u) * 16 + kg * 4;
-          const bool kok = k < a.K;
-          float4 av[NT];
+          for (int u = 0; u < KU; ++u) {
+            const int k = (it + u) * 16 + kg * 4;
+            const bool kok = k < a.K;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            av[nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
-          mma(bv[u], av);
-          if (KU > 1) __builtin_amdgcn_sched_barrier(0);
+            for (int nt = 0; nt < NT; ++nt)
+              av[u][nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
+          }
+#pragma unroll
+          for (int u = 0; u < KU; ++u) mma(bv[u], av[u]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < KU; ++u) {
+            const int k = (it + u) * 16 + kg * 4;
+            const bool kok = k < a.K;
+            float4 av[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              av[nt] = keep_if(load4<KM == KM_VEC>(wrow[nt], k, a.K), wok[nt] && kok);
+            mma(bv[u], av);
+          }
         }
       }
     }
@@ -921,6 +946,8 @@ __global__ void pack_multi_kernel(PackTable t) {
   }
 }
 
+// maps up to this many pixels take four k-steps per round trip (conv_fwd_kernel's KU_)
+constexpr int64_t kDeepKMaxPixels = 32768;
 struct Mode {
   int km;
   bool gather, pro, vecn, epi;
@@ -931,27 +958,37 @@ template <int MT, int NT, bool WS = false>
 int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
   const int64_t Mtot = (int64_t)a.g.B * a.g.Ho * a.g.Wo;
   dim3 grid((unsigned)cdiv64(Mtot, (WS ? 16 : 64) * MT), cdiv(a.N, (WS ? 64 : 16) * NT), 1);
-#define GO(KM_, G_, P_, V_)                                                                       \
+  const bool deep = Mtot <= kDeepKMaxPixels && g_conv_deep_k.load() != 0;
+#define GO_(KM_, G_, P_, V_, KUX)                                                                       \
   do {                                                                                            \
     if (md.stats == 2) {                                                                          \
       if constexpr ((V_) && !(P_) && KM_ != KM_FLAT)                                              \
-        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 2, WS>), grid,        \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 2, WS, KUX>), grid,        \
                            dim3(256), 0, s, a);                                                   \
     } else if (md.stats == 3) {                                                                   \
       if constexpr ((V_) && !(P_) && KM_ != KM_FLAT)                                              \
-        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 3, WS>), grid,        \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 3, WS, KUX>), grid,        \
                            dim3(256), 0, s, a);                                                   \
     } else if (md.stats) {                                                                        \
       if constexpr (V_)                                                                           \
-        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 1, WS>), grid,        \
+        hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 1, WS, KUX>), grid,        \
                            dim3(256), 0, s, a);                                                   \
     } else if (md.epi || !(V_)) {                                                                 \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true, 0, WS>), grid,           \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, true, 0, WS, KUX>), grid,           \
                          dim3(256), 0, s, a);                                                     \
     } else {                                                                                      \
-      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 0, WS>), grid,          \
+      hipLaunchKernelGGL((conv_fwd_kernel<MT, NT, KM_, G_, P_, V_, false, 0, WS, KUX>), grid,          \
                          dim3(256), 0, s, a);                                                     \
     }                                                                                             \
+  } while (0)
+#define GO(KM_, G_, P_, V_)                                   \
+  do {                                                        \
+    if constexpr (MT == 1 && KM_ == KM_VEC) {                 \
+      if (deep) GO_(KM_, G_, P_, V_, 4);                      \
+      else GO_(KM_, G_, P_, V_, NASSEG_CONV_KU);              \
+    } else {                                                  \
+      GO_(KM_, G_, P_, V_, NASSEG_CONV_KU);                   \
+    }                                                         \
   } while (0)
   if (md.km == KM_FLAT) {
     if constexpr (NT <= 4 && !WS) {
@@ -978,6 +1015,7 @@ int launch_one(const FwdArgs& a, const Mode& md, hipStream_t s) {
     GO(KM_VEC, false, false, true);
   }
 #undef GO
+#undef GO_
   NASSEG_LAUNCH_CHECK("conv_fwd_kernel");
   return NASSEG_OK;
 }
@@ -1019,6 +1057,14 @@ int launch_pw(const FwdArgs& a, const PwFwdPlan& p, int stats, hipStream_t s) {
     case 12: return launch_pw_nt<12, 1>(a, p, stats, s);
     default: return launch_pw_nt<14, 1>(a, p, stats, s);
   }
+}
+
+// SMALL maps (at most kDeepKMaxPixels pixels): a workgroup owns 16 pixels and its four waves 16 output channels each,
+// whatever N - 16 x 11 x 11 pixels into 64 channels are 31 workgroups of 64 x 64 tiles otherwise, 124 waves on 1024
+// SIMDs each multiplying for 8 us (3x3, 64 -> 64: 33 us; 484 waves and 11 us this way).  A function of (pixels, N, K)
+// alone: nasseg_conv_fwd_stats_blocks must predict the rows.  K >= 8 keeps the flat small-K form out of it.
+inline bool conv_small_ws(int64_t Mtot, int N, int K) {
+  return g_conv_deep_k.load() != 0 && Mtot <= kDeepKMaxPixels && (N & 3) == 0 && (K & 3) == 0 && K >= 8;
 }
 
 inline int fwd_pack_mode(int K, int kh, int kw) { return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0; }
@@ -1071,6 +1117,12 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s, const TailArgs* tai
     if (tiles == 2) return launch_lds3x3<2>(a, md.vecn, veck, s);
     if (tiles == 3) return launch_lds3x3<3>(a, md.vecn, veck, s);
     return launch_lds3x3<4>(a, md.vecn, veck, s);
+  }
+  if (conv_small_ws((int64_t)g.B * g.Ho * g.Wo, N, K)) {
+    if (md.km == KM_VEC && md.vecn) return launch_one<1, 1, true>(a, md, s);
+    // (statistics rows were counted for that kernel's 16-pixel workgroups)
+    NASSEG_REQUIRE(md.stats != 1 && md.stats != 2,
+                   "conv_fwd: statistics on a small map need channel strides that are multiples of 4");
   }
   if (tiles <= 1) return launch_small<1>(a, md, s);
   if (tiles == 2) return launch_small<2>(a, md, s);
@@ -1147,6 +1199,12 @@ int nasseg_pack_weights(int count, const float* const* w, float* const* wp, cons
 int64_t nasseg_conv_pw_min_pixels(int64_t v) {
   return v == -1 ? g_pw_min_pixels.load() : g_pw_min_pixels.exchange(v < 0 ? -2 : v);
 }
+// four k-steps per round trip in the general kernel on maps of at most 32768 pixels: 1 (initial) on, 0 off;
+// v < 0 only queries.  Returns the previous setting.  Bit-identical results (the same accumulation order).
+int nasseg_conv_deep_k(int v) {
+  if (v < 0) return g_conv_deep_k.load();
+  return g_conv_deep_k.exchange(v ? 1 : 0);
+}
 #endif  // NASSEG_FP32_ONLY
 
 #if NASSEG_FP32_ONLY
@@ -1161,6 +1219,7 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int po
     const PwFwdPlan pw = pw_fwd_plan(Mtot, N, K, pointwise);
     if (pw.ok) return pw.grid;
   }
+  if (conv_small_ws(Mtot, N, K)) return cdiv64(Mtot, 16);
   return cdiv64(Mtot, (tiles > 4 ? 16 : 64) * pick_mt(Mtot, tiles));
 }
 #endif  // NASSEG_FP32_ONLY

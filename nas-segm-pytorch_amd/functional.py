@@ -2338,8 +2338,10 @@ def _apply_library_knobs():
         lib.query("nasseg_conv_pwn_mode", int(_PWN_MODE))
         lib._memo.clear()
     # NASSEG_DW_WGRAD_LDS=0: the strip kernel for 5x5 depthwise weight gradients too; NASSEG_DW_SWIZZLE=1: XCD-aware
-    # tile order of the depthwise strips (A/B switches, include/nasseg.h)
-    for env, fn in (("NASSEG_DW_WGRAD_LDS", "nasseg_dw_wgrad_lds"), ("NASSEG_DW_SWIZZLE", "nasseg_dw_swizzle")):
+    # tile order of the depthwise strips; NASSEG_CONV_DEEP_K=0: one k-step per round trip on small maps as well
+    # (A/B switches, include/nasseg.h)
+    for env, fn in (("NASSEG_DW_WGRAD_LDS", "nasseg_dw_wgrad_lds"), ("NASSEG_DW_SWIZZLE", "nasseg_dw_swizzle"),
+                    ("NASSEG_CONV_DEEP_K", "nasseg_conv_deep_k")):
         if os.environ.get(env) is not None:
             lib.query(fn, int(os.environ[env]))
             lib._memo.clear()
