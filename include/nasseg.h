@@ -124,6 +124,11 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
  * nasseg_conv_bwd_data_bn call - those may take the persistent pointwise kernel (weight in LDS, inputs
  * prefetched, one statistics row per workgroup of a grid that depends on K) */
 int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int pointwise);
+/* ... of a FORWARD call with any kernel size: nasseg_conv_fwd_stats_blocks for 1x1 and strided forms, the tile count of
+ * the LDS-tiled kernel for the stride-1 3x3 forms it takes (dilation 1 ... 3, N <= 64, maps of at least 8 x 32 pixels:
+ * conv3x3 / conv3x3_dil3 of the CVPR cells, layer_factory.py:56-75).  A forward call that passes `stats` for a 3x3
+ * geometry must size them with THIS query. */
+int64_t nasseg_conv_fwd_stats_rows(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil);
 /* tuning / testing knob: which pointwise calls take the persistent kernel.  -2 (initial): where it measured
  * faster; v >= 0: every call it supports over at least v output pixels (0 = all, a huge value = none);
  * v == -1 only queries.  Returns the previous setting.  Outputs are bit-identical either way; BatchNorm

@@ -701,7 +701,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// 3x3 stride-1 convolution (dilation 1 or 2) with the input tile staged in LDS.
+// 3x3 stride-1 convolution (dilation 1 ... 3) with the input tile staged in LDS.
 // The gather kernel above re-reads X once per tap through L1/L2 (9x the tensor), which
 // is what bounds the 64->19 class head and its backward-data; here a workgroup owns an
 // 8 x 32 patch of output pixels, stages the (8+2d) x (32+2d) input patch of a 32-channel
@@ -713,11 +713,15 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 // weights (pack kind 5) and pad' = d*(k-1) - pad.
 // ---------------------------------------------------------------------------
 constexpr int kLdsTH = 8, kLdsTW = 32, kLdsKC = 32, kLdsKS = kLdsKC + 4;
-constexpr int kLdsMaxIt = ((kLdsTH + 4) * (kLdsTW + 4) * (kLdsKC / 4) + 255) / 256;  // float4 of the patch per thread (d <= 2)
+constexpr int kLdsMaxDil = 3;
+constexpr int kLdsMaxIt = ((kLdsTH + 2 * kLdsMaxDil) * (kLdsTW + 2 * kLdsMaxDil) * (kLdsKC / 4) + 255) / 256;  // float4 of the patch per thread
 
-template <int NT, bool VECN, bool VECK>
+// STATS == 1: per-workgroup sums of y and y^2 per output channel (the BatchNorm that follows a conv3x3 / conv3x3_dil3
+// op of the CVPR cells, layer_factory.py:56-75) to stats[tile][2][N], tile = (b * tiles_y + ty) * tiles_x + tx.
+template <int NT, bool VECN, bool VECK, int STATS = 0>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
   extern __shared__ float tile[];
+  __shared__ float sred3[STATS ? 4 : 1][2][STATS ? NT * 16 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15;
@@ -849,6 +853,46 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
     }
   }
 
+  if constexpr (STATS == 1) {
+    // over the wave's four subtiles in registers, its 16 pixel lanes by DPP, the four waves through LDS
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + (mt & 1) * 16 + j;
+        const bool pok = oy < a.g.Ho && ox < a.g.Wo;
+        const f32x4 c = acc[mt][nt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = keep_if(c[r], pok);
+          sx[r] += v;
+          sq[r] = fmaf(v, v, sq[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sx[r] = row16_allsum(sx[r]);
+        sq[r] = row16_allsum(sq[r]);
+      }
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sred3[wave][0][nt * 16 + kg * 4 + r] = sx[r];
+          sred3[wave][1][nt * 16 + kg * 4 + r] = sq[r];
+        }
+      }
+    }
+    __syncthreads();
+    const int64_t row = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (int t = threadIdx.x; t < NT * 16; t += 256) {
+      if (t < a.N) {
+        float* po = a.stats + row * 2 * a.N + t;
+        po[0] = (sred3[0][0][t] + sred3[1][0][t]) + (sred3[2][0][t] + sred3[3][0][t]);
+        po[a.N] = (sred3[0][1][t] + sred3[1][1][t]) + (sred3[2][1][t] + sred3[3][1][t]);
+      }
+    }
+  }
   // epilogue: lane holds pixel j of each subtile, channels nt*16 + 4*kg + {0..3}
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
@@ -887,13 +931,26 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
 }
 
 template <int NT>
-int launch_lds3x3(const FwdArgs& a, bool vecn, bool veck, hipStream_t s) {
+int launch_lds3x3(const FwdArgs& a, bool vecn, bool veck, bool stats, hipStream_t s) {
   const int dil = a.g.dil;
   const size_t lds = (size_t)(kLdsTH + 2 * dil) * (kLdsTW + 2 * dil) * kLdsKS * sizeof(float);
   dim3 grid(cdiv(a.g.Wo, kLdsTW), cdiv(a.g.Ho, kLdsTH), a.g.B);
-#define GO3(V_, K_) hipLaunchKernelGGL((conv3x3_lds_kernel<NT, V_, K_>), grid, dim3(256), lds, s, a)
-  if (vecn) { if (veck) GO3(true, true); else GO3(true, false); }
-  else { if (veck) GO3(false, true); else GO3(false, false); }
+  if (lds > (size_t)(64 << 10)) {  // (dilation 3: 76.6 KB)
+    static std::atomic<int> raised{0};
+    if (!raised.load()) {
+#define ATTR3(V_, K_, S_)                                                                                    \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<NT, V_, K_, S_>),              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10)
+      ATTR3(true, true, 0); ATTR3(true, false, 0); ATTR3(false, true, 0); ATTR3(false, false, 0);
+      ATTR3(true, true, 1); ATTR3(true, false, 1);
+#undef ATTR3
+      raised.store(1);
+    }
+  }
+#define GO3(V_, K_, S_) hipLaunchKernelGGL((conv3x3_lds_kernel<NT, V_, K_, S_>), grid, dim3(256), lds, s, a)
+  if (stats) { if (veck) GO3(true, true, 1); else GO3(true, false, 1); }  // (statistics need N % 4 == 0)
+  else if (vecn) { if (veck) GO3(true, true, 0); else GO3(true, false, 0); }
+  else { if (veck) GO3(false, true, 0); else GO3(false, false, 0); }
 #undef GO3
   NASSEG_LAUNCH_CHECK("conv3x3_lds_kernel");
   return NASSEG_OK;
@@ -1067,6 +1124,12 @@ inline bool conv_small_ws(int64_t Mtot, int N, int K) {
   return g_conv_deep_k.load() != 0 && Mtot <= kDeepKMaxPixels && (N & 3) == 0 && (K & 3) == 0 && K >= 8;
 }
 
+// geometries of the LDS-tiled 3x3 kernel (conv3x3_lds_kernel); K * 9 > 64 keeps the flat small-K form out
+inline bool lds3x3_geometry(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil) {
+  return kh == 3 && kw == 3 && stride == 1 && dil >= 1 && dil <= kLdsMaxDil && K * 9 > 64 && cdiv(N, 16) <= 4 &&
+         Wo >= kLdsTW && Ho >= kLdsTH && B <= 65535 && pad >= 0 && pad <= 2 * dil;
+}
+
 inline int fwd_pack_mode(int K, int kh, int kw) { return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0; }
 
 int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s, const TailArgs* tail = nullptr) {
@@ -1108,15 +1171,15 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s, const TailArgs* tai
       if (aligned) return launch_pw(a, pw, md.stats, s);
     }
   }
-  // 3x3, stride 1, dilation <= 2, maps at least one tile large: input patch staged in LDS
-  if (!g.transposed && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.dil <= 2 && md.km != KM_FLAT &&
-      !md.pro && !md.stats && tiles <= 4 && g.Wo >= kLdsTW && g.Ho >= kLdsTH && g.B <= 65535 &&
-      g.pad >= 0 && g.pad <= 2 * g.dil) {
+  // 3x3, stride 1, dilation <= 3, maps at least one tile large: input patch staged in LDS (with the forward
+  // statistics rows when asked for: nasseg_conv_fwd_stats_rows counts them under the same condition)
+  if (!g.transposed && lds3x3_geometry(g.B, g.Ho, g.Wo, N, K, g.kh, g.kw, g.stride, g.pad, g.dil) && md.km != KM_FLAT &&
+      !md.pro && (md.stats == 0 || (md.stats == 1 && md.vecn))) {
     const bool veck = md.km == KM_VEC;
-    if (tiles <= 1) return launch_lds3x3<1>(a, md.vecn, veck, s);
-    if (tiles == 2) return launch_lds3x3<2>(a, md.vecn, veck, s);
-    if (tiles == 3) return launch_lds3x3<3>(a, md.vecn, veck, s);
-    return launch_lds3x3<4>(a, md.vecn, veck, s);
+    if (tiles <= 1) return launch_lds3x3<1>(a, md.vecn, veck, md.stats == 1, s);
+    if (tiles == 2) return launch_lds3x3<2>(a, md.vecn, veck, md.stats == 1, s);
+    if (tiles == 3) return launch_lds3x3<3>(a, md.vecn, veck, md.stats == 1, s);
+    return launch_lds3x3<4>(a, md.vecn, veck, md.stats == 1, s);
   }
   if (conv_small_ws((int64_t)g.B * g.Ho * g.Wo, N, K)) {
     if (md.km == KM_VEC && md.vecn) return launch_one<1, 1, true>(a, md, s);
@@ -1221,6 +1284,18 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int po
   }
   if (conv_small_ws(Mtot, N, K)) return cdiv64(Mtot, 16);
   return cdiv64(Mtot, (tiles > 4 ? 16 : 64) * pick_mt(Mtot, tiles));
+}
+#endif  // NASSEG_FP32_ONLY
+
+#if NASSEG_FP32_ONLY
+// statistic rows of a FORWARD nasseg_conv_fwd call with this geometry (any kernel size): what
+// nasseg_conv_fwd_stats_blocks says for 1x1 and strided forms, the tile count of the LDS-tiled kernel for the
+// stride-1 3x3 forms it takes (N % 4 == 0, no input prologue)
+int64_t nasseg_conv_fwd_stats_rows(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil) {
+  const int pointwise = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? 1 : 0;
+  if (!pointwise && (N & 3) == 0 && lds3x3_geometry(B, Ho, Wo, N, K, kh, kw, stride, pad, dil))
+    return (int64_t)cdiv(Wo, kLdsTW) * cdiv(Ho, kLdsTH) * B;
+  return nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N, K, pointwise);
 }
 #endif  // NASSEG_FP32_ONLY
 

@@ -102,6 +102,8 @@ struct Upd {
   bool has_buf;
 };
 
+// (where torch's own kernels evaluate a + alpha * b in one expression the compiler fuses it: the same fused forms
+//  here make an SGD step bit-identical to torch's and an Adam step equal to it to the last bit or two)
 __device__ __forceinline__ void update1(const Upd& u, float& p, float& g, float& s1, float& s2) {
   g = g * u.coef;
   float d = u.wd != 0.f ? __fadd_rn(g, __fmul_rn(u.wd, p)) : g;  // grad.add(param, alpha=weight_decay)
@@ -110,12 +112,12 @@ __device__ __forceinline__ void update1(const Upd& u, float& p, float& g, float&
       s1 = __fadd_rn(__fmul_rn(s1, u.mom), d);  // buf.mul_(momentum).add_(d_p)
       d = s1;
     }
-    p = __fadd_rn(p, __fmul_rn(-u.lr, d));  // param.add_(d_p, alpha=-lr)
+    p = fmaf(-u.lr, d, p);  // param.add_(d_p, alpha=-lr)
   } else {
-    s1 = __fadd_rn(s1, __fmul_rn(u.w1, __fsub_rn(d, s1)));                 // exp_avg.lerp_(grad, 1 - beta1)
-    s2 = __fadd_rn(__fmul_rn(s2, u.b2), __fmul_rn(__fmul_rn(u.w2, d), d)); // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    s1 = fmaf(u.w1, __fsub_rn(d, s1), s1);                     // exp_avg.lerp_(grad, 1 - beta1)
+    s2 = fmaf(__fmul_rn(u.w2, d), d, __fmul_rn(s2, u.b2));     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
     const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(s2), u.bc2s), u.eps);
-    p = __fadd_rn(p, __fmul_rn(-u.step_size, __fdiv_rn(s1, denom)));      // param.addcdiv_(exp_avg, denom, value=-step_size)
+    p = fmaf(-u.step_size, __fdiv_rn(s1, denom), p);           // param.addcdiv_(exp_avg, denom, value=-step_size)
   }
 }
 

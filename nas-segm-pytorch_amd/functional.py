@@ -861,7 +861,7 @@ class _ConvChain(torch.autograd.Function):
                     elif kind == "dw":
                         nblk = lib.query("nasseg_dwconv_stats_blocks", B, N, Ho, Wo, kh, stride, dil)
                     else:
-                        nblk = lib.query("nasseg_conv_fwd_stats_blocks", B, Ho, Wo, N, K, int(pointwise))
+                        nblk = lib.query("nasseg_conv_fwd_stats_rows", B, Ho, Wo, N, K, kh, kw, stride, pad, dil)
                     part = _ws(cur, (nblk + 64) * 2 * N)
             o_sc = o_sh = o_res = None
             o_act = ACT_NONE

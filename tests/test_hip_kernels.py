@@ -1878,3 +1878,38 @@ def test_small_map_bn_backward_in_one_launch(shape, act, training, with_dx):
     assert float((sums.double() - want).abs().max()) <= float((sums_ref.double() - want).abs().max()) + tol * 0.1
     if with_dx:
         assert_close(dx, dx_ref, 2e-5 * float(dx_ref.abs().max()) + 1e-6, 1e-4, "dx")
+
+
+@pytest.mark.parametrize("case", [
+    # B, K, H, W, N, pad, dil: the LDS-tiled 3x3 kernel with the statistics epilogue - conv3x3 / conv3x3_dil3 of the
+    # CVPR cells at 81 x 81, ragged tiles, one to four channel tiles, dilation 2 and 3, K not a multiple of 32
+    (2, 64, 20, 70, 64, 1, 1), (1, 32, 17, 45, 48, 3, 3), (2, 16, 12, 40, 32, 2, 2), (2, 64, 9, 33, 24, 3, 3),
+    (1, 48, 81, 81, 64, 3, 3), (1, 24, 8, 32, 16, 1, 1),
+])
+def test_3x3_forward_statistics_from_the_lds_tiled_kernel(case):
+    f = F()
+    B, K, H, W, N, pad, dil = case
+    Ho, Wo = H + 2 * pad - 2 * dil, W + 2 * pad - 2 * dil
+    x = dev(rnd(B, K, H, W, seed=1))
+    w = rnd(N, K, 3, 3, seed=2, scale=1.0 / np.sqrt(9 * K)).to(DEV)
+    wp = torch.empty(9 * N * K, device=DEV)
+    s = f.current_stream()
+    f.lib.call("nasseg_conv_pack_weight", f.ptr(w), f.ptr(wp), N, K, 3, 3, 0, s)
+    rows = f.lib.query("nasseg_conv_fwd_stats_rows", B, Ho, Wo, N, K, 3, 3, 1, pad, dil)
+    assert rows == B * ((Ho + 7) // 8) * ((Wo + 31) // 32)  # (the tile count: this geometry takes the LDS kernel)
+    part = torch.full(((rows + 64) * 2 * N,), float("nan"), device=DEV)
+    y = dev(torch.empty(B, N, Ho, Wo))
+    f.lib.call("nasseg_conv_fwd", f.ptr(x), K, f.ptr(wp), f.ptr(y), N, None, None, 0, None, None, 0, None, 0, B, H, W,
+               K, Ho, Wo, N, 3, 3, 1, pad, dil, 0, f.ptr(part), s)
+    y0 = dev(torch.empty(B, N, Ho, Wo))
+    f.lib.call("nasseg_conv_fwd", f.ptr(x), K, f.ptr(wp), f.ptr(y0), N, None, None, 0, None, None, 0, None, 0, B, H, W,
+               K, Ho, Wo, N, 3, 3, 1, pad, dil, 0, None, s)
+    assert torch.equal(y, y0)
+    ref = TF.conv2d(x.cpu().contiguous(), w.cpu(), None, 1, pad, dil)
+    assert_close(y, ref, 3e-5 * float(ref.abs().max()) + 1e-6, 1e-4, "y")
+    sums = torch.empty(2 * N, device=DEV)
+    f.lib.call("nasseg_rows_sum", f.ptr(part), rows, 2 * N, f.ptr(sums), s)
+    yd = y.permute(1, 0, 2, 3).reshape(N, -1).double()
+    want = torch.cat([yd.sum(1), (yd * yd).sum(1)])
+    assert_close(sums.double(), want, 2e-6 * float(B * Ho * Wo) ** 0.5 * float(yd.abs().max()) ** 2 + 1e-5, 2e-5,
+                 "column sums of y and y^2")

@@ -208,3 +208,28 @@ def test_what_is_not_plain_sgd_or_adam_goes_to_torch():
         p.grad = g.to(DEV)
     clip_and_step([(ps, 1.0, o)])
     assert all(not torch.equal(b, p.detach()) for b, p in zip(before, ps))
+
+
+def test_against_torch_optimisers_on_the_device():
+    """torch's own kernels on the same device: plain SGD and SGD with weight decay give identical bits (the engine
+    tests compare steps taken by either); with momentum 1 element in a thousand differs in its last bit, Adam's second
+    moment likewise (where torch's compiler fused a multiply-add is its own matter - tools/diag_optim_bits.py)"""
+    from nas_segm_amd.engine.optim_native import NativeStep
+
+    for kind, hp, exact in (("sgd", dict(lr=1e-3), True), ("sgd", dict(lr=1e-3, weight_decay=1e-5), True),
+                            ("sgd", dict(lr=1e-3, momentum=0.9, weight_decay=1e-5), False),
+                            ("adam", dict(lr=3e-3, weight_decay=1e-5), False)):
+        ref = [nn.Parameter(p.detach().to(DEV)) for p in _params(7)]
+        ps = [nn.Parameter(p.detach().to(DEV)) for p in _params(7)]
+        ro, o = _make(kind, ref, hp), _make(kind, ps, hp)
+        native = NativeStep.build([(ps, 0.0, o)])
+        for s in range(4):
+            for p, r, g in zip(ps, ref, _grads(ref, s, 0.3)):
+                p.grad, r.grad = g.to(DEV), g.to(DEV)
+            native.step()
+            ro.step()
+        for p, r in zip(ps, ref):
+            if exact:
+                assert torch.equal(p.detach(), r.detach()), hp
+            else:
+                assert torch.allclose(p.detach(), r.detach(), rtol=1e-6, atol=1e-8), hp
