@@ -122,7 +122,11 @@ class NativeStep(object):
         # tables: pinned host sources + device twins, allocated ONCE (nothing is allocated when a step is recorded
         # into a hipGraph; the recorded copy nodes read the pinned sources again at every replay, so an object
         # whose step was captured is used by that graph only - engine/graphed.py builds its own)
-        self._host_t = torch.zeros(n, _COLS, dtype=torch.int64).pin_memory()
+        # (two pinned tensor tables, used in turn: a step that only moved its gradients fills the other one
+        #  while the previous upload may still be in flight)
+        self._host_tt = [torch.zeros(n, _COLS, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._tt_events = [None, None]
+        self._cur = 0
         self._host_c = torch.zeros(max_chunks, 2, dtype=torch.int32).pin_memory()
         self._dev_t = torch.zeros(n, _COLS, dtype=torch.int64, device=device)
         self._dev_c = torch.zeros(max_chunks, 2, dtype=torch.int32, device=device)
@@ -130,7 +134,7 @@ class NativeStep(object):
         self._norms = torch.zeros(max(1, len(self.clip_norms)), device=device, dtype=torch.float32)
         self._hyper = (ctypes.c_double * (6 * len(self.hyper_src)))()
         self._clips = (ctypes.c_double * (3 * max(1, len(self.clip_norms))))()
-        self._uploaded = None   # event behind the last table upload
+        self._uploaded = None   # event behind the last upload of the chunk list
         self._key = None        # gradient addresses the tables were built for
         self._sig = None        # identity of the optimisers' state mappings at that time
         self._n_chunks = 0
@@ -138,6 +142,7 @@ class NativeStep(object):
         self._host_steps_seen = [0.0] * n
         self._dirty_steps = True
         self.rebuilds = 0
+        self.moves = 0
 
     # -- optimiser state, with torch's names ------------------------------------------------------
     def _state(self, entry):
@@ -197,9 +202,45 @@ class NativeStep(object):
 
     def prepare_capture(self):
         """before this object's step is recorded into a hipGraph: nothing of an earlier upload is in flight"""
-        if self._uploaded is not None:
-            self._uploaded.synchronize()
-            self._uploaded = None
+        for ev in [self._uploaded] + self._tt_events:
+            if ev is not None:
+                ev.synchronize()
+        self._uploaded = None
+        self._tt_events = [None, None]
+
+    def _next_table(self):
+        """the pinned tensor table to fill now (numpy view): the one not used by the last upload, once its own
+        last upload is through"""
+        self._cur ^= 1
+        ev = self._tt_events[self._cur]
+        if ev is not None:
+            ev.synchronize()
+            self._tt_events[self._cur] = None
+        return self._host_tt[self._cur].numpy()
+
+    def _upload_table(self):
+        self._dev_t.copy_(self._host_tt[self._cur], non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record()
+            self._tt_events[self._cur] = ev
+
+    def _move_gradients(self, key):
+        """the same tensors got their gradients at other addresses (the usual host-launched step: backward's
+        allocations do not repeat exactly): column 1 and the alignment flags of the table, nothing else"""
+        import numpy as np
+
+        for e in self._stepped:
+            if not e[0].grad.is_contiguous():
+                raise _Unsupported()
+        prev = self._host_tt[self._cur].numpy()
+        table = self._next_table()
+        np.copyto(table, prev)
+        ptrs = np.array(key, dtype=np.int64)
+        table[:, 1] = ptrs
+        table[:, 7] = self._static_aligned & (ptrs % 16 == 0)
+        self._upload_table()
+        self.moves += 1
 
     # -- tables -------------------------------------------------------------------------------------
     def _build_tables(self):
@@ -213,11 +254,14 @@ class NativeStep(object):
             s1, s2 = self._state(e)
             live.append((e, g, s1, s2))
         live.sort(key=lambda l: (l[0][4] < 0, l[0][4]))  # clip sets first, each one's chunks consecutive
+        import numpy as np
+
         if self._uploaded is not None:
-            self._uploaded.synchronize()  # (the previous upload may still be reading the pinned sources)
-        table = self._host_t.numpy()
+            self._uploaded.synchronize()  # (the previous upload may still be reading the pinned chunk list)
+        table = self._next_table()
         chunks = self._host_c.numpy()
         table[:] = 0
+        self._static_aligned = np.zeros(len(self.entries), dtype=np.int64)
         by_clip = {}
         n_chunks = 0
         for e, g, s1, s2 in live:
@@ -226,6 +270,7 @@ class NativeStep(object):
                     s2.data_ptr() if s2 is not None else 0)
             t = self._slot[id(p)]
             table[t] = ptrs + (p.numel(), e[4], e[5], 1 if all(a % 16 == 0 for a in ptrs) else 0)
+            self._static_aligned[t] = 1 if all(a % 16 == 0 for a in (ptrs[0], ptrs[2], ptrs[3])) else 0
             k = (p.numel() + self.chunk - 1) // self.chunk
             chunks[n_chunks:n_chunks + k, 0] = t
             chunks[n_chunks:n_chunks + k, 1] = range(0, k * self.chunk, self.chunk)
@@ -236,21 +281,29 @@ class NativeStep(object):
         if any(c not in by_clip for c in range(len(self.clip_norms))):
             raise _Unsupported()
         self._live_clips = [(mx,) + tuple(by_clip[c]) for c, mx in enumerate(self.clip_norms)]
-        self._dev_t.copy_(self._host_t, non_blocking=True)
+        self._upload_table()
         self._dev_c.copy_(self._host_c, non_blocking=True)
         if not torch.cuda.is_current_stream_capturing():
             self._uploaded = torch.cuda.Event()
             self._uploaded.record()
         self._n_chunks = n_chunks
         self._stepped = [l[0] for l in live]
-        self._held = [l[1:] for l in live]  # (the addresses in the table stay valid whatever the caller drops)
+        # the state tensors stay referenced (their addresses are in the table whatever the caller drops); the
+        # gradients do NOT: they are read by the launch that follows, in stream order, and holding them would keep
+        # their memory from being handed out again - next step's gradients would land elsewhere, and the tables
+        # would be rebuilt every step
+        self._held = [l[2:] for l in live]
         self.rebuilds += 1
 
     def step(self):
         """clip + step every parameter that has a gradient; returns the clip sets' total norms (device tensor)"""
         key = tuple(0 if e[0].grad is None else e[0].grad.data_ptr() for e in self.entries)
         sig = self._signature()
-        if key != self._key or sig != self._sig:
+        if sig == self._sig and self._key is not None and key != self._key and len(key) == len(self._key) \
+                and all((a == 0) == (b == 0) for a, b in zip(key, self._key)):
+            self._move_gradients(key)
+            self._key = key
+        elif key != self._key or sig != self._sig:
             self._build_tables()
             self._key, self._sig = key, self._signature()
         if not self._stepped:
