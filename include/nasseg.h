@@ -143,7 +143,7 @@ int64_t nasseg_conv_pw_min_pixels(int64_t v);
  * statistics differ in the rounding of their partial sums; row counts from nasseg_conv_fwd_stats_blocks are valid
  * for the setting they were asked under. */
 int nasseg_conv_pwn_mode(int v);
-/* The general MFMA kernel on maps of at most 32768 pixels (the 11 x 11 ... 41 x 41 maps of the CVPR decoders and of the
+/* The general MFMA kernel on maps of at most 8192 pixels (the 11 x 11 ... 21 x 21 maps of the CVPR decoders and of the
  * MobileNetV2 tail at 321 x 321): 1 (initial) four 16-channel steps of the reduction per memory round trip instead of
  * one - with a workgroup per CU or fewer there is no other wave to hide it (960 -> 160 at 16 x 11 x 11: 60 round trips,
  * 78 us for 0.6 GFLOP); 0: one step, as on large maps.  v < 0 only queries.  Returns the previous setting.

@@ -102,7 +102,7 @@ __device__ __forceinline__ float4 load4(const bf16_t* row, int k, int K) {
 // STATS == 3: only the act' mask of STATS == 2 (b_scale / b_shift may be null = identity): the
 // backward of an activation that was applied on load, without a pass over dx and x.
 // KU_: k-steps of X requested per iteration (see NASSEG_CONV_KU): 1 on large maps, where other waves hide a round
-// trip; 4 on SMALL maps (launch_one: at most kDeepKMaxPixels pixels), where a workgroup per CU or fewer runs and the
+// trip; 4 on SMALL maps (launch_one: at most kDeepKMaxPixels = 8192 pixels), where a workgroup per CU or fewer runs and the
 // reduction is a chain of round trips - 960 -> 160 at 16 x 11 x 11: 60 of them, 78 us for 0.6 GFLOP.
 template <int MT, int NT, int KM, bool GATHER, bool PRO, bool VECN, bool EPI, int STATS, bool WS,
           int KU_ = NASSEG_CONV_KU>
@@ -1003,8 +1003,10 @@ __global__ void pack_multi_kernel(PackTable t) {
   }
 }
 
-// maps up to this many pixels take four k-steps per round trip (conv_fwd_kernel's KU_)
-constexpr int64_t kDeepKMaxPixels = 32768;
+// maps up to this many pixels take four k-steps per round trip (conv_fwd_kernel's KU_) and the 16-pixel workgroups
+// of conv_small_ws (32768 measured worse on the teacher's 256-channel 3x3 convs at 16 x 32 x 32: 64 x K x 9 weights
+// per 16 pixels)
+constexpr int64_t kDeepKMaxPixels = 8192;
 struct Mode {
   int km;
   bool gather, pro, vecn, epi;
@@ -1120,8 +1122,12 @@ int launch_pw(const FwdArgs& a, const PwFwdPlan& p, int stats, hipStream_t s) {
 // whatever N - 16 x 11 x 11 pixels into 64 channels are 31 workgroups of 64 x 64 tiles otherwise, 124 waves on 1024
 // SIMDs each multiplying for 8 us (3x3, 64 -> 64: 33 us; 484 waves and 11 us this way).  A function of (pixels, N, K)
 // alone: nasseg_conv_fwd_stats_blocks must predict the rows.  K >= 8 keeps the flat small-K form out of it.
+// N * K <= 192 K: a workgroup reads 64 x K weights for its 16 pixels - the KD teacher's 1024 -> 1024 ... 2048 -> 2048
+// convs on 16 x 8 x 8 ... 16 x 16 x 16 maps re-read megabytes of weights per workgroup this way (teacher inference
+// 1127 -> 956 images/s before this bound); MobileNetV2's 960 -> 160 (47 instead of 78 us) is inside.
 inline bool conv_small_ws(int64_t Mtot, int N, int K) {
-  return g_conv_deep_k.load() != 0 && Mtot <= kDeepKMaxPixels && (N & 3) == 0 && (K & 3) == 0 && K >= 8;
+  return g_conv_deep_k.load() != 0 && Mtot <= kDeepKMaxPixels && (N & 3) == 0 && (K & 3) == 0 && K >= 8 &&
+         (int64_t)N * K <= 196608;
 }
 
 // geometries of the LDS-tiled 3x3 kernel (conv3x3_lds_kernel); K * 9 > 64 keeps the flat small-K form out
@@ -1181,7 +1187,11 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s, const TailArgs* tai
     if (tiles == 3) return launch_lds3x3<3>(a, md.vecn, veck, md.stats == 1, s);
     return launch_lds3x3<4>(a, md.vecn, veck, md.stats == 1, s);
   }
-  if (conv_small_ws((int64_t)g.B * g.Ho * g.Wo, N, K)) {
+  // (without statistics rows to keep in step with the dispatch is free to look at the taps as well: a workgroup of the
+  //  small-map form reads 64 x K x taps weights for 16 pixels - past 1024 x 64 of them the large-map tiling wins, the KD
+  //  teacher's 256 -> 256 3x3 convs at 16 x 16 x 16)
+  const bool rows_asked = md.stats == 1 || md.stats == 2;
+  if (conv_small_ws((int64_t)g.B * g.Ho * g.Wo, N, K) && (rows_asked || K * g.kh * g.kw <= 1024)) {
     if (md.km == KM_VEC && md.vecn) return launch_one<1, 1, true>(a, md, s);
     // (statistics rows were counted for that kernel's 16-pixel workgroups)
     NASSEG_REQUIRE(md.stats != 1 && md.stats != 2,
@@ -1262,7 +1272,7 @@ int nasseg_pack_weights(int count, const float* const* w, float* const* wp, cons
 int64_t nasseg_conv_pw_min_pixels(int64_t v) {
   return v == -1 ? g_pw_min_pixels.load() : g_pw_min_pixels.exchange(v < 0 ? -2 : v);
 }
-// four k-steps per round trip in the general kernel on maps of at most 32768 pixels: 1 (initial) on, 0 off;
+// four k-steps per round trip in the general kernel on maps of at most 8192 pixels: 1 (initial) on, 0 off;
 // v < 0 only queries.  Returns the previous setting.  Bit-identical results (the same accumulation order).
 int nasseg_conv_deep_k(int v) {
   if (v < 0) return g_conv_deep_k.load();

@@ -11,7 +11,7 @@ WHAT="${1:-all}"
 python -c "import torch; print(torch.__version__, torch.cuda.is_available(), torch.cuda.get_device_name(0))" > $OUT/env.log 2>&1
 (rocm-smi --showuniqueid --showpower 2>/dev/null | grep -i "unique\|power" | head -4) >> $OUT/env.log; nproc >> $OUT/env.log; grep -m1 "model name" /proc/cpuinfo >> $OUT/env.log
 if [[ "$WHAT" == "all" || "$WHAT" == "tests" ]]; then
-  for f in tests/test_hip_kernels.py tests/test_hip_anchor.py tests/test_hip_golden.py tests/test_hip_engine.py tests/test_hip_bf16.py tests/test_hip_fullsize.py; do
+  for f in tests/test_hip_kernels.py tests/test_hip_anchor.py tests/test_hip_golden.py tests/test_hip_engine.py tests/test_hip_bf16.py tests/test_hip_fullsize.py tests/test_hip_optim.py; do
     n=$(basename $f .py)
     timeout 900 python -m pytest $f -m gpu -q --tb=short --timeout 600 -p no:cacheprovider -s > $OUT/$n.log 2>&1
     echo "$n exit $?" >> $OUT/summary.log
