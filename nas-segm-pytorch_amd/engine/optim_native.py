@@ -334,11 +334,16 @@ def _find(groups):
     first = next((o for _, _, o in groups if o is not None), None)
     if first is None or not ENABLED:
         return None
-    key = tuple((id(o), float(m), len(p)) for p, m, o in groups)
+    params = [p if isinstance(p, (list, tuple)) else list(p) for p, _, _ in groups]
+    # (what a cached stepper was built for: these optimiser objects, these parameter lists - first and last tensor and
+    #  the count -, these clip norms, the optimisers' own groups as they are now)
+    key = tuple((id(o), float(m), len(p), id(p[0]) if p else 0, id(p[-1]) if p else 0,
+                 0 if o is None else len(o.param_groups),
+                 0 if o is None else sum(len(g["params"]) for g in o.param_groups))
+                for p, (_, m, o) in zip(params, groups))
     cached = getattr(first, "_nasseg_native_step", None)
     if cached is not None and cached[0] == key:
         return cached[1]
-    params = [list(p) for p, _, _ in groups]
     stepper = NativeStep.build([(p, m, o) for p, (_, m, o) in zip(params, groups)])
     first._nasseg_native_step = (key, stepper)
     return stepper

@@ -233,3 +233,29 @@ def test_against_torch_optimisers_on_the_device():
                 assert torch.equal(p.detach(), r.detach()), hp
             else:
                 assert torch.allclose(p.detach(), r.detach(), rtol=1e-6, atol=1e-8), hp
+
+
+def test_cached_stepper_follows_the_objects_it_is_handed():
+    """clip_and_step caches its NativeStep on the optimiser; another parameter list, an added param_group or another
+    clip norm must not be stepped with the old tables"""
+    from nas_segm_amd.engine.trainer_common import clip_and_step
+
+    ps = [nn.Parameter(p.detach().to(DEV)) for p in _params(8)]
+    extra = nn.Parameter(torch.randn(33, device=DEV))
+    ref = [nn.Parameter(p.detach().cpu().clone()) for p in ps]
+    rextra = nn.Parameter(extra.detach().cpu().clone())
+    o, ro = torch.optim.SGD(ps, lr=0.1, momentum=0.9), torch.optim.SGD(ref, lr=0.1, momentum=0.9)
+    for s in range(4):
+        if s == 2:
+            o.add_param_group({"params": [extra], "lr": 0.05})
+            ro.add_param_group({"params": [rextra], "lr": 0.05})
+            ps, ref = ps + [extra], ref + [rextra]
+        for p, r, g in zip(ps, ref, _grads(ref, s, 1.0)):
+            p.grad, r.grad = g.to(DEV), g.clone()
+        clip = 0.7 if s < 3 else 0.4
+        clip_and_step([(ps, clip, o)])
+        nn.utils.clip_grad_norm_(ref, clip)
+        ro.step()
+        assert o._nasseg_native_step[1] is not None
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-7)
