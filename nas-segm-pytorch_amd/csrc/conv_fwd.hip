@@ -1006,7 +1006,12 @@ __global__ void pack_multi_kernel(PackTable t) {
 // maps up to this many pixels take four k-steps per round trip (conv_fwd_kernel's KU_) and the 16-pixel workgroups
 // of conv_small_ws (32768 measured worse on the teacher's 256-channel 3x3 convs at 16 x 32 x 32: 64 x K x 9 weights
 // per 16 pixels)
-constexpr int64_t kDeepKMaxPixels = 8192;
+// (16384 measured on one box: config-5 shape bf16 replayed 775 -> 767, the KD teacher 1123 -> 1087, CVPR 321x321 and
+//  task0 unchanged)
+#ifndef NASSEG_DEEPK_MAX
+#define NASSEG_DEEPK_MAX 8192
+#endif
+constexpr int64_t kDeepKMaxPixels = NASSEG_DEEPK_MAX;
 struct Mode {
   int km;
   bool gather, pro, vecn, epi;
