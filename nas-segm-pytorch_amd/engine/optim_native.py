@@ -19,6 +19,7 @@ NASSEG_NATIVE_OPTIM=0 switches this off (A/B measurements).
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -328,6 +329,17 @@ class _Unsupported(RuntimeError):
     """(a RuntimeError: a hipGraph capture that meets it falls back to host launches, engine/trainer.py)"""
 
 
+# steppers built by clip_and_step, per (first) optimiser object - kept OUTSIDE the optimiser (a weak mapping), so that
+# copying or pickling an optimiser never meets device tensors and events of ours
+_CACHE = weakref.WeakKeyDictionary()
+
+
+def cached_stepper(optim):
+    """the NativeStep clip_and_step last used with `optim` as its first optimiser (None: torch's implementations)"""
+    ent = _CACHE.get(optim)
+    return None if ent is None else ent[1]
+
+
 def _find(groups):
     """the NativeStep cached for these (parameters, max_norm, optimiser) groups, built on first use; None when
     torch's implementations have to run"""
@@ -341,11 +353,11 @@ def _find(groups):
                  0 if o is None else len(o.param_groups),
                  0 if o is None else sum(len(g["params"]) for g in o.param_groups))
                 for p, (_, m, o) in zip(params, groups))
-    cached = getattr(first, "_nasseg_native_step", None)
+    cached = _CACHE.get(first)
     if cached is not None and cached[0] == key:
         return cached[1]
     stepper = NativeStep.build([(p, m, o) for p, (_, m, o) in zip(params, groups)])
-    first._nasseg_native_step = (key, stepper)
+    _CACHE[first] = (key, stepper)
     return stepper
 
 
@@ -358,6 +370,6 @@ def native_clip_and_step(groups):
         stepper.step()
     except _Unsupported:
         first = next(o for _, _, o in groups if o is not None)
-        first._nasseg_native_step = (first._nasseg_native_step[0], None)
+        _CACHE[first] = (_CACHE[first][0], None)
         return False
     return True

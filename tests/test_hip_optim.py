@@ -256,6 +256,7 @@ def test_cached_stepper_follows_the_objects_it_is_handed():
         clip_and_step([(ps, clip, o)])
         nn.utils.clip_grad_norm_(ref, clip)
         ro.step()
-        assert o._nasseg_native_step[1] is not None
+        from nas_segm_amd.engine.optim_native import cached_stepper
+        assert cached_stepper(o) is not None
     for p, r in zip(ps, ref):
         assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-7)

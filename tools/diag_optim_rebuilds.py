@@ -5,6 +5,7 @@ import torch
 import bench
 import nas_segm_amd  # noqa: F401
 from nas_segm_amd.engine.trainer import segmenter_step
+from nas_segm_amd.engine.optim_native import cached_stepper
 dev = torch.device("cuda", 0)
 for wl_name in ("headline", "cvpr321"):
     wl = bench.WORKLOADS[wl_name]
@@ -16,5 +17,5 @@ for wl_name in ("headline", "cvpr321"):
     for i in range(8):
         segmenter_step(seg, image, mask, oe, od, 255, 3.0, 3.0, -1)
     torch.cuda.synchronize()
-    print(wl_name, "steps 8, table rebuilds", oe._nasseg_native_step[1].rebuilds, "gradient moves", oe._nasseg_native_step[1].moves)
+    print(wl_name, "steps 8, table rebuilds", cached_stepper(oe).rebuilds, "gradient moves", cached_stepper(oe).moves)
     del seg, net, oe, od
