@@ -433,13 +433,15 @@ def kernel_family(name, a):
             NF.lib.query("nasseg_conv_pointwise_kernel", B, Ho, Wo, N, K, mode)]
 
     if base == "nasseg_conv_fwd":
-        # (conv_fwd.hip:conv_dispatch) 3x3, stride 1, dilation <= 2, plain forward form, at least one
-        # 8x32 tile, N <= 64, not the flat small-K path: the LDS-tiled kernel
+        # (conv_fwd.hip:conv_dispatch) 3x3, stride 1, plain forward form: the LDS-tiled kernel where the library says so
         B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil, transposed = a[13:26]
         pro = bool(a[5] or a[6] or a[7])
-        if (not transposed and kh == 3 and kw == 3 and stride == 1 and dil <= 2 and kh * kw * K > 64 and not pro
-                and not a[26] and N <= 64 and Wo >= 32 and Ho >= 8 and 0 <= pad <= 2 * dil):
-            return "conv3x3_lds_kernel"
+        if not transposed and not pro and kh == 3 and kw == 3:
+            from nas_segm_amd import functional as NF
+
+            # (the library's own answer, as for the pointwise kernels: dilation <= 3, statistics rows included)
+            if NF.lib.query("nasseg_conv_fwd_lds3x3", B, Ho, Wo, N, K, kh, kw, stride, pad, dil, int(bool(a[26]))):
+                return "conv3x3_lds_kernel"
         if kh == 1 and kw == 1 and stride == 1 and pad == 0 and (Hs, Ws) == (Ho, Wo) and K % 4 == 0 and N % 4 == 0:
             return pointwise_kernel(B, Ho, Wo, N, K, 1)
         return "conv_fwd_kernel"

@@ -154,6 +154,11 @@ int nasseg_conv_deep_k(int v);
  * as for nasseg_conv_fwd_stats_blocks (1 forward, 2 backward-data).  For measurement tools (bench.py names kernel
  * families by it). */
 int64_t nasseg_conv_pointwise_kernel(int B, int Ho, int Wo, int N, int K, int pointwise);
+/* 1 when a plain (not transposed, no input prologue) nasseg_conv_fwd call of this geometry takes the LDS-tiled 3x3
+ * kernel (conv3x3_lds_kernel): stride 1, dilation <= 3, at least one 8 x 32 tile, N <= 64; with_stats: the call asks for
+ * statistics rows (served there when N % 4 == 0).  For measurement tools, like nasseg_conv_pointwise_kernel. */
+int64_t nasseg_conv_fwd_lds3x3(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil,
+                               int with_stats);
 /* nasseg_conv_fwd with statistics rows (no output epilogue, no residual), and the BatchNorm behind it finished in
  * the SAME launch where the kernel that serves the call can (csrc/tail.h: the workgroup that finishes last sums the
  * rows - write-through rows, drained stores, a device-scope ticket, no fence - in a fixed order, fp64).  Returns 1

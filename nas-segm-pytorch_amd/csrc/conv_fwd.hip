@@ -1328,6 +1328,17 @@ int64_t nasseg_conv_pointwise_kernel(int B, int Ho, int Wo, int N, int K, int po
 #endif  // NASSEG_FP32_ONLY
 
 #if NASSEG_FP32_ONLY
+// does a plain forward call take conv3x3_lds_kernel?  (conv_dispatch's own condition, for measurement tools)
+int64_t nasseg_conv_fwd_lds3x3(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil,
+                               int with_stats) {
+  return lds3x3_geometry(B, Ho, Wo, N, K, kh, kw, stride, pad, dil) && fwd_pack_mode(K, kh, kw) != 2 &&
+                 (!with_stats || (N & 3) == 0)
+             ? 1
+             : 0;
+}
+#endif  // NASSEG_FP32_ONLY
+
+#if NASSEG_FP32_ONLY
 // which packing nasseg_conv_fwd expects for a forward (non-transposed) convolution
 int nasseg_conv_fwd_pack_mode(int K, int kh, int kw) { return fwd_pack_mode(K, kh, kw); }
 #endif  // NASSEG_FP32_ONLY

@@ -62,8 +62,11 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
 __global__ __launch_bounds__(256) void optim_norm_kernel(OptimArgs a) {
   __shared__ double red[16];
   const int tid = threadIdx.x;
+  // (only rows that are stepped: a table row without a gradient this step - T_G == 0 - is not stepped by torch
+  //  either, and its bias correction must not run ahead of the optimiser's own state["step"])
   if (blockIdx.x == 0)
-    for (int i = tid; i < a.n_tensors; i += 256) a.dstep[i] += 1.f;
+    for (int i = tid; i < a.n_tensors; i += 256)
+      if (a.tensors[(int64_t)i * T_COLS + T_G] != 0) a.dstep[i] += 1.f;
   if (a.n_chunks == 0) return;
   const int t = a.chunks[2 * blockIdx.x], off = a.chunks[2 * blockIdx.x + 1];
   const int64_t* row = a.tensors + (int64_t)t * T_COLS;

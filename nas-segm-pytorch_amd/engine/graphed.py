@@ -200,6 +200,7 @@ class _GraphedStep(object):
         # capturing executes nothing: state is exactly as restored above.  The gradients the
         # capture left in ``param.grad`` are the static tensors every replay refills.
         self._static_grads = [(p, p.grad) for p in self._params if p.grad is not None]
+        self._captured_hyper = self._native.hyper_values() if self._native is not None else None
 
     def _sync_gradients(self):
         """the step's gradient collective - RankParallel's, so that the failure protocol (status element,
@@ -212,8 +213,16 @@ class _GraphedStep(object):
 
     def _replay(self):
         native = self._native if self.capture_optimisers else None
-        if native is not None and not native.host_steps_match():
-            native.sync_steps()  # (the optimisers were stepped or reloaded outside this graph)
+        if native is not None:
+            # lr, weight decay, betas, eps and the clip norms were recorded BY VALUE (kernel arguments of
+            # nasseg_optim_step): a schedule that edits param_group["lr"] must not be ignored silently
+            if native.hyper_values() != self._captured_hyper:
+                raise F.NassegError("graphed step: an optimiser's hyper-parameters changed after its step was "
+                                    "captured (capture_optimisers=True bakes lr / weight decay / betas / eps / "
+                                    "max_norm into the graph) - build a new stepper, or keep the optimisers "
+                                    "outside the graph (capture_optimisers=False reads param_groups every step)")
+            if not native.host_steps_match():
+                native.sync_steps()  # (the optimisers were stepped or reloaded outside this graph)
         self.graph.replay()
         if native is not None:
             native.bump_host_steps()

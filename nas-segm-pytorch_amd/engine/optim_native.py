@@ -70,7 +70,12 @@ class NativeStep(object):
 
     def __init__(self, groups):
         self.chunk = int(F.lib.query("nasseg_optim_chunk"))
-        self.entries = []   # (param, optimiser, param_group, kind, clip set or -1, hyper group index)
+        # (param, weak reference to its optimiser, param_group, kind, clip set or -1, hyper group index).  The
+        # optimisers are referenced WEAKLY: this object lives in a cache keyed by one of them (_CACHE), and a cached
+        # value that owned its key would keep optimiser, parameters, gradients, state and the pinned tables below
+        # alive for the life of the process - the search makes new optimisers per candidate and task
+        # (src/main_search.py:575)
+        self.entries = []
         self.clip_norms = []  # max_norm per clip set
         self.hyper_src = []  # (kind, param_group) per hyper group
         seen = set()
@@ -80,6 +85,7 @@ class NativeStep(object):
             if optim is None or type(optim) not in (torch.optim.SGD, torch.optim.Adam):
                 raise _Unsupported()
             kind = 0 if type(optim) is torch.optim.SGD else 1
+            oref = weakref.ref(optim)
             clip = -1
             if max_norm > 0:
                 clip = len(self.clip_norms)
@@ -108,12 +114,12 @@ class NativeStep(object):
                 if id(g) not in hyper_of:
                     hyper_of[id(g)] = len(self.hyper_src)
                     self.hyper_src.append((kind, g))
-                self.entries.append((p, optim, g, kind, clip, hyper_of[id(g)]))
+                self.entries.append((p, oref, g, kind, clip, hyper_of[id(g)]))
         if not self.entries or len(self.hyper_src) > 8 or len(self.clip_norms) > 8:
             raise _Unsupported()
         self.device = device
         self._slot = dict((id(e[0]), i) for i, e in enumerate(self.entries))
-        self._optims = []
+        self._optims = []  # (weak references, one per optimiser)
         for e in self.entries:
             if not any(e[1] is o for o in self._optims):
                 self._optims.append(e[1])
@@ -147,10 +153,10 @@ class NativeStep(object):
 
     # -- optimiser state, with torch's names ------------------------------------------------------
     def _state(self, entry):
-        p, optim, group, kind = entry[:4]
+        p, oref, group, kind = entry[:4]
         if kind == 0 and group["momentum"] == 0:
             return None, None  # (torch keeps no state for it either: optim.state stays without an entry)
-        st = optim.state[p]
+        st = _alive(oref).state[p]
         if kind == 0:
             if st.get("momentum_buffer") is None:
                 # torch clones d_p here on the first step; zeros + "buf = momentum * buf + d_p" is the same value
@@ -169,14 +175,14 @@ class NativeStep(object):
         """changes when an optimiser's state mapping was replaced (load_state_dict), emptied or extended, or its
         param_groups edited: the tables hold addresses of state tensors"""
         return tuple((id(o.state), len(o.state), len(o.param_groups), sum(len(g["params"]) for g in o.param_groups))
-                     for o in self._optims)
+                     for o in (_alive(r) for r in self._optims))
 
     def sync_steps(self):
         """device step counters := the optimisers' ``state["step"]`` (after load_state_dict, after the state was
         put back behind a graph capture's warm-up, after torch itself stepped in between ...)"""
         host = []
         for e in self.entries:
-            st = e[1].state.get(e[0], {})
+            st = _alive(e[1]).state.get(e[0], {})
             host.append(float(st["step"]) if e[3] == 1 and "step" in st else 0.0)
         self.dstep.copy_(torch.tensor(host, dtype=torch.float32))
         self._host_steps_seen = host
@@ -187,19 +193,23 @@ class NativeStep(object):
         optim.step() or another NativeStep on the same optimisers moves it)"""
         for i, e in enumerate(self._stepped):
             if e[3] == 1:
-                st = e[1].state.get(e[0])
+                st = _alive(e[1]).state.get(e[0])
                 return (st is not None and "step" in st
                         and float(st["step"]) == self._host_steps_seen[self._slot[id(e[0])]])
         return True
 
     def bump_host_steps(self):
         """the CPU step counters follow the device's (after a host-launched step, after a hipGraph replay)"""
-        steps = [e[1].state[e[0]]["step"] for e in self._stepped if e[3] == 1]
+        steps = [_alive(e[1]).state[e[0]]["step"] for e in self._stepped if e[3] == 1]
         if steps:
             torch._foreach_add_(steps, 1)
             for e in self._stepped:
                 if e[3] == 1:
                     self._host_steps_seen[self._slot[id(e[0])]] += 1.0
+
+    def hyper_values(self):
+        """what a recorded step has baked in by value: every hyper group's numbers and the clip norms"""
+        return (tuple(_hyper(kind, g) for kind, g in self.hyper_src), tuple(self.clip_norms))
 
     def prepare_capture(self):
         """before this object's step is recorded into a hipGraph: nothing of an earlier upload is in flight"""
@@ -327,6 +337,15 @@ class NativeStep(object):
 
 class _Unsupported(RuntimeError):
     """(a RuntimeError: a hipGraph capture that meets it falls back to host launches, engine/trainer.py)"""
+
+
+def _alive(oref):
+    """the optimiser behind a NativeStep's weak reference (callers hand the optimisers in with every step, so a
+    dead one means the stepper outlived its owner: torch's path then)"""
+    optim = oref()
+    if optim is None:
+        raise _Unsupported()
+    return optim
 
 
 # steppers built by clip_and_step, per (first) optimiser object - kept OUTSIDE the optimiser (a weak mapping), so that

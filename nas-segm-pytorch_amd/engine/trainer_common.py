@@ -15,6 +15,8 @@ def clip_and_step(groups, native=None):
     if native is not None:
         native.step()
         return
+    # (a caller may hand generators - model.parameters(): both the native path and torch's walk them)
+    groups = [(p if isinstance(p, (list, tuple)) else list(p), m, o) for p, m, o in groups]
     from .optim_native import native_clip_and_step
 
     if native_clip_and_step(groups):

@@ -260,3 +260,52 @@ def test_cached_stepper_follows_the_objects_it_is_handed():
         assert cached_stepper(o) is not None
     for p, r in zip(ps, ref):
         assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_cache_dies_with_its_optimiser():
+    """the stepper cache is keyed weakly by the first optimiser and its values hold the optimisers weakly: dropping
+    optimiser and parameters frees the stepper - parameters, gradients, state, device tables and pinned buffers (the
+    search makes new optimisers per candidate and task, src/main_search.py:575)"""
+    import gc
+    import weakref
+
+    from nas_segm_amd.engine import optim_native
+    from nas_segm_amd.engine.trainer_common import clip_and_step
+
+    gc.collect()
+    before = len(optim_native._CACHE)
+    probes = []
+    for seed in range(5):
+        ps = [nn.Parameter(p.detach().to(DEV)) for p in _params(20 + seed)]
+        o = torch.optim.Adam(ps, lr=1e-3)
+        for p, g in zip(ps, _grads(ps, 0, 1.0)):
+            p.grad = g.to(DEV)
+        clip_and_step([(ps, 1.0, o)])
+        stepper = optim_native.cached_stepper(o)
+        assert stepper is not None
+        probes.append((weakref.ref(o), weakref.ref(stepper), weakref.ref(ps[0])))
+        del ps, o, stepper, p, g
+    gc.collect()
+    assert len(optim_native._CACHE) == before
+    assert all(r() is None for probe in probes for r in probe)
+
+
+def test_adam_parameter_that_misses_steps_keeps_its_own_step_count():
+    """a parameter without a gradient is not stepped - by torch or here - and its bias correction resumes from ITS
+    count when the gradient comes back (the device counters advance for stepped rows only)"""
+    from nas_segm_amd.engine.optim_native import NativeStep
+
+    ref = [nn.Parameter(p.detach().clone()) for p in _params(11)]
+    ps = [nn.Parameter(p.detach().to(DEV)) for p in _params(11)]
+    ro, o = torch.optim.Adam(ref, lr=3e-3), torch.optim.Adam(ps, lr=3e-3)
+    native = NativeStep.build([(ps, 0.0, o)])
+    for s in range(6):
+        skip = (1, 4) if 1 <= s <= 3 else ()
+        for p, r, g in zip(ps, ref, _grads(ref, s, 0.5, skip=skip)):
+            p.grad, r.grad = (None if g is None else g.to(DEV)), g
+        native.step()
+        ro.step()
+    for i, (p, r) in enumerate(zip(ps, ref)):
+        assert float(o.state[p]["step"]) == float(ro.state[r]["step"]), i
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=2e-5, atol=1e-7), i
+    assert [float(v) for v in native.dstep.cpu()] == [float(ro.state[r]["step"]) for r in ref]

@@ -413,3 +413,27 @@ def test_native_call_shim_agrees_with_ctypes():
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stderr[-2000:]
     assert int(out.stdout.strip()) == lib.query("nasseg_cat_src_blocks", 4, 32, 64, 64)
+
+
+def test_clip_and_step_accepts_generators():
+    """clip_and_step is a public helper: parameters handed as a generator - model.parameters() -
+    are clipped AND stepped on torch's path too (an exhausted generator would skip the clipping silently)"""
+    import torch
+    from torch import nn
+
+    from nas_segm_amd.engine.trainer_common import clip_and_step
+
+    def run(as_generator):
+        torch.manual_seed(0)
+        m = nn.Linear(7, 5)
+        o = torch.optim.SGD(m.parameters(), lr=0.5)
+        for p in m.parameters():
+            p.grad = torch.full_like(p, 3.0)
+        clip_and_step([(m.parameters() if as_generator else list(m.parameters()), 0.1, o)])
+        return [p.detach().clone() for p in m.parameters()], [p.grad.clone() for p in m.parameters()]
+
+    (pg, gg), (pl, gl) = run(True), run(False)
+    for a, b in zip(pg + gg, pl + gl):
+        assert torch.equal(a, b)
+    total = torch.sqrt(sum((g ** 2).sum() for g in gg))
+    assert abs(float(total) - 0.1) < 1e-4  # (the gradients WERE clipped)
