@@ -275,15 +275,20 @@ int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* 
 int nasseg_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
                         int C, int train, int act, float* dx, void* stream);
-/* nasseg_bn_bwd_reduce and (dx not NULL) nasseg_bn_bwd_apply of a small map as ONE launch: a workgroup per four
- * channels walks the M <= nasseg_bn_bwd_small_max_pixels() pixels twice (the second time out of registers or L2).
- * sums[2][C] out; dx = scale * (g - sums0/M - xhat * sums1/M) (train) or scale * g (eval), g = dy * act'(x*scale+shift).
- * The 16 x 11 x 11 ... 16 x 21 x 21 maps of the CVPR cells (micro_decoders.py:54-121) spend three launches of 5-13 us
- * on this otherwise. */
-int64_t nasseg_bn_bwd_small_max_pixels(void);
-int nasseg_bn_bwd_small(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t M, int C,
-                        const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                        int train, float* sums, float* dx, int64_t lddx, void* stream);
+/* BatchNorm backward whose consumer adds up the partial rows of the sums itself (the small maps of the CVPR cells,
+ * micro_decoders.py:54-121: a row-summing launch in front of every BatchNorm backward costs a dependent ~5 us).
+ * nasseg_bn_bwd_reduce_rows: the first stage of nasseg_bn_bwd_reduce only - rows [nasseg_colred_rows(1, M, C)][2][C] in
+ * a buffer of nasseg_colred_workspace(1, M, C) floats.  nasseg_bn_bwd_apply_rows: nasseg_bn_bwd_apply from such rows
+ * (or the statistics rows of a fused backward-data kernel): every workgroup adds them in fp64 in a fixed order; sums_out
+ * (null or [2][C]) receives {sum g, sum g*xhat}.  Meant for nrows * 2 * C * 4 <= nasseg_bn_bwd_apply_rows_max_bytes(). */
+int64_t nasseg_colred_rows(int S, int64_t R, int C);
+int64_t nasseg_bn_bwd_apply_rows_max_bytes(void);
+int nasseg_bn_bwd_reduce_rows(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t M, int C,
+                              const float* scale, const float* shift, const float* mean, const float* invstd, int act,
+                              float* rows, void* stream);
+int nasseg_bn_bwd_apply_rows(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, const float* rows, int nrows, float* sums_out, int64_t M, int C,
+                             int train, int act, float* dx, void* stream);
 
 /* ---- elementwise / copies ----------------------------------------------------
  * BN apply + ReLU/ReLU6 + residual (layer_factory.py:94-158), cell sums
@@ -344,6 +349,16 @@ int64_t nasseg_cat_src_blocks(int B, int Ho, int Wo, int C);
 int nasseg_psum_bwd(const float* dy, const float* za, const float* tsa, int act_a, const float* ca, float* ga,
                     float* part_a, const float* zb, const float* tsb, int act_b, const float* cb, float* gb,
                     float* part_b, float* cpart, int B, int H, int W, int C, void* stream);
+/* Gradient junction of a node with several consumers (a cell's node read by several ops, a block's output read by
+ * later blocks and collect_all: micro_decoders.py:95-121,380-398; torch's autograd adds such gradients pairwise, one
+ * launch and three tensor passes per add): out = g0 + g1 + ... + g(n-1), 1 <= n <= 8, added in that order, all dense
+ * [B*H*W][C]; unused pointers null.  With z / tstats (the node is a conv chain's raw output whose BatchNorm + activation
+ * is pending; tstats: mean | invstd | scale | shift) out is also multiplied by act'(scale*z + shift) and part
+ * [nasseg_cat_src_blocks(B, H, W, C) + 64][2][C] (null: none) receives that BatchNorm's backward sums {sum out,
+ * sum out * xhat} as rows. */
+int nasseg_grad_junction(const float* g0, const float* g1, const float* g2, const float* g3, const float* g4,
+                         const float* g5, const float* g6, const float* g7, int n, const float* z, const float* tstats,
+                         int act, float* out, float* part, int B, int H, int W, int C, void* stream);
 int nasseg_cat_src_fwd(const float* x, const float* scale, const float* shift, int act, float* y, int64_t ldy,
                        int yoff, float* stats, int B, int Hi, int Wi, int C, int Ho, int Wo, void* stream);
 int nasseg_cat_src_bwd(const float* du, const float* slab, int64_t ld, int off, const float* sscale,
@@ -448,9 +463,17 @@ int nasseg_bf16_add_act2(const nasseg_bf16_t* xa, const float* sa, const float* 
 int nasseg_bf16_bn_bwd_apply(const nasseg_bf16_t* dy, const nasseg_bf16_t* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
                         int C, int train, int act, nasseg_bf16_t* dx, void* stream);
-int nasseg_bf16_bn_bwd_small(const nasseg_bf16_t* dy, int64_t lddy, const nasseg_bf16_t* x, int64_t ldx, int64_t M, int C,
-                             const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                             int train, float* sums, nasseg_bf16_t* dx, int64_t lddx, void* stream);
+int nasseg_bf16_bn_bwd_reduce_rows(const nasseg_bf16_t* dy, int64_t lddy, const nasseg_bf16_t* x, int64_t ldx, int64_t M,
+                                   int C, const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   int act, float* rows, void* stream);
+int nasseg_bf16_bn_bwd_apply_rows(const nasseg_bf16_t* dy, const nasseg_bf16_t* x, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, const float* rows, int nrows, float* sums_out,
+                                  int64_t M, int C, int train, int act, nasseg_bf16_t* dx, void* stream);
+int nasseg_bf16_grad_junction(const nasseg_bf16_t* g0, const nasseg_bf16_t* g1, const nasseg_bf16_t* g2,
+                              const nasseg_bf16_t* g3, const nasseg_bf16_t* g4, const nasseg_bf16_t* g5,
+                              const nasseg_bf16_t* g6, const nasseg_bf16_t* g7, int n, const nasseg_bf16_t* z,
+                              const float* tstats, int act, nasseg_bf16_t* out, float* part, int B, int H, int W, int C,
+                              void* stream);
 int nasseg_bf16_axpby(const nasseg_bf16_t* a, const nasseg_bf16_t* b, const float* alpha, const float* beta, nasseg_bf16_t* y,
                  int64_t n, int C, int act, void* stream);
 int nasseg_bf16_act_bwd(const nasseg_bf16_t* dy, const nasseg_bf16_t* ref, nasseg_bf16_t* dx, int64_t n, int act, void* stream);

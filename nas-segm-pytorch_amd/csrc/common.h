@@ -229,6 +229,71 @@ __device__ __forceinline__ double reduce_partials_n(const float* __restrict__ pa
   __syncthreads();
   return tot;
 }
+// Two columns (e0, e1) of the same rows at once - the sum and the sum of squares of a BatchNorm channel: their loads
+// share one round trip and their slices one set of barriers (bn_stats_finalize_t ran reduce_partials_n twice: loads,
+// wait, barriers, then the same again - on the dependency chain of every BatchNorm of the step).  Per column the
+// order of every addition is that of reduce_partials_n: identical bits.
+template <int SLICES>
+__device__ __forceinline__ void reduce_partials2_n(const float* __restrict__ partial, int nblk, int64_t per,
+                                                   int64_t e0, int64_t e1, bool valid,
+                                                   double (*red0)[NASSEG_RP_ELEMS + 1],
+                                                   double (*red1)[NASSEG_RP_ELEMS + 1], double& out0, double& out1) {
+  const int slice = rp_slice();
+  const int el = rp_elem();
+  double s[8], q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s[i] = q[i] = 0.0;
+  if (valid) {
+    int b = slice;
+    for (; b + 7 * SLICES < nblk; b += 8 * SLICES) {
+      float v[8], w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = partial[(int64_t)(b + i * SLICES) * per + e0];
+        w[i] = partial[(int64_t)(b + i * SLICES) * per + e1];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        s[i] += (double)v[i];
+        q[i] += (double)w[i];
+      }
+    }
+    for (; b < nblk; b += SLICES) {
+      const float v = partial[(int64_t)b * per + e0], w = partial[(int64_t)b * per + e1];
+      s[0] += (double)v;
+      q[0] += (double)w;
+    }
+  }
+  red0[slice][el] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  red1[slice][el] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+  __syncthreads();
+  if (SLICES > 32) {
+    double p0 = 0.0, p1 = 0.0;
+    if (slice < 32) {
+#pragma unroll
+      for (int i = 0; i < SLICES / 32; ++i) {
+        p0 += red0[slice * (SLICES / 32) + i][el];
+        p1 += red1[slice * (SLICES / 32) + i][el];
+      }
+    }
+    __syncthreads();
+    if (slice < 32) {
+      red0[slice][el] = p0;
+      red1[slice][el] = p1;
+    }
+    __syncthreads();
+  }
+  double t0 = 0.0, t1 = 0.0;
+  if (slice == 0) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      t0 += red0[i][el];
+      t1 += red1[i][el];
+    }
+  }
+  out0 = t0;
+  out1 = t1;
+}
 __device__ __forceinline__ double reduce_partials16(const float* __restrict__ partial, int nblk,
                                                     int64_t per, int64_t e, bool valid,
                                                     double (*red)[NASSEG_RP_ELEMS + 1]) {

@@ -86,6 +86,77 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+// bn_bwd_apply_kernel that ADDS UP the partial rows of the sums itself: rows [nrows][2][C] = per-workgroup {sum g,
+// sum g*xhat} as a first-stage reduction (colred_kernel) or a fused backward-data epilogue left them.  Every workgroup
+// sums the few rows it is given in fp64 in a fixed order (thread = (group of four columns, slice of the rows); the slices
+// meet in LDS in slice order), workgroup 0 also writes the sums out (they are the BatchNorm's parameter gradients).  On the
+// small maps of the CVPR cells (src/nn/micro_decoders.py:54-121: 16 x 11 x 11 ... 16 x 41 x 41, 8 - 128 rows) this
+// replaces the row-summing launch in front of every BatchNorm backward: a dependent 5 us launch against one extra
+// round trip to L2 at the head of a kernel that is launched anyway.
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(
+    const act_t* __restrict__ dy, const act_t* __restrict__ x, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ rows, int nrows, float* __restrict__ sums_out, float invM, int train, int act,
+    act_t* __restrict__ dx, int64_t n4, int C4) {
+  extern __shared__ double apply_rows_lds[];
+  double* dsum = apply_rows_lds;                                     // [slices][4 * groups here] <= 1024 doubles
+  float* fin = reinterpret_cast<float*>(apply_rows_lds + 1024);      // [2 C]
+  const int C = C4 * 4, cols = 2 * C, ncol4 = cols >> 2;
+  const int tid = threadIdx.x;
+  for (int cg0 = 0; cg0 < ncol4; cg0 += 256) {
+    const int nh = ncol4 - cg0 < 256 ? ncol4 - cg0 : 256;
+    const int slices = 256 / nh;
+    const int cg = tid % nh, sl = tid / nh;
+    if (sl < slices) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      const float* p = rows + (size_t)(cg0 + cg) * 4;
+#pragma unroll 8
+      for (int r = sl; r < nrows; r += slices) {
+        const float4 v = ld4(p + (size_t)r * cols);
+        a0 += (double)v.x;
+        a1 += (double)v.y;
+        a2 += (double)v.z;
+        a3 += (double)v.w;
+      }
+      double* po = dsum + (size_t)(sl * nh + cg) * 4;
+      po[0] = a0;
+      po[1] = a1;
+      po[2] = a2;
+      po[3] = a3;
+    }
+    __syncthreads();
+    for (int e = tid; e < nh * 4; e += 256) {
+      double t = 0.0;
+      for (int q = 0; q < slices; ++q) t += dsum[(size_t)(q * nh + (e >> 2)) * 4 + (e & 3)];
+      fin[cg0 * 4 + e] = (float)t;
+    }
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && sums_out)
+    for (int e = tid; e < cols; e += 256) sums_out[e] = fin[e];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const float4 d = lda4(dy + i * 4);
+    const float4 v = lda4(x + i * 4);
+    const float4 s = lda4(scale + c4 * 4);
+    const float4 h = lda4(shift + c4 * 4);
+    const float4 z = fma4(v, s, h);
+    float4 g = make_float4(d.x * act_mask(z.x, act), d.y * act_mask(z.y, act),
+                           d.z * act_mask(z.z, act), d.w * act_mask(z.w, act));
+    if (train) {
+      const float4 mu = lda4(mean + c4 * 4);
+      const float4 is = lda4(invstd + c4 * 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(fin + c4 * 4);
+      const float4 s1 = *reinterpret_cast<const float4*>(fin + C + c4 * 4);
+      g.x = g.x - s0.x * invM - (v.x - mu.x) * is.x * s1.x * invM;
+      g.y = g.y - s0.y * invM - (v.y - mu.y) * is.y * s1.y * invM;
+      g.z = g.z - s0.z * invM - (v.z - mu.z) * is.z * s1.z * invM;
+      g.w = g.w - s0.w * invM - (v.w - mu.w) * is.w * s1.w * invM;
+    }
+    sta4(dx + i * 4, mul4(g, s));
+  }
+}
+
 // y = act(alpha[c]*a + beta[c]*b); alpha / beta null = 1; b null = absent
 __global__ __launch_bounds__(256) void axpby_kernel(const act_t* __restrict__ a,
                                                     const act_t* __restrict__ b,
@@ -213,6 +284,28 @@ int NASSEG_FN(bn_bwd_apply)(const act_t* dy, const act_t* x, const float* scale,
   NASSEG_LAUNCH_CHECK("bn_bwd_apply");
   return NASSEG_OK;
 }
+
+// nasseg_bn_bwd_apply from the ROWS of the sums: rows [nrows][2][C] (first-stage partials of nasseg_bn_bwd_reduce_rows,
+// or the statistics rows of a fused backward-data kernel) are added up by every workgroup of this launch (fp64, fixed
+// order) - no nasseg_rows_sum / finalising launch in front of it; sums_out (null or [2][C]) receives the sums, i.e. the
+// BatchNorm's {dbeta, dgamma}.  Meant for few rows: nrows * 2 * C * 4 bytes are read by every workgroup (the caller
+// bounds them; nasseg_bn_bwd_apply_rows_max_bytes()).
+int NASSEG_FN(bn_bwd_apply_rows)(const act_t* dy, const act_t* x, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, const float* rows, int nrows, float* sums_out,
+                                 int64_t M, int C, int train, int act, act_t* dx, void* stream) {
+  NASSEG_REQUIRE(C > 0 && C % 4 == 0 && C <= 1024 && M > 0 && nrows > 0 && rows, "bn_bwd_apply_rows: bad arguments");
+  const size_t lds = 1024 * sizeof(double) + (size_t)2 * C * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(ew_grid(M * C / 4)), dim3(256), lds, (hipStream_t)stream, dy, x,
+                     scale, shift, mean, invstd, rows, nrows, sums_out, (float)(1.0 / (double)M), train, act, dx,
+                     M * C / 4, C / 4);
+  NASSEG_LAUNCH_CHECK("bn_bwd_apply_rows");
+  return NASSEG_OK;
+}
+
+#if NASSEG_FP32_ONLY
+// bytes of rows (nrows * 2 * C * 4) up to which nasseg_bn_bwd_apply_rows is meant to replace a row-summing launch
+int64_t nasseg_bn_bwd_apply_rows_max_bytes(void) { return 64 << 10; }
+#endif
 
 // y = act(alpha[c]*a + beta[c]*b)
 int NASSEG_FN(axpby)(const act_t* a, const act_t* b, const float* alpha, const float* beta, act_t* y,

@@ -215,11 +215,12 @@ __global__ __launch_bounds__(8 * SLICES) void bn_stats_finalize_t(
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
     float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* nbt) {
   __shared__ double red[SLICES][NASSEG_RP_ELEMS + 1];
+  __shared__ double red1[SLICES][NASSEG_RP_ELEMS + 1];
   const int c = blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = c < C;
   const int64_t per = 2 * (int64_t)C;
-  const double s0 = reduce_partials_n<SLICES>(partial, nblk, per, c, valid, red);
-  const double s1 = reduce_partials_n<SLICES>(partial, nblk, per, (int64_t)C + c, valid, red);
+  double s0, s1;  // (both columns of a channel in one pass over the rows: one round trip, one set of barriers)
+  reduce_partials2_n<SLICES>(partial, nblk, per, c, (int64_t)C + c, valid, red, red1, s0, s1);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
   if (!valid || rp_slice() != 0) return;
   const double mu = s0 / M;
@@ -272,108 +273,6 @@ __global__ __launch_bounds__(8 * SLICES) void rows_group_sum_t(const float* __re
   const bool valid = e < per;
   const double s = reduce_partials_n<SLICES>(partial + (int64_t)r0 * per, nr, per, e, valid, red);
   if (valid && rp_slice() == 0) out[(int64_t)g * per + e] = (float)s;
-}
-
-// ---------------------------------------------------------------------------
-// BatchNorm (+ activation) backward of a SMALL map in one launch: the sums {sum g, sum g*xhat} and, if asked for, dx.
-// The general path is three launches (colred_kernel, colred_finalize, bn_bwd_apply_kernel) of 13 + 5 + 6 us at the
-// 16 x 11 x 11 ... 16 x 21 x 21 maps of the CVPR cells - 81 + 81 + 102 launches of the 856 of a replayed 321 x 321
-// step.  Here one workgroup owns one group of four channels: its 256 threads walk the pixels twice (the tensors are
-// a few hundred KB: the second walk is L2 hits, and up to 2048 pixels it is registers), the sums meet in LDS in fp64
-// in a fixed order in between.  Same arithmetic per element as bn_bwd_apply_kernel.
-// ---------------------------------------------------------------------------
-#define NASSEG_BN_SMALL_MAX_PIXELS 2048
-constexpr int kBnSmallKeep = 8;  // pixels per thread kept in registers between the two walks
-
-template <int NTH>  // threads: 256, or 1024 above 2048 pixels (a workgroup streams what its waves have in flight)
-__global__ __launch_bounds__(NTH) void bn_bwd_small_kernel(
-    const act_t* __restrict__ dy, int64_t lddy, const act_t* __restrict__ x, int64_t ldx,
-    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ invstd, int act, int train, float* __restrict__ sums, act_t* __restrict__ dx,
-    int64_t lddx, int M, int C) {
-  __shared__ double red[NTH / 16][8];
-  const int tid = threadIdx.x;
-  const int c = blockIdx.x * 4;
-  const float4 sc = lda4(scale + c), sh = lda4(shift + c);
-  const float4 mu = lda4(mean + c), is = lda4(invstd + c);
-  const bool keep = M <= NTH * kBnSmallKeep;
-  float4 gk[kBnSmallKeep], xk[kBnSmallKeep];
-  double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
-  auto masked = [&](float4 d, float4 v) {
-    const float4 z = fma4(v, sc, sh);
-    return make_float4(d.x * act_mask(z.x, act), d.y * act_mask(z.y, act), d.z * act_mask(z.z, act),
-                       d.w * act_mask(z.w, act));
-  };
-  auto add = [&](float4 g, float4 v) {
-    s0[0] += (double)g.x; s0[1] += (double)g.y; s0[2] += (double)g.z; s0[3] += (double)g.w;
-    s1[0] += (double)(g.x * ((v.x - mu.x) * is.x));
-    s1[1] += (double)(g.y * ((v.y - mu.y) * is.y));
-    s1[2] += (double)(g.z * ((v.z - mu.z) * is.z));
-    s1[3] += (double)(g.w * ((v.w - mu.w) * is.w));
-  };
-  // batches of kBnSmallKeep pixels per thread: their loads are issued together (one round trip per batch)
-  auto load_batch = [&](int p0) {
-#pragma unroll
-    for (int i = 0; i < kBnSmallKeep; ++i) {
-      const int p = p0 + tid + i * NTH;
-      const int pc = p < M ? p : 0;
-      const float4 d = lda4(dy + (int64_t)pc * lddy + c), v = lda4(x + (int64_t)pc * ldx + c);
-      const float4 gm = masked(d, v);
-      const bool in = p < M;
-      gk[i] = make_float4(in ? gm.x : 0.f, in ? gm.y : 0.f, in ? gm.z : 0.f, in ? gm.w : 0.f);
-      xk[i] = v;
-    }
-  };
-  for (int p0 = 0; p0 < M; p0 += NTH * kBnSmallKeep) {
-    load_batch(p0);
-#pragma unroll
-    for (int i = 0; i < kBnSmallKeep; ++i) add(gk[i], xk[i]);
-  }
-  // 8 sums over the threads: rows of 16 lanes by DPP, the rows in order through LDS
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    s0[r] = row16_allsum(s0[r]);
-    s1[r] = row16_allsum(s1[r]);
-  }
-  if ((tid & 15) == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      red[tid >> 4][r] = s0[r];
-      red[tid >> 4][4 + r] = s1[r];
-    }
-  }
-  __syncthreads();
-  float t[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) {
-    double a = 0.0;
-#pragma unroll
-    for (int w = 0; w < NTH / 16; ++w) a += red[w][r];
-    t[r] = (float)a;
-  }
-  if (tid == 0) {
-    sta4(sums + c, make_float4(t[0], t[1], t[2], t[3]));
-    sta4(sums + C + c, make_float4(t[4], t[5], t[6], t[7]));
-  }
-  if (!dx) return;
-  const float invM = (float)(1.0 / (double)M);
-  auto finish = [&](float4 g, float4 v) {
-    if (train) {
-      g.x = g.x - t[0] * invM - (v.x - mu.x) * is.x * t[4] * invM;
-      g.y = g.y - t[1] * invM - (v.y - mu.y) * is.y * t[5] * invM;
-      g.z = g.z - t[2] * invM - (v.z - mu.z) * is.z * t[6] * invM;
-      g.w = g.w - t[3] * invM - (v.w - mu.w) * is.w * t[7] * invM;
-    }
-    return mul4(g, sc);
-  };
-  for (int p0 = 0; p0 < M; p0 += NTH * kBnSmallKeep) {
-    if (!keep) load_batch(p0);  // (one batch in all: it is still in registers)
-#pragma unroll
-    for (int i = 0; i < kBnSmallKeep; ++i) {
-      const int p = p0 + tid + i * NTH;
-      if (p < M) sta4(dx + (int64_t)p * lddx + c, finish(gk[i], xk[i]));
-    }
-  }
 }
 
 // partial rows from which the 1024-thread second stage is used (one round of loads per thread instead of
@@ -583,26 +482,27 @@ int NASSEG_FN(bn_bwd_reduce)(const act_t* dy, int64_t lddy, const act_t* x, int6
   return NASSEG_OK;
 }
 
-// BatchNorm (+ activation) backward of a small map in ONE launch (bn_bwd_small_kernel): sums[2][C] as
-// nasseg_bn_bwd_reduce leaves them and, when dx is not null, dx as nasseg_bn_bwd_apply computes it from them.
-// M <= nasseg_bn_bwd_small_max_pixels(), C and the three row strides multiples of 4.
-int NASSEG_FN(bn_bwd_small)(const act_t* dy, int64_t lddy, const act_t* x, int64_t ldx, int64_t M, int C,
-                            const float* scale, const float* shift, const float* mean, const float* invstd, int act,
-                            int train, float* sums, act_t* dx, int64_t lddx, void* stream) {
-  NASSEG_REQUIRE(M > 0 && M <= NASSEG_BN_SMALL_MAX_PIXELS && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 &&
-                     (!dx || lddx % 4 == 0),
-                 "bn_bwd_small: at most %d pixels, channels and strides multiples of 4", NASSEG_BN_SMALL_MAX_PIXELS);
-  NASSEG_REQUIRE(dy && x && scale && shift && mean && invstd && sums, "bn_bwd_small: null argument");
-  // (above 2048 pixels the three launches win: a workgroup reads 16 bytes of every 4 C-byte pixel row, and C / 4
-  //  workgroups are all there are - 7056 pixels x 64 channels: 45 us against 12, tools/kbench_bnsmall.py)
-  hipLaunchKernelGGL(bn_bwd_small_kernel<256>, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, dy, lddy, x, ldx,
-                       scale, shift, mean, invstd, act, train, sums, dx, lddx, (int)M, C);
-  NASSEG_LAUNCH_CHECK("bn_bwd_small");
-  return NASSEG_OK;
+// First stage of nasseg_bn_bwd_reduce ONLY: rows [nasseg_colred_rows(1, M, C)][2][C] of per-workgroup {sum g, sum g*xhat}
+// in `rows` (a buffer of nasseg_colred_workspace(1, M, C) floats) - for a consumer that adds them up itself
+// (nasseg_bn_bwd_apply_rows).  C and both strides multiples of 4.
+int NASSEG_FN(bn_bwd_reduce_rows)(const act_t* dy, int64_t lddy, const act_t* x, int64_t ldx, int64_t M, int C,
+                                  const float* scale, const float* shift, const float* mean, const float* invstd,
+                                  int act, float* rows, void* stream) {
+  NASSEG_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && rows,
+                 "bn_bwd_reduce_rows: channels and strides must be multiples of 4");
+  RedArgs q = {};
+  q.a = dy; q.lda = lddy; q.b = x; q.ldb = ldx;
+  q.scale = scale; q.shift = shift; q.mean = mean; q.invstd = invstd; q.act = act;
+  q.S = 1; q.R = M; q.C = C; q.partial = rows;
+  return launch_colred<RED_BN_BWD>(q, (hipStream_t)stream);
 }
 
 #if NASSEG_FP32_ONLY
-int64_t nasseg_bn_bwd_small_max_pixels(void) { return NASSEG_BN_SMALL_MAX_PIXELS; }
+// rows the first stage of a per-channel reduction over [S][R][C] leaves per segment (C % 4 == 0, aligned strides)
+int64_t nasseg_colred_rows(int S, int64_t R, int C) {
+  if (S <= 0 || R <= 0 || C <= 0 || (C & 3) || C / 4 > 256) return 0;
+  return red_plan(S, R, C, 4).nblk;
+}
 #endif
 
 }  // extern "C"

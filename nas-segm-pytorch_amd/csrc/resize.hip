@@ -353,6 +353,71 @@ __global__ __launch_bounds__(256) void psum_bwd_kernel(
   block_reduce_groups<2, 2>(scf, sred, cpart + (size_t)blk * 2 * C, base, C4);
 }
 
+// Gradient junction of a node with several consumers (a cell's node read by several ops, a block's output read by the
+// next repeats / blocks and collect_all: src/nn/micro_decoders.py:95-121,380-398): the NG gradients its consumers
+// returned are summed in index order - one launch and NG + 1 tensor passes where autograd's accumulation took NG - 1
+// launches of three passes each - and, when the node is a conv chain's raw output whose BatchNorm + activation is
+// pending (ts: mean | invstd | scale | shift), the sum is multiplied by act'(scale*z + shift) and comes with that
+// BatchNorm's backward sums {sum g, sum g * xhat} as per-workgroup rows `part` (the chain's own mask-and-reduce pass
+// over gradient and z is gone).  Workgroup layout of cat_src_fwd_kernel / psum_bwd_kernel.
+struct JunctionSrc {
+  const act_t* g[8];
+};
+template <int NG>
+__global__ __launch_bounds__(256) void grad_junction_kernel(JunctionSrc src, const act_t* __restrict__ z,
+                                                            const float* __restrict__ ts, int act,
+                                                            act_t* __restrict__ out, float* __restrict__ part, int R,
+                                                            int Wo, int C4) {
+  __shared__ float4 sred[2][4][64];
+  const int C = C4 * 4;
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 256;
+  const int pos = base + tid;
+  const bool live = pos < Wo * C4;
+  const int ox = live ? pos / C4 : 0;
+  const int c4 = live ? pos - ox * C4 : 0;
+  float4 mu = f4zero(), is = f4zero(), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+  if (ts) {
+    mu = lda4(ts + c4 * 4);
+    is = lda4(ts + C + c4 * 4);
+    sc = lda4(ts + 2 * C + c4 * 4);
+    sh = lda4(ts + 3 * C + c4 * 4);
+  }
+  const ActSel as = act_sel(ts ? act : NASSEG_ACT_NONE);
+  float4 acc[2] = {f4zero(), f4zero()};
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const int64_t e = ((int64_t)r * Wo + ox) * C + c4 * 4;
+    float4 gv[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) gv[i] = lda4(src.g[i] + e);
+    float4 zv = f4zero();
+    if (ts) zv = lda4(z + e);
+    float4 g = gv[0];
+#pragma unroll
+    for (int i = 1; i < NG; ++i) g = add4(g, gv[i]);
+    if (ts) {
+      const float4 t = fma4(zv, sc, sh);
+      g = make_float4(g.x * act_mask(t.x, as), g.y * act_mask(t.y, as), g.z * act_mask(t.z, as), g.w * act_mask(t.w, as));
+    }
+    g = keep_if4(g, live);
+    if (live) sta4(out + e, g);
+    if (part) {
+#ifdef NASSEG_BF16
+      g = make_float4(bf16_to_f32(f32_to_bf16(g.x)), bf16_to_f32(f32_to_bf16(g.y)), bf16_to_f32(f32_to_bf16(g.z)),
+                      bf16_to_f32(f32_to_bf16(g.w)));  // (what a reduction pass over the stored gradient would read)
+#endif
+      const float4 xh = make_float4((zv.x - mu.x) * is.x, (zv.y - mu.y) * is.y, (zv.z - mu.z) * is.z,
+                                    (zv.w - mu.w) * is.w);
+      acc[0] = add4(acc[0], g);
+      acc[1] = fma4(g, xh, acc[1]);
+    }
+  }
+  if (part) {
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    block_reduce_groups<2, 2>(acc, sred, part + (size_t)blk * 2 * C, base, C4);
+  }
+}
+
 struct CatGrid {
   int gx, gy;
 };
@@ -707,6 +772,34 @@ int NASSEG_FN(psum_bwd)(const act_t* dy, const act_t* za, const float* tsa, int 
   hipLaunchKernelGGL(psum_bwd_kernel, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, dy, za, tsa, act_a, ca, ga,
                      part_a, zb, tsb, act_b, cb, gb, part_b, cpart, B * H, W, C / 4);
   NASSEG_LAUNCH_CHECK("psum_bwd");
+  return NASSEG_OK;
+}
+
+// out = g0 + g1 + ... (n of them, 1 <= n <= 8, added in that order; dense [B*H*W][C] like out) - and, with a pending
+// BatchNorm + activation of the node (z, tstats: mean | invstd | scale | shift), out *= act'(scale*z + shift) with the
+// rows part [nasseg_cat_src_blocks(B, H, W, C) + 64][2][C] of {sum out, sum out * xhat} (null: no rows).
+int NASSEG_FN(grad_junction)(const act_t* g0, const act_t* g1, const act_t* g2, const act_t* g3, const act_t* g4,
+                             const act_t* g5, const act_t* g6, const act_t* g7, int n, const act_t* z,
+                             const float* tstats, int act, act_t* out, float* part, int B, int H, int W, int C,
+                             void* stream) {
+  JunctionSrc src = {{g0, g1, g2, g3, g4, g5, g6, g7}};
+  NASSEG_REQUIRE(n >= 1 && n <= 8 && out && nasseg_cat_src_blocks(B, H, W, C) > 0 && (!z == !tstats) && (!part || z),
+                 "grad_junction: bad arguments");
+  for (int i = 0; i < n; ++i) NASSEG_REQUIRE(src.g[i], "grad_junction: gradient %d is null", i);
+  const CatGrid gr = cat_grid(B, H, W, C);
+  const dim3 grid(gr.gx, gr.gy), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (n) {
+    case 1: hipLaunchKernelGGL(grad_junction_kernel<1>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+    case 2: hipLaunchKernelGGL(grad_junction_kernel<2>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+    case 3: hipLaunchKernelGGL(grad_junction_kernel<3>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+    case 4: hipLaunchKernelGGL(grad_junction_kernel<4>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+    case 5: hipLaunchKernelGGL(grad_junction_kernel<5>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+    case 6: hipLaunchKernelGGL(grad_junction_kernel<6>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+    case 7: hipLaunchKernelGGL(grad_junction_kernel<7>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+    default: hipLaunchKernelGGL(grad_junction_kernel<8>, grid, block, 0, s, src, z, tstats, act, out, part, B * H, W, C / 4); break;
+  }
+  NASSEG_LAUNCH_CHECK("grad_junction");
   return NASSEG_OK;
 }
 

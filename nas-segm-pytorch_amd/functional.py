@@ -65,16 +65,47 @@ def _vec(like, n):
 # boundary + 5-8 us finaliser it replaces.  The entry points stay (tested, bit-reproducible) for parts where a kernel
 # boundary costs more.
 FUSE_TAIL = os.environ.get("NASSEG_FUSE_TAIL", "0") != "0"
-# BatchNorm backward of a small map (<= 2048 pixels: the 16 x 11 x 11 maps of the CVPR cells) as one launch instead
-# of three (nasseg_bn_bwd_small).  OFF by default: measured neutral on the replayed CVPR 321x321 step (1348 vs 1346
-# img/s with 39 launches fewer - back to back in one stream the three launches cost 10 us, the one 7.7; above 2048
-# pixels the one-workgroup-per-channel-group walk loses outright, tools/kbench_bnsmall.py).  NASSEG_BN_BWD_SMALL=1
-# switches it on.
-BN_BWD_SMALL = os.environ.get("NASSEG_BN_BWD_SMALL", "0") != "0"
+# BatchNorm backward whose apply kernel adds up the partial rows of its sums itself (nasseg_bn_bwd_apply_rows): on the
+# small maps of the CVPR cells the sums come as 8 - 128 rows (the first stage of the reduction over gradient and conv
+# output, or the statistics rows of a fused backward-data kernel), and the launch that summed them - colred_finalize /
+# rows_group_sum, ~5 us on the dependency chain of every BatchNorm backward, 81 + 60 of the ~1000 kernels of a replayed
+# CVPR 321x321 step - is replaced by one more round trip to L2 at the head of the apply kernel.  Rows beyond
+# nasseg_bn_bwd_apply_rows_max_bytes() keep the summing launch.  NASSEG_APPLY_ROWS=0 restores it everywhere (A/B).
+APPLY_ROWS = os.environ.get("NASSEG_APPLY_ROWS", "1") != "0"
 
 
-def _bn_small_ok(M, C):
-    return BN_BWD_SMALL and C % 4 == 0 and M <= lib.query("nasseg_bn_bwd_small_max_pixels")
+def _rows_small(nrows, C):
+    """few enough rows of 2 C floats for every workgroup of the apply kernel to add them up itself"""
+    return (APPLY_ROWS and C % 4 == 0 and C <= 1024 and 0 < nrows
+            and nrows * 2 * C * 4 <= lib.query("nasseg_bn_bwd_apply_rows_max_bytes"))
+
+
+def _bn_bwd_apply(g, z, scale, shift, mean, invstd, sums, M, C, training, act, dz, rows=None):
+    """dz of a BatchNorm (+ activation) backward from the summed sums, or - rows = (buffer, count) - from their
+    partial rows (``sums`` then RECEIVES the totals: they are the BatchNorm's parameter gradients)"""
+    if rows is not None:
+        lib.call(_k("nasseg_bn_bwd_apply_rows", g), ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                 ptr(rows[0]), rows[1], ptr(sums), M, C, int(training), act, ptr(dz), current_stream())
+    else:
+        lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                 ptr(sums), M, C, int(training), act, ptr(dz), current_stream())
+    return dz
+
+
+def _bn_bwd_reduce(g, z, scale, shift, mean, invstd, act, sums, M, C, for_apply):
+    """{sum g', sum g' * xhat} of a BatchNorm backward over the M pixels of g, z: into ``sums`` (returns None), or -
+    when the caller goes on to _bn_bwd_apply (for_apply) and the first stage leaves few rows - only the rows, which
+    are returned as (buffer, count) for the apply kernel to add up"""
+    ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, C))
+    if for_apply:
+        nrows = lib.query("nasseg_colred_rows", 1, M, C)
+        if _rows_small(nrows, C):
+            lib.call(_k("nasseg_bn_bwd_reduce_rows", g), ptr(g), C, ptr(z), C, M, C, ptr(scale), ptr(shift), ptr(mean),
+                     ptr(invstd), act, ptr(ws), current_stream())
+            return ws, nrows
+    lib.call(_k("nasseg_bn_bwd_reduce", g), ptr(g), C, ptr(z), C, M, C, ptr(scale), ptr(shift), ptr(mean),
+             ptr(invstd), act, ptr(sums), ptr(ws), current_stream())
+    return None
 
 
 _TICKETS = {}
@@ -1028,59 +1059,46 @@ class _ConvChain(torch.autograd.Function):
             if has_bn:
                 mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
                 sums = _vec(z, 2 * N) if (pre is None or len(pre) < 3 or pre[2] is None) else pre[2]
-                reduce_here = False
-                if pre is not None and sums is (pre[2] if len(pre) > 2 else None):
-                    pass  # g arrived masked and its sums were finished by the kernel that produced it
-                elif pre is not None:
-                    # g arrived masked, with its per-workgroup {sum g, sum g*xhat} rows
-                    lib.call("nasseg_rows_sum", ptr(pre[0]), pre[1], 2 * N, ptr(sums), s)
-                else:
-                    reduce_here = True
-                if ctx.needs_input_grad[3 + 6 * i + 1]:
-                    grads[6 * i + 1] = sums[N:2 * N]
-                if ctx.needs_input_grad[3 + 6 * i + 2]:
-                    grads[6 * i + 2] = sums[0:N]
                 act_left = ACT_NONE if (pre is not None or g_masked) else act  # (the mask still to be applied to g)
                 pw_bact = act_left
                 go_on = need_dw or need_dx
                 pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops) if go_on else 0
                 dw_rows = _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops) if go_on else 0
-                small_dz = None
-                if reduce_here and _bn_small_ok(M, N):
-                    # a small map: the sums and - where no kernel below applies the BatchNorm backward on load -
-                    # dz by ONE launch
-                    wants_dz = (go_on and not (pw_nsl > 0 or dw_rows > 0)
-                                and not _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z)
-                                and not (need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil)))
-                    if wants_dz:
-                        small_dz = torch.empty_like(z)
-                    lib.call(_k("nasseg_bn_bwd_small", g), ptr(g), N, ptr(z), N, M, N, ptr(scale), ptr(shift),
-                             ptr(mean), ptr(invstd), act_left, int(training), ptr(sums), ptr(small_dz), N, s)
-                elif reduce_here:
-                    ws = _ws(z, lib.query("nasseg_colred_workspace", 1, M, N))
-                    lib.call(_k("nasseg_bn_bwd_reduce", g), ptr(g), N, ptr(z), N, M, N, ptr(scale),
-                             ptr(shift), ptr(mean), ptr(invstd), ACT_NONE if g_masked else act, ptr(sums),
-                             ptr(ws), s)
+                # the stem (small-K k x k conv, no gradient for the image): BatchNorm backward on load in the
+                # weight-gradient kernel, dz never written (nasseg_conv_wgrad_bn_flat)
+                flat_bn = go_on and _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z)
+                on_load = go_on and (pw_nsl > 0 or dw_rows > 0 or flat_bn)  # (a kernel below applies the BatchNorm backward)
+                wgrad_bn = go_on and not on_load and need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil)
+                plain_apply = go_on and not on_load and not wgrad_bn  # (dz by a bn_bwd_apply pass)
+                lazy_rows = None  # the sums as rows the apply kernel adds up itself
+                if pre is not None and sums is (pre[2] if len(pre) > 2 else None):
+                    pass  # g arrived masked and its sums were finished by the kernel that produced it
+                elif pre is not None:
+                    # g arrived masked, with its per-workgroup {sum g, sum g*xhat} rows
+                    if plain_apply and _rows_small(pre[1], N):
+                        lazy_rows = (pre[0], pre[1])
+                    else:
+                        lib.call("nasseg_rows_sum", ptr(pre[0]), pre[1], 2 * N, ptr(sums), s)
+                else:
+                    lazy_rows = _bn_bwd_reduce(g, z, scale, shift, mean, invstd, act_left, sums, M, N, plain_apply)
+                if ctx.needs_input_grad[3 + 6 * i + 1]:
+                    grads[6 * i + 1] = sums[N:2 * N]
+                if ctx.needs_input_grad[3 + 6 * i + 2]:
+                    grads[6 * i + 2] = sums[0:N]
                 if not go_on:
                     g = None
                     break
-                # the stem (small-K k x k conv, no gradient for the image): BatchNorm backward on load in the
-                # weight-gradient kernel, dz never written (nasseg_conv_wgrad_bn_flat)
-                flat_bn = _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z)
-                if pw_nsl > 0 or dw_rows > 0 or flat_bn:
-                    dz = None  # (the one-kernel pointwise backward below applies the BatchNorm backward on load)
-                elif small_dz is not None:
-                    dz = small_dz
-                elif need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil):
+                if on_load:
+                    dz = None  # (the one-kernel backward / flat weight gradient below applies the BatchNorm backward on load)
+                elif wgrad_bn:
                     # the weight-gradient kernel below computes dz while it loads g and z (masking
                     # g first if it did not arrive masked) and leaves it behind for the
                     # backward-data kernel
                     fused_bn = (scale, shift, mean, invstd, sums, training, act_left)
                     dz = None
                 else:
-                    dz = torch.empty_like(z)
-                    lib.call(_k("nasseg_bn_bwd_apply", g), ptr(g), ptr(z), ptr(scale), ptr(shift), ptr(mean),
-                             ptr(invstd), ptr(sums), M, N, int(training), act_left, ptr(dz), s)
+                    dz = _bn_bwd_apply(g, z, scale, shift, mean, invstd, sums, M, N, training, act_left,
+                                       torch.empty_like(z), lazy_rows)
             else:
                 dz = g
                 pw_nsl = dw_rows = 0
@@ -1278,6 +1296,91 @@ def materialize(x):
     return x.materialize() if isinstance(x, Pending) else x
 
 
+# Nodes with several consumers (a cell's node read by several ops and sums, a decoder map read by several blocks and
+# collect_all: src/nn/micro_decoders.py:95-121,237-251,380-398) go through ONE gradient junction instead of autograd's
+# pairwise accumulation (an at::native add launch and three tensor passes per extra consumer) - and a junction over a
+# Pending node also does the mask-and-reduce pass of its producer's BatchNorm backward.  NASSEG_JUNCTION=0: as before.
+JUNCTION = os.environ.get("NASSEG_JUNCTION", "1") != "0"
+_JUNCTION_MAX = 8  # gradients one nasseg_grad_junction launch adds
+
+
+class _Junction(torch.autograd.Function):
+    """Fan a node out to its consumers.  forward(z, stats, act, n_raw, n_fin): n_raw aliases of z for consumers that
+    take the node as it is - a plain tensor (stats None), or a conv chain's raw output whose BatchNorm + activation they
+    apply on load (the caller wraps them into Pending objects) - and n_fin aliases of the FINISHED map act(scale*z +
+    shift), written once, for consumers that need it.  Backward: whatever gradients came back (all of them w.r.t. the
+    finished value: Pending's contract) are added by one nasseg_grad_junction launch; over a pending node the sum is
+    also multiplied by act' (a contribution that arrived masked stays as it is: the mask is 0 / 1) and comes with the
+    producer's BatchNorm-backward sums as rows, handed to the chain's backward by the side of the gradient
+    (_TAIL_ROWS) - which then skips its own pass over gradient and z."""
+
+    @staticmethod
+    def forward(ctx, z, stats, act, n_raw, n_fin):
+        z = _cl(z)
+        C = z.shape[1]
+        fin = None
+        if n_fin:
+            fin = z if stats is None else _affine_act(z, stats[2 * C:3 * C], stats[3 * C:], None, act)
+        outs = [z.view_as(z) for _ in range(n_raw)] + [fin.view_as(fin) for _ in range(n_fin)]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z if stats is not None else None, stats)
+        ctx.cfg = (int(act), tuple(z.shape), z.dtype, z.device)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        z, stats = ctx.saved_tensors
+        act, shape, dtype, device = ctx.cfg
+        live = [_cl(g) for g in grads if g is not None]
+        if not live:
+            return None, None, None, None, None
+        if len(live) == 1 and stats is None:
+            return live[0], None, None, None, None
+        B, C, H, W = shape
+        s = current_stream()
+        nrows = lib.query("nasseg_cat_src_blocks", B, H, W, C)
+        if nrows <= 0:  # (a width the row layout does not serve: C / 4 > 256)
+            out = live[0]
+            for g in live[1:]:
+                out = _axpby(out, g, None, None)
+            return out, None, None, None, None
+        # more than eight consumers: partial sums first (plain adds), the mask and the rows with the last launch
+        while len(live) > _JUNCTION_MAX:
+            head, live = live[:_JUNCTION_MAX], live[_JUNCTION_MAX:]
+            part_sum = torch.empty_like(head[0])
+            lib.call(_k("nasseg_grad_junction", head[0]), *([ptr(g) for g in head] + [len(head), None, None, ACT_NONE,
+                     ptr(part_sum), None, B, H, W, C, s]))
+            live.insert(0, part_sum)
+        # (a pending node whose only gradient came from one consumer: the mask and the rows alone, n = 1)
+        out = torch.empty(shape, device=device, dtype=dtype, memory_format=torch.channels_last)
+        rows = _ws(out, (nrows + 64) * 2 * C) if (stats is not None and FUSE_TAIL_ROWS) else None
+        args = [ptr(g) for g in live] + [None] * (_JUNCTION_MAX - len(live))
+        lib.call(_k("nasseg_grad_junction", out), *(args + [len(live), ptr(z) if stats is not None else None,
+                 ptr(stats), act, ptr(out), ptr(rows), B, H, W, C, s]))
+        if rows is not None:
+            for key in [k for k, e in _TAIL_ROWS.items() if e[0]() is None]:
+                del _TAIL_ROWS[key]
+            _TAIL_ROWS[out.data_ptr()] = (weakref.ref(out), rows, nrows, out._version)
+        return out, None, None, None, None
+
+
+def fan_out(x, n_raw, n_fin=0):
+    """Handles of a node for its consumers: ``n_raw`` that take it as it is (x itself, or - x a Pending - Pending
+    objects whose tail the consumer applies on load) followed by ``n_fin`` finished maps (plain tensors).  With one
+    consumer in all, a width the junction kernel does not serve, no gradient to route, or NASSEG_JUNCTION=0 the
+    handles are x itself / its memoised materialisation: autograd accumulates as it always did."""
+    n = n_raw + n_fin
+    pending = isinstance(x, Pending)
+    z = x.z if pending else x
+    if (n < 2 or not JUNCTION or z.dim() != 4 or z.shape[1] % 4 != 0 or not torch.is_grad_enabled()
+            or not z.requires_grad):
+        return [x] * n_raw + [materialize(x)] * n_fin if n_fin else [x] * n_raw
+    if pending:
+        outs = _Junction.apply(x.z, x.stats, x.act, n_raw, n_fin)
+        return [Pending(t, x.stats, x.act) for t in outs[:n_raw]] + list(outs[n_raw:])
+    return list(_Junction.apply(x, None, ACT_NONE, n, 0))
+
+
 def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None, defer_tail=False):
     """ops: list of (weight, stride, padding, dilation, depthwise, bn, act) where ``bn`` is None
     or (gamma, beta, running_mean, running_var, num_batches_tracked, training, momentum, eps).
@@ -1370,16 +1473,9 @@ class _BatchNormAct(torch.autograd.Function):
         s = current_stream()
         sums = _vec(x, 2 * C)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        if _bn_small_ok(M, C):
-            lib.call(_k("nasseg_bn_bwd_small", dy), ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift), ptr(mean),
-                     ptr(invstd), act, int(training), ptr(sums), ptr(dx), C, s)
-        else:
-            ws = _ws(x, lib.query("nasseg_colred_workspace", 1, M, C))
-            lib.call(_k("nasseg_bn_bwd_reduce", dy), ptr(dy), C, ptr(x), C, M, C, ptr(scale), ptr(shift),
-                     ptr(mean), ptr(invstd), act, ptr(sums), ptr(ws), s)
-            if dx is not None:
-                lib.call(_k("nasseg_bn_bwd_apply", dy), ptr(dy), ptr(x), ptr(scale), ptr(shift), ptr(mean),
-                         ptr(invstd), ptr(sums), M, C, int(training), act, ptr(dx), s)
+        rows = _bn_bwd_reduce(dy, x, scale, shift, mean, invstd, act, sums, M, C, dx is not None and C % 4 == 0)
+        if dx is not None:
+            _bn_bwd_apply(dy, x, scale, shift, mean, invstd, sums, M, C, training, act, dx, rows)
         dgamma = sums[C:2 * C] if (affine and ctx.needs_input_grad[1]) else None
         dbeta = sums[0:C] if (affine and ctx.needs_input_grad[2]) else None
         dres = dy if (has_res and ctx.needs_input_grad[10]) else None
@@ -1902,7 +1998,10 @@ class _AddPending(torch.autograd.Function):
     """a + b where one or both are conv-chain outputs with a pending BatchNorm + activation (Pending): the tails
     are applied as the raw conv outputs are loaded (nasseg_add_act2) - one launch and three tensor passes instead
     of up to three launches and seven passes.  Backward: the gradient w.r.t. a sum's operands is the incoming one -
-    and a Pending's slot carries the gradient w.r.t. its NORMALISED value (see Pending), so nothing is computed."""
+    and a Pending's slot carries the gradient w.r.t. its NORMALISED value (see Pending), so nothing is computed.
+    (Masking the operands' gradients here with their chains' BatchNorm-backward rows by the side - nasseg_psum_bwd
+    with unit coefficients - was tried in round 5: on the small maps this runs on it leaves 88 - 336 rows per
+    operand, too many for the chains' apply kernels to add up themselves, and the launch count went UP by 4.)"""
 
     @staticmethod
     def forward(ctx, za, zb, sta, stb, act_a, act_b):

@@ -29,6 +29,47 @@ def _takes_pending_types():
 _TAKES_PENDING = _takes_pending_types()  # ops whose first layer is a conv chain (it applies a pending input itself)
 
 
+def _applies_pending(op):
+    """Does ``op`` apply a pending BatchNorm + activation of its input as it loads - a conv at its head with no
+    activation in front (SepConv, the dense conv + BN + ReLU ops)?  DilConv starts with a ReLU of its own and takes the
+    finished map, like the pooling / skip / global-pool ops."""
+    from .layer_factory import SepConv
+    from .modules import _chainable, _flatten
+
+    if isinstance(op, SepConv):
+        return True
+    if isinstance(op, FusedSequential):
+        mods = _flatten(op._modules.values())
+        return bool(mods) and _chainable(mods[0])
+    return False
+
+
+class _Handles(object):
+    """The consumers' handles of a list of nodes (functional.fan_out): a node with several consumers is fanned out
+    once, when its first consumer asks, and every consumer takes its own alias - in backward their gradients meet in
+    ONE junction launch instead of autograd's pairwise adds.  ``finished[idx]``: per consumer of node idx, in
+    consumption order, whether it needs the finished map of a node that is still pending."""
+
+    def __init__(self, nodes, finished):
+        self.nodes, self.finished, self.out = nodes, finished, {}
+
+    def take(self, idx):
+        flags = self.finished[idx]
+        if len(flags) < 2:
+            node = self.nodes[idx]
+            return F.materialize(node) if (flags and flags[0]) else node
+        queue = self.out.get(idx)
+        if queue is None:
+            node = self.nodes[idx]
+            if not isinstance(node, F.Pending):
+                flags = [False] * len(flags)
+            n_fin = sum(flags)
+            got = F.fan_out(node, len(flags) - n_fin, n_fin)
+            raw, fin = got[:len(flags) - n_fin], got[len(flags) - n_fin:]
+            queue = self.out[idx] = [fin.pop(0) if f else raw.pop(0) for f in flags]
+        return queue.pop(0)
+
+
 def _hw(t):
     return (int(t.size(2)), int(t.size(3)))
 
@@ -150,23 +191,45 @@ class ContextualCell(nn.Module):
             self._collect_inds.append(step * 3 + 1)
             self._pools.append("sum({},{})".format(self._pools[node_a], self._pools[node_b]))
 
+    def _consumers(self):
+        """per node, in the order forward() consumes it: does that consumer need the FINISHED map of a pending node
+        (an op that does not apply a pending input itself), or does it take the node as it is (ops with a conv at
+        their head, the sums of a step, the sum of the loose ends)?"""
+        table = getattr(self, "_consumer_table", None)
+        if table is None:
+            table = [[] for _ in range(len(self._ops) + 1)]
+            for src, op in zip(self._pos, self._ops):
+                if isinstance(src, list):
+                    for node in src:
+                        table[node].append(False)
+                else:
+                    table[src].append(not _applies_pending(op))
+            for node in self._collect_inds:
+                table[node].append(False)
+            self._consumer_table = table
+        return table
+
     def forward(self, x):
         # Ops that end in conv + BatchNorm + ReLU hand their raw conv output over with the tail pending
         # (functional.Pending): the sums of a step and of the loose ends apply it as they load, an op that starts
         # with a conv takes it as its prologue, anything else gets the normalised map (computed once per node).
+        # A node with several consumers is fanned out (_Handles): their gradients meet in one junction launch,
+        # which for a pending node also is the mask-and-reduce pass of its producer's BatchNorm backward.
         nodes = [x]
+        handles = _Handles(nodes, self._consumers())
         for src, op in zip(self._pos, self._ops):
             if isinstance(src, list):
                 assert len(src) == 2, "Two ops must be provided"
-                nodes.append(op(nodes[src[0]], nodes[src[1]]))
+                nodes.append(op(handles.take(src[0]), handles.take(src[1])))
             else:
-                inp = nodes[src]
+                inp = handles.take(src)
                 if not isinstance(op, _TAKES_PENDING):
                     inp = F.materialize(inp)
                 nodes.append(run_op(op, inp, defer_tail=True))
         out = None
         for i in self._collect_inds:
-            out = nodes[i] if out is None else F.add(out, nodes[i])
+            node = handles.take(i)
+            out = node if out is None else F.add(out, node)
         return F.materialize(out)
 
     def prettify(self):
@@ -242,13 +305,22 @@ class MicroDecoder(nn.Module):
 
     def forward(self, x):
         maps = [getattr(self, "adapt{}".format(n + 1))(t) for n, t in enumerate(x)]
+        # consumers of every map, in order: the cells' inputs, the auxiliary head of a cell's output, collect_all
+        uses = [[] for _ in range(len(maps) + len(self.conns))]
+        for block, (a, b) in enumerate(self.conns):
+            uses[a].append(False)
+            uses[b].append(False)
+            uses[len(x) + block].append(False)  # (its auxiliary classifier)
+        for i in self.collect_inds:
+            uses[i].append(False)
+        handles = _Handles(maps, uses)
         aux_outs = []
-        for cell, head, (a, b) in zip(self.cells, self.aux_clfs, self.conns):
-            merged = cell(maps[a], maps[b])
-            maps.append(merged)
-            aux_outs.append(head(merged))
+        for block, (cell, head, (a, b)) in enumerate(zip(self.cells, self.aux_clfs, self.conns)):
+            maps.append(cell(handles.take(a), handles.take(b)))
+            aux_outs.append(head(handles.take(len(x) + block)))
         # F.relu(collect_all(...)) of the reference: the ReLU is applied as pre_clf loads
-        out = collect_all(maps, self.collect_inds)
+        picked = {i: handles.take(i) for i in self.collect_inds}
+        out = collect_all(picked, self.collect_inds)
         return self.conv_clf(self.pre_clf(out, relu_in=True)), aux_outs
 
 
@@ -333,19 +405,42 @@ class TemplateDecoder(nn.Module):
 
     def forward(self, x):
         maps = list(x)
-        for pos, ops, n_rep in zip(self._pos, self._ops, self._repeats):
+        # Every value with several consumers - an encoder map or a block's output read by several blocks / repeats and
+        # by collect_all, a repeat's output read by the next two repeats - is fanned out (functional.fan_out): the
+        # consumers' gradients meet in one junction launch instead of autograd's pairwise adds.  Values are numbered
+        # as they appear: the maps first, then every repeat's output (a block's last one doubles as its map).
+        n_maps = len(maps) + len(self._pos)
+        uses = [[] for _ in range(n_maps)]
+        plan = []  # per block: [(left value, right value, output value) per repeat]
+        for block, (pos, n_rep) in enumerate(zip(self._pos, self._repeats)):
             assert isinstance(pos, list), "Must be list"
-            left, right = maps[pos[0]], maps[pos[1]]
+            left, right = pos[0], pos[1]
+            reps = []
             for rep in range(n_rep):
+                if rep == n_rep - 1:
+                    out_id = len(x) + block
+                else:
+                    out_id = len(uses)
+                    uses.append([])
+                uses[left].append(False)
+                uses[right].append(False)
+                reps.append((left, right, out_id))
+                left, right = right, out_id
+            plan.append(reps)
+        for i in self._collect_inds:
+            uses[i].append(False)
+        values = maps + [None] * (len(uses) - len(maps))
+        handles = _Handles(values, uses)
+        for reps, ops in zip(plan, self._ops):
+            for rep, (left, right, out_id) in enumerate(reps):
                 # (an aggregation op that applies its producers' last BatchNorm + ReLU as it loads gets their
                 #  raw conv outputs: the normalised maps are never written)
                 defer = getattr(ops[rep * 3 + 2], "accepts_pending", False)
-                a = run_op(ops[rep * 3], left, defer)
-                b = run_op(ops[rep * 3 + 1], right, defer)
-                merged = ops[rep * 3 + 2](a, b)
+                a = run_op(ops[rep * 3], handles.take(left), defer)
+                b = run_op(ops[rep * 3 + 1], handles.take(right), defer)
                 # the next repeat consumes (previous right input, previous output)
-                left, right = right, merged
-            maps.append(merged)
+                values[out_id] = ops[rep * 3 + 2](a, b)
         # F.relu(collect_all(...)) of the reference: the ReLU is applied as pre_clf loads
-        out = collect_all(maps, self._collect_inds)
+        picked = {i: handles.take(i) for i in self._collect_inds}
+        out = collect_all(picked, self._collect_inds)
         return self.conv_clf(self.pre_clf(out, relu_in=True))

@@ -391,7 +391,8 @@ def test_cat_reduce_cell_against_torch_cpu_autograd(kind, mode, monkeypatch):
     # (... and producers SMALLER than the slab, which keep their own, cheap, reduction: sep_dil_up's DilConv and
     #  adapt_conv's second SepConv)
     want_reduce = {"sep_sep_down": 0, "sep_dil_up": 1, "pool_sep_same": 0, "adapt_conv": 2}[kind]
-    assert seen.count("nasseg_bn_bwd_reduce") == want_reduce, seen.count("nasseg_bn_bwd_reduce")
+    n_reduce = seen.count("nasseg_bn_bwd_reduce") + seen.count("nasseg_bn_bwd_reduce_rows")
+    assert n_reduce == want_reduce, n_reduce
     assert ("nasseg_bilinear_bwd_act" in seen) == (kind == "sep_sep_down")
     assert "nasseg_chan_copy" not in seen
     if kind != "adapt_conv":
@@ -505,7 +506,8 @@ def test_param_sum_cell_against_torch_cpu_autograd(kind, monkeypatch):
     assert seen.count("nasseg_add_act2") == 1 and seen.count("nasseg_psum_bwd") == 1, sorted(set(seen))
     assert "nasseg_axpby" not in seen and "nasseg_colred" not in seen
     # producers whose pending output went straight into the sum need no reduction pass of their own
-    assert seen.count("nasseg_bn_bwd_reduce") == {"sep_sep_same": 0, "sep_pool_same": 0, "adapt_resize": 2}[kind]
+    n_reduce = seen.count("nasseg_bn_bwd_reduce") + seen.count("nasseg_bn_bwd_reduce_rows")
+    assert n_reduce == {"sep_sep_same": 0, "sep_pool_same": 0, "adapt_resize": 2}[kind]
     assert not Fm._TAIL_ROWS
 
     def floor(ref32, ref64_):
@@ -569,3 +571,102 @@ def test_partial_row_finalisation_levels(nblk):
     assert_close(rm, 0.1 * mu, 1e-6, 1e-5, "running_mean")
     assert_close(rv, 0.9 + 0.1 * var * M / (M - 1), 1e-6, 1e-5, "running_var")
     assert int(nbt) == 1
+
+
+@pytest.mark.parametrize("size", [(11, 11), (21, 23)], ids=["11x11", "21x23"])
+@pytest.mark.parametrize("name", ["cvpr_arch0", "cvpr_arch1_search", "cvpr_arch2_depth"])
+def test_contextual_cell_with_gradient_junctions_against_torch_cpu_autograd(name, size, monkeypatch):
+    """A ContextualCell (src/nn/micro_decoders.py:54-121) of the three published / searched CVPR genotypes on the
+    small maps of the CVPR decoder: the cell's input feeds up to five ops, op outputs with a pending BatchNorm + ReLU
+    feed a sum AND another op (or a global-average-pool op that needs the finished map).  Round 5: every node with
+    several consumers goes through ONE gradient junction (nasseg_grad_junction: the consumers' gradients summed,
+    masked, with the producer's BatchNorm-backward rows) instead of autograd's pairwise adds, and the BatchNorm
+    backwards add up their few partial rows inside the apply kernel (nasseg_bn_bwd_reduce_rows /
+    nasseg_bn_bwd_apply_rows).  Output, input gradient, every parameter gradient and the BatchNorm buffers against
+    torch's own autograd of the same graph on the CPU (oracle.nets.contextual_cell: plain torch.nn.functional),
+    floors from the same graph in float64; then the same step with both switches off, which must agree with the
+    junction path to rounding."""
+    import json
+    import os
+
+    from nas_segm_amd.nn.micro_decoders import ContextualCell
+    from oracle import nets as onets
+
+    Fm = F()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "nets_meta.json")) as fh:
+        cfg = json.load(fh)[name]["genotype"][0]
+    C, repeats, B = 32, 2, 8
+    torch.manual_seed(23)
+    cell = ContextualCell(cfg, C, repeats=repeats)
+    randomise(cell, 5)
+    sd0 = {k: v.detach().clone() for k, v in cell.state_dict().items()}
+    pkeys = {k for k, _ in cell.named_parameters()}
+    x = rnd(B, C, *size, seed=2)
+    cot = None
+
+    def reference(dtype):
+        sd = {"cell." + k: (v.to(dtype).clone().requires_grad_(True) if k in pkeys else
+                            (v.to(dtype).clone() if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
+        xin = x.to(dtype).clone().requires_grad_(True)
+        out = onets.contextual_cell(sd, "cell", cfg, xin, C, repeats, True)
+        return sd, xin, out
+
+    sd32, x32, y32 = reference(torch.float32)
+    cot = rnd(*y32.shape, seed=3)
+    y32.backward(cot)
+    sd64, x64, y64 = reference(torch.float64)
+    y64.backward(cot.double())
+
+    def floor(a, b):
+        return float((a.detach().double() - b.detach()).abs().max())
+
+    def run(junction, apply_rows):
+        monkeypatch.setattr(Fm, "JUNCTION", junction)
+        monkeypatch.setattr(Fm, "APPLY_ROWS", apply_rows)
+        m = ContextualCell(cfg, C, repeats=repeats)
+        m.load_state_dict(sd0)
+        m = m.to(DEV).train()
+        seen = []
+        orig = Fm.lib.call
+
+        def rec(fn, *a):
+            seen.append(fn)
+            return orig(fn, *a)
+
+        monkeypatch.setattr(Fm.lib, "call", rec)
+        xg = dev(x.clone()).requires_grad_(True)
+        yg = m(xg)
+        yg.backward(dev(cot))
+        torch.cuda.synchronize()
+        monkeypatch.setattr(Fm.lib, "call", orig)
+        return m, xg, yg, seen
+
+    m, xg, yg, seen = run(True, True)
+    assert seen.count("nasseg_grad_junction") >= 2, sorted(set(seen))
+    assert seen.count("nasseg_bn_bwd_apply_rows") >= 1 and seen.count("nasseg_bn_bwd_reduce_rows") >= 1
+    assert not Fm._TAIL_ROWS
+    assert_close(yg, y32, 1e-4 * float(y32.abs().max()) + 4 * floor(y32, y64), 1e-4, name + ": output")
+    gx, rx = xg.grad.cpu(), x32.grad
+    assert_close(gx, rx, 2e-4 * float(rx.abs().max()) + 4 * floor(rx, x64.grad), 1e-4, name + ": input gradient")
+    gp = dict(m.named_parameters())
+    for k in sorted(pkeys):
+        ref, ref64 = sd32["cell." + k].grad, sd64["cell." + k].grad
+        assert ref is not None and gp[k].grad is not None, k
+        assert_close(gp[k].grad, ref, 2e-4 * float(ref.abs().max()) + 4 * floor(ref, ref64) + 1e-7, 1e-4,
+                     "{}: gradient of {}".format(name, k))
+    for k, v in m.named_buffers():
+        ref = sd32["cell." + k]
+        if ref.dtype == torch.int64:
+            assert int(v) == int(ref), k
+        else:
+            assert_close(v, ref, 1e-6, 5e-5, "{}: buffer {}".format(name, k))
+    # autograd's accumulation + the summing launches (round 4's path): same numbers to rounding
+    m0, xg0, yg0, seen0 = run(False, False)
+    assert "nasseg_grad_junction" not in seen0 and "nasseg_bn_bwd_apply_rows" not in seen0
+    assert torch.equal(yg0, yg)  # (the forward is the same launch sequence)
+    assert_close(xg0.grad, xg.grad, 2e-5 * float(rx.abs().max()) + 4 * floor(rx, x64.grad), 1e-4, "switches: input gradient")
+    gp0 = dict(m0.named_parameters())
+    for k in sorted(pkeys):
+        ref, ref64 = sd32["cell." + k].grad, sd64["cell." + k].grad
+        assert_close(gp0[k].grad, gp[k].grad, 2e-5 * float(ref.abs().max()) + 4 * floor(ref, ref64) + 1e-7, 1e-4,
+                     "switches: gradient of {}".format(k))

@@ -1842,32 +1842,37 @@ def test_pending_sum_kernels_against_torch(case, pend, dtype):
 
 
 @pytest.mark.parametrize("shape", [(16, 64, 11, 11), (4, 64, 21, 21), (2, 24, 13, 17), (1, 8, 1, 1), (3, 144, 5, 7),
-                                   (2, 32, 32, 32)])
+                                   (2, 32, 32, 32), (1, 320, 11, 11), (2, 960, 6, 6), (16, 64, 41, 41)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("training", [True, False])
-@pytest.mark.parametrize("with_dx", [True, False])
-def test_small_map_bn_backward_in_one_launch(shape, act, training, with_dx):
-    """nasseg_bn_bwd_small == nasseg_bn_bwd_reduce + nasseg_bn_bwd_apply (the sums to rounding of their order, dx
-    computed from its own sums with the same arithmetic)"""
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_backward_apply_adds_up_its_rows(shape, act, training, dtype):
+    """nasseg_bn_bwd_reduce_rows + nasseg_bn_bwd_apply_rows == nasseg_bn_bwd_reduce + nasseg_bn_bwd_apply: the sums
+    (written out by the apply kernel) against float64 and no worse than the two-launch reduction's, dx from those
+    sums with the same arithmetic"""
     f = F()
     B, C, H, W = shape
     M = B * H * W
-    assert M <= f.lib.query("nasseg_bn_bwd_small_max_pixels")
-    dy, x = dev(rnd(B, C, H, W, seed=1)), dev(rnd(B, C, H, W, seed=2, scale=2.0))
+    pre = "nasseg_" if dtype == torch.float32 else "nasseg_bf16_"
+    dy, x = dev(rnd(B, C, H, W, seed=1)).to(dtype), dev(rnd(B, C, H, W, seed=2, scale=2.0)).to(dtype)
     scale, shift, mean, invstd = _bn_vectors(C, 3)
     s = f.current_stream()
     sums_ref = torch.empty(2 * C, device=DEV)
     ws = torch.empty(f.lib.query("nasseg_colred_workspace", 1, M, C), device=DEV)
-    f.lib.call("nasseg_bn_bwd_reduce", f.ptr(dy), C, f.ptr(x), C, M, C, f.ptr(scale), f.ptr(shift), f.ptr(mean),
+    f.lib.call(pre + "bn_bwd_reduce", f.ptr(dy), C, f.ptr(x), C, M, C, f.ptr(scale), f.ptr(shift), f.ptr(mean),
                f.ptr(invstd), act, f.ptr(sums_ref), f.ptr(ws), s)
     dx_ref = torch.empty_like(x)
-    f.lib.call("nasseg_bn_bwd_apply", f.ptr(dy), f.ptr(x), f.ptr(scale), f.ptr(shift), f.ptr(mean), f.ptr(invstd),
+    f.lib.call(pre + "bn_bwd_apply", f.ptr(dy), f.ptr(x), f.ptr(scale), f.ptr(shift), f.ptr(mean), f.ptr(invstd),
                f.ptr(sums_ref), M, C, int(training), act, f.ptr(dx_ref), s)
+    nrows = f.lib.query("nasseg_colred_rows", 1, M, C)
+    assert 0 < nrows <= 768
+    rows = torch.full((f.lib.query("nasseg_colred_workspace", 1, M, C),), float("nan"), device=DEV)
+    f.lib.call(pre + "bn_bwd_reduce_rows", f.ptr(dy), C, f.ptr(x), C, M, C, f.ptr(scale), f.ptr(shift), f.ptr(mean),
+               f.ptr(invstd), act, f.ptr(rows), s)
     sums = torch.full((2 * C,), float("nan"), device=DEV)
-    dx = torch.full_like(x, float("nan")) if with_dx else None
-    f.lib.call("nasseg_bn_bwd_small", f.ptr(dy), C, f.ptr(x), C, M, C, f.ptr(scale), f.ptr(shift), f.ptr(mean),
-               f.ptr(invstd), act, int(training), f.ptr(sums), f.ptr(dx), C, s)
-    # float64 reference of the sums
+    dx = torch.full_like(x, float("nan"))
+    f.lib.call(pre + "bn_bwd_apply_rows", f.ptr(dy), f.ptr(x), f.ptr(scale), f.ptr(shift), f.ptr(mean), f.ptr(invstd),
+               f.ptr(rows), nrows, f.ptr(sums), M, C, int(training), act, f.ptr(dx), s)
     yv = x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
     mask = torch.ones_like(yv) if act == 0 else ((yv > 0) if act == 1 else ((yv > 0) & (yv < 6))).double()
     g = dy.double() * mask
@@ -1876,8 +1881,58 @@ def test_small_map_bn_backward_in_one_launch(shape, act, training, with_dx):
     tol = 2e-6 * float(M) ** 0.5 * float(g.abs().max()) * float(xh.abs().max() + 1)
     assert_close(sums.double(), want, tol, 1e-5, "sums against float64")
     assert float((sums.double() - want).abs().max()) <= float((sums_ref.double() - want).abs().max()) + tol * 0.1
-    if with_dx:
-        assert_close(dx, dx_ref, 2e-5 * float(dx_ref.abs().max()) + 1e-6, 1e-4, "dx")
+    rel = 2e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert_close(dx.float(), dx_ref.float(), rel * float(dx_ref.float().abs().max()) + 1e-6, 1e-4, "dx")
+    # no output: the sums alone (a BatchNorm whose input needs no gradient still owes its parameter gradients)
+    assert bool(torch.isfinite(sums).all()) and bool(torch.isfinite(dx.float()).all())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 11, 11), (16, 64, 21, 21), (1, 24, 13, 17), (2, 8, 3, 5), (1, 144, 40, 64),
+                                   (2, 32, 64, 96)])
+@pytest.mark.parametrize("n", [2, 3, 5, 8])
+@pytest.mark.parametrize("pending", [0, 1, 2], ids=["plain", "relu", "relu6"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gradient_junction_against_float64(shape, n, pending, dtype):
+    """nasseg_grad_junction: the sum of n gradients in index order; with a pending BatchNorm + activation of the node
+    also the mask act'(scale*z + shift) and the rows of {sum g, sum g*xhat} (added up here by nasseg_rows_sum)"""
+    f = F()
+    B, C, H, W = shape
+    pre = "nasseg_" if dtype == torch.float32 else "nasseg_bf16_"
+    gs = [dev(rnd(B, C, H, W, seed=10 + i)).to(dtype) for i in range(n)]
+    z = dev(rnd(B, C, H, W, seed=3, scale=2.0)).to(dtype)
+    scale, shift, mean, invstd = _bn_vectors(C, 5)
+    tstats = torch.cat([mean, invstd, scale, shift]).contiguous()
+    nrows = f.lib.query("nasseg_cat_src_blocks", B, H, W, C)
+    assert nrows > 0
+    out = torch.full_like(z, float("nan"))
+    part = torch.full(((nrows + 64) * 2 * C,), float("nan"), device=DEV) if pending else None
+    ptrs = [f.ptr(t) for t in gs] + [None] * (8 - n)
+    f.lib.call(pre + "grad_junction", *ptrs, n, f.ptr(z) if pending else None, f.ptr(tstats) if pending else None,
+               pending, f.ptr(out), f.ptr(part), B, H, W, C, f.current_stream())
+    acc = gs[0].float()
+    for t in gs[1:]:
+        acc = acc + t.float()  # (fp32 adds in index order: what the kernel does)
+    want = acc.double()
+    sure = torch.ones_like(want, dtype=torch.bool)
+    if pending:
+        yv = z.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+        want = want * ((yv > 0) if pending == 1 else ((yv > 0) & (yv < 6))).double()
+        # (an activation argument within fp32 rounding of a kink may fall on either side of it)
+        sure = (yv.abs() > 1e-5) & ((yv - 6.0).abs() > 1e-5)
+        assert float(sure.double().mean()) > 0.999
+    if dtype == torch.float32:
+        assert torch.equal(out.double()[sure], want[sure])
+    else:
+        assert_close(out.float()[sure], want.float()[sure], 2.0 ** -8 * float(want.abs().max()) + 1e-6, 1e-4, "sum")
+    if pending:
+        sums = torch.empty(2 * C, device=DEV)
+        f.lib.call("nasseg_rows_sum", f.ptr(part), nrows, 2 * C, f.ptr(sums), f.current_stream())
+        g_seen = out.double()  # (the rows are sums over the STORED gradient)
+        xh = (z.double() - mean.double().view(1, -1, 1, 1)) * invstd.double().view(1, -1, 1, 1)
+        M = B * H * W
+        tol = 2e-6 * float(M) ** 0.5 * (float(g_seen.abs().max()) + 1e-3) * float(xh.abs().max() + 1)
+        assert_close(sums[0:C].double(), g_seen.sum((0, 2, 3)), tol, 1e-4, "sum g")
+        assert_close(sums[C:].double(), (g_seen * xh).sum((0, 2, 3)), tol * 4, 1e-4, "sum g*xhat")
 
 
 @pytest.mark.parametrize("case", [

@@ -306,8 +306,14 @@ def _dry_run(monkeypatch, build, inputs):
     net = build().train()
     xs = [torch.empty(*shape).contiguous(memory_format=torch.channels_last).requires_grad_(True) for shape in inputs]
     out = net(xs)
+    out = out[0] if isinstance(out, tuple) else out
     n_fwd = len(calls)
-    out.backward(torch.empty_like(out))
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        out.backward(torch.empty_like(out))
+    # autograd's own accumulation of a gradient over several consumers is the only ATen add of such a backward
+    _dry_run.accumulations = sum(1 for e in prof.events() if e.name in ("aten::add", "aten::add_"))
     return F, calls[:n_fwd], calls[n_fwd:], xs
 
 
@@ -336,8 +342,12 @@ def test_template_decoder_hands_pending_batchnorms_to_concat_reduce(monkeypatch)
     pending_inputs = sum(1 for n, a in bwd if n == "nasseg_cat_src_bwd" and a[9] is not None)
     assert pending_inputs >= n_cat  # at least one pending producer per ConcatReduce here
     # every pending producer got its sums by the side: what still reduces is pre_clf's tail and materialised inputs
-    assert b_names.count("nasseg_bn_bwd_reduce") <= 1 + f_names.count("nasseg_affine_act")
-    assert b_names.count("nasseg_rows_sum") >= pending_inputs
+    reduces = b_names.count("nasseg_bn_bwd_reduce") + b_names.count("nasseg_bn_bwd_reduce_rows")
+    assert reduces <= 1 + f_names.count("nasseg_affine_act")
+    # (the rows that came by the side are summed by a launch of their own or - few rows - by the apply kernel itself)
+    by_side = b_names.count("nasseg_rows_sum") + sum(
+        1 for n, a in bwd if n == "nasseg_bn_bwd_apply_rows") - b_names.count("nasseg_bn_bwd_reduce_rows")
+    assert by_side >= pending_inputs
     assert not F._TAIL_ROWS, "rows left behind: {}".format(len(F._TAIL_ROWS))
     assert all(x.grad is not None for x in xs)
 
@@ -374,6 +384,7 @@ def test_pending_tail_is_materialised_for_consumers_that_do_not_take_it(monkeypa
     f_names, b_names = [n for n, _ in fwd], [n for n, _ in bwd]
     assert f_names.count("nasseg_affine_act") == 0 and f_names.count("nasseg_add_act2") == 1
     assert b_names.count("nasseg_psum_bwd") == 1 and b_names.count("nasseg_bn_bwd_reduce") == 0
+    assert b_names.count("nasseg_bn_bwd_reduce_rows") == 0
     assert b_names.count("nasseg_axpby") == 0 and b_names.count("nasseg_colred") == 0
     assert not F._TAIL_ROWS
     monkeypatch.setattr(F, "FUSE_PENDING_PSUM", False)
@@ -437,3 +448,43 @@ def test_clip_and_step_accepts_generators():
         assert torch.equal(a, b)
     total = torch.sqrt(sum((g ** 2).sum() for g in gg))
     assert abs(float(total) - 0.1) < 1e-4  # (the gradients WERE clipped)
+
+
+def test_gradient_junctions_replace_autograd_accumulation(monkeypatch):
+    """Nodes with several consumers - a cell's input read by five ops, op outputs read by a sum and another op, the
+    decoder maps read by several cells / blocks and collect_all (src/nn/micro_decoders.py:95-121,237-251,380-398) -
+    are fanned out (functional.fan_out): backward adds their consumers' gradients in ONE nasseg_grad_junction launch
+    per node, autograd accumulates nothing; a junction over a pending node hands the producer's BatchNorm-backward
+    rows on, so that chain runs no reduction of its own.  NASSEG_JUNCTION=0 is the old graph."""
+    from nas_segm_amd.nn.micro_decoders import MicroDecoder, TemplateDecoder
+
+    rec = load_json("nets_meta.json")
+    cvpr, wacv = rec["cvpr_arch0"], rec["wacv_arch0"]
+    shapes4 = [(2, 24, 24, 24), (2, 32, 12, 12), (2, 96, 6, 6), (2, 320, 6, 6)]
+    shapes2 = [(2, 24, 32, 64), (2, 32, 16, 32)]
+    builders = {
+        "cvpr": (lambda: MicroDecoder([24, 32, 96, 320], 21, cvpr["genotype"], agg_size=32, repeats=2), shapes4),
+        "wacv": (lambda: TemplateDecoder([24, 32], 19, wacv["genotype"], agg_size=32, repeats=2), shapes2),
+    }
+    for name, (build, shapes) in builders.items():
+        F, fwd, bwd, xs = _dry_run(monkeypatch, build, shapes)
+        with_j = (_dry_run.accumulations, [n for n, _ in bwd])
+        assert not F._TAIL_ROWS
+        assert sum(x.grad is not None for x in xs) >= len(xs) - 1  # (the CVPR genotype leaves one encoder map unused)
+        monkeypatch.setattr(F, "JUNCTION", False)
+        F, fwd0, bwd0, xs0 = _dry_run(monkeypatch, build, shapes)
+        without = (_dry_run.accumulations, [n for n, _ in bwd0])
+        monkeypatch.setattr(F, "JUNCTION", True)
+        assert [n for n, _ in fwd] == [n for n, _ in fwd0] or name == "cvpr"  # (cvpr: finished maps written by the junction)
+        assert with_j[0] == 0, (name, with_j[0])
+        assert without[0] >= 4 and "nasseg_grad_junction" not in without[1]
+        n_j = with_j[1].count("nasseg_grad_junction")
+        assert 1 <= n_j <= without[0], (name, n_j, without[0])
+        if name == "cvpr":
+            # junctions over pending nodes replaced their chains' reduction passes
+            def reduces(names):
+                return names.count("nasseg_bn_bwd_reduce") + names.count("nasseg_bn_bwd_reduce_rows")
+
+            assert reduces(with_j[1]) < reduces(without[1])
+            # every launch the old graph made that the new one does not is a reduction; what the new one adds are junctions
+            assert len(with_j[1]) - n_j <= len(without[1])

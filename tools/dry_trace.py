@@ -53,9 +53,17 @@ od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
 real_backward = torch.Tensor.backward
 
 
+acc = []  # autograd's own accumulations of a tensor's gradient over several consumers (one ATen add each)
+
+
 def backward(self, *a, **k):
+    from torch.profiler import ProfilerActivity, profile
+
     phase[0] = "bwd"
-    real_backward(self, *a, **k)
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        real_backward(self, *a, **k)
+    # (nothing else in backward is an ATen add: the kernels are not run)
+    acc.extend(e for e in prof.events() if e.name in ("aten::add", "aten::add_"))
     phase[0] = "post"
 
 
@@ -64,7 +72,12 @@ trainer.segmenter_step(net, image, mask, oe, od, 255, 0.0, 0.0, -1)  # (no clipp
 
 by = collections.Counter((p, n) for p, n, _ in calls)
 tot = collections.Counter(n for _, n, _ in calls)
-sys.stdout.write("{} nasseg launches per step (ATen optimiser kernels not included)\n".format(len(calls)))
+# entry points that are two kernels (a first stage and its finaliser)
+TWO = ("nasseg_bn_bwd_reduce", "nasseg_colred", "nasseg_bn_stats")
+kernels = len(calls) + sum(1 for _, n, _ in calls if n.replace("nasseg_bf16_", "nasseg_") in TWO)
+n_acc = len(acc)
+sys.stdout.write("{} nasseg launches per step = {} kernels (ATen optimiser kernels not included), {} gradient "
+                 "accumulations by autograd (one ATen add each)\n".format(len(calls), kernels, n_acc))
 for n, c in tot.most_common():
     sys.stdout.write("  {:34s} {:4d}   fwd {:3d}  bwd {:3d}\n".format(n, c, by[("fwd", n)], by[("bwd", n)]))
 if want_list or grep:
