@@ -438,7 +438,7 @@ inline int pw_round_tiles(int t) {
 }
 // a function of (pixels, N, K, kind of call) only: nasseg_conv_fwd_stats_blocks must predict the grid.
 // mode 1: nasseg_conv_fwd, 2: nasseg_conv_bwd_data_bn.
-// Measured against conv_fwd_kernel on the headline step (tools/ab_breakdown.sh, us old -> new): it wins
+// Measured against conv_fwd_kernel on the headline step (tools/gpu.sh flags, us old -> new): it wins
 // where the reduction is long and the output narrow - 128->64 @128x256 51 -> 37, 192->32 46 -> 36,
 // 64->64 @256x512 129 -> 106 (forward) / 121 -> 99 (backward-data), 224->64 216 -> 199, 144->24 102 -> 96,
 // 32->32 @256x512 50 -> 43 - and loses on the expanding convs, where a tile is two k-blocks of

@@ -58,7 +58,7 @@ def _vec(like, n):
 
 # Finalising per-channel reductions inside the kernel that produced their rows (csrc/tail.h) needs a few counters that
 # are zero between launches: one set per (device, stream) - launches on one stream run one after the other.
-# OFF by default - measured on MI355X (tools/gpu_r4_ab_env.sh NASSEG_FUSE_TAIL "0 1"): it removes 37 of the 452 launches
+# OFF by default - measured on MI355X (tools/gpu.sh ab OUT NASSEG_FUSE_TAIL "0 1"): it removes 37 of the 452 launches
 # of a headline step, 35 of CVPR 321x321's 885, 25 of task0's 680, and the steps get SLOWER by 0.5-0.8 % (267.0 -> 265.6,
 # 1105 -> 1097, 5482 -> 5446 img/s): the last workgroup's drain -> ticket -> row loads -> group row -> ticket -> loads
 # -> finish is a chain of six or seven memory round trips at the end of the producing kernel, as long as the

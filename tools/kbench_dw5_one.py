@@ -1,5 +1,5 @@
 """one depthwise 5x5 dilation-6 forward (64 channels, 4 x 256 x 512, prologue + statistics), a few launches on
-rotated buffers: the target of tools/gpu_r4_dwpmc.sh's counter passes"""
+rotated buffers: the target of the counter passes of `tools/gpu.sh pmc`"""
 import os
 import sys
 
