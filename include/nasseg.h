@@ -149,6 +149,10 @@ int nasseg_conv_pwn_mode(int v);
  * 78 us for 0.6 GFLOP); 0: one step, as on large maps.  v < 0 only queries.  Returns the previous setting.
  * Bit-identical results. */
 int nasseg_conv_deep_k(int v);
+/* stride-1 3x3 max pooling (nasseg_maxpool_bn_fwd / _bwd) on the strip kernels - a thread owns four rows of a column
+ * and loads the 6 x 3 values their windows touch once: 1 (initial) / 0.  v < 0 only queries.  Returns the previous
+ * setting.  Identical outputs. */
+int nasseg_pool_strip(int v);
 /* which kernel a 1x1, stride-1, unpadded call with these sizes takes under the current settings: 0 the general MFMA
  * kernel, 1 the persistent kernel whose waves own all output channels, 2 the N-split persistent kernel.  pointwise
  * as for nasseg_conv_fwd_stats_blocks (1 forward, 2 backward-data).  For measurement tools (bench.py names kernel

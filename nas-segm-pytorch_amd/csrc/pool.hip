@@ -9,6 +9,8 @@
 // backward pass is a gather (deterministic, no atomics).
 #include <math.h>
 
+#include <atomic>
+
 #include "dw_common.h"
 
 namespace {
@@ -301,14 +303,181 @@ __global__ __launch_bounds__(256) void maxpool3_bn_bwd_kernel(const act_t* __res
   block_reduce_groups<2, 2>(ssum, sred, stats + (size_t)blk * 2 * C, base, C4);
 }
 
+// ---- stride 1: vertical strips ------------------------------------------------------------------------------
+// The kernels above load 9 taps per output (forward) / 9 (gradient, winner) pairs per input pixel (backward): at
+// stride 1 every element is fetched nine times, and they ran at 2.2 - 2.4 TB/s where the depthwise strips - same
+// access pattern - reach 4.5.  Here a thread owns P (4 or 2) consecutive rows of one (x, channel-group) column: the
+// (P + 2) x 3 values its windows touch are loaded ONCE (unconditionally, clamped coordinates + masks) and serve all
+// P rows - 4.5 (6) loads per element instead of 9, the BatchNorm affine once per loaded value.  Tap order, winner rule
+// and arithmetic per element are those of the kernels above: identical outputs.
+template <int P>
+__global__ __launch_bounds__(256) void maxpool3_bn_fwd_strip_kernel(const act_t* __restrict__ z,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    act_t* __restrict__ y, uint8_t* __restrict__ idx,
+                                                                    int B, int H, int W, int C4) {
+  const int C = C4 * 4;
+  const int chunks = (H + P - 1) / P;
+  const int64_t total = (int64_t)B * chunks * W * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int ox = (int)(p % W);
+    p /= W;
+    const int ch = (int)(p % chunks);
+    const int b = (int)(p / chunks);
+    const int oy0 = ch * P;
+    const act_t* zb = z + (int64_t)b * H * W * C + c4 * 4;
+    const float4 sc = scale ? lda4(scale + c4 * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? lda4(shift + c4 * 4) : f4zero();
+    float4 v[P + 2][3];
+    bool ok[P + 2][3];
+#pragma unroll
+    for (int r = 0; r < P + 2; ++r) {
+      const int iy = oy0 - 1 + r;
+      const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int ix = ox - 1 + tx;
+        const int ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        ok[r][tx] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        v[r][tx] = lda4(zb + ((int64_t)iyc * W + ixc) * C);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < P + 2; ++r)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) v[r][tx] = fma4(v[r][tx], sc, sh);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      int mx = 0, my = 0, mz = 0, mw = 0;
+      bool seeded = false;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 a = v[j + t / 3][t % 3];
+        const bool in = ok[j + t / 3][t % 3];
+        // torch: take a when (a > max) or isnan(a); the first in-bounds tap seeds the index
+        const bool tx_ = in && (!seeded || a.x > m.x || a.x != a.x);
+        const bool ty_ = in && (!seeded || a.y > m.y || a.y != a.y);
+        const bool tz_ = in && (!seeded || a.z > m.z || a.z != a.z);
+        const bool tw_ = in && (!seeded || a.w > m.w || a.w != a.w);
+        m.x = tx_ ? a.x : m.x; mx = tx_ ? t : mx;
+        m.y = ty_ ? a.y : m.y; my = ty_ ? t : my;
+        m.z = tz_ ? a.z : m.z; mz = tz_ ? t : mz;
+        m.w = tw_ ? a.w : m.w; mw = tw_ ? t : mw;
+        seeded = seeded || in;
+      }
+      const int oy = oy0 + j;
+      if (oy < H) {
+        const int64_t o = ((((int64_t)b * H + oy) * W + ox) * C4 + c4) * 4;
+        sta4(y + o, m);
+        if (idx) *reinterpret_cast<uchar4*>(idx + o) = make_uchar4((uint8_t)mx, (uint8_t)my, (uint8_t)mz, (uint8_t)mw);
+      }
+    }
+  }
+}
+
+// workgroup (bx, by): lanes = 256 consecutive (x, channel-group) positions of an input row; chunks of P rows
+// by, by + gdy, ... of the flattened (image, row / P) axis.  Same outputs and row layout as maxpool3_bn_bwd_kernel.
+template <int P>
+__global__ __launch_bounds__(256) void maxpool3_bn_bwd_strip_kernel(const act_t* __restrict__ dy,
+                                                                    const uint8_t* __restrict__ idx,
+                                                                    const act_t* __restrict__ z,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    act_t* __restrict__ g, float* __restrict__ stats,
+                                                                    int B, int H, int W, int C4) {
+  __shared__ float4 sred[2][4][64];
+  const int C = C4 * 4;
+  const int tid = threadIdx.x;
+  const int base = blockIdx.x * 256;
+  const int pos = base + tid;
+  const bool live = pos < W * C4;
+  const int ix = live ? pos / C4 : 0;
+  const int c4 = live ? pos - ix * C4 : 0;
+  const float4 mu = lda4(mean + c4 * 4), is = lda4(invstd + c4 * 4);
+  // the three window columns that contain ix: tap column tx belongs to the window at ox = ix + 1 - tx
+  int oxs[3];
+  bool oxok[3];
+#pragma unroll
+  for (int tx = 0; tx < 3; ++tx) {
+    const int ox = ix + 1 - tx;
+    oxok[tx] = live && ox >= 0 && ox < W;
+    oxs[tx] = ox < 0 ? 0 : (ox >= W ? W - 1 : ox);
+  }
+  float4 ssum[2] = {f4zero(), f4zero()};
+  const int chunks = (H + P - 1) / P;
+  const int R = B * chunks;
+  for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    const int b = r / chunks, iy0 = (r - b * chunks) * P;
+    // output rows iy0 - 1 ... iy0 + P (the windows of input row iy are at oy = iy + 1 - ty)
+    float4 d[P + 2][3];
+    uchar4 w[P + 2][3];
+    bool rok[P + 2];
+#pragma unroll
+    for (int q = 0; q < P + 2; ++q) {
+      const int oy = iy0 - 1 + q;
+      rok[q] = oy >= 0 && oy < H;
+      const int oyc = oy < 0 ? 0 : (oy >= H ? H - 1 : oy);
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const int64_t o = ((((int64_t)b * H + oyc) * W + oxs[tx]) * C4 + c4) * 4;
+        w[q][tx] = *reinterpret_cast<const uchar4*>(idx + o);
+        d[q][tx] = lda4(dy + o);
+      }
+    }
+    float4 zv[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int iy = iy0 + j < H ? iy0 + j : H - 1;
+      zv[j] = lda4(z + (((int64_t)b * H + iy) * W + ix) * C + c4 * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      float4 acc = f4zero();
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // tap (ty, tx) of the window at output row iy + 1 - ty = iy0 - 1 + (j + 2 - ty)
+        const int q = j + 2 - t / 3, tx = t % 3;
+        const bool in = rok[q] && oxok[tx];
+        acc.x += (in && w[q][tx].x == t) ? d[q][tx].x : 0.f;
+        acc.y += (in && w[q][tx].y == t) ? d[q][tx].y : 0.f;
+        acc.z += (in && w[q][tx].z == t) ? d[q][tx].z : 0.f;
+        acc.w += (in && w[q][tx].w == t) ? d[q][tx].w : 0.f;
+      }
+      const bool rowok = live && iy0 + j < H;
+      if (rowok) sta4(g + (((int64_t)b * H + iy0 + j) * W + ix) * C + c4 * 4, acc);
+#ifdef NASSEG_BF16
+      acc = make_float4(bf16_to_f32(f32_to_bf16(acc.x)), bf16_to_f32(f32_to_bf16(acc.y)),
+                        bf16_to_f32(f32_to_bf16(acc.z)), bf16_to_f32(f32_to_bf16(acc.w)));  // (what a reduction pass would read)
+#endif
+      const float4 gm = keep_if(acc, rowok);
+      ssum[0] = add4(ssum[0], gm);
+      ssum[1] = fma4(gm, make_float4((zv[j].x - mu.x) * is.x, (zv[j].y - mu.y) * is.y, (zv[j].z - mu.z) * is.z,
+                                     (zv[j].w - mu.w) * is.w), ssum[1]);
+    }
+  }
+  const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+  block_reduce_groups<2, 2>(ssum, sred, stats + (size_t)blk * 2 * C, base, C4);
+}
+
 struct PoolBnGrid {
   int gx, gy;
 };
-inline PoolBnGrid pool_bn_grid(int B, int H, int W, int C) {
+#if NASSEG_FP32_ONLY
+// stride-1 max pooling on the strip kernels: 1 (initial) four rows per thread, 2 two rows per thread; 0: one tap
+// gather per element (A/B switch)
+std::atomic<int> g_pool_strip{1};
+#endif
+extern "C" int nasseg_pool_strip(int v);
+
+inline int pool_strip_rows(int mode) { return mode == 1 ? 4 : (mode == 2 ? 2 : 1); }
+inline PoolBnGrid pool_bn_grid(int B, int H, int W, int C, int strip = 0) {
   PoolBnGrid g;
   g.gx = cdiv(W * (C / 4), 256);
-  int64_t gy = 2048 / g.gx;  // ~2048 workgroups, at least two rows each
-  const int64_t rows = (int64_t)B * H;
+  int64_t gy = 2048 / g.gx;  // ~2048 workgroups, at least two rows (strip kernel: chunks of rows) each
+  const int64_t rows = (int64_t)B * cdiv(H, pool_strip_rows(strip));
   if (gy > rows / 2) gy = rows / 2;
   if (gy < 1) gy = 1;
   if (gy > 65535) gy = 65535;
@@ -324,8 +493,15 @@ extern "C" {
 // statistics rows of nasseg_maxpool_bn_bwd (0: geometry not served - use the unfused ops)
 int64_t nasseg_maxpool_bn_bwd_blocks(int B, int H, int W, int C, int K, int stride, int pad) {
   if (K != 3 || pad != 1 || (stride != 1 && stride != 2) || C % 4 || C / 4 > 256 || B <= 0 || H <= 0 || W <= 0) return 0;
-  const PoolBnGrid g = pool_bn_grid(B, H, W, C);
+  const PoolBnGrid g = pool_bn_grid(B, H, W, C, stride == 1 ? nasseg_pool_strip(-1) : 0);
   return (int64_t)g.gx * g.gy;
+}
+// stride-1 3x3 max pooling on the strip kernels (four rows per thread: 4.5 loads per element instead of 9): 1 (initial)
+// / 0; v < 0 only queries.  Returns the previous setting.  Identical outputs; the statistics rows are other partitions of
+// the same sums.
+int nasseg_pool_strip(int v) {
+  if (v < 0) return g_pool_strip.load();
+  return g_pool_strip.exchange(v > 2 ? 1 : v);
 }
 #else
 int64_t nasseg_maxpool_bn_bwd_blocks(int B, int H, int W, int C, int K, int stride, int pad);
@@ -337,6 +513,18 @@ int NASSEG_FN(maxpool_bn_fwd)(const act_t* z, const float* scale, const float* s
                               int B, int H, int W, int C, int Ho, int Wo, int stride, int pad, void* stream) {
   NASSEG_REQUIRE(C > 0 && C % 4 == 0 && stride > 0 && pad >= 0 && pad <= 2, "maxpool_bn_fwd: bad arguments");
   const int64_t n4 = (int64_t)B * Ho * Wo * (C / 4);
+  const int strip = nasseg_pool_strip(-1);
+  if (stride == 1 && pad == 1 && Ho == H && Wo == W && strip) {
+    const dim3 grid(pool_grid((int64_t)B * cdiv(H, pool_strip_rows(strip)) * W * (C / 4)));
+    if (strip == 1)
+      hipLaunchKernelGGL(maxpool3_bn_fwd_strip_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, z, scale, shift, y,
+                         idx, B, H, W, C / 4);
+    else
+      hipLaunchKernelGGL(maxpool3_bn_fwd_strip_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, z, scale, shift, y,
+                         idx, B, H, W, C / 4);
+    NASSEG_LAUNCH_CHECK("maxpool_bn_fwd");
+    return NASSEG_OK;
+  }
   hipLaunchKernelGGL(maxpool3_bn_fwd_kernel, dim3(pool_grid(n4)), dim3(256), 0, (hipStream_t)stream, z, scale,
                      shift, y, idx, B, H, W, C / 4, Ho, Wo, stride, pad);
   NASSEG_LAUNCH_CHECK("maxpool_bn_fwd");
@@ -351,9 +539,18 @@ int NASSEG_FN(maxpool_bn_bwd)(const act_t* dy, const uint8_t* idx, const act_t* 
                               int Wo, int stride, int pad, void* stream) {
   NASSEG_REQUIRE(dy && idx && z && mean && invstd && g && stats, "maxpool_bn_bwd: null argument");
   NASSEG_REQUIRE(nasseg_maxpool_bn_bwd_blocks(B, H, W, C, 3, stride, pad) > 0, "maxpool_bn_bwd: geometry not served");
-  const PoolBnGrid gr = pool_bn_grid(B, H, W, C);
-  hipLaunchKernelGGL(maxpool3_bn_bwd_kernel, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, dy, idx, z,
-                     mean, invstd, g, stats, B, H, W, C / 4, Ho, Wo, stride, pad);
+  const int strip = stride == 1 ? nasseg_pool_strip(-1) : 0;
+  NASSEG_REQUIRE(!strip || (Ho == H && Wo == W), "maxpool_bn_bwd: stride 1 keeps the size");
+  const PoolBnGrid gr = pool_bn_grid(B, H, W, C, strip);
+  if (strip == 1)
+    hipLaunchKernelGGL(maxpool3_bn_bwd_strip_kernel<4>, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, dy, idx,
+                       z, mean, invstd, g, stats, B, H, W, C / 4);
+  else if (strip == 2)
+    hipLaunchKernelGGL(maxpool3_bn_bwd_strip_kernel<2>, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, dy, idx,
+                       z, mean, invstd, g, stats, B, H, W, C / 4);
+  else
+    hipLaunchKernelGGL(maxpool3_bn_bwd_kernel, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, dy, idx, z,
+                       mean, invstd, g, stats, B, H, W, C / 4, Ho, Wo, stride, pad);
   NASSEG_LAUNCH_CHECK("maxpool_bn_bwd");
   return NASSEG_OK;
 }

@@ -2440,7 +2440,7 @@ def _apply_library_knobs():
     # tile order of the depthwise strips; NASSEG_CONV_DEEP_K=0: one k-step per round trip on small maps as well
     # (A/B switches, include/nasseg.h)
     for env, fn in (("NASSEG_DW_WGRAD_LDS", "nasseg_dw_wgrad_lds"), ("NASSEG_DW_SWIZZLE", "nasseg_dw_swizzle"),
-                    ("NASSEG_CONV_DEEP_K", "nasseg_conv_deep_k")):
+                    ("NASSEG_CONV_DEEP_K", "nasseg_conv_deep_k"), ("NASSEG_POOL_STRIP", "nasseg_pool_strip")):
         if os.environ.get(env) is not None:
             lib.query(fn, int(os.environ[env]))
             lib._memo.clear()

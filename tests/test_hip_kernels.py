@@ -1968,3 +1968,54 @@ def test_3x3_forward_statistics_from_the_lds_tiled_kernel(case):
     want = torch.cat([yd.sum(1), (yd * yd).sum(1)])
     assert_close(sums.double(), want, 2e-6 * float(B * Ho * Wo) ** 0.5 * float(yd.abs().max()) ** 2 + 1e-5, 2e-5,
                  "column sums of y and y^2")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 33, 64), (1, 24, 7, 5), (3, 64, 16, 19), (2, 8, 1, 9), (1, 144, 9, 1),
+                                   (4, 32, 64, 128)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_strip_max_pooling_equals_the_tap_gather(shape, dtype):
+    """nasseg_maxpool_bn_fwd / _bwd at stride 1: the strip kernels (nasseg_pool_strip 1: four rows per thread,
+    2: two rows) against the one-gather-per-element kernels (0) - outputs, winner indices and gradients bit for bit
+    (ragged last chunks, one-pixel rows / columns, negative BatchNorm scales, NaN-free ties), the BatchNorm-backward
+    rows to the rounding of another partition of the same sums"""
+    f = F()
+    B, C, H, W = shape
+    pre = "nasseg_" if dtype == torch.float32 else "nasseg_bf16_"
+    z = dev(rnd(B, C, H, W, seed=1)).to(dtype)
+    z[:, :, ::3, ::2] = z[:, :, ::3, ::2].round()  # (ties: the first maximum in window order must win)
+    dy = dev(rnd(B, C, H, W, seed=2)).to(dtype)
+    scale, shift, mean, invstd = _bn_vectors(C, 3)
+    s = f.current_stream()
+    prev = f.lib.query("nasseg_pool_strip", -1)
+    got = {}
+    try:
+        for mode in (0, 1, 2):
+            f.lib.query("nasseg_pool_strip", mode)
+            f.lib._memo.clear()
+            y = torch.full_like(z, float("nan"))
+            idx = torch.full((B, H, W, C), 255, device=DEV, dtype=torch.uint8)
+            f.lib.call(pre + "maxpool_bn_fwd", f.ptr(z), f.ptr(scale), f.ptr(shift), f.ptr(y), f.ptr(idx), B, H, W, C,
+                       H, W, 1, 1, s)
+            nb = f.lib.query("nasseg_maxpool_bn_bwd_blocks", B, H, W, C, 3, 1, 1)
+            assert nb > 0
+            part = torch.full(((nb + 64) * 2 * C,), float("nan"), device=DEV)
+            g = torch.full_like(z, float("nan"))
+            f.lib.call(pre + "maxpool_bn_bwd", f.ptr(dy), f.ptr(idx), f.ptr(z), f.ptr(mean), f.ptr(invstd), f.ptr(g),
+                       f.ptr(part), B, H, W, C, H, W, 1, 1, s)
+            sums = torch.empty(2 * C, device=DEV)
+            f.lib.call("nasseg_rows_sum", f.ptr(part), nb, 2 * C, f.ptr(sums), s)
+            torch.cuda.synchronize()
+            got[mode] = (y.clone(), idx.clone(), g.clone(), sums.clone())
+    finally:
+        f.lib.query("nasseg_pool_strip", prev)
+        f.lib._memo.clear()
+    for mode in (1, 2):
+        for k, what in enumerate(("output", "winner index", "gradient")):
+            assert torch.equal(got[mode][k], got[0][k]), "mode {}: {}".format(mode, what)
+        tol = 2e-6 * float(B * H * W) ** 0.5 * (float(got[0][2].float().abs().max()) + 1e-3) * 8
+        assert_close(got[mode][3], got[0][3], tol, 1e-4, "mode {}: BatchNorm-backward sums".format(mode))
+    # ... and the torch reference of the forward (max pooling of the affine map)
+    ref = torch.nn.functional.max_pool2d(z.float().cpu() * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1),
+                                         3, 1, 1)
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -7
+    assert_close(got[1][0].float(), ref, tol * float(ref.abs().max()) + 1e-6, 1e-5, "forward against torch")
