@@ -77,12 +77,6 @@ int nasseg_dwconv_wgrad(const float* x, const float* dy, float* dw, float* ws,
                         const float* in_scale, const float* in_shift, int in_act, int B, int H, int W,
                         int C, int Ho, int Wo, int K, int stride, int pad, int dil, void* stream);
 
-/* XCD-aware tile order of the depthwise strip kernels: workgroups reach the 8 XCDs (one L2 each) round-robin in
- * dispatch order; with 1 XCD k works through the k-th eighth of the tiles, ordered so that tiles sharing input rows
- * and halo columns follow each other in one L2.  0 (initial): the identity mapping - the experiment measured neutral
- * to 3 % slower (tools/kbench_dwswz.py).  v < 0 only queries.  Returns the previous setting.  Outputs are
- * bit-identical either way. */
-int nasseg_dw_swizzle(int v);
 /* backward-weight of stride-1 5x5 depthwise layers (any dilation that divides the padding): 1 (initial) a kernel that
  * stages its tiles in LDS - the prologue applied once per element, the 5x8 window of a thread read from LDS, a dilated
  * conv cut into its dil^2 pixel classes; 0: the strip kernel of the other geometries.  v < 0 only queries.  Returns
@@ -163,25 +157,6 @@ int64_t nasseg_conv_pointwise_kernel(int B, int Ho, int Wo, int N, int K, int po
  * statistics rows (served there when N % 4 == 0).  For measurement tools, like nasseg_conv_pointwise_kernel. */
 int64_t nasseg_conv_fwd_lds3x3(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil,
                                int with_stats);
-/* nasseg_conv_fwd with statistics rows (no output epilogue, no residual), and the BatchNorm behind it finished in
- * the SAME launch where the kernel that serves the call can (csrc/tail.h: the workgroup that finishes last sums the
- * rows - write-through rows, drained stores, a device-scope ticket, no fence - in a fixed order, fp64).  Returns 1
- * when mean / invstd / scale / shift / the running statistics / num_batches_tracked are written (the outputs and
- * arithmetic of nasseg_bn_finalize), 0 when only the rows are (call nasseg_bn_finalize as before), < 0 on error.
- * tickets: 33 zero-initialised 32-bit words that no other launch in flight uses; zero again when the kernel ends. */
-int nasseg_conv_fwd_bn(const float* x, int ldx, const float* wp, float* y, int ldy, const float* in_scale,
-                       const float* in_shift, int in_act, int B, int Hs, int Ws, int K, int Ho, int Wo, int N,
-                       int kh, int kw, int stride, int pad, int dil, float* stats, unsigned int* tickets,
-                       float eps, float momentum, const float* gamma, const float* beta, float* mean,
-                       float* invstd, float* scale, float* shift, float* running_mean, float* running_var,
-                       int64_t* num_batches_tracked, void* stream);
-/* nasseg_conv_bwd_data_bn with statistics rows, summed in the same launch where the kernel can: returns 1 when
- * sums[2][N] = {sum g, sum g*xhat} is written (what nasseg_rows_sum makes of the rows), 0 when only the rows are */
-int nasseg_conv_bwd_data_bn_sums(const float* dy, int lddy, const float* wp, float* g, int ldg, const float* z,
-                                 int ldz, const float* scale, const float* shift, const float* mean,
-                                 const float* invstd, int act, int B, int Hs, int Ws, int K, int Ho, int Wo, int N,
-                                 int kh, int kw, int stride, int pad, int dil, float* stats, unsigned int* tickets,
-                                 float* sums, void* stream);
 /* dense twin of nasseg_dwconv_bwd_data_bn (arguments as nasseg_conv_fwd, transposed) */
 int nasseg_conv_bwd_data_bn(const float* dy, int lddy, const float* wp, float* g, int ldg,
                             const float* z, int ldz, const float* scale, const float* shift,
@@ -546,17 +521,6 @@ int nasseg_bf16_conv_fwd(const nasseg_bf16_t* x, int ldx, const float* wp, nasse
                     const float* out_scale, const float* out_shift, int out_act, const nasseg_bf16_t* res,
                     int ldres, int B, int Hs, int Ws, int K, int Ho, int Wo, int N, int kh, int kw,
                     int stride, int pad, int dil, int transposed, float* stats, void* stream);
-int nasseg_bf16_conv_fwd_bn(const nasseg_bf16_t* x, int ldx, const float* wp, nasseg_bf16_t* y, int ldy,
-                            const float* in_scale, const float* in_shift, int in_act, int B, int Hs, int Ws, int K,
-                            int Ho, int Wo, int N, int kh, int kw, int stride, int pad, int dil, float* stats,
-                            unsigned int* tickets, float eps, float momentum, const float* gamma, const float* beta,
-                            float* mean, float* invstd, float* scale, float* shift, float* running_mean,
-                            float* running_var, int64_t* num_batches_tracked, void* stream);
-int nasseg_bf16_conv_bwd_data_bn_sums(const nasseg_bf16_t* dy, int lddy, const float* wp, nasseg_bf16_t* g, int ldg,
-                                      const nasseg_bf16_t* z, int ldz, const float* scale, const float* shift,
-                                      const float* mean, const float* invstd, int act, int B, int Hs, int Ws, int K,
-                                      int Ho, int Wo, int N, int kh, int kw, int stride, int pad, int dil,
-                                      float* stats, unsigned int* tickets, float* sums, void* stream);
 int nasseg_bf16_conv_bwd_data_bn(const nasseg_bf16_t* dy, int lddy, const float* wp, nasseg_bf16_t* g, int ldg,
                             const nasseg_bf16_t* z, int ldz, const float* scale, const float* shift,
                             const float* mean, const float* invstd, int act, int B, int Hs, int Ws,

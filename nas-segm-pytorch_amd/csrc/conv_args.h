@@ -3,7 +3,6 @@
 // non-exported functions carry the build in their name (NASSEG_INTERNAL).
 #pragma once
 #include "conv_common.h"
-#include "tail.h"
 
 #ifdef NASSEG_BF16
 #define NASSEG_INTERNAL(name) nasseg_internal_bf16_##name
@@ -48,6 +47,4 @@ struct PwnPlan {
   size_t lds;
 };
 NASSEG_HIDDEN PwnPlan nasseg_internal_pwn_plan(int64_t M, int N, int K, int mode);
-// tail (may be null): finalise the statistics rows in the same launch (tail.h); returns 1 when it did
-NASSEG_HIDDEN int NASSEG_INTERNAL(pwn_launch)(const FwdArgs& a, const PwnPlan& p, int stats, const TailArgs* tail,
-                                              hipStream_t s);
+NASSEG_HIDDEN int NASSEG_INTERNAL(pwn_launch)(const FwdArgs& a, const PwnPlan& p, int stats, hipStream_t s);

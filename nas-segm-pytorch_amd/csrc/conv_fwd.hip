@@ -1143,7 +1143,7 @@ inline bool lds3x3_geometry(int B, int Ho, int Wo, int N, int K, int kh, int kw,
 
 inline int fwd_pack_mode(int K, int kh, int kw) { return (kh * kw > 1 && kh * kw * K <= 64) ? 2 : 0; }
 
-int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s, const TailArgs* tail = nullptr) {
+int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   const int K = a.K, N = a.N;
   const ConvGeom& g = a.g;
   NASSEG_REQUIRE(g.B > 0 && g.Hs > 0 && g.Ws > 0 && g.Ho > 0 && g.Wo > 0, "conv_fwd: bad geometry");
@@ -1171,7 +1171,7 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s, const TailArgs* tai
       const bool aligned = md.km == KM_VEC && md.vecn && (stats_mode < 2 || (a.ldbz & 3) == 0);
       NASSEG_REQUIRE(aligned || (md.stats != 1 && md.stats != 2),
                      "conv_fwd: the pointwise statistics path needs channel strides that are multiples of 4");
-      if (aligned) return NASSEG_INTERNAL(pwn_launch)(a, pn, md.stats, tail, s);
+      if (aligned) return NASSEG_INTERNAL(pwn_launch)(a, pn, md.stats, s);
     }
     const PwFwdPlan pw = pw_fwd_plan((int64_t)g.B * g.Ho * g.Wo, N, K, stats_mode >= 2 ? 2 : 1);
     if (pw.ok) {
@@ -1400,55 +1400,6 @@ int NASSEG_FN(conv_bwd_data_bn)(const act_t* dy, int lddy, const float* wp, act_
   a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
   a.g.transposed = 1;
   return conv_dispatch(a, stats ? 2 : 3, (hipStream_t)stream);
-}
-
-// nasseg_conv_fwd with statistics, and the BatchNorm that consumes them finished in the SAME launch where the
-// kernel that runs can do it (csrc/tail.h - today the N-split persistent pointwise kernel): returns 1 when mean /
-// invstd / scale / shift / running statistics / num_batches_tracked are written (nasseg_bn_finalize's outputs,
-// its arithmetic), 0 when only the rows are (the caller then calls nasseg_bn_finalize as before), < 0 on error.
-// tickets: NASSEG_TAIL_WORDS (33) zero-initialised words that no other launch in flight uses; they are zero again
-// when the kernel ends.  stats must not be null.
-int NASSEG_FN(conv_fwd_bn)(const act_t* x, int ldx, const float* wp, act_t* y, int ldy, const float* in_scale,
-                           const float* in_shift, int in_act, int B, int Hs, int Ws, int K, int Ho, int Wo, int N,
-                           int kh, int kw, int stride, int pad, int dil, float* stats, unsigned int* tickets,
-                           float eps, float momentum, const float* gamma, const float* beta, float* mean,
-                           float* invstd, float* scale, float* shift, float* running_mean, float* running_var,
-                           int64_t* num_batches_tracked, void* stream) {
-  NASSEG_REQUIRE(stats && tickets && mean && invstd && scale && shift, "conv_fwd_bn: null argument");
-  FwdArgs a = {};
-  a.x = x; a.ldx = ldx; a.w = wp; a.y = y; a.ldy = ldy;
-  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
-  a.stats = stats; a.K = K; a.N = N;
-  a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
-  a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
-  TailArgs t = {};
-  t.tickets = tickets; t.kind = 1; t.M = (double)B * Ho * Wo; t.eps = eps; t.momentum = momentum;
-  t.gamma = gamma; t.beta = beta; t.mean = mean; t.invstd = invstd; t.scale = scale; t.shift = shift;
-  t.running_mean = running_mean; t.running_var = running_var; t.nbt = (long long*)num_batches_tracked;
-  return conv_dispatch(a, 1, (hipStream_t)stream, &t);
-}
-
-// nasseg_conv_bwd_data_bn with statistics, and their rows summed in the same launch where the kernel can
-// (returns 1: sums[2][N] = {sum g, sum g*xhat} written - what nasseg_rows_sum would produce; 0: rows only).
-int NASSEG_FN(conv_bwd_data_bn_sums)(const act_t* dy, int lddy, const float* wp, act_t* g, int ldg, const act_t* z,
-                                     int ldz, const float* scale, const float* shift, const float* mean,
-                                     const float* invstd, int act, int B, int Hs, int Ws, int K, int Ho, int Wo,
-                                     int N, int kh, int kw, int stride, int pad, int dil, float* stats,
-                                     unsigned int* tickets, float* sums, void* stream) {
-  NASSEG_REQUIRE(z && stats && tickets && sums && scale && shift && mean && invstd,
-                 "conv_bwd_data_bn_sums: null argument");
-  NASSEG_REQUIRE((ldz & 3) == 0 && ldz >= N, "conv_bwd_data_bn_sums: bad ldz");
-  FwdArgs a = {};
-  a.x = dy; a.ldx = lddy; a.w = wp; a.y = g; a.ldy = ldg;
-  a.stats = stats; a.K = K; a.N = N;
-  a.bz = z; a.ldbz = ldz; a.b_scale = scale; a.b_shift = shift; a.b_mean = mean;
-  a.b_invstd = invstd; a.b_act = act;
-  a.g.B = B; a.g.Hs = Hs; a.g.Ws = Ws; a.g.Ho = Ho; a.g.Wo = Wo;
-  a.g.kh = kh; a.g.kw = kw; a.g.stride = stride; a.g.pad = pad; a.g.dil = dil;
-  a.g.transposed = 1;
-  TailArgs t = {};
-  t.tickets = tickets; t.kind = 2; t.out = sums;
-  return conv_dispatch(a, 2, (hipStream_t)stream, &t);
 }
 
 }  // extern "C"

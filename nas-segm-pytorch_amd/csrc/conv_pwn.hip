@@ -81,7 +81,7 @@ __device__ __forceinline__ float4 sel4(bool c, float4 a, float4 b) {
 // N 4 / PS ways.  MTW = 4 / PS subtiles of 16 pixels per wave, NTU units (NTW = 2 NTU channel tiles) per wave:
 // tile nt of a wave is channel tile 2 * (nw + NS * (nt / 2)) + nt % 2.
 template <int PS, int NTU, int STATS>
-__global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a, TailArgs tail) {
+__global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a) {
   constexpr int MTW = 4 / PS;
   constexpr int NS = 4 / PS;
   constexpr int NTW = 2 * NTU;
@@ -360,24 +360,22 @@ __global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a, TailArgs ta
         if (STATS == 1) {
           float* po = a.stats + (int64_t)blockIdx.x * 4 * N + n;
           const float hx = (float)vx, hq = (float)vq;
-          st_agent(po, hx);
-          st_agent(po + N, hq);
-          st_agent(po + 2 * N, (float)((double)vx - (double)hx));
-          st_agent(po + 3 * N, (float)((double)vq - (double)hq));
+          po[0] = hx;
+          po[N] = hq;
+          po[2 * N] = (float)((double)vx - (double)hx);
+          po[3 * N] = (float)((double)vq - (double)hq);
         } else {
           float* po = a.stats + (int64_t)blockIdx.x * 2 * N + n;
-          st_agent(po, (float)vx);
-          st_agent(po + N, (float)vq);
+          po[0] = (float)vx;
+          po[N] = (float)vq;
         }
       }
     }
-    // the rows of all workgroups summed and the statistics finished by whichever workgroup arrives last (tail.h)
-    if (tail.tickets) stats_tail(tail, blockIdx.x, smem);
   }
 }
 
 template <int PS, int NTU, int STATS>
-int launch_one(const FwdArgs& a, const PwnPlan& p, const TailArgs& t, hipStream_t s) {
+int launch_one(const FwdArgs& a, const PwnPlan& p, hipStream_t s) {
   static std::atomic<int> raised{0};
   if (p.lds > (size_t)(64 << 10) && !raised.load()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pwn_kernel<PS, NTU, STATS>),
@@ -387,18 +385,18 @@ int launch_one(const FwdArgs& a, const PwnPlan& p, const TailArgs& t, hipStream_
     }
     raised.store(1);
   }
-  hipLaunchKernelGGL((conv_pwn_kernel<PS, NTU, STATS>), dim3(p.grid), dim3(256), p.lds, s, a, t);
+  hipLaunchKernelGGL((conv_pwn_kernel<PS, NTU, STATS>), dim3(p.grid), dim3(256), p.lds, s, a);
   NASSEG_LAUNCH_CHECK("conv_pwn_kernel");
   return NASSEG_OK;
 }
 
 template <int PS, int NTU>
-int launch_stats(const FwdArgs& a, const PwnPlan& p, int stats, const TailArgs& t, hipStream_t s) {
+int launch_stats(const FwdArgs& a, const PwnPlan& p, int stats, hipStream_t s) {
   switch (stats) {
-    case 0: return launch_one<PS, NTU, 0>(a, p, t, s);
-    case 1: return launch_one<PS, NTU, 1>(a, p, t, s);
-    case 2: return launch_one<PS, NTU, 2>(a, p, t, s);
-    default: return launch_one<PS, NTU, 3>(a, p, t, s);
+    case 0: return launch_one<PS, NTU, 0>(a, p, s);
+    case 1: return launch_one<PS, NTU, 1>(a, p, s);
+    case 2: return launch_one<PS, NTU, 2>(a, p, s);
+    default: return launch_one<PS, NTU, 3>(a, p, s);
   }
 }
 
@@ -458,20 +456,8 @@ extern "C" int nasseg_conv_pwn_mode(int v) {
 }
 #endif  // NASSEG_FP32_ONLY
 
-int NASSEG_INTERNAL(pwn_launch)(const FwdArgs& a, const PwnPlan& p, int stats, const TailArgs* tail, hipStream_t s) {
-  TailArgs t = {};
-  const bool with_tail = tail && tail->tickets && (stats == 1 || stats == 2) && tail->kind == stats;
-  if (with_tail) {
-    t = *tail;
-    t.rows = a.stats;
-    t.nent = p.grid;
-    t.rpe = stats == 1 ? 2 : 1;
-    t.cols = 2 * a.N;
-    t.lvl = a.stats + (size_t)t.nent * t.rpe * t.cols;  // (the 64 spare rows every statistics buffer has)
-  }
-  int rc;
-  if (p.ps == 1) rc = p.ntw == 1 ? launch_stats<1, 1>(a, p, stats, t, s) : launch_stats<1, 2>(a, p, stats, t, s);
-  else if (p.ps == 2) rc = launch_stats<2, 1>(a, p, stats, t, s);
-  else rc = launch_stats<4, 1>(a, p, stats, t, s);
-  return rc < 0 ? rc : (with_tail ? 1 : 0);
+int NASSEG_INTERNAL(pwn_launch)(const FwdArgs& a, const PwnPlan& p, int stats, hipStream_t s) {
+  if (p.ps == 1) return p.ntw == 1 ? launch_stats<1, 1>(a, p, stats, s) : launch_stats<1, 2>(a, p, stats, s);
+  if (p.ps == 2) return launch_stats<2, 1>(a, p, stats, s);
+  return launch_stats<4, 1>(a, p, stats, s);
 }

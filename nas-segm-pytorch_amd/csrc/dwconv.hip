@@ -60,10 +60,8 @@ static inline int dw_fwd_rows(int K, int e, int Ho, int px = 1) {
 }
 
 #if NASSEG_FP32_ONLY
-std::atomic<int> g_dw_swizzle{0};
 std::atomic<int> g_dw_wgrad_lds{1};
 #else
-extern std::atomic<int> g_dw_swizzle;
 extern std::atomic<int> g_dw_wgrad_lds;
 #endif
 
@@ -138,7 +136,7 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ scale, const float* __restrict__ shift, int H, int W, int C4, int Ho,
     int Wo, int stride, int pad, int dil, int g, int nchunk, int act, float* __restrict__ stats,
-    BnBwd bn, int swz) {
+    BnBwd bn) {
   __shared__ float4 lw[WLDS ? K * K : 1][WLDS ? 64 : 1];
   __shared__ float4 sred[STATS ? 2 : 1][STATS ? 4 : 1][STATS ? 64 : 1];
   const int C = C4 * 4;
@@ -149,29 +147,12 @@ __global__ __launch_bounds__(256) void dw_fwd_strip(
     }
     __syncthreads();
   }
-  // Which tile this workgroup takes.  Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest),
-  // each XCD with an L2 of its own: with the identity mapping the 2 * dil columns of halo a tile shares with
-  // its horizontal neighbours and the (K - E) of Q input rows it shares with the next chunk of its row class
-  // are fetched by several L2s - 2.5 x 2 times the tensor for 5x5 at dilation 6.  swz (off by default: it measured
-  // neutral - the Infinity Cache behind the L2s already serves those re-reads): XCD k takes the k-th
-  // eighth of the tiles in order, and the order is (image, row class r, chunk, x): the tiles that share input
-  // rows - same class, consecutive chunks - follow each other in ONE L2 (rows of different classes are disjoint).
-  int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z, r, chunk;
-  if (swz) {
-    const unsigned gx = gridDim.x, gy = gridDim.y;
-    const unsigned T8 = (gx * gy * gridDim.z) & ~7u;
-    unsigned L = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
-    if (L < T8) L = (L & 7u) * (T8 >> 3) + (L >> 3);
-    bx = L % gx;
-    const unsigned q = L / gx;
-    by = q % gy;
-    b = q / gy;
-    r = by / nchunk;
-    chunk = by - r * nchunk;
-  } else {
-    r = by % g;
-    chunk = by / g;
-  }
+  // (An XCD-aware tile order - XCD k working through the k-th eighth of the tiles so that tiles sharing halo rows and
+  //  columns meet in ONE L2 - brought the fabric reads of the dilated 5x5 kernel from 2.7x to 1.05x the tensor and
+  //  changed its time by nothing, rounds 3-4: the kernel is issue-bound and the Infinity Cache serves the re-reads.
+  //  Removed in round 5.)
+  const int bx = blockIdx.x, by = blockIdx.y, b = blockIdx.z;
+  const int r = by % g, chunk = by / g;
   const int base = bx * 256;
   const int idx = base + threadIdx.x;
   const int oy0 = chunk * (P * g) + r;
@@ -1181,7 +1162,6 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
   const bool strip_ok = !transposed && (K == 3 || K == 5) && (sc.e == 1 || sc.e == 2) && B <= 65535;
   if (strip_ok) {
     constexpr int P = 4, P3 = NASSEG_DW_P3;  // output rows per thread (see dw_fwd_rows)
-    const int swz = g_dw_swizzle.load();
     const int px = dw_fwd_px(K, stride, dil, Wo);
     const int nchunk = cdiv(Ho, dw_fwd_rows(K, sc.e, Ho, px) * sc.g);
     dim3 grid(cdiv(dw_fwd_xgroups(K, stride, dil, Wo) * C4, 256), nchunk * sc.g, B);
@@ -1194,7 +1174,7 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                             \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, \
-                     act, stats, bn, swz)
+                     act, stats, bn)
 #define LAUNCH_FWD(KK, EE, WL)                                    \
   do {                                                            \
     if (stats_mode == 2) LAUNCH_FWD3(KK, EE, WL, false, 2);       \
@@ -1210,19 +1190,19 @@ static int dwconv_impl(const act_t* x, const float* wt, act_t* y, const float* i
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                                   \
   hipLaunchKernelGGL((dw_fwd_strip<KK, NASSEG_DW5_P, EE, WL, PR, ST, NASSEG_DW5_PX>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk,    \
-                     act, stats, bn, swz)
+                     act, stats, bn)
     if (K == 5 && px > 1) { if (wl) LAUNCH_FWD(5, 1, true); else LAUNCH_FWD(5, 1, false); }
 #undef LAUNCH_FWD3
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                              \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P3, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk,  \
-                     act, stats, bn, swz)
+                     act, stats, bn)
     if (K == 3 && sc.e == 1 && dw_fwd_rows(K, sc.e, Ho) == P3) LAUNCH_FWD(3, 1, false);
 #undef LAUNCH_FWD3
 #define LAUNCH_FWD3(KK, EE, WL, PR, ST)                                                             \
   hipLaunchKernelGGL((dw_fwd_strip<KK, P, EE, WL, PR, ST>), grid, dim3(256), 0, s, x, wt, y, in_scale, \
                      in_shift, in_act, scale, shift, H, W, C4, Ho, Wo, stride, pad, dil, sc.g, nchunk, \
-                     act, stats, bn, swz)
+                     act, stats, bn)
     if (K == 3 && sc.e == 1 && dw_fwd_rows(K, sc.e, Ho) == P) LAUNCH_FWD(3, 1, false);
     else if (K == 3 && sc.e == 2) LAUNCH_FWD(3, 2, false);
 #undef LAUNCH_FWD3
@@ -1662,14 +1642,6 @@ int NASSEG_FN(dwconv_bwd_bn)(const act_t* xz, const act_t* g, const act_t* z, co
 }
 
 #if NASSEG_FP32_ONLY
-// XCD-aware tile order of the depthwise strip kernels (dw_fwd_strip): 1 on, 0 (initial) the identity mapping;
-// v < 0 only queries.  Measured neutral to -3 % (tools/kbench_dwswz.py): these kernels are bound by their loads'
-// issue rate, not by what their L2s share.  Returns the previous setting.  Outputs are bit-identical either way; statistics rows hold
-// other tiles' sums (their total differs in rounding only).
-int nasseg_dw_swizzle(int v) {
-  if (v < 0) return g_dw_swizzle.load();
-  return g_dw_swizzle.exchange(v ? 1 : 0);
-}
 // backward-weight of stride-1 5x5 depthwise layers: 1 (initial) the LDS-tiled kernel where its plan applies, 0 the
 // strip kernel; v < 0 only queries.  Returns the previous setting.  Same partial-row layout either way.
 int nasseg_dw_wgrad_lds(int v) {

@@ -219,24 +219,42 @@ __global__ __launch_bounds__(8 * SLICES) void bn_stats_finalize_t(
   const int c = blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = c < C;
   const int64_t per = 2 * (int64_t)C;
+  // what the finishing threads need besides the sums is requested BEFORE the rows (it used to be loaded after the
+  // second reduction: one more dependent round trip at the end of a kernel that is nothing but round trips)
+  const bool fin = valid && rp_slice() == 0;
+  float g_ = 1.f, bt_ = 0.f, rm_ = 0.f, rv_ = 0.f;
+  if (fin) {
+    if (gamma) g_ = gamma[c];
+    if (beta) bt_ = beta[c];
+    if (running_mean) {
+      rm_ = running_mean[c];
+      rv_ = running_var[c];
+    }
+  }
   double s0, s1;  // (both columns of a channel in one pass over the rows: one round trip, one set of barriers)
-  reduce_partials2_n<SLICES>(partial, nblk, per, c, (int64_t)C + c, valid, red, red1, s0, s1);
+#ifdef NASSEG_ROWSUM_OLD  // (A/B: the two-pass form of rounds 1-4, tools/gpu.sh flags)
+  s0 = reduce_partials_n<SLICES>(partial, nblk, per, c, valid, red);
+  s1 = reduce_partials_n<SLICES>(partial, nblk, per, (int64_t)C + c, valid, red);
+  (void)red1;
+#else
+  reduce_rows_n<SLICES, 2>(partial, nblk, per, c, (int64_t)C + c, valid, red, red1, s0, s1);
+#endif
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-  if (!valid || rp_slice() != 0) return;
+  if (!fin) return;
   const double mu = s0 / M;
   double var = s1 / M - mu * mu;
   if (var < 0.0) var = 0.0;
   const double is = 1.0 / sqrt(var + (double)eps);
   mean[c] = (float)mu;
   invstd[c] = (float)is;
-  const double g = gamma ? (double)gamma[c] : 1.0;
-  const double bt = beta ? (double)beta[c] : 0.0;
+  const double g = (double)g_;
+  const double bt = (double)bt_;
   scale[c] = (float)(g * is);
   shift[c] = (float)(bt - mu * g * is);
   if (running_mean) {
-    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+    running_mean[c] = (float)((1.0 - momentum) * (double)rm_ + momentum * mu);
     const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
+    running_var[c] = (float)((1.0 - momentum) * (double)rv_ + momentum * unb);
   }
 }
 
@@ -271,7 +289,13 @@ __global__ __launch_bounds__(8 * SLICES) void rows_group_sum_t(const float* __re
   if (nr > rows_per_group) nr = rows_per_group;
   const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = e < per;
-  const double s = reduce_partials_n<SLICES>(partial + (int64_t)r0 * per, nr, per, e, valid, red);
+  double s, unused;
+#ifdef NASSEG_ROWSUM_OLD
+  s = reduce_partials_n<SLICES>(partial + (int64_t)r0 * per, nr, per, e, valid, red);
+  (void)unused;
+#else
+  reduce_rows_n<SLICES, 1>(partial + (int64_t)r0 * per, nr, per, e, e, valid, red, red, s, unused);
+#endif
   if (valid && rp_slice() == 0) out[(int64_t)g * per + e] = (float)s;
 }
 

@@ -56,15 +56,6 @@ def _vec(like, n):
     return torch.empty((int(n),), device=like.device, dtype=torch.float32)
 
 
-# Finalising per-channel reductions inside the kernel that produced their rows (csrc/tail.h) needs a few counters that
-# are zero between launches: one set per (device, stream) - launches on one stream run one after the other.
-# OFF by default - measured on MI355X (tools/gpu.sh ab OUT NASSEG_FUSE_TAIL "0 1"): it removes 37 of the 452 launches
-# of a headline step, 35 of CVPR 321x321's 885, 25 of task0's 680, and the steps get SLOWER by 0.5-0.8 % (267.0 -> 265.6,
-# 1105 -> 1097, 5482 -> 5446 img/s): the last workgroup's drain -> ticket -> row loads -> group row -> ticket -> loads
-# -> finish is a chain of six or seven memory round trips at the end of the producing kernel, as long as the
-# boundary + 5-8 us finaliser it replaces.  The entry points stay (tested, bit-reproducible) for parts where a kernel
-# boundary costs more.
-FUSE_TAIL = os.environ.get("NASSEG_FUSE_TAIL", "0") != "0"
 # BatchNorm backward whose apply kernel adds up the partial rows of its sums itself (nasseg_bn_bwd_apply_rows): on the
 # small maps of the CVPR cells the sums come as 8 - 128 rows (the first stage of the reduction over gradient and conv
 # output, or the statistics rows of a fused backward-data kernel), and the launch that summed them - colred_finalize /
@@ -106,17 +97,6 @@ def _bn_bwd_reduce(g, z, scale, shift, mean, invstd, act, sums, M, C, for_apply)
     lib.call(_k("nasseg_bn_bwd_reduce", g), ptr(g), C, ptr(z), C, M, C, ptr(scale), ptr(shift), ptr(mean),
              ptr(invstd), act, ptr(sums), ptr(ws), current_stream())
     return None
-
-
-_TICKETS = {}
-
-
-def _tickets(like, stream):
-    key = (like.device.index, stream)
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(64, device=like.device, dtype=torch.int32)
-    return t
 
 
 # ---------------------------------------------------------------------------
@@ -918,14 +898,6 @@ class _ConvChain(torch.autograd.Function):
             elif kind == "dw":
                 lib.call(_k("nasseg_dwconv", cur), ptr(cur), ptr(wp), ptr(z), ptr(psc), ptr(psh), pact, ptr(o_sc),
                          ptr(o_sh), o_act, B, H, W, K, Ho, Wo, kh, stride, pad, dil, 0, ptr(part), s)
-            elif part is not None and FUSE_TAIL and pointwise and not fold:
-                # conv + statistics + the BatchNorm's finalisation in one launch where the kernel can (returns 1)
-                finalised = lib.call(_k("nasseg_conv_fwd_bn", cur), ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh),
-                                     pact, B, H, W, K, Ho, Wo, N, kh, kw, stride, pad, dil, ptr(part),
-                                     ptr(_tickets(cur, s)), float(eps), float(momentum), ptr(gamma), ptr(beta),
-                                     ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(rm), ptr(rv), ptr(nbt), s)
-                if finalised:
-                    part = False  # (statistics done: no nasseg_bn_finalize below)
             else:
                 lib.call(_k("nasseg_conv_fwd", cur), ptr(cur), K, ptr(wp), ptr(z), N, ptr(psc), ptr(psh), pact,
                          ptr(o_sc), ptr(o_sh), o_act, ptr(o_res), N, B, H, W, K, Ho, Wo, N, kh, kw,
@@ -941,9 +913,7 @@ class _ConvChain(torch.autograd.Function):
                 continue
             if has_bn:
                 if training:
-                    if part is False:
-                        pass  # (finalised by the producing kernel)
-                    elif part is not None:
+                    if part is not None:
                         lib.call("nasseg_bn_finalize", ptr(part), nblk, M, N, float(eps), float(momentum),
                                  ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                  ptr(rm), ptr(rv), ptr(nbt), s)
@@ -1058,7 +1028,7 @@ class _ConvChain(torch.autograd.Function):
             fused_bn = None  # BatchNorm backward applied by the weight-gradient kernel on load
             if has_bn:
                 mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
-                sums = _vec(z, 2 * N) if (pre is None or len(pre) < 3 or pre[2] is None) else pre[2]
+                sums = _vec(z, 2 * N)
                 act_left = ACT_NONE if (pre is not None or g_masked) else act  # (the mask still to be applied to g)
                 pw_bact = act_left
                 go_on = need_dw or need_dx
@@ -1071,9 +1041,7 @@ class _ConvChain(torch.autograd.Function):
                 wgrad_bn = go_on and not on_load and need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil)
                 plain_apply = go_on and not on_load and not wgrad_bn  # (dz by a bn_bwd_apply pass)
                 lazy_rows = None  # the sums as rows the apply kernel adds up itself
-                if pre is not None and sums is (pre[2] if len(pre) > 2 else None):
-                    pass  # g arrived masked and its sums were finished by the kernel that produced it
-                elif pre is not None:
+                if pre is not None:
                     # g arrived masked, with its per-workgroup {sum g, sum g*xhat} rows
                     if plain_apply and _rows_small(pre[1], N):
                         lazy_rows = (pre[0], pre[1])
@@ -1210,20 +1178,10 @@ class _ConvChain(torch.autograd.Function):
                         nb = (lib.query("nasseg_conv_fwd_stats_blocks", Bc, H, W, K, N, 2 * int(pw1))
                               if pmu_ is not None else 0)
                         part = _ws(cur, (nb + 64) * 2 * K) if nb else None
-                        summed = None
-                        if nb and pw1 and FUSE_TAIL:
-                            # ... with the rows summed by the same launch where the kernel can (returns 1)
-                            summed = _vec(cur, 2 * K)
-                            if not lib.call(_k("nasseg_conv_bwd_data_bn_sums", dz), ptr(dz), N, ptr(wb), ptr(g), K,
-                                            ptr(zp), K, ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo,
-                                            N, H, W, K, kh, kw, stride, pad, dil, ptr(part), ptr(_tickets(cur, s)),
-                                            ptr(summed), s):
-                                summed = None
-                        else:
-                            lib.call(_k("nasseg_conv_bwd_data_bn", dz), ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
-                                     ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
-                                     K, kh, kw, stride, pad, dil, ptr(part), s)
-                        pre = (part, nb, summed)
+                        lib.call(_k("nasseg_conv_bwd_data_bn", dz), ptr(dz), N, ptr(wb), ptr(g), K, ptr(zp), K,
+                                 ptr(psc_), ptr(psh_), ptr(pmu_), ptr(pis_), pact_, Bc, Ho, Wo, N, H, W,
+                                 K, kh, kw, stride, pad, dil, ptr(part), s)
+                        pre = (part, nb)
                     else:
                         g = _dense_backward_data(dz, wb, _dense_dgrad_form(w, stride, pad, dil),
                                                  (Bc, K, H, W), N, kh, kw, stride, pad, dil)
@@ -1242,8 +1200,6 @@ class _ConvChain(torch.autograd.Function):
 # for the very tensor object it was made for (a dead or different object: the chain reduces as usual).
 _TAIL_ROWS = {}
 FUSE_TAIL_ROWS = os.environ.get("NASSEG_FUSE_TAIL_ROWS", "1") != "0"
-_TAIL_ROWS_UP = os.environ.get("NASSEG_TAIL_ROWS_UP", "0") == "1"  # (A/B switch: also for up-sampled producers)
-_PENDING_IN = os.environ.get("NASSEG_PENDING_IN", "1") != "0"  # (A/B switch: chains take a Pending as their prologue)
 
 
 class Pending(object):
@@ -1401,7 +1357,7 @@ def conv_chain(x, ops, in_act0=ACT_NONE, residual=None, pool=None, defer_tail=Fa
             tensors.extend([weight, gamma, beta, rm, rv, nbt if training else None])
     cfg = (int(in_act0), tuple(cfg_ops), torch.is_grad_enabled())
     if isinstance(x, Pending):
-        if in_act0 != ACT_NONE or not cfg_ops or not _PENDING_IN:
+        if in_act0 != ACT_NONE or not cfg_ops:
             x = x.materialize()  # (an activation on top of a pending one: not fused)
         else:
             # cfg[3] pool, cfg[4] deferred tail, cfg[5] the pending input's activation (its statistics vector
@@ -1925,7 +1881,7 @@ class _CatReduce(torch.autograd.Function):
                     # (a producer SMALLER than the slab keeps its own reduction pass: over its few pixels that is
                     #  cheaper than four taps of z per slab pixel - 3 launches of the headline step, +15 us each)
                     rows = (_ws(slab, (nrows + 64) * 2 * C)
-                            if (st is not None and FUSE_TAIL_ROWS and (H * W >= Ho * Wo or _TAIL_ROWS_UP)) else None)
+                            if (st is not None and FUSE_TAIL_ROWS and H * W >= Ho * Wo) else None)
                     d = _new(slab, B, C, Ho, Wo)
                     lib.call(_k("nasseg_cat_src_bwd", g), ptr(g), ptr(slab), Ct, off * C, ptr(scale), ptr(mean),
                              ptr(invstd), ptr(sums), int(training), ptr(z) if rows is not None else None,
@@ -2436,11 +2392,11 @@ def _apply_library_knobs():
     if _PWN_MODE is not None:
         lib.query("nasseg_conv_pwn_mode", int(_PWN_MODE))
         lib._memo.clear()
-    # NASSEG_DW_WGRAD_LDS=0: the strip kernel for 5x5 depthwise weight gradients too; NASSEG_DW_SWIZZLE=1: XCD-aware
-    # tile order of the depthwise strips; NASSEG_CONV_DEEP_K=0: one k-step per round trip on small maps as well
-    # (A/B switches, include/nasseg.h)
-    for env, fn in (("NASSEG_DW_WGRAD_LDS", "nasseg_dw_wgrad_lds"), ("NASSEG_DW_SWIZZLE", "nasseg_dw_swizzle"),
-                    ("NASSEG_CONV_DEEP_K", "nasseg_conv_deep_k"), ("NASSEG_POOL_STRIP", "nasseg_pool_strip")):
+    # NASSEG_DW_WGRAD_LDS=0: the strip kernel for 5x5 depthwise weight gradients too; NASSEG_CONV_DEEP_K=0: one
+    # k-step per round trip on small maps as well; NASSEG_POOL_STRIP=0 / 2: stride-1 max pooling one gather per
+    # element / two rows per thread (A/B switches, include/nasseg.h)
+    for env, fn in (("NASSEG_DW_WGRAD_LDS", "nasseg_dw_wgrad_lds"), ("NASSEG_CONV_DEEP_K", "nasseg_conv_deep_k"),
+                    ("NASSEG_POOL_STRIP", "nasseg_pool_strip")):
         if os.environ.get(env) is not None:
             lib.query(fn, int(os.environ[env]))
             lib._memo.clear()

@@ -1423,88 +1423,6 @@ def test_nsplit_pointwise_statistics_of_nearly_constant_channels():
     assert float(((got_var - var).abs() / var).max()) < 1e-4, float(((got_var - var).abs() / var).max())
 
 
-TAIL_CASES = [
-    # B, H, W, K, N: one workgroup, fewer workgroups than groups (32), more, several members per group, the
-    # persistent grid's maximum (768 / 512 workgroups, two rows each in the forward form)
-    (1, 5, 7, 16, 16), (1, 20, 30, 32, 64), (2, 40, 50, 24, 96), (1, 100, 150, 16, 32), (2, 200, 256, 32, 64),
-    (1, 256, 400, 64, 144),
-]
-
-
-@pytest.mark.parametrize("case", TAIL_CASES)
-def test_statistics_finalised_inside_the_producing_kernel(case):
-    """csrc/tail.h: nasseg_conv_fwd_bn / nasseg_conv_bwd_data_bn_sums (conv_pwn_kernel + the last workgroup's
-    finalisation) against the two-launch forms nasseg_conv_fwd + nasseg_bn_finalize / nasseg_conv_bwd_data_bn +
-    nasseg_rows_sum - same rows, fp64 sums in another fixed order: equal to fp32 rounding of the results.  Ten
-    launches in a row on fresh data while a copy stream keeps the memory system busy: a stale row (a missed
-    write-through, a ticket that did not return to zero) would show as a wrong statistic in some repetition."""
-    f = F()
-    B, H, W, K, N = case
-    M = B * H * W
-    s = f.current_stream()
-    w = rnd(N, K, 1, 1, seed=2, scale=0.3).to(DEV)
-    gamma, beta = _bn_vectors(N, 3)[:2]
-    osc, osh, omu, ois = _bn_vectors(N, 6)
-    tickets = torch.zeros(64, device=DEV, dtype=torch.int32)
-    noise_a = torch.empty(64 << 20, device=DEV)
-    noise_b = torch.empty(64 << 20, device=DEV)
-    side = torch.cuda.Stream()
-    with _pwn_mode(2):
-        assert f.lib.query("nasseg_conv_pointwise_kernel", B, H, W, N, K, 1) == 2
-        nb = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, N, K, 1)
-        nb2 = f.lib.query("nasseg_conv_fwd_stats_blocks", B, H, W, N, K, 2)
-        for rep in range(10):
-            x = dev(rnd(B, K, H, W, seed=10 + rep) + 0.3 * rep)
-            z = dev(rnd(B, N, H, W, seed=40 + rep))
-            with torch.cuda.stream(side):
-                noise_b.copy_(noise_a)
-            # ---- forward: statistics -> BatchNorm parameters ----
-            outs = []
-            for fused in (False, True):
-                y = dev(torch.empty(B, N, H, W))
-                part = torch.full(((nb + 64) * 2 * N,), float("nan"), device=DEV)
-                st = torch.full((4 * N,), float("nan"), device=DEV)
-                rm, rv = torch.full((N,), 0.25, device=DEV), torch.full((N,), 2.0, device=DEV)
-                nbt = torch.full((1,), 7, device=DEV, dtype=torch.int64)
-                fin = (0.001, 0.1, f.ptr(gamma), f.ptr(beta), f.ptr(st[0:N]), f.ptr(st[N:2 * N]),
-                       f.ptr(st[2 * N:3 * N]), f.ptr(st[3 * N:]), f.ptr(rm), f.ptr(rv), f.ptr(nbt))
-                if fused:
-                    rc = f.lib.call("nasseg_conv_fwd_bn", f.ptr(x), K, f.ptr(w), f.ptr(y), N, None, None, 0, B, H, W, K,
-                                    H, W, N, 1, 1, 1, 0, 1, f.ptr(part), f.ptr(tickets), *fin, s)
-                    assert rc == 1
-                else:
-                    f.lib.call("nasseg_conv_fwd", f.ptr(x), K, f.ptr(w), f.ptr(y), N, None, None, 0, None, None, 0,
-                               None, 0, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, 0, f.ptr(part), s)
-                    f.lib.call("nasseg_bn_finalize", f.ptr(part), nb, M, N, *fin, s)
-                outs.append((y, st, rm, rv, nbt))
-            (y0, st0, rm0, rv0, n0), (y1, st1, rm1, rv1, n1) = outs
-            assert torch.equal(y0, y1) and int(n0) == int(n1) == 8
-            for a, b, what in ((st0, st1, "mean|invstd|scale|shift"), (rm0, rm1, "running_mean"), (rv0, rv1, "running_var")):
-                assert not torch.isnan(b).any(), what
-                assert_close(b, a, 1e-6 * float(a.abs().max()), 1e-5, "{} (repetition {})".format(what, rep))
-            # ---- backward-data: rows -> {sum g, sum g*xhat} ----
-            dy = dev(rnd(B, K, H, W, seed=70 + rep))
-            wb = rnd(K, N, 1, 1, seed=5, scale=0.3).to(DEV).reshape(K, N).contiguous()  # ([K][N]: mode 1 of a 1x1 conv)
-            res = []
-            for fused in (False, True):
-                gout = dev(torch.empty(B, N, H, W))
-                part = torch.full(((nb2 + 64) * 2 * N,), float("nan"), device=DEV)
-                sums = torch.full((2 * N,), float("nan"), device=DEV)
-                common = (f.ptr(dy), K, f.ptr(wb), f.ptr(gout), N, f.ptr(z), N, f.ptr(osc), f.ptr(osh), f.ptr(omu),
-                          f.ptr(ois), 2, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, f.ptr(part))
-                if fused:
-                    assert f.lib.call("nasseg_conv_bwd_data_bn_sums", *common, f.ptr(tickets), f.ptr(sums), s) == 1
-                else:
-                    f.lib.call("nasseg_conv_bwd_data_bn", *common, s)
-                    f.lib.call("nasseg_rows_sum", f.ptr(part), nb2, 2 * N, f.ptr(sums), s)
-                res.append((gout, sums))
-            assert torch.equal(res[0][0], res[1][0])
-            assert_close(res[1][1], res[0][1], 1e-6 * float(res[0][1].abs().max()) + 1e-7, 1e-5,
-                         "BatchNorm-backward sums (repetition {})".format(rep))
-        torch.cuda.synchronize()
-        assert int(tickets.abs().sum()) == 0, "the tickets did not return to zero"
-
-
 def test_nsplit_pointwise_kernel_on_a_channel_slice_and_in_bf16():
     """the same kernel reading a channel slice of a wider slab (ldx > K), writing into one (ldy > N), and its
     bfloat16-storage twin: equal to the general kernel bit for bit"""

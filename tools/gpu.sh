@@ -12,7 +12,7 @@
 #   tools/gpu.sh trace    OUT [bench args]          rocprofv3 kernel trace: durations per family, gaps between kernels
 #   tools/gpu.sh stats    OUT [bench args]          rocprofv3 --kernel-trace --stats summary (+ per-family table)
 #   tools/gpu.sh tree     OUT DIR                   this tree against another BUILT tree (git worktree under the repo)
-#   tools/gpu.sh flags    OUT SRC KBENCH|- FLAG...  compile-time variants of one source (-D flags; "none" = plain)
+#   tools/gpu.sh flags    OUT SRC KBENCH|- FLAG...  compile-time variants of one source (-D flags; "none" = plain; FLAGS_ALSO)
 #   tools/gpu.sh lib      OUT NAME                  in-tree library against tools/build/variants/lib_NAME.so
 #   tools/gpu.sh kbench   OUT SCRIPT [args]         one tools/kbench_*.py table
 #   tools/gpu.sh pmc      OUT SCRIPT "C1 C2"...     rocprofv3 --pmc passes (one per quoted counter set) over a tools/ script
@@ -119,7 +119,12 @@ flags)
     else NASSEG_EXTRA_FLAGS="$f" python nas-segm-pytorch_amd/build.py > /dev/null; fi
     echo "=== $f" | tee -a $SUM
     [ "$KB" != "-" ] && python tools/$KB 2>&1 | tail -20 | tee -a $SUM
-    for i in 1 2; do bench "flag_$(echo "$f" | tr -c 'a-zA-Z0-9' '_')_$i" --steps 20 --warmup 5 --no-roofline; done
+    for i in 1 2; do
+      bench "flag_$(echo "$f" | tr -c 'a-zA-Z0-9' '_')_$i" --steps 20 --warmup 5 --no-roofline
+      # FLAGS_ALSO="--workload cvpr321 --graph 2;--workload task0": further bench lines per variant
+      IFS=';' read -ra more <<< "${FLAGS_ALSO:-}"
+      for m in "${more[@]}"; do [ -n "$m" ] && bench "flag_$(echo "$f $m" | tr -c 'a-zA-Z0-9' '_')_$i" --steps 20 --warmup 5 --no-roofline $m; done
+    done
   done ;;
 lib)
   V=$1

@@ -15,8 +15,6 @@ DEV = "cuda:0"
 B, C, H, W, K, stride, pad, dil = 4, 64, 256, 512, 5, 1, 12, 6
 if len(sys.argv) > 1:
     K, pad, dil = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-if len(sys.argv) > 4:
-    lib.call("nasseg_dw_swizzle", int(sys.argv[4]))
 n = 4
 xs = [torch.randn(B, H, W, C, device=DEV) for _ in range(n)]
 ys = [torch.empty(B, H, W, C, device=DEV) for _ in range(n)]
