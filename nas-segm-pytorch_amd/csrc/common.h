@@ -229,70 +229,6 @@ __device__ __forceinline__ double reduce_partials_n(const float* __restrict__ pa
   __syncthreads();
   return tot;
 }
-// The row sums on the dependency chain of every BatchNorm (bn_stats_finalize_t: 74 launches per headline step at
-// 8 - 10 us, rows_group_sum_t: 61 at 5): NCOL (1 or 2) columns of the same rows at once, every load of a round issued
-// before the first is used, rounds of kRowsInFlight rows per thread with clamped addresses and masks - no scalar tail
-// loop (reduce_partials_n adds what is left after its rounds of eight one dependent load at a time: four extra round
-// trips for the 1536 rows of a conv_pwn_kernel launch), and the two columns of a BatchNorm channel - sum and sum of
-// squares - share ONE round trip and one set of barriers instead of running the whole reduction twice.  Order of the
-// additions fixed by (round, position, slice): deterministic; not the order of reduce_partials_n (the weight-gradient
-// finalisers keep that one: their deferred and immediate forms must agree bit for bit).
-constexpr int kRowsInFlight = 16;
-template <int SLICES, int NCOL>
-__device__ __forceinline__ void reduce_rows_n(const float* __restrict__ partial, int nblk, int64_t per, int64_t e0,
-                                              int64_t e1, bool valid, double (*red0)[NASSEG_RP_ELEMS + 1],
-                                              double (*red1)[NASSEG_RP_ELEMS + 1], double& out0, double& out1) {
-  const int slice = rp_slice();
-  const int el = rp_elem();
-  double s = 0.0, q = 0.0;
-  if (valid) {
-    for (int b0 = slice; b0 < nblk; b0 += kRowsInFlight * SLICES) {  // (trip count: uniform over the slices of a wave or not, every load is in range)
-      float v[kRowsInFlight], w[kRowsInFlight];
-#pragma unroll
-      for (int i = 0; i < kRowsInFlight; ++i) {
-        const int b = b0 + i * SLICES;
-        const int64_t row = (int64_t)(b < nblk ? b : b0) * per;
-        v[i] = partial[row + e0];
-        if (NCOL == 2) w[i] = partial[row + e1];
-      }
-#pragma unroll
-      for (int i = 0; i < kRowsInFlight; ++i) {
-        const bool in = b0 + i * SLICES < nblk;
-        s += in ? (double)v[i] : 0.0;
-        if (NCOL == 2) q += in ? (double)w[i] : 0.0;
-      }
-    }
-  }
-  red0[slice][el] = s;
-  if (NCOL == 2) red1[slice][el] = q;
-  __syncthreads();
-  if (SLICES > 32) {
-    double p0 = 0.0, p1 = 0.0;
-    if (slice < 32) {
-#pragma unroll
-      for (int i = 0; i < SLICES / 32; ++i) {
-        p0 += red0[slice * (SLICES / 32) + i][el];
-        if (NCOL == 2) p1 += red1[slice * (SLICES / 32) + i][el];
-      }
-    }
-    __syncthreads();
-    if (slice < 32) {
-      red0[slice][el] = p0;
-      if (NCOL == 2) red1[slice][el] = p1;
-    }
-    __syncthreads();
-  }
-  double t0 = 0.0, t1 = 0.0;
-  if (slice == 0) {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-      t0 += red0[i][el];
-      if (NCOL == 2) t1 += red1[i][el];
-    }
-  }
-  out0 = t0;
-  out1 = t1;
-}
 __device__ __forceinline__ double reduce_partials16(const float* __restrict__ partial, int nblk,
                                                     int64_t per, int64_t e, bool valid,
                                                     double (*red)[NASSEG_RP_ELEMS + 1]) {

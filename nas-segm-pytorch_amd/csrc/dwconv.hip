@@ -35,7 +35,7 @@
 #endif
 // (maps of fewer than 128 rows keep 4: the launch is short of workgroups there, not of bandwidth)
 // output columns per thread of the forward strip kernel (dw_fwd_strip's PX): dilated 5x5 at stride 1 on maps at least
-// four column groups wide (tools/kbench_dwswz.py, us PX 1 -> 4: 64 channels 256x512 dilation 6 124 -> 98, 32 channels
+// four column groups wide (round 4, us PX 1 -> 4: 64 channels 256x512 dilation 6 124 -> 98, 32 channels
 // 128x256 dilation 6 21.5 -> 20; at dilation 1 the taps of a row share cache lines anyway: 17.8 -> 18.7)
 #ifndef NASSEG_DW5_P
 #define NASSEG_DW5_P 4

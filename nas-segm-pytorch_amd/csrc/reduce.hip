@@ -215,46 +215,33 @@ __global__ __launch_bounds__(8 * SLICES) void bn_stats_finalize_t(
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
     float* __restrict__ running_mean, float* __restrict__ running_var, int64_t* nbt) {
   __shared__ double red[SLICES][NASSEG_RP_ELEMS + 1];
-  __shared__ double red1[SLICES][NASSEG_RP_ELEMS + 1];
   const int c = blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = c < C;
   const int64_t per = 2 * (int64_t)C;
-  // what the finishing threads need besides the sums is requested BEFORE the rows (it used to be loaded after the
-  // second reduction: one more dependent round trip at the end of a kernel that is nothing but round trips)
-  const bool fin = valid && rp_slice() == 0;
-  float g_ = 1.f, bt_ = 0.f, rm_ = 0.f, rv_ = 0.f;
-  if (fin) {
-    if (gamma) g_ = gamma[c];
-    if (beta) bt_ = beta[c];
-    if (running_mean) {
-      rm_ = running_mean[c];
-      rv_ = running_var[c];
-    }
-  }
-  double s0, s1;  // (both columns of a channel in one pass over the rows: one round trip, one set of barriers)
-#ifdef NASSEG_ROWSUM_OLD  // (A/B: the two-pass form of rounds 1-4, tools/gpu.sh flags)
-  s0 = reduce_partials_n<SLICES>(partial, nblk, per, c, valid, red);
-  s1 = reduce_partials_n<SLICES>(partial, nblk, per, (int64_t)C + c, valid, red);
-  (void)red1;
-#else
-  reduce_rows_n<SLICES, 2>(partial, nblk, per, c, (int64_t)C + c, valid, red, red1, s0, s1);
-#endif
+  // (Round 5 tried the two columns in ONE pass over the rows, every load of a round in flight - 16 rows per thread,
+  //  masks instead of the scalar tail loop - and gamma / beta / running statistics requested ahead of the rows: the
+  //  kernel got SLOWER, 7.9 -> 9.7 us per launch on the headline's 1024 - 1536 rows and 0.3 - 0.5 % on every workload
+  //  of a same-box A/B (tools/gpu.sh flags: headline 242.0 -> 241.3, CVPR 321x321 replayed 1261 -> 1255, task0 5562 ->
+  //  5538): with 1024 threads per workgroup the masked loads of rows that do not exist cost more issue slots than the
+  //  round trips they save.  The two-pass form stays.)
+  const double s0 = reduce_partials_n<SLICES>(partial, nblk, per, c, valid, red);
+  const double s1 = reduce_partials_n<SLICES>(partial, nblk, per, (int64_t)C + c, valid, red);
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
-  if (!fin) return;
+  if (!valid || rp_slice() != 0) return;
   const double mu = s0 / M;
   double var = s1 / M - mu * mu;
   if (var < 0.0) var = 0.0;
   const double is = 1.0 / sqrt(var + (double)eps);
   mean[c] = (float)mu;
   invstd[c] = (float)is;
-  const double g = (double)g_;
-  const double bt = (double)bt_;
+  const double g = gamma ? (double)gamma[c] : 1.0;
+  const double bt = beta ? (double)beta[c] : 0.0;
   scale[c] = (float)(g * is);
   shift[c] = (float)(bt - mu * g * is);
   if (running_mean) {
-    running_mean[c] = (float)((1.0 - momentum) * (double)rm_ + momentum * mu);
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
     const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-    running_var[c] = (float)((1.0 - momentum) * (double)rv_ + momentum * unb);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unb);
   }
 }
 
@@ -289,13 +276,7 @@ __global__ __launch_bounds__(8 * SLICES) void rows_group_sum_t(const float* __re
   if (nr > rows_per_group) nr = rows_per_group;
   const int64_t e = (int64_t)blockIdx.x * NASSEG_RP_ELEMS + rp_elem();
   const bool valid = e < per;
-  double s, unused;
-#ifdef NASSEG_ROWSUM_OLD
-  s = reduce_partials_n<SLICES>(partial + (int64_t)r0 * per, nr, per, e, valid, red);
-  (void)unused;
-#else
-  reduce_rows_n<SLICES, 1>(partial + (int64_t)r0 * per, nr, per, e, e, valid, red, red, s, unused);
-#endif
+  const double s = reduce_partials_n<SLICES>(partial + (int64_t)r0 * per, nr, per, e, valid, red);
   if (valid && rp_slice() == 0) out[(int64_t)g * per + e] = (float)s;
 }
 

@@ -730,6 +730,11 @@ _PWN_MODE = os.environ.get("NASSEG_PWN_MODE")
 # holds the tile in LDS and its two phases do not overlap within a workgroup).  3x3 stages and
 # inference (no depthwise output written) win at every size measured.
 _SEPCONV_5X5_TRAIN_MAX = 10 << 20
+# ... and, with 64 or more channels, already from 4 M elements (round 5, same table on MI355X: 64ch 128x256 45.1 / 42.6,
+# 64ch 16x81x81 dilation 6 50.2 / 44.2 - but 64ch 64x128 14.5 / 19.6): the fused kernel's depthwise phase is bound by
+# its vector-instruction issue (1721 VALU instructions per wave, tools/gpu.sh pmc), and the wider the tile's channel
+# axis the fewer columns share a workgroup's weights
+_SEPCONV_5X5_TRAIN_MAX_WIDE = 4 << 20
 
 
 def _sepconv_ok(x, w_dw, w_pw, op_dw, op_pw, needs_grad):
@@ -746,7 +751,8 @@ def _sepconv_ok(x, w_dw, w_pw, op_dw, op_pw, needs_grad):
     Ho, Wo = conv_out_size(H, k, stride, pad, dil), conv_out_size(W, k, stride, pad, dil)
     if Ho <= 0 or Wo <= 0:
         return False
-    if k == 5 and B * Ho * Wo * C > _SEPCONV_5X5_TRAIN_MAX and (needs_grad or C % 16 != 0):
+    limit = _SEPCONV_5X5_TRAIN_MAX_WIDE if (C >= 64 and needs_grad) else _SEPCONV_5X5_TRAIN_MAX
+    if k == 5 and B * Ho * Wo * C > limit and (needs_grad or C % 16 != 0):
         return False
     return lib.query("nasseg_sepconv_blocks", B, C, Ho, Wo, N, k, stride, dil) > 0
 

@@ -156,6 +156,51 @@ def test_train_step_at_size_matches_the_oracle(net_name, batch, monkeypatch):
         net_name, B, err_out, floor_out, worst))
 
 
+@pytest.mark.parametrize("net_name", ["wacv_arch0", "wacv_arch1"])
+def test_baseline_batch_replay_equals_host_launches(net_name):
+    """The BASELINE headline / config-3 step at its own per-GPU batch, 4x3x1024x2048, with the reference's optimisers
+    (src/utils/default_args.py:57-66) and gradient clipping: two steps launched from the host and the same two steps
+    replayed from a hipGraph (forward + loss + backward captured, clip + optimisers outside: what the engine does
+    for steps it replays) leave bit-identical losses, parameters, BatchNorm buffers and optimiser state - and the
+    step is the one bench.py times (decreasing, finite loss near log 19 on random labels)."""
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    rec = load_json("nets_meta.json")[net_name]
+    gen = torch.Generator().manual_seed(61)
+    B, H, W = 4, 1024, 2048
+    x = _cl(torch.randn(B, 3, H, W, generator=gen))
+    t = _labels(gen, B, H, W, 19).to(DEV)
+
+    def run(graphed):
+        m = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 7).to(DEV).train()
+        oe = torch.optim.SGD(m.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(m.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        losses = []
+        if graphed:
+            stepper = GraphedSegmenterStep(m, x, t, oe, od, 255, 3.0, 3.0, -1)
+            for _ in range(2):
+                losses.append(float(stepper.step(x, t)))
+            del stepper
+        else:
+            for _ in range(2):
+                losses.append(float(segmenter_step(m, x, t, oe, od, 255, 3.0, 3.0, -1)))
+        state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        moments = [v.detach().cpu() for o in (oe, od) for st in o.state.values() for v in st.values()
+                   if torch.is_tensor(v) and v.numel() > 1]
+        del m, oe, od
+        torch.cuda.empty_cache()
+        return losses, state, moments
+
+    l0, sd0, mo0 = run(False)
+    assert all(np.isfinite(v) for v in l0) and abs(l0[0] - np.log(19.0)) < 1.0 and l0[1] < l0[0] + 0.5
+    l1, sd1, mo1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    assert len(mo0) == len(mo1) and all(torch.equal(a, b) for a, b in zip(mo0, mo1))
+
+
 def _frozen_bn_gradients(net, x, backward):
     """parameter gradients with every BatchNorm on its running statistics (the engine's freeze_bn
     mode): per-sample computations are then independent of the rest of the batch"""
