@@ -31,6 +31,11 @@ namespace {
 #ifndef NASSEG_PW_CHUNK
 #define NASSEG_PW_CHUNK 3
 #endif
+// 1: the narrow kernel RECOMPUTES the conv's raw output z = W x from the input tile it holds anyway instead of
+// loading it, wherever its weight sits in LDS (round 5; 0: load z as rounds 2-4 did - A/B, tools/gpu.sh flags)
+#ifndef NASSEG_PW_RECOMPUTE_Z
+#define NASSEG_PW_RECOMPUTE_Z 1
+#endif
 constexpr int kPwTile = 64;         // pixels per tile (16 per wave)
 constexpr int kPwMaxTiles = 24;     // (n, k) accumulator tiles per wave
 
@@ -97,6 +102,14 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   extern __shared__ float smem[];
   constexpr int LSN = pw_lsn(NT), LSK = pw_lsk(KT), NPc = NT * 16, KPc = KT * 16;
   constexpr bool WL = pw_weight_in_lds(NT, KT), PF = pw_prefetch(NT, KT);
+  // Recompute z.  dz = ca*g' + cb*z + cd needs the conv's raw output z, N floats per pixel that the forward wrote
+  // and this kernel used to read back - for the expansions of the encoder (16 -> 96, 24 -> 144: N >> K) 43 % of
+  // everything it moves.  But z = W x, x is the input tile this kernel stages for the weight gradient anyway, and
+  // the weight is in LDS: K / 16 MFMA steps per channel tile rebuild it, in the operand mapping and accumulation
+  // order of the forward kernels (conv_fwd.hip / conv_pwn.hip: k-blocks ascending, the four components of a lane's
+  // float4 in turn, zero-padded to a multiple of 16) - the same bits the forward stored.  The loader then brings g
+  // alone; a wave turns its 16 pixels of g into dz in place once z is there (one more workgroup barrier per tile).
+  constexpr bool RZ = WL && NASSEG_PW_RECOMPUTE_Z != 0;
   float* dzt = smem;                       // [64][LSN]
   float* xt = dzt + kPwTile * LSN;         // [64][LSK]
   float* ca = xt + kPwTile * LSK;          // ca | cb | cd | cs [NPc each], psc | psh [KPc each]
@@ -153,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   if (p_end > a.M) p_end = a.M;
 
   // item u of a thread: float4 number tid + 256*u of the [64][NPc] (or [64][KPc]) tile
-  float4 gv[PF ? NT : 1], zv[PF ? NT : 1], xv[KT];
+  float4 gv[PF ? NT : 1], zv[(PF && !RZ) ? NT : 1], xv[KT];
   auto issue_nz = [&](int t0, int u_lo, int u_hi, float4* G, float4* Z) {
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
       const int p = t0 + px;
       const int64_t off = (int64_t)(p < p_end ? p : p_end - 1) * N + (n < N ? n : 0);
       G[u - u_lo] = lda4(a.g + off);
-      Z[u - u_lo] = lda4(a.z + off);
+      if constexpr (!RZ) Z[u - u_lo] = lda4(a.z + off);
     }
   };
   auto issue_x = [&](int t0) {
@@ -187,21 +200,26 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
       const int it = tid + 256 * u;
       const int px = it / (NPc / 4), n = (it - px * (NPc / 4)) * 4;
       const bool ok = t0 + px < p_end && n < N;
-      const float4 va = ld4(ca + n), vb = ld4(cb + n), vd = ld4(cd + n);
-      float4 g2 = G[u - u_lo];
-      const float4 z2 = Z[u - u_lo];
-      if (a.bn_act) {
-        const float4 y = fma4(z2, va, ld4(cs + n));
-        g2 = make_float4(g2.x * act_mask(y.x, a.bn_act), g2.y * act_mask(y.y, a.bn_act),
-                         g2.z * act_mask(y.z, a.bn_act), g2.w * act_mask(y.w, a.bn_act));
-      }
-      float4 dz = fma4(g2, va, fma4(z2, vb, vd));
+      if constexpr (RZ) {
+        // (g as it came: the wave that owns the pixel makes dz of it below, once z is rebuilt)
+        *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(G[u - u_lo], ok);
+      } else {
+        const float4 va = ld4(ca + n), vb = ld4(cb + n), vd = ld4(cd + n);
+        float4 g2 = G[u - u_lo];
+        const float4 z2 = Z[u - u_lo];
+        if (a.bn_act) {
+          const float4 y = fma4(z2, va, ld4(cs + n));
+          g2 = make_float4(g2.x * act_mask(y.x, a.bn_act), g2.y * act_mask(y.y, a.bn_act),
+                           g2.z * act_mask(y.z, a.bn_act), g2.w * act_mask(y.w, a.bn_act));
+        }
+        float4 dz = fma4(g2, va, fma4(z2, vb, vd));
 #ifdef NASSEG_BF16
-      // (what the two-kernel form stores and reads back)
-      dz = make_float4(bf16_to_f32(f32_to_bf16(dz.x)), bf16_to_f32(f32_to_bf16(dz.y)),
-                       bf16_to_f32(f32_to_bf16(dz.z)), bf16_to_f32(f32_to_bf16(dz.w)));
+        // (what the two-kernel form stores and reads back)
+        dz = make_float4(bf16_to_f32(f32_to_bf16(dz.x)), bf16_to_f32(f32_to_bf16(dz.y)),
+                         bf16_to_f32(f32_to_bf16(dz.z)), bf16_to_f32(f32_to_bf16(dz.w)));
 #endif
-      *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(dz, ok);
+        *reinterpret_cast<float4*>(&dzt[px * LSN + n]) = keep_if(dz, ok);
+      }
     }
   };
   float4 sx[DXS ? KT : 1], sq[DXS ? KT : 1], smu[DXS ? KT : 1], sis[DXS ? KT : 1];
@@ -243,6 +261,64 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
     }
     __syncthreads();
     if (PF && t0 + kPwTile < p_end) issue(t0 + kPwTile);  // in flight until the top of the next pass
+    if constexpr (RZ) {
+      // ---- z of this wave's 16 pixels rebuilt on the matrix cores, g -> dz in place ----------------
+      // (channel tiles in groups of ZG: the whole of z at once - NT accumulators and 4 NT weight operands next to the
+      //  prefetched tile and the N x K accumulator - cost 24 -> 144 its second wave per SIMD)
+      constexpr int ZG = NT % 3 == 0 ? 3 : 2;
+      const bool pok = t0 + wave * 16 + j < p_end;
+      float4 bx[KT];
+#pragma unroll
+      for (int kb = 0; kb < KT; ++kb)
+        bx[kb] = *reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LSK + kb * 16 + kg * 4]);
+#pragma unroll
+      for (int n0 = 0; n0 < NT; n0 += ZG) {
+        f32x4 zc[ZG];
+#pragma unroll
+        for (int q = 0; q < ZG; ++q) zc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KT; ++kb) {
+          const float* wk = wl + (kb * 16 + kg * 4) * LSN + (n0 * 16 + j);  // W[n = 16 nt + j][k = 16 kb + 4 kg + c] = wl[k][n]
+#pragma unroll
+          for (int q = 0; q < ZG; ++q) {
+            if (n0 + q < NT) {
+              zc[q] = mfma16(wk[q * 16], bx[kb].x, zc[q]);
+              zc[q] = mfma16(wk[LSN + q * 16], bx[kb].y, zc[q]);
+              zc[q] = mfma16(wk[2 * LSN + q * 16], bx[kb].z, zc[q]);
+              zc[q] = mfma16(wk[3 * LSN + q * 16], bx[kb].w, zc[q]);
+            }
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < ZG; ++q) {
+          if (n0 + q >= NT) continue;
+          const int n = (n0 + q) * 16 + kg * 4;  // (lane: pixel j of the wave's 16, channels n .. n + 3)
+          float* slot = &dzt[(wave * 16 + j) * LSN + n];
+          float4 g2 = *reinterpret_cast<const float4*>(slot);
+          float4 z2 = make_float4(zc[q][0], zc[q][1], zc[q][2], zc[q][3]);
+#ifdef NASSEG_BF16
+          // (the value the forward stored and every other consumer of z reads)
+          z2 = make_float4(bf16_to_f32(f32_to_bf16(z2.x)), bf16_to_f32(f32_to_bf16(z2.y)), bf16_to_f32(f32_to_bf16(z2.z)),
+                           bf16_to_f32(f32_to_bf16(z2.w)));
+#endif
+          const float4 va = ld4(ca + n), vb = ld4(cb + n), vd = ld4(cd + n);
+          if (a.bn_act) {
+            const float4 y = fma4(z2, va, ld4(cs + n));
+            g2 = make_float4(g2.x * act_mask(y.x, a.bn_act), g2.y * act_mask(y.y, a.bn_act),
+                             g2.z * act_mask(y.z, a.bn_act), g2.w * act_mask(y.w, a.bn_act));
+          }
+          float4 dz = fma4(g2, va, fma4(z2, vb, vd));
+#ifdef NASSEG_BF16
+          dz = make_float4(bf16_to_f32(f32_to_bf16(dz.x)), bf16_to_f32(f32_to_bf16(dz.y)),
+                           bf16_to_f32(f32_to_bf16(dz.z)), bf16_to_f32(f32_to_bf16(dz.w)));
+#endif
+          *reinterpret_cast<float4*>(slot) = keep_if(dz, pok && n < N);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (one group at a time: keeps the next group's operands out of this one's registers)
+      }
+      // (no barrier: both products below read only the rows of dz of THIS wave's 16 pixels, and a wave's LDS
+      //  accesses execute in issue order)
+    }
     // ---- input gradient of this wave's 16 pixels: dx[p][k] = sum_n wb[k][n] * dz[p][n] -----------
     {
       f32x4 acc1[KT];
