@@ -88,9 +88,13 @@ def algorithmic_bytes(name, a):
     if name == "nasseg_conv_wgrad":
         B, Hs, Ws, K, Ho, Wo, N, kh, kw = a[9], a[10], a[11], a[12], a[13], a[14], a[15], a[16], a[17]
         return 4 * (B * Hs * Ws * K + B * Ho * Wo * N + N * K * kh * kw)
-    if name == "nasseg_conv_pw_bwd_bn":  # x, g, z read, dx written; dz never leaves the CU
+    if name == "nasseg_conv_pw_bwd_bn":  # x, g [, z] read, dx written; dz never leaves the CU
         B, H, W, K, N = a[18], a[19], a[20], a[21], a[22]
-        return 4 * (B * H * W * (2 * K + 2 * N) + 2 * N * K)
+        from nas_segm_amd import functional as NF
+
+        # (z = W x is rebuilt from the input tile where the kernel can: not an operand it needs, not charged)
+        nz = 2 if NF.lib.query("nasseg_conv_pw_bwd_reads_z", B, H, W, K, N) else 1
+        return 4 * (B * H * W * (2 * K + nz * N) + 2 * N * K)
     if name == "nasseg_dwconv_bwd_bn":  # xz, g, z read, ge written
         B, H, W, C, Ho, Wo = a[20], a[21], a[22], a[23], a[24], a[25]
         return 4 * (2 * B * C * H * W + 2 * B * C * Ho * Wo + 18 * C)

@@ -218,6 +218,10 @@ int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float
  * raw output of a BatchNorm with statistics in_mean / in_invstd, dx_act = in_act): also that BatchNorm's backward
  * sums {sum dx, sum dx*xhat} per slab, rows [slabs][2][K] for nasseg_rows_sum (buffer: slabs + 64 rows). */
 int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N);
+/* 1: nasseg_conv_pw_bwd_bn loads z for this geometry; 0: it rebuilds z = W x from the input tile it stages anyway (the
+ * narrow kernel with its weight in LDS: same operand mapping and accumulation order as the forward kernels, the same
+ * bits) and z is not read.  Either way z must BE the conv's raw output.  For measurement tools and tests. */
+int64_t nasseg_conv_pw_bwd_reads_z(int B, int H, int W, int K, int N);
 int nasseg_conv_pw_bwd_bn(const float* x, const float* g, const float* z, const float* wb, float* dx, float* dw,
                           float* ws, const float* in_scale, const float* in_shift, int in_act, int dx_act,
                           const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,

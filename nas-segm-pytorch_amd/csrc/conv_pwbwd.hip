@@ -743,9 +743,22 @@ int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N) {
 }
 #endif  // NASSEG_FP32_ONLY
 
+#if NASSEG_FP32_ONLY
+// 1: nasseg_conv_pw_bwd_bn loads the conv's raw output z for this geometry; 0: it rebuilds z = W x from the input
+// tile on the matrix cores (the narrow kernel, weight in LDS - z is then not read at all).  For measurement tools
+// (bench.py charges the bytes a launch needs) and tests.
+int64_t nasseg_conv_pw_bwd_reads_z(int B, int H, int W, int K, int N) {
+  const PwPlan p = pw_plan((int64_t)B * H * W, N, K);
+  if (!p.ok || p.wide) return 1;
+  return (NASSEG_PW_RECOMPUTE_Z != 0 && pw_weight_in_lds(p.nt, p.kt)) ? 0 : 1;
+}
+#endif  // NASSEG_FP32_ONLY
+
 // Backward of y = BatchNorm(conv1x1(in_act(in_scale*x + in_shift))):
 //   g [P][N]: gradient w.r.t. the BatchNorm output - masked already (bn_act == 0) or to be masked with
-//   act'(scale*z + shift) here; z [P][N] the conv's raw output; sums[2][N] = {sum g', sum g'*xhat};
+//   act'(scale*z + shift) here; z [P][N] the conv's raw output - it MUST be that output: where
+//   nasseg_conv_pw_bwd_reads_z() is 0 the kernel rebuilds it from x and wb instead of reading it;
+//   sums[2][N] = {sum g', sum g'*xhat};
 //   wb: the weight packed for backward-data ([K][N], pack mode 1); P = B*H*W pixels.
 // dx_act != 0 (= in_act): dx is multiplied by in_act'(in_scale*x + in_shift), i.e. it is the gradient
 // w.r.t. the affine's output - w.r.t. x itself for a bare activation (the ReLU that pre_clf applies to its

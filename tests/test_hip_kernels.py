@@ -1039,6 +1039,18 @@ def test_gather_rows_is_an_index_select_without_a_layout_change(dtype):
 
 # ---------------------------------------------------------------------------
 # backward of pointwise conv + BatchNorm in one kernel (csrc/conv_pwbwd.hip)
+def _pointwise_output(f, x, w, psc, psh, pact):
+    """z = conv1x1(act(psc * x + psh)) by nasseg_conv_fwd, stored like x: the raw conv output the backward kernels
+    are handed - the one-kernel backward REBUILDS it from x and w where its weight sits in LDS (round 5), so a test
+    must not feed it an unrelated tensor"""
+    B, K, H, W = x.shape
+    N = w.shape[0]
+    z = dev(torch.empty(B, N, H, W)).to(x.dtype)
+    f.lib.call(f._k("nasseg_conv_fwd", x), f.ptr(x), K, f.ptr(w), f.ptr(z), N, f.ptr(psc), f.ptr(psh), pact, None, None,
+               0, None, 0, B, H, W, K, H, W, N, 1, 1, 1, 0, 1, 0, None, f.current_stream())
+    return z
+
+
 @pytest.mark.parametrize("case", [
     # B, H, W, K, N
     (2, 13, 17, 16, 96), (2, 24, 20, 24, 144), (1, 31, 33, 32, 192), (2, 16, 16, 32, 32),
@@ -1060,13 +1072,13 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
     M = B * H * W
     x = dev(rnd(B, K, H, W, seed=1)).to(dtype)
     g = dev(rnd(B, N, H, W, seed=2)).to(dtype)
-    z = dev(rnd(B, N, H, W, seed=3)).to(dtype)
     w = dev(rnd(N, K, 1, 1, seed=4) * 0.3)
     wb = torch.empty(N * K, device=DEV)
     lib.call("nasseg_conv_pack_weight", ptr(w), ptr(wb), N, K, 1, 1, 1, stream())
     psc = (rnd(K, seed=5) * 0.2 + 1).to(DEV) if pro else None
     psh = (rnd(K, seed=6) * 0.2).to(DEV) if pro else None
     pact = 2 if pro else 0
+    z = _pointwise_output(Fm, x, w, psc, psh, pact)  # (the conv's own output: the one-kernel form rebuilds it)
     scale, shift = (rnd(N, seed=7) * 0.2 + 1).to(DEV), (rnd(N, seed=8) * 0.2).to(DEV)
     mean, invstd = (rnd(N, seed=9) * 0.1).to(DEV), (rnd(N, seed=10).abs() + 0.5).to(DEV)
     sums = (rnd(2 * N, seed=11) * 3).to(DEV)
@@ -1091,6 +1103,17 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
     rel = 2e-5 if dtype == torch.float32 else 1e-2  # (bf16: dx is stored rounded)
     assert_close(dx, dx_ref, rel * float(dx_ref.float().abs().max()), rel, "dx")
     assert_close(dw, dw_ref, 5e-5 * float(dw_ref.abs().max()) * max(1.0, (M / 4096.0) ** 0.5), 1e-4, "dw")
+    if not lib.query("nasseg_conv_pw_bwd_reads_z", B, H, W, K, N):
+        # the kernel rebuilt z = W x on the matrix cores (same bits as the stored one): the tensor it was handed is
+        # not read - a NaN-filled one gives the same results, bit for bit
+        assert K <= 64
+        dx_n, dw_n = torch.full_like(x, float("nan")), torch.full_like(w, float("nan"))
+        lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(torch.full_like(z, float("nan"))), ptr(wb), ptr(dx_n),
+                 ptr(dw_n), ptr(ws2), ptr(psc), ptr(psh), pact, 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+                 ptr(sums), int(train), bact, B, H, W, K, N, None, None, None, stream())
+        assert torch.equal(dx_n, dx) and torch.equal(dw_n, dw)
+    else:
+        assert K > 64 or N > 144  # (the wide kernel, and 32 -> 192 whose weight does not fit LDS twice per CU)
     # dw == NULL: partial rows only, finalised by nasseg_wgrad_finalize_many
     ws3 = torch.full_like(ws2, float("nan"))
     lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws3), ptr(psc),
@@ -1100,12 +1123,15 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
     if not pro:
         # a bare activation applied to x on load (pre_clf's ReLU): dx masked with its derivative
         for a_ in (1, 2):
+            z = _pointwise_output(Fm, x, w, None, None, a_)
             lib.call(name("nasseg_conv_wgrad_bn"), ptr(x), K, ptr(g), N, ptr(z), N, ptr(dz), N, ptr(dw_ref), ptr(ws),
                      None, None, a_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact,
                      B, H, W, K, N, stream())
             lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), ptr(dw), ptr(ws2), None,
                      None, a_, a_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(train), bact, B,
                      H, W, K, N, None, None, None, stream())
+            lib.call(name("nasseg_conv_fwd"), ptr(dz), N, ptr(wb), ptr(dx_ref), K, None, None, 0, None, None, 0, None, 0,
+                     B, H, W, N, H, W, K, 1, 1, 1, 0, 1, 1, None, stream())  # (dx of THIS dz, unmasked)
             xf = x.float()
             m_ = ((xf > 0) & ((xf < 6) | (a_ == 1))).float()
             assert_close(dx, dx_ref.float() * m_, rel * float(dx_ref.float().abs().max()), rel, "masked dx")
@@ -1530,10 +1556,10 @@ def test_pointwise_backward_emits_the_sums_of_the_batchnorm_in_front(case, in_ac
     M = B * H * W
     x = dev(rnd(B, K, H, W, seed=1))
     g = dev(rnd(B, N, H, W, seed=2))
-    z = dev(rnd(B, N, H, W, seed=3))
     w = rnd(N, K, 1, 1, seed=4, scale=0.3).to(DEV)
     wb = f._pack_dense(w, 1)
     psc, psh, pmu, pis = _bn_vectors(K, 5)
+    z = _pointwise_output(f, x, w, psc, psh, in_act)
     scale, shift, mean, invstd = _bn_vectors(N, 6)
     sums = (torch.randn(2 * N, generator=torch.Generator().manual_seed(7)) * 3).to(DEV)
     s = stream()
