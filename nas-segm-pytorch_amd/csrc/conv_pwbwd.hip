@@ -32,7 +32,7 @@ namespace {
 #define NASSEG_PW_CHUNK 3
 #endif
 // 1: the narrow kernel RECOMPUTES the conv's raw output z = W x from the input tile it holds anyway instead of
-// loading it, wherever its weight sits in LDS (round 5; 0: load z as rounds 2-4 did - A/B, tools/gpu.sh flags)
+// loading it, where that measured faster (pw_plan; round 5; 0: load z everywhere as rounds 2-4 did - A/B, tools/gpu.sh flags)
 #ifndef NASSEG_PW_RECOMPUTE_Z
 #define NASSEG_PW_RECOMPUTE_Z 1
 #endif
@@ -97,7 +97,7 @@ __host__ __device__ constexpr bool pw_prefetch(int NT, int KT) { return NT * KT 
 // and a tile's loads were issued, waited for and used in turn - 24 -> 144 at 4x256x512: 260 us before).
 // DXS: also emit the sums of the BatchNorm in front (a.dx_stats) - a separate instantiation: its 16*KT
 // registers per lane would cost every other call a resident wave
-template <int NT, int KT, bool PRO, bool DXS = false>
+template <int NT, int KT, bool PRO, bool DXS = false, bool RZ_ = false>
 __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   extern __shared__ float smem[];
   constexpr int LSN = pw_lsn(NT), LSK = pw_lsk(KT), NPc = NT * 16, KPc = KT * 16;
@@ -109,7 +109,12 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
   // order of the forward kernels (conv_fwd.hip / conv_pwn.hip: k-blocks ascending, the four components of a lane's
   // float4 in turn, zero-padded to a multiple of 16) - the same bits the forward stored.  The loader then brings g
   // alone; a wave turns its 16 pixels of g into dz in place once z is there (one more workgroup barrier per tile).
-  constexpr bool RZ = WL && NASSEG_PW_RECOMPUTE_Z != 0;
+  // Where it pays (pw_plan: K <= 32, N <= 96, maps of at least 2^18 pixels): tools/kbench_pwbwd.py on MI355X, us
+  // loading z -> rebuilding it: 16 -> 96 at 4x512x1024 405 -> 328, 32 -> 32 at 4x512x1024 217 -> 171, 24 -> 64 at
+  // 4x256x512 104 -> 87; but 24 -> 144 173 -> 182 (nine channel tiles: the 72 extra MFMAs per tile and the registers of
+  // two more k-steps), 64 -> 64 at 4x128x256 40 -> 44, 32 -> 32 at 4x128x256 15.8 -> 16.9 (small maps are not bound by
+  // their bytes).  Headline on one box 275.5 -> 279.0 images/s with every supported geometry rebuilding.
+  constexpr bool RZ = WL && RZ_;
   float* dzt = smem;                       // [64][LSN]
   float* xt = dzt + kPwTile * LSN;         // [64][LSK]
   float* ca = xt + kPwTile * LSK;          // ca | cb | cd | cs [NPc each], psc | psh [KPc each]
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_wide_kernel(PwArgs a) {
 }
 
 struct PwPlan {
-  int ok, nt, kt, nslab, pix_per_slab, wide;
+  int ok, nt, kt, nslab, pix_per_slab, wide, rz;
 };
 inline int pw_round_nt(int nt) {
   const int allowed[] = {2, 3, 4, 6, 9, 12};
@@ -708,25 +713,28 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
   ppb = (ppb + kPwTile - 1) / kPwTile * kPwTile;
   p.pix_per_slab = (int)ppb;
   p.nslab = (int)cdiv64(M, ppb);
+  // rebuild z instead of loading it (conv_pw_bwd_kernel<.., RZ_ = true>): where it measured faster
+  p.rz = NASSEG_PW_RECOMPUTE_Z != 0 && !p.wide && p.kt <= 2 && p.nt <= 6 && pw_weight_in_lds(p.nt, p.kt) &&
+         M >= (1 << 18);
   p.ok = 1;
   return p;
 }
 
-template <int NT, int KT>
+template <int NT, int KT, bool RZ = false>
 void pw_launch(const PwArgs& a, int nslab, bool pro, hipStream_t s) {
   constexpr size_t lds = (size_t)pw_lds_floats(NT, KT, pw_weight_in_lds(NT, KT)) * sizeof(float);
   constexpr size_t lds_dxs = lds + (size_t)kPwTile * pw_lsk(KT) * sizeof(float);  // (+ the raw input tile)
   if (lds_dxs > (64 << 10)) {  // above the default limit of dynamic LDS (per device: set on every launch)
-    (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true, true>,
+    (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true, true, RZ>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dxs);
-    if (pro) (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true>,
+    if (pro) (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, true, false, RZ>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, false>,
+    else (void)hipFuncSetAttribute((const void*)conv_pw_bwd_kernel<NT, KT, false, false, RZ>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  if (a.dx_stats) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true, true>), dim3(nslab), dim3(256), lds_dxs, s, a);
-  else if (pro) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true>), dim3(nslab), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, false>), dim3(nslab), dim3(256), lds, s, a);
+  if (a.dx_stats) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true, true, RZ>), dim3(nslab), dim3(256), lds_dxs, s, a);
+  else if (pro) hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, true, false, RZ>), dim3(nslab), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((conv_pw_bwd_kernel<NT, KT, false, false, RZ>), dim3(nslab), dim3(256), lds, s, a);
 }
 
 }  // namespace
@@ -749,8 +757,7 @@ int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N) {
 // (bench.py charges the bytes a launch needs) and tests.
 int64_t nasseg_conv_pw_bwd_reads_z(int B, int H, int W, int K, int N) {
   const PwPlan p = pw_plan((int64_t)B * H * W, N, K);
-  if (!p.ok || p.wide) return 1;
-  return (NASSEG_PW_RECOMPUTE_Z != 0 && pw_weight_in_lds(p.nt, p.kt)) ? 0 : 1;
+  return (p.ok && p.rz) ? 0 : 1;
 }
 #endif  // NASSEG_FP32_ONLY
 
@@ -826,6 +833,9 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
     const int dims_w[5] = {p.nslab, 1, N, K, 0};
     return nasseg_wgrad_finalize_many(1, parts_w, outs_w, dims_w, stream);
   }
+#define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_ && p.rz) pw_launch<NT_, KT_, true>(a, p.nslab, pro, s); else
+  PW_CASE(2, 1) PW_CASE(3, 1) PW_CASE(4, 1) PW_CASE(6, 1) PW_CASE(2, 2) PW_CASE(3, 2) PW_CASE(4, 2) PW_CASE(6, 2)
+#undef PW_CASE
 #define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_) pw_launch<NT_, KT_>(a, p.nslab, pro, s); else
   PW_CASE(2, 1) PW_CASE(3, 1) PW_CASE(4, 1) PW_CASE(6, 1) PW_CASE(9, 1) PW_CASE(12, 1)
   PW_CASE(2, 2) PW_CASE(3, 2) PW_CASE(4, 2) PW_CASE(6, 2) PW_CASE(9, 2) PW_CASE(12, 2)
