@@ -126,7 +126,9 @@ def algorithmic_bytes(name, a):
         return 4 * B * C * (Hi * Wi + Ho * Wo)
     if name == "nasseg_cat_src_bwd":  # du and slab slices (+ the pending producer's z) read, g written
         B, Ho, Wo, C = a[14], a[15], a[16], a[17]
-        return 4 * B * Ho * Wo * C * (2 + (1 if a[8] else 0) + (1 if a[9] else 0))
+        # (a pending input of the slab's size: its slab slice is rebuilt from z, not read)
+        slab_read = bool(a[8]) and not (a[9] and (a[18], a[19]) == (Ho, Wo))
+        return 4 * B * Ho * Wo * C * (2 + int(slab_read) + (1 if a[9] else 0))
     if name == "nasseg_maxpool_bn_fwd":  # z read, pooled map (+ uint8 winner index) written
         B, H, W, C, Ho, Wo = a[5], a[6], a[7], a[8], a[9], a[10]
         return 4 * B * C * (H * W + Ho * Wo) + (B * C * Ho * Wo if a[4] else 0)

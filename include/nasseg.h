@@ -222,6 +222,9 @@ int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N);
  * narrow kernel with its weight in LDS: same operand mapping and accumulation order as the forward kernels, the same
  * bits) and z is not read.  Either way z must BE the conv's raw output.  For measurement tools and tests. */
 int64_t nasseg_conv_pw_bwd_reads_z(int B, int H, int W, int K, int N);
+/* pixels from which nasseg_conv_pw_bwd_bn rebuilds z (where it can: K <= 32, N <= 96): 2^18 initially; 0: every
+ * supported geometry, a huge value: none.  v < 0 only queries.  Returns the previous setting. */
+int64_t nasseg_conv_pw_bwd_rz_min_pixels(int64_t v);
 int nasseg_conv_pw_bwd_bn(const float* x, const float* g, const float* z, const float* wb, float* dx, float* dw,
                           float* ws, const float* in_scale, const float* in_shift, int in_act, int dx_act,
                           const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,

@@ -19,12 +19,20 @@
 // pixels for both products and keeps the whole N x K accumulator (N*K <= 6144); waves are
 // combined through LDS in a fixed order, slabs by the deterministic second stage of
 // conv_wgrad.hip (nasseg_wgrad_finalize_many) - no float atomics.
+#include <atomic>
 #include <type_traits>
 
 #include "conv_common.h"
 
 extern "C" int nasseg_wgrad_finalize_many(int count, const float* const* partial, float* const* dw,
                                           const int* dims, void* stream);
+
+#if NASSEG_FP32_ONLY
+// pixels from which the narrow kernel rebuilds z instead of loading it (nasseg_conv_pw_bwd_rz_min_pixels)
+std::atomic<int64_t> g_pw_rz_min_pixels{1 << 18};
+#else
+extern std::atomic<int64_t> g_pw_rz_min_pixels;
+#endif
 
 namespace {
 
@@ -715,7 +723,7 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
   p.nslab = (int)cdiv64(M, ppb);
   // rebuild z instead of loading it (conv_pw_bwd_kernel<.., RZ_ = true>): where it measured faster
   p.rz = NASSEG_PW_RECOMPUTE_Z != 0 && !p.wide && p.kt <= 2 && p.nt <= 6 && pw_weight_in_lds(p.nt, p.kt) &&
-         M >= (1 << 18);
+         M >= g_pw_rz_min_pixels.load();
   p.ok = 1;
   return p;
 }
@@ -758,6 +766,14 @@ int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N) {
 int64_t nasseg_conv_pw_bwd_reads_z(int B, int H, int W, int K, int N) {
   const PwPlan p = pw_plan((int64_t)B * H * W, N, K);
   return (p.ok && p.rz) ? 0 : 1;
+}
+// maps of at least this many pixels have z rebuilt (where the kernel can: K <= 32, N <= 96): 2^18 initially - below,
+// the launches are not bound by their bytes and the extra MFMAs lose (32 -> 32 at 4x128x256: 15.8 -> 16.9 us); 0: every
+// supported geometry (what the parity tests of the small maps use), a huge value: none.  v < 0 only queries.  Returns
+// the previous setting.
+int64_t nasseg_conv_pw_bwd_rz_min_pixels(int64_t v) {
+  if (v < 0) return g_pw_rz_min_pixels.load();
+  return g_pw_rz_min_pixels.exchange(v);
 }
 #endif  // NASSEG_FP32_ONLY
 

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void cat_src_fwd_kernel(const act_t* __restric
 // producer has ANOTHER size (z [B][Hi][Wi][C]): v is written unmasked (nasseg_bilinear_bwd_act masks what it
 // transposes), the sums are formed against the interpolated mask / mask * xhat.
 // Same workgroup layout as cat_src_fwd_kernel.
-template <bool RESIZE>
+// ZSAME: the input came in pending and has the slab's size - its slice of the slab is act(tscale*z + tshift), what
+// nasseg_cat_src_fwd wrote there: it is rebuilt from z (which is read for the mask anyway) instead of being loaded
+// (round 5: three tensor passes instead of four).
+template <bool RESIZE, bool ZSAME = false>
 __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
     const act_t* __restrict__ du, const act_t* __restrict__ slab, int64_t ld, int off,
     const float* __restrict__ sscale, const float* __restrict__ smean, const float* __restrict__ sinvstd,
@@ -228,8 +231,22 @@ __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
     const int64_t pix = (int64_t)r * Wo + ox;
     const float4 d = lda4(du + pix * ld + sc);
     float4 v = d;
+    float4 zs = f4zero(), ts = f4zero();
+    if (ZSAME) {
+      zs = lda4(z + pix * C + c4 * 4);
+      ts = fma4(zs, tsc, tsh);
+    }
     if (train) {
-      const float4 x = lda4(slab + pix * ld + sc);
+      float4 x;
+      if (ZSAME) {
+        x = act_apply4(ts, act);  // (the expression nasseg_cat_src_fwd stored)
+#ifdef NASSEG_BF16
+        x = make_float4(bf16_to_f32(f32_to_bf16(x.x)), bf16_to_f32(f32_to_bf16(x.y)), bf16_to_f32(f32_to_bf16(x.z)),
+                        bf16_to_f32(f32_to_bf16(x.w)));
+#endif
+      } else {
+        x = lda4(slab + pix * ld + sc);
+      }
       v.x = d.x - s0.x * invM - (x.x - smu.x) * sis.x * s1.x * invM;
       v.y = d.y - s0.y * invM - (x.y - smu.y) * sis.y * s1.y * invM;
       v.z = d.z - s0.z * invM - (x.z - smu.z) * sis.z * s1.z * invM;
@@ -238,9 +255,9 @@ __global__ __launch_bounds__(256) void cat_src_bwd_kernel(
     v = mul4(v, ssc);
     float4 xh = f4zero();
     float4 ms = make_float4(1.f, 1.f, 1.f, 1.f);  // RESIZE: interpolated mask, xh: interpolated mask * xhat
-    if (z && !RESIZE) {
-      const float4 zv = lda4(z + pix * C + c4 * 4);
-      const float4 t = fma4(zv, tsc, tsh);
+    if (ZSAME || (z && !RESIZE)) {
+      const float4 zv = ZSAME ? zs : lda4(z + pix * C + c4 * 4);
+      const float4 t = ZSAME ? ts : fma4(zv, tsc, tsh);
       v = make_float4(v.x * act_mask(t.x, act), v.y * act_mask(t.y, act), v.z * act_mask(t.z, act),
                       v.w * act_mask(t.w, act));
       xh = make_float4((zv.x - tmu.x) * tis.x, (zv.y - tmu.y) * tis.y, (zv.z - tmu.z) * tis.z,
@@ -746,7 +763,11 @@ int NASSEG_FN(cat_src_bwd)(const act_t* du, const act_t* slab, int64_t ld, int o
   const CatGrid gr = cat_grid(B, Ho, Wo, C);
   const double M = (double)B * Ho * Wo;
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
-  if (Hi == Ho && Wi == Wo)
+  if (Hi == Ho && Wi == Wo && z)  // (a pending input of the slab's size: its slice of the slab is rebuilt from z)
+    hipLaunchKernelGGL((cat_src_bwd_kernel<false, true>), dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, du, slab,
+                       ld, off, sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho,
+                       Wo, C / 4, Ho, Hi, Wi, sh, sw);
+  else if (Hi == Ho && Wi == Wo)
     hipLaunchKernelGGL(cat_src_bwd_kernel<false>, dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, du, slab, ld,
                        off, sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho, Wo,
                        C / 4, Ho, Hi, Wi, sh, sw);

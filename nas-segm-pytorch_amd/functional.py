@@ -2400,9 +2400,11 @@ def _apply_library_knobs():
         lib._memo.clear()
     # NASSEG_DW_WGRAD_LDS=0: the strip kernel for 5x5 depthwise weight gradients too; NASSEG_CONV_DEEP_K=0: one
     # k-step per round trip on small maps as well; NASSEG_POOL_STRIP=0 / 2: stride-1 max pooling one gather per
-    # element / two rows per thread (A/B switches, include/nasseg.h)
+    # element / two rows per thread; NASSEG_PW_RZ_MIN_PIXELS: maps from which the one-kernel pointwise backward rebuilds
+    # z instead of loading it (A/B switches, include/nasseg.h)
     for env, fn in (("NASSEG_DW_WGRAD_LDS", "nasseg_dw_wgrad_lds"), ("NASSEG_CONV_DEEP_K", "nasseg_conv_deep_k"),
-                    ("NASSEG_POOL_STRIP", "nasseg_pool_strip")):
+                    ("NASSEG_POOL_STRIP", "nasseg_pool_strip"),
+                    ("NASSEG_PW_RZ_MIN_PIXELS", "nasseg_conv_pw_bwd_rz_min_pixels")):
         if os.environ.get(env) is not None:
             lib.query(fn, int(os.environ[env]))
             lib._memo.clear()

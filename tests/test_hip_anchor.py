@@ -52,6 +52,21 @@ def lower_thresholds(monkeypatch):
     for name in ("_GROUP_WGRAD_BYTES", "_PW_BWD_MIN_BYTES", "_PW_BWD_WIDE_MIN_PIXELS", "_DW_BWD_MIN_BYTES",
                  "_FLAT_WGRAD_BN_MIN_BYTES"):
         monkeypatch.setattr(Fm, name, 0)
+    # ... and the one-kernel pointwise backward rebuilds z = W x on these small maps as it does on the large ones
+    prev = Fm.lib.query("nasseg_conv_pw_bwd_rz_min_pixels", -1)
+    Fm.lib.query("nasseg_conv_pw_bwd_rz_min_pixels", 0)
+    Fm.lib._memo.clear()
+
+    class _Restore(object):  # (monkeypatch undoes attribute patches in reverse order: this one restores the knob)
+        def __setattr__(self, name, value):
+            if name == "armed" and value is False:
+                Fm.lib.query("nasseg_conv_pw_bwd_rz_min_pixels", prev)
+                Fm.lib._memo.clear()
+            object.__setattr__(self, name, value)
+
+    r = _Restore()
+    object.__setattr__(r, "armed", False)
+    monkeypatch.setattr(r, "armed", True)  # undone at teardown -> armed = False -> knob restored
     return Fm
 
 

@@ -1051,6 +1051,18 @@ def _pointwise_output(f, x, w, psc, psh, pact):
     return z
 
 
+@pytest.fixture
+def rebuild_z_everywhere():
+    """the one-kernel pointwise backward rebuilds z on maps of any size where its plan can (production: >= 2^18 pixels)"""
+    f = F()
+    prev = f.lib.query("nasseg_conv_pw_bwd_rz_min_pixels", -1)
+    f.lib.query("nasseg_conv_pw_bwd_rz_min_pixels", 0)
+    f.lib._memo.clear()
+    yield
+    f.lib.query("nasseg_conv_pw_bwd_rz_min_pixels", prev)
+    f.lib._memo.clear()
+
+
 @pytest.mark.parametrize("case", [
     # B, H, W, K, N
     (2, 13, 17, 16, 96), (2, 24, 20, 24, 144), (1, 31, 33, 32, 192), (2, 16, 16, 32, 32),
@@ -1060,12 +1072,15 @@ def _pointwise_output(f, x, w, psc, psh, pact):
 ], ids=lambda c: "B{}_{}x{}_K{}N{}".format(*c))
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("pro,bact,train", [(False, 0, True), (True, 1, True), (True, 2, False)])
-def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train):
+@pytest.mark.parametrize("rebuild", [True, False], ids=["rebuild_z", "load_z"])
+def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train, rebuild, request):
     """nasseg_conv_pw_bwd_bn against the two-kernel form it replaces (nasseg_conv_wgrad_bn, which
     also writes dz, + nasseg_conv_fwd as backward-data over that dz): same dz arithmetic, MFMA sums
     in another order - dx and dw agree to fp32 rounding of the sums."""
     Fm = F()
     lib, ptr, stream = Fm.lib, Fm.ptr, Fm.current_stream
+    if rebuild:
+        request.getfixturevalue("rebuild_z_everywhere")
     B, H, W, K, N = case
     nsl = lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N)
     assert nsl > 0
@@ -1112,8 +1127,9 @@ def test_pointwise_backward_with_bn_in_one_kernel(case, dtype, pro, bact, train)
                  ptr(dw_n), ptr(ws2), ptr(psc), ptr(psh), pact, 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
                  ptr(sums), int(train), bact, B, H, W, K, N, None, None, None, stream())
         assert torch.equal(dx_n, dx) and torch.equal(dw_n, dw)
+        assert rebuild and K <= 32 and N <= 96
     else:
-        assert K > 64 or N > 144  # (the wide kernel, and 32 -> 192 whose weight does not fit LDS twice per CU)
+        assert not rebuild or K > 32 or N > 96  # (the plan rebuilds wherever K <= 32 and N <= 96 once asked to)
     # dw == NULL: partial rows only, finalised by nasseg_wgrad_finalize_many
     ws3 = torch.full_like(ws2, float("nan"))
     lib.call(name("nasseg_conv_pw_bwd_bn"), ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws3), ptr(psc),
@@ -1655,6 +1671,10 @@ def test_cat_src_kernels_against_torch(case):
     sscale, smean, sinv = torch.rand(Ct, generator=g) + 0.5, torch.randn(Ct, generator=g) * 0.2, torch.rand(Ct, generator=g) + 0.5
     sums = torch.randn(2 * Ct, generator=g) * (M ** 0.5)
     c = slice(off, off + C)
+    if pending and (Hi, Wi) == (Ho, Wo):
+        # (a pending input of the slab's size: the backward kernel REBUILDS its slice of the slab from z - round 5 -,
+        #  so the slab it is handed must hold what nasseg_cat_src_fwd wrote there)
+        sl[:, c] = slab[:, off:off + C].float().cpu()
     v = du[:, c].double()
     if train:
         xh = (sl[:, c].double() - smean[c].double().view(1, C, 1, 1)) * sinv[c].double().view(1, C, 1, 1)
