@@ -763,7 +763,10 @@ int NASSEG_FN(cat_src_bwd)(const act_t* du, const act_t* slab, int64_t ld, int o
   const CatGrid gr = cat_grid(B, Ho, Wo, C);
   const double M = (double)B * Ho * Wo;
   const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
-  if (Hi == Ho && Wi == Wo && z)  // (a pending input of the slab's size: its slice of the slab is rebuilt from z)
+#ifndef NASSEG_CAT_ZSAME  // (0: load the slab slice as rounds 3-4 did - A/B, tools/gpu.sh flags)
+#define NASSEG_CAT_ZSAME 1
+#endif
+  if (NASSEG_CAT_ZSAME && Hi == Ho && Wi == Wo && z)  // (a pending input of the slab's size: its slice of the slab is rebuilt from z)
     hipLaunchKernelGGL((cat_src_bwd_kernel<false, true>), dim3(gr.gx, gr.gy), dim3(256), 0, (hipStream_t)stream, du, slab,
                        ld, off, sscale, smean, sinvstd, sums, (float)(1.0 / M), train, z, tstats, act, g, part, B * Ho,
                        Wo, C / 4, Ho, Hi, Wi, sh, sw);
