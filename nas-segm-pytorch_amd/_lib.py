@@ -68,11 +68,14 @@ class LaunchProfiler(object):
     """Optional per-entry-point timing with HIP events on the launch stream.
 
     While installed (``lib.profiler = LaunchProfiler()``) every status-returning
-    call is bracketed by a pair of events recorded on torch's current stream -
-    the stream the kernels are launched on.  ``summary()`` synchronises and
+    call is bracketed by a pair of events recorded on the stream the kernels
+    are launched on (torch's current stream, or a registered second one).  ``summary()`` synchronises and
     returns {entry point: (launches, total ms, [per-launch (ms, args)])}.
     Used by bench.py for the roofline figures; off by default (zero overhead).
     """
+
+    streams = {}  # raw handle -> torch stream, for launches that go to another stream than the current one
+    #               (functional._wgrad_stream registers its second stream here)
 
     def __init__(self, names=None):
         self.names = set(names) if names else None
@@ -86,9 +89,12 @@ class LaunchProfiler(object):
 
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        on = self.streams.get(args[-1]) if args and isinstance(args[-1], int) else None
+        if on is None:
+            on = torch.cuda.current_stream()
+        e0.record(on)
         rc = fn(*args)
-        e1.record()
+        e1.record(on)
         self.records.append((name, args, e0, e1))
         return rc
 

@@ -13,7 +13,7 @@ import weakref
 
 import torch
 
-from ._lib import NassegError, current_stream, lib, ptr, require_device
+from ._lib import LaunchProfiler, NassegError, current_stream, lib, ptr, require_device
 
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 RED_SUM, RED_SUMSQ, RED_DOT2, RED_DOT1 = 0, 1, 3, 4
@@ -121,6 +121,9 @@ class deferred_wgrad(object):
     grouped = {}   # (entry point, dtype) -> [(tensors the kernels read, launch arguments)]: first
     #                stages of small layers, launched side by side at the exit
     #                (nasseg_conv_wgrad_many / nasseg_dwconv_wgrad_many)
+    side_ok = False  # first stages may go to a second stream (WGRAD_STREAM; never while a hipGraph is captured)
+    side_used = {}   # device -> that stream, once a launch went there
+    side_keep = []   # what those launches read and write: alive until the streams have joined
 
     def __init__(self, enabled=True, params=None):
         """params: the parameters being trained; when given, the exit verifies that every
@@ -130,20 +133,33 @@ class deferred_wgrad(object):
         self.params = params
 
     def __enter__(self):
-        self.prev = deferred_wgrad.active
+        self.prev = deferred_wgrad.active, deferred_wgrad.side_ok
         deferred_wgrad.active = self.enabled
+        deferred_wgrad.side_ok = bool(self.enabled and WGRAD_STREAM and torch.cuda.is_available()
+                                      and not torch.cuda.is_current_stream_capturing())
         return self
 
+    @staticmethod
+    def _launch_group(entry, dtype, calls, stream):
+        flat = [v for _, desc in calls for v in desc]
+        table = (ctypes.c_int64 * len(flat))(*flat)
+        name = entry if dtype == torch.float32 else entry.replace("nasseg_", "nasseg_bf16_", 1)
+        lib.call(name, len(calls), table, stream)
+
     def __exit__(self, exc_type, exc, tb):
-        deferred_wgrad.active = self.prev
+        deferred_wgrad.active, deferred_wgrad.side_ok = self.prev
         todo, deferred_wgrad.pending = deferred_wgrad.pending, []
         groups, deferred_wgrad.grouped = deferred_wgrad.grouped, {}
+        sides, deferred_wgrad.side_used = deferred_wgrad.side_used, {}
+        keep, deferred_wgrad.side_keep = deferred_wgrad.side_keep, []
         if exc_type is None:
             for (entry, dtype), calls in groups.items():
-                flat = [v for _, desc in calls for v in desc]
-                table = (ctypes.c_int64 * len(flat))(*flat)
-                name = entry if dtype == torch.float32 else entry.replace("nasseg_", "nasseg_bf16_", 1)
-                lib.call(name, len(calls), table, current_stream())
+                self._launch_group(entry, dtype, calls, current_stream())
+        # the second stream's launches read tensors of this one and fill the partial sums finalised below: join
+        # (also after an exception: what they read is released when this returns)
+        for dev, side in sides.items():
+            torch.cuda.current_stream(dev).wait_stream(side)
+        del keep
         if todo and exc_type is None:
             n = len(todo)
             parts = (ctypes.c_void_p * n)(*[ptr(ws) for ws, _, _ in todo])
@@ -163,6 +179,46 @@ class deferred_wgrad(object):
 # largest x + dy footprint (bytes) of a layer whose backward-weight launch is grouped
 _GROUP_WGRAD_BYTES = 48 << 20
 
+# Weight gradients on a second stream.  Inside deferred_wgrad nothing on the backward chain waits for a weight
+# gradient: its first stage reads the layer's input and the gradient w.r.t. its output, writes partial sums, and the
+# second stage runs at the exit.  Launched on the stream of the chain, those kernels - 20 - 230 us each, many of them
+# too few workgroups to fill 256 CUs - sit between the backward-data kernels; on a stream of their own (which first
+# waits for what the chain has launched so far) the GPU runs them beside the chain, and the chain's stream waits for
+# that stream once, at the exit.  1: the launches that were immediate; 2: also the grouped small layers, eight at a
+# time as they come.  0: everything on the chain's stream (A/B).  Never while a hipGraph is being captured (a second
+# stream inside a capture crashes this runtime).  Same kernels on the same data: bit-identical.
+WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "1"))
+_SIDE_STREAMS = {}
+_SIDE_GROUP = 8
+
+
+def _wgrad_stream(t, keep):
+    """the stream a first-stage weight-gradient launch over ``t`` goes to, after it has been made to wait for the
+    current one: the second stream (``keep`` then stays referenced until the exit of deferred_wgrad), else the current"""
+    if not (deferred_wgrad.side_ok and t.is_cuda):
+        return current_stream()
+    side = deferred_wgrad.side_used.get(t.device)
+    if side is None:
+        side = _SIDE_STREAMS.get(t.device)
+        if side is None:
+            side = _SIDE_STREAMS[t.device] = torch.cuda.Stream(t.device)
+            LaunchProfiler.streams[side.cuda_stream] = side
+        deferred_wgrad.side_used[t.device] = side
+    side.wait_stream(torch.cuda.current_stream(t.device))
+    deferred_wgrad.side_keep.append(keep)
+    return side.cuda_stream
+
+
+def _group_wgrad(entry, cur, tensors, desc):
+    """queue a small layer's first stage; with WGRAD_STREAM >= 2, launch the queue on the second stream when it holds
+    _SIDE_GROUP layers"""
+    key = (entry, cur.dtype)
+    calls = deferred_wgrad.grouped.setdefault(key, [])
+    calls.append((tensors, desc))
+    if WGRAD_STREAM >= 2 and deferred_wgrad.side_ok and cur.is_cuda and len(calls) >= _SIDE_GROUP:
+        del deferred_wgrad.grouped[key]
+        deferred_wgrad._launch_group(entry, cur.dtype, calls, _wgrad_stream(cur, calls))
+
 
 def _dw_wgrad(cur, dz, w, psc, psh, pact, geom):
     """Weight gradient of a depthwise conv (geom = B, H, W, C, Ho, Wo, k, stride, pad, dil); see
@@ -172,12 +228,11 @@ def _dw_wgrad(cur, dz, w, psc, psh, pact, geom):
     ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, k))
     if deferred_wgrad.active and (B * H * W * C + B * Ho * Wo * C) * cur.element_size() <= _GROUP_WGRAD_BYTES:
         desc = (ptr(cur), ptr(dz), ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
-        deferred_wgrad.grouped.setdefault(("nasseg_dwconv_wgrad_many", cur.dtype), []).append(
-            ((cur, dz, psc, psh), desc))
         _finish_wgrad(ws, dwt, k * k, C, 1, 0)
+        _group_wgrad("nasseg_dwconv_wgrad_many", cur, (cur, dz, psc, psh, ws), desc)
         return dwt
     lib.call(_k("nasseg_dwconv_wgrad", cur), ptr(cur), ptr(dz), _finish_wgrad(ws, dwt, k * k, C, 1, 0), ptr(ws),
-             ptr(psc), ptr(psh), pact, *geom, current_stream())
+             ptr(psc), ptr(psh), pact, *geom, _wgrad_stream(cur, (cur, dz, psc, psh, ws)))
     return dwt
 
 
@@ -195,12 +250,11 @@ def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
             and not (psc is None and psh is None and not pact
                      and lib.query("nasseg_conv_wgrad_lds3x3", B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil))):
         desc = (ptr(cur), K, ptr(dz), N, ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
-        deferred_wgrad.grouped.setdefault(("nasseg_conv_wgrad_many", cur.dtype), []).append(
-            ((cur, dz, psc, psh), desc))
         _finish_wgrad(ws, dwt, kh * kw, N, K, flat)
+        _group_wgrad("nasseg_conv_wgrad_many", cur, (cur, dz, psc, psh, ws), desc)
         return dwt
     lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N, _finish_wgrad(ws, dwt, kh * kw, N, K, flat),
-             ptr(ws), ptr(psc), ptr(psh), pact, *geom, current_stream())
+             ptr(ws), ptr(psc), ptr(psh), pact, *geom, _wgrad_stream(cur, (cur, dz, psc, psh, ws)))
     return dwt
 
 
@@ -775,6 +829,9 @@ class _ConvChain(torch.autograd.Function):
         in_act0, ops = cfg[:2]
         x = _cl(x)
         s = current_stream()
+        # the statistics vector a deferred tail hands out never has a gradient: without this autograd would
+        # materialise a zero "gradient" for it in every backward (one fill launch per chain and step)
+        ctx.set_materialize_grads(False)
         # (under no_grad ctx.needs_input_grad still reports the parameters' requires_grad flags: nothing
         #  will ever call backward then, and inference may fold every BatchNorm into its conv's epilogue.
         #  The grad mode is the CALLER's - cfg[2]: inside forward() autograd has switched it off)
@@ -972,6 +1029,7 @@ class _ConvChain(torch.autograd.Function):
                 saved.append(pool_idx)
             ctx.save_for_backward(*[t for t in saved])
             ctx.meta = (cfg, meta, residual is not None, tuple(x.shape), pool_fused)
+            ctx.n_inputs = 3 + len(tensors)
         if defer:
             if tail is None:
                 return y, None
@@ -981,6 +1039,8 @@ class _ConvChain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, *_unused):
+        if dy is None:  # (no gradient reaches the chain's output: nothing to hand on)
+            return (None,) * ctx.n_inputs
         cfg, meta, has_res, x_shape = ctx.meta[:4]
         pool_fused = ctx.meta[4] if len(ctx.meta) > 4 else False
         in_act0, ops = cfg[:2]
