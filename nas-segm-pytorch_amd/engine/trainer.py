@@ -333,7 +333,7 @@ def make_task0_step(Xy_train, segmenter, optim_dec, batch_size, ignore_index=255
                         aux_out = F.bilinear_resize(aux_out, out_size)
                         loss = loss + F.log_softmax_nll(aux_out, target, ignore_index) * aux_weight
                 _zero_grads(segmenter, (optim_dec,))
-                with F.deferred_wgrad(params=dec_params):
+                with F.deferred_wgrad(params=dec_params, second_stream=False):  # (crops of the feature cache: launch-bound)
                     loss.backward()
             if _distributed(segmenter):
                 # the feature cache is sharded: every rank steps on its own cached samples and the
@@ -420,7 +420,9 @@ def segmenter_step(segmenter, image, target, optim_enc, optim_dec, ignore_index=
             _zero_grads(segmenter, (optim_enc, optim_dec))
             # gradients were just cleared: the second stages of all weight-gradient reductions run
             # batched when backward is through
-            with F.deferred_wgrad(params=groups[0] + groups[1]):
+            # (a step small enough to be worth replaying from a hipGraph is launch-bound when it is not: no second stream)
+            side = image.shape[0] * image.shape[2] * image.shape[3] > _graphed().AUTO_GRAPH_MAX_PIXELS
+            with F.deferred_wgrad(params=groups[0] + groups[1], second_stream=side):
                 loss.backward()
         finish_step(segmenter, groups, optim_enc, optim_dec, enc_grad_clip, dec_grad_clip)
     except Exception as e:

@@ -125,17 +125,19 @@ class deferred_wgrad(object):
     side_used = {}   # device -> that stream, once a launch went there
     side_keep = []   # what those launches read and write: alive until the streams have joined
 
-    def __init__(self, enabled=True, params=None):
+    def __init__(self, enabled=True, params=None, second_stream=True):
         """params: the parameters being trained; when given, the exit verifies that every
         deferred gradient is the tensor autograd adopted as some ``param.grad`` (it would be a
-        copy - of unwritten memory - had a condition above been violated) and fails loudly."""
+        copy - of unwritten memory - had a condition above been violated) and fails loudly.
+        second_stream: first stages may be launched on a second stream (WGRAD_STREAM below)."""
         self.enabled = bool(enabled)
         self.params = params
+        self.second_stream = bool(second_stream)
 
     def __enter__(self):
         self.prev = deferred_wgrad.active, deferred_wgrad.side_ok
         deferred_wgrad.active = self.enabled
-        deferred_wgrad.side_ok = bool(self.enabled and WGRAD_STREAM and torch.cuda.is_available()
+        deferred_wgrad.side_ok = bool(self.enabled and self.second_stream and WGRAD_STREAM and torch.cuda.is_available()
                                       and not torch.cuda.is_current_stream_capturing())
         return self
 
@@ -181,21 +183,26 @@ _GROUP_WGRAD_BYTES = 48 << 20
 
 # Weight gradients on a second stream.  Inside deferred_wgrad nothing on the backward chain waits for a weight
 # gradient: its first stage reads the layer's input and the gradient w.r.t. its output, writes partial sums, and the
-# second stage runs at the exit.  Launched on the stream of the chain, those kernels - 20 - 230 us each, many of them
-# too few workgroups to fill 256 CUs - sit between the backward-data kernels; on a stream of their own (which first
-# waits for what the chain has launched so far) the GPU runs them beside the chain, and the chain's stream waits for
-# that stream once, at the exit.  1: the launches that were immediate; 2: also the grouped small layers, eight at a
-# time as they come.  0: everything on the chain's stream (A/B).  Never while a hipGraph is being captured (a second
-# stream inside a capture crashes this runtime).  Same kernels on the same data: bit-identical.
-WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "1"))
+# second stage runs at the exit.  Launched on the stream of the chain, those kernels sit between the backward-data
+# kernels - or, the grouped small layers, behind the whole backward - although many of them have too few workgroups
+# to fill 256 CUs; on a stream of their own (which first waits for what the chain has launched so far) the GPU runs
+# them beside the chain, and the chain's stream waits for that stream once, at the exit.  Bits of NASSEG_WGRAD_STREAM:
+# 1 = the launches of large layers, 2 = the grouped small layers, _SIDE_GROUP at a time as they come.  Measured on one
+# box (profiles/r05_ab_wgrad_stream_same_box.txt): either bit alone is level, both together +0.5 % on the headline
+# step and +1.2 - 1.5 % on WACV arch1.  0: everything on the chain's stream (A/B).  Never while a hipGraph is being
+# captured (one second stream inside a capture made the replay slower, two crash this runtime: DESIGN_HISTORY.md),
+# and only where the caller asks for it (deferred_wgrad(second_stream=...): a step that is launch-bound on the host
+# gains nothing from more launches - CVPR 321x321 from the host 750.5 / 745.8).  Same kernels on the same data:
+# bit-identical.
+WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "3"))
 _SIDE_STREAMS = {}
-_SIDE_GROUP = 8
+_SIDE_GROUP = int(os.environ.get("NASSEG_WGRAD_SIDE_GROUP", "8"))
 
 
 def _wgrad_stream(t, keep):
     """the stream a first-stage weight-gradient launch over ``t`` goes to, after it has been made to wait for the
     current one: the second stream (``keep`` then stays referenced until the exit of deferred_wgrad), else the current"""
-    if not (deferred_wgrad.side_ok and t.is_cuda):
+    if not (deferred_wgrad.side_ok and t.is_cuda and (WGRAD_STREAM & 1 or isinstance(keep, list))):
         return current_stream()
     side = deferred_wgrad.side_used.get(t.device)
     if side is None:
@@ -210,12 +217,12 @@ def _wgrad_stream(t, keep):
 
 
 def _group_wgrad(entry, cur, tensors, desc):
-    """queue a small layer's first stage; with WGRAD_STREAM >= 2, launch the queue on the second stream when it holds
-    _SIDE_GROUP layers"""
+    """queue a small layer's first stage; with WGRAD_STREAM & 2, launch the queue on the second stream when it holds
+    _SIDE_GROUP layers (a list as ``keep`` marks such a launch for _wgrad_stream)"""
     key = (entry, cur.dtype)
     calls = deferred_wgrad.grouped.setdefault(key, [])
     calls.append((tensors, desc))
-    if WGRAD_STREAM >= 2 and deferred_wgrad.side_ok and cur.is_cuda and len(calls) >= _SIDE_GROUP:
+    if WGRAD_STREAM & 2 and deferred_wgrad.side_ok and cur.is_cuda and len(calls) >= _SIDE_GROUP:
         del deferred_wgrad.grouped[key]
         deferred_wgrad._launch_group(entry, cur.dtype, calls, _wgrad_stream(cur, calls))
 

@@ -880,6 +880,54 @@ def test_grouped_depthwise_weight_gradients_are_bit_identical():
         assert_close(g, wr.grad, 1e-5, 1e-3, "dw %r" % ((c, k, st, dil, relu_in),))
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_weight_gradients_on_the_second_stream_are_bit_identical(mode, monkeypatch):
+    """inside deferred_wgrad the first stages may run on a second stream (functional.WGRAD_STREAM: 1 = the launches of
+    large layers, 2 = the grouped small ones, eight at a time as backward meets them) that waits for the chain's stream
+    before each launch and is waited for once at the exit: same gradients bit for bit as with everything on one
+    stream - on poisoned memory, with the memory the launches read released and overwritten right after the exit"""
+    f = F()
+    torch.manual_seed(5)
+    # 20 small layers (two groups of eight flushed during backward + a rest at the exit), alternating dense /
+    # depthwise, then one layer above the grouping limit (x + dy = 2 x 2 x 48 x 256 x 320 x 4 B = 63 MB)
+    small = [(24, 24, 1), (24, 1, 3), (24, 32, 3), (32, 1, 5)] * 5
+    ws = []
+    for k, n, ks in small:
+        ws.append((torch.randn(k if n == 1 else n, 1 if n == 1 else k, ks, ks) / (ks * (1 if n == 1 else k) ** 0.5)).to(DEV))
+    wbig = (torch.randn(48, 48, 1, 1) / 48 ** 0.5).to(DEV)
+    wdwbig = (torch.randn(48, 1, 5, 5) * 0.2).to(DEV)
+    xs = dev(rnd(2, 24, 36, 44, seed=2))
+    xb = dev(rnd(2, 48, 256, 320, seed=3))
+
+    def run(m):
+        monkeypatch.setattr(f, "WGRAD_STREAM", m)
+        leaves = [w.clone().requires_grad_(True) for w in ws + [wbig, wdwbig]]
+        x = xs
+        for w, (k, n, ks) in zip(leaves, small):
+            x = f.depthwise_conv2d(x, w, 1, ks // 2, 1) if n == 1 else f.conv2d(x, w, None, 1, ks // 2, 1)
+            if x.shape[1] == 32 and (k, n, ks) == (32, 1, 5):
+                x = x[:, :24].contiguous(memory_format=torch.channels_last)
+        loss = (x * x).mean()
+        yb = f.depthwise_conv2d(f.conv2d(xb, leaves[-2], None, 1, 0, 1), leaves[-1], 1, 2, 1)
+        loss = loss + (yb * yb).mean()
+        poison = torch.full((64 << 20,), float("nan"), device=DEV)
+        del poison
+        with f.deferred_wgrad():
+            loss.backward()
+            used = bool(f.deferred_wgrad.side_used)
+        del x, yb, loss
+        poison = torch.full((96 << 20,), float("nan"), device=DEV)  # (recycles what the second stream was reading)
+        del poison
+        assert not f.deferred_wgrad.side_used and not f.deferred_wgrad.side_keep
+        return [t.grad.clone() for t in leaves], used
+
+    g0, used0 = run(0)
+    g1, used1 = run(mode)
+    assert not used0 and used1
+    for a, b in zip(g0, g1):
+        assert bool(torch.isfinite(b).all()) and torch.equal(a, b)
+
+
 def test_deferred_weight_gradient_detects_an_early_copy():
     """a weight used twice makes autograd add its two gradients during backward, i.e. before the
     deferred finalisation: with ``params`` given the context fails loudly instead of training on
