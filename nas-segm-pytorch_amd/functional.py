@@ -124,6 +124,7 @@ class deferred_wgrad(object):
     side_ok = False  # first stages may go to a second stream (WGRAD_STREAM; never while a hipGraph is captured)
     side_used = {}   # device -> that stream, once a launch went there
     side_keep = []   # what those launches read and write: alive until the streams have joined
+    side_done = []   # addresses of the gradients whose second stage already ran on that stream
 
     def __init__(self, enabled=True, params=None, second_stream=True):
         """params: the parameters being trained; when given, the exit verifies that every
@@ -143,10 +144,21 @@ class deferred_wgrad(object):
 
     @staticmethod
     def _launch_group(entry, dtype, calls, stream):
-        flat = [v for _, desc in calls for v in desc]
+        flat = [v for c in calls for v in c[1]]
         table = (ctypes.c_int64 * len(flat))(*flat)
         name = entry if dtype == torch.float32 else entry.replace("nasseg_", "nasseg_bf16_", 1)
         lib.call(name, len(calls), table, stream)
+
+    @staticmethod
+    def _finalize(todo, stream):
+        """second stages of the layers in ``todo`` (partials, address of the gradient, dims) on ``stream``"""
+        n = len(todo)
+        parts = (ctypes.c_void_p * n)(*[ptr(ws) for ws, _, _ in todo])
+        outs = (ctypes.c_void_p * n)(*[addr for _, addr, _ in todo])
+        dims = (ctypes.c_int * (5 * n))()
+        for j, (_, _, d) in enumerate(todo):
+            dims[5 * j:5 * j + 5] = d
+        lib.call("nasseg_wgrad_finalize_many", n, parts, outs, dims, stream)
 
     def __exit__(self, exc_type, exc, tb):
         deferred_wgrad.active, deferred_wgrad.side_ok = self.prev
@@ -154,25 +166,22 @@ class deferred_wgrad(object):
         groups, deferred_wgrad.grouped = deferred_wgrad.grouped, {}
         sides, deferred_wgrad.side_used = deferred_wgrad.side_used, {}
         keep, deferred_wgrad.side_keep = deferred_wgrad.side_keep, []
+        done, deferred_wgrad.side_done = deferred_wgrad.side_done, []
         if exc_type is None:
             for (entry, dtype), calls in groups.items():
                 self._launch_group(entry, dtype, calls, current_stream())
+                todo.extend(c[2] for c in calls)
         # the second stream's launches read tensors of this one and fill the partial sums finalised below: join
         # (also after an exception: what they read is released when this returns)
         for dev, side in sides.items():
             torch.cuda.current_stream(dev).wait_stream(side)
         del keep
-        if todo and exc_type is None:
-            n = len(todo)
-            parts = (ctypes.c_void_p * n)(*[ptr(ws) for ws, _, _ in todo])
-            outs = (ctypes.c_void_p * n)(*[addr for _, addr, _ in todo])
-            dims = (ctypes.c_int * (5 * n))()
-            for j, (_, _, d) in enumerate(todo):
-                dims[5 * j:5 * j + 5] = d
-            lib.call("nasseg_wgrad_finalize_many", n, parts, outs, dims, current_stream())
-            if self.params is not None:
+        if exc_type is None:
+            if todo:
+                self._finalize(todo, current_stream())
+            if self.params is not None and (todo or done):
                 adopted = set(p.grad.data_ptr() for p in self.params if p.grad is not None)
-                if any(addr not in adopted for _, addr, _ in todo):
+                if any(addr not in adopted for _, addr, _ in todo) or any(addr not in adopted for addr in done):
                     raise NassegError("deferred_wgrad: autograd copied a weight gradient before it was "
                                       "finalised (gradients not cleared, or a weight used twice?)")
         return False
@@ -187,16 +196,18 @@ _GROUP_WGRAD_BYTES = 48 << 20
 # kernels - or, the grouped small layers, behind the whole backward - although many of them have too few workgroups
 # to fill 256 CUs; on a stream of their own (which first waits for what the chain has launched so far) the GPU runs
 # them beside the chain, and the chain's stream waits for that stream once, at the exit.  Bits of NASSEG_WGRAD_STREAM:
-# 1 = the launches of large layers, 2 = the grouped small layers, _SIDE_GROUP at a time as they come.  Measured on one
+# 1 = the launches of large layers, 2 = the grouped small layers, _SIDE_GROUP at a time as they come, 4 = second stages
+# too (_SIDE_FINALIZE layers at a time, behind their first stages).  Measured on one
 # box (profiles/r05_ab_wgrad_stream_same_box.txt): either bit alone is level, both together +0.5 % on the headline
 # step and +1.2 - 1.5 % on WACV arch1.  0: everything on the chain's stream (A/B).  Never while a hipGraph is being
 # captured (one second stream inside a capture made the replay slower, two crash this runtime: DESIGN_HISTORY.md),
 # and only where the caller asks for it (deferred_wgrad(second_stream=...): a step that is launch-bound on the host
 # gains nothing from more launches - CVPR 321x321 from the host 750.5 / 745.8).  Same kernels on the same data:
 # bit-identical.
-WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "3"))
+WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "7"))
 _SIDE_STREAMS = {}
 _SIDE_GROUP = int(os.environ.get("NASSEG_WGRAD_SIDE_GROUP", "8"))
+_SIDE_FINALIZE = 16  # (bit 4: second stages too, whenever this many layers wait for theirs)
 
 
 def _wgrad_stream(t, keep):
@@ -213,18 +224,28 @@ def _wgrad_stream(t, keep):
         deferred_wgrad.side_used[t.device] = side
     side.wait_stream(torch.cuda.current_stream(t.device))
     deferred_wgrad.side_keep.append(keep)
+    if WGRAD_STREAM & 4 and len(deferred_wgrad.pending) >= _SIDE_FINALIZE:
+        # every first stage queued for finalisation so far was launched before this point - on the chain's stream,
+        # which the second one has just been made to wait for, or earlier on the second one: their second stages
+        # can run there now instead of on the chain's stream behind the whole backward
+        todo, deferred_wgrad.pending = deferred_wgrad.pending, []
+        deferred_wgrad._finalize(todo, side.cuda_stream)
+        deferred_wgrad.side_keep.append(todo)
+        deferred_wgrad.side_done.extend(addr for _, addr, _ in todo)
     return side.cuda_stream
 
 
-def _group_wgrad(entry, cur, tensors, desc):
-    """queue a small layer's first stage; with WGRAD_STREAM & 2, launch the queue on the second stream when it holds
-    _SIDE_GROUP layers (a list as ``keep`` marks such a launch for _wgrad_stream)"""
+def _group_wgrad(entry, cur, tensors, desc, fin):
+    """queue a small layer's first stage (``fin``: what its second stage needs, queued once the first is launched);
+    with WGRAD_STREAM & 2, launch the queue on the second stream when it holds _SIDE_GROUP layers (a list as ``keep``
+    marks such a launch for _wgrad_stream)"""
     key = (entry, cur.dtype)
     calls = deferred_wgrad.grouped.setdefault(key, [])
-    calls.append((tensors, desc))
+    calls.append((tensors, desc, fin))
     if WGRAD_STREAM & 2 and deferred_wgrad.side_ok and cur.is_cuda and len(calls) >= _SIDE_GROUP:
         del deferred_wgrad.grouped[key]
         deferred_wgrad._launch_group(entry, cur.dtype, calls, _wgrad_stream(cur, calls))
+        deferred_wgrad.pending.extend(c[2] for c in calls)
 
 
 def _dw_wgrad(cur, dz, w, psc, psh, pact, geom):
@@ -235,11 +256,11 @@ def _dw_wgrad(cur, dz, w, psc, psh, pact, geom):
     ws = _ws(cur, lib.query("nasseg_dwconv_wgrad_workspace", B, C, Ho, Wo, k))
     if deferred_wgrad.active and (B * H * W * C + B * Ho * Wo * C) * cur.element_size() <= _GROUP_WGRAD_BYTES:
         desc = (ptr(cur), ptr(dz), ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
-        _finish_wgrad(ws, dwt, k * k, C, 1, 0)
-        _group_wgrad("nasseg_dwconv_wgrad_many", cur, (cur, dz, psc, psh, ws), desc)
+        _group_wgrad("nasseg_dwconv_wgrad_many", cur, (cur, dz, psc, psh, ws), desc, _fin_entry(ws, dwt, k * k, C, 1, 0))
         return dwt
+    st = _wgrad_stream(cur, (cur, dz, psc, psh, ws))  # (before this layer is queued for finalisation)
     lib.call(_k("nasseg_dwconv_wgrad", cur), ptr(cur), ptr(dz), _finish_wgrad(ws, dwt, k * k, C, 1, 0), ptr(ws),
-             ptr(psc), ptr(psh), pact, *geom, _wgrad_stream(cur, (cur, dz, psc, psh, ws)))
+             ptr(psc), ptr(psh), pact, *geom, st)
     return dwt
 
 
@@ -257,11 +278,12 @@ def _dense_wgrad(cur, dz, w, psc, psh, pact, geom):
             and not (psc is None and psh is None and not pact
                      and lib.query("nasseg_conv_wgrad_lds3x3", B, Hs, Ws, K, Ho, Wo, N, kh, kw, stride, pad, dil))):
         desc = (ptr(cur), K, ptr(dz), N, ptr(ws), ptr(psc) or 0, ptr(psh) or 0, pact) + tuple(geom)
-        _finish_wgrad(ws, dwt, kh * kw, N, K, flat)
-        _group_wgrad("nasseg_conv_wgrad_many", cur, (cur, dz, psc, psh, ws), desc)
+        _group_wgrad("nasseg_conv_wgrad_many", cur, (cur, dz, psc, psh, ws), desc,
+                     _fin_entry(ws, dwt, kh * kw, N, K, flat))
         return dwt
+    st = _wgrad_stream(cur, (cur, dz, psc, psh, ws))  # (before this layer is queued for finalisation)
     lib.call(_k("nasseg_conv_wgrad", cur), ptr(cur), K, ptr(dz), N, _finish_wgrad(ws, dwt, kh * kw, N, K, flat),
-             ptr(ws), ptr(psc), ptr(psh), pact, *geom, _wgrad_stream(cur, (cur, dz, psc, psh, ws)))
+             ptr(ws), ptr(psc), ptr(psh), pact, *geom, st)
     return dwt
 
 
@@ -357,8 +379,12 @@ def _finish_wgrad(ws, dw, taps, N, K, flat):
     or NULL with the second stage queued when finalisation is deferred."""
     if not deferred_wgrad.active:
         return ptr(dw)
-    deferred_wgrad.pending.append((ws, dw.data_ptr(), (ws.numel() // (taps * N * K), taps, N, K, flat)))
+    deferred_wgrad.pending.append(_fin_entry(ws, dw, taps, N, K, flat))
     return None
+
+
+def _fin_entry(ws, dw, taps, N, K, flat):
+    return (ws, dw.data_ptr(), (ws.numel() // (taps * N * K), taps, N, K, flat))
 
 
 def conv_out_size(size, k, stride, pad, dil):
@@ -645,19 +671,20 @@ def _dense_dgrad_form(w, stride, pad, dil):
     return form
 
 
-def _dense_backward_data(dz, wb, form, x_shape, N, kh, kw, stride, pad, dil):
-    """dx of a dense conv; wb packed with kind ``form`` (_dgrad_form)."""
+def _dense_backward_data(dz, wb, form, x_shape, N, kh, kw, stride, pad, dil, res=None):
+    """dx of a dense conv; wb packed with kind ``form`` (_dgrad_form); ``res`` (a map of dx's shape) is added in
+    the epilogue."""
     B, K, H, W = x_shape
     Ho, Wo = dz.shape[2], dz.shape[3]
     dx = _new(dz, B, K, H, W)
     if form == 5:
         lib.call(_k("nasseg_conv_fwd", dz), ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
-                 ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, 1, dil * (kh - 1) - pad, dil, 0,
-                 None, current_stream())
+                 ACT_NONE, ptr(res), K if res is not None else 0, B, Ho, Wo, N, H, W, K, kh, kw, 1,
+                 dil * (kh - 1) - pad, dil, 0, None, current_stream())
     else:
         lib.call(_k("nasseg_conv_fwd", dz), ptr(dz), N, ptr(wb), ptr(dx), K, None, None, 0, None, None,
-                 ACT_NONE, None, 0, B, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1, None,
-                 current_stream())
+                 ACT_NONE, ptr(res), K if res is not None else 0, B, Ho, Wo, N, H, W, K, kh, kw, stride, pad, dil, 1,
+                 None, current_stream())
     return dx
 
 
@@ -758,6 +785,7 @@ def _identity_vectors(like, n):
 # backward of pointwise conv + BatchNorm as one kernel where the chain allows it (csrc/conv_pwbwd.hip),
 # for maps whose input + output exceed this many bytes (tools/kbench_pwbwd.py: 32 -> 32 at 4x128x256,
 # 33 MB, one kernel 21 us / two kernels 26 us; 64 -> 64 at 4x32x64, 4 MB, 35 / 19 us - too few slabs)
+FUSE_RES_GRAD = os.environ.get("NASSEG_FUSE_RES_GRAD", "1") != "0"  # (_ConvChain.backward: dx + dres in one epilogue)
 FUSE_PW_BWD = os.environ.get("NASSEG_FUSE_PW_BWD", "1") != "0"
 _PW_BWD_MIN_BYTES = int(os.environ.get("NASSEG_PW_BWD_MIN_BYTES", 24 << 20))
 # the wide-input variant (K > 64: the four waves split N; round 3: chunks of the input and of the
@@ -834,6 +862,7 @@ class _ConvChain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, x, residual, *tensors):
         in_act0, ops = cfg[:2]
+        res_is_x = residual is not None and residual is x  # (InvertedResidual: the block's input is its skip)
         x = _cl(x)
         s = current_stream()
         # the statistics vector a deferred tail hands out never has a gradient: without this autograd would
@@ -1035,7 +1064,7 @@ class _ConvChain(torch.autograd.Function):
             if pool is not None:
                 saved.append(pool_idx)
             ctx.save_for_backward(*[t for t in saved])
-            ctx.meta = (cfg, meta, residual is not None, tuple(x.shape), pool_fused)
+            ctx.meta = (cfg, meta, residual is not None, tuple(x.shape), pool_fused, res_is_x)
             ctx.n_inputs = 3 + len(tensors)
         if defer:
             if tail is None:
@@ -1059,6 +1088,10 @@ class _ConvChain(torch.autograd.Function):
         n_ops = len(ops)
         grads = [None] * (6 * n_ops)
         dres = g if (has_res and ctx.needs_input_grad[2]) else None
+        # x is also the residual: both gradients go to the same tensor, and autograd would add them with a launch of
+        # its own - where op 0's input gradient comes from the plain backward-data call, its epilogue adds dres
+        fuse_res = (FUSE_RES_GRAD and len(ctx.meta) > 5 and ctx.meta[5] and dres is not None
+                    and ctx.needs_input_grad[1] and not in_act0)
         pre = None  # BatchNorm-backward partial rows of op i that came with g (fused dgrad epilogue)
         g_masked = False  # g already carries act' of op i's activation (with or without such rows)
         if _TAIL_ROWS and pool is None:
@@ -1257,7 +1290,10 @@ class _ConvChain(torch.autograd.Function):
                         pre = (part, nb)
                     else:
                         g = _dense_backward_data(dz, wb, _dense_dgrad_form(w, stride, pad, dil),
-                                                 (Bc, K, H, W), N, kh, kw, stride, pad, dil)
+                                                 (Bc, K, H, W), N, kh, kw, stride, pad, dil,
+                                                 dres if (fuse_res and i == 0) else None)
+                        if fuse_res and i == 0:
+                            dres = None  # (it is inside dx)
         dx = None
         if g is not None and ctx.needs_input_grad[1]:
             dx = g

@@ -217,6 +217,55 @@ def test_fused_chain_kernels_against_torch_cpu_autograd(kind, batch, monkeypatch
             assert_close(gb[k], cb[k], 1e-6, 2e-5, "{}: buffer {}".format(kind, k))
 
 
+@pytest.mark.parametrize("cfg", [(24, 24, 6, 33, 40), (64, 64, 6, 16, 20), (32, 32, 6, 20, 28)])
+def test_residual_gradient_in_the_backward_data_epilogue(cfg, monkeypatch):
+    """InvertedResidual on a small map (src/nn/layer_factory.py:276-321): the block's input is also its skip, and the
+    plain backward-data call of its first conv adds the skip's gradient in its epilogue (functional.FUSE_RES_GRAD)
+    instead of leaving dx + dres to an accumulation by autograd - same bits as that, and torch-CPU autograd's values"""
+    from nas_segm_amd.nn.layer_factory import InvertedResidual
+
+    Fm = F()
+    cin, cout, t, H, W = cfg
+    torch.manual_seed(4)
+    mods = InvertedResidual(cin, cout, 1, t).conv
+    randomise(mods, 6)
+    ref = copy.deepcopy(mods).train()
+    mods = mods.to(DEV).train()
+    x0 = rnd(2, cin, H, W, seed=9)
+    xc = x0.clone().requires_grad_(True)
+    yc = torch_reference(ref._modules.values(), xc, xc)
+    cot = rnd(*yc.shape, seed=10)
+    yc.backward(cot)
+
+    def run(fuse):
+        monkeypatch.setattr(Fm, "FUSE_RES_GRAD", fuse)
+        seen = []
+        orig = Fm.lib.call
+
+        def rec(fn, *a):
+            seen.append((fn, a))
+            return orig(fn, *a)
+
+        monkeypatch.setattr(Fm.lib, "call", rec)
+        for prm in mods.parameters():
+            prm.grad = None
+        xg = dev(x0.clone()).requires_grad_(True)
+        yg = mods(xg, residual=xg)
+        yg.backward(dev(cot))
+        monkeypatch.setattr(Fm.lib, "call", orig)
+        # (the plain backward-data call: nasseg_conv_fwd with transposed = 1 or the flipped-weights form; its
+        #  residual pointer is argument 11)
+        with_res = [a for fn, a in seen if fn == "nasseg_conv_fwd" and a[11]]
+        assert "nasseg_conv_pw_bwd_bn" not in [fn for fn, _ in seen]
+        return xg.grad.clone(), with_res
+
+    g1, r1 = run(True)
+    g0, r0 = run(False)
+    assert len(r1) == len(r0) + 1
+    assert torch.equal(g0, g1)
+    assert_close(g1, xc.grad, 1e-4 * float(xc.grad.abs().max()), 1e-4, "dx")
+
+
 @pytest.mark.parametrize("path", ["bn_stats", "conv_epilogue", "dw_epilogue"])
 @pytest.mark.parametrize("ratio", [5.0, 50.0])
 def test_batchnorm_statistics_when_the_mean_dwarfs_the_deviation(path, ratio):

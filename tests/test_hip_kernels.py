@@ -880,12 +880,13 @@ def test_grouped_depthwise_weight_gradients_are_bit_identical():
         assert_close(g, wr.grad, 1e-5, 1e-3, "dw %r" % ((c, k, st, dil, relu_in),))
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 7])
 def test_weight_gradients_on_the_second_stream_are_bit_identical(mode, monkeypatch):
     """inside deferred_wgrad the first stages may run on a second stream (functional.WGRAD_STREAM: 1 = the launches of
-    large layers, 2 = the grouped small ones, eight at a time as backward meets them) that waits for the chain's stream
-    before each launch and is waited for once at the exit: same gradients bit for bit as with everything on one
-    stream - on poisoned memory, with the memory the launches read released and overwritten right after the exit"""
+    large layers, 2 = the grouped small ones, eight at a time as backward meets them, 4 = second stages as well,
+    whenever enough layers wait for theirs) that waits for the chain's stream before each launch and is waited for
+    once at the exit: same gradients bit for bit as with everything on one stream - on poisoned memory, with the
+    memory the launches read released and overwritten right after the exit"""
     f = F()
     torch.manual_seed(5)
     # 20 small layers (two groups of eight flushed during backward + a rest at the exit), alternating dense /
@@ -898,6 +899,8 @@ def test_weight_gradients_on_the_second_stream_are_bit_identical(mode, monkeypat
     wdwbig = (torch.randn(48, 1, 5, 5) * 0.2).to(DEV)
     xs = dev(rnd(2, 24, 36, 44, seed=2))
     xb = dev(rnd(2, 48, 256, 320, seed=3))
+
+    monkeypatch.setattr(f, "_SIDE_FINALIZE", 4)
 
     def run(m):
         monkeypatch.setattr(f, "WGRAD_STREAM", m)
@@ -912,13 +915,14 @@ def test_weight_gradients_on_the_second_stream_are_bit_identical(mode, monkeypat
         loss = loss + (yb * yb).mean()
         poison = torch.full((64 << 20,), float("nan"), device=DEV)
         del poison
-        with f.deferred_wgrad():
+        with f.deferred_wgrad(params=leaves):
             loss.backward()
             used = bool(f.deferred_wgrad.side_used)
+            assert bool(f.deferred_wgrad.side_done) == bool(m & 4)
         del x, yb, loss
         poison = torch.full((96 << 20,), float("nan"), device=DEV)  # (recycles what the second stream was reading)
         del poison
-        assert not f.deferred_wgrad.side_used and not f.deferred_wgrad.side_keep
+        assert not f.deferred_wgrad.side_used and not f.deferred_wgrad.side_keep and not f.deferred_wgrad.side_done
         return [t.grad.clone() for t in leaves], used
 
     g0, used0 = run(0)
