@@ -94,7 +94,8 @@ def algorithmic_bytes(name, a):
 
         # (z = W x is rebuilt from the input tile where the kernel can: not an operand it needs, not charged)
         nz = 2 if NF.lib.query("nasseg_conv_pw_bwd_reads_z", B, H, W, K, N) else 1
-        return 4 * (B * H * W * (2 * K + nz * N) + 2 * N * K)
+        skip = 1 if a[26] else 0  # (dx_res: the skip's gradient, read once)
+        return 4 * (B * H * W * ((2 + skip) * K + nz * N) + 2 * N * K)
     if name == "nasseg_dwconv_bwd_bn":  # xz, g, z read, ge written
         B, H, W, C, Ho, Wo = a[20], a[21], a[22], a[23], a[24], a[25]
         return 4 * (2 * B * C * H * W + 2 * B * C * Ho * Wo + 18 * C)

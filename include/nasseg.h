@@ -216,7 +216,9 @@ int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float
  * (= in_act): dx additionally multiplied by in_act'(in_scale*x + in_shift), i.e. the gradient w.r.t. the affine's
  * output (w.r.t. x itself for a bare activation); dw == NULL: partial rows only.  dx_stats != NULL (K <= 64; x is the
  * raw output of a BatchNorm with statistics in_mean / in_invstd, dx_act = in_act): also that BatchNorm's backward
- * sums {sum dx, sum dx*xhat} per slab, rows [slabs][2][K] for nasseg_rows_sum (buffer: slabs + 64 rows). */
+ * sums {sum dx, sum dx*xhat} per slab, rows [slabs][2][K] for nasseg_rows_sum (buffer: slabs + 64 rows).
+ * dx_res != NULL (K % 4 == 0, no dx_stats): a [P][K] map added to dx after the mask - the gradient of a skip connection
+ * that x feeds as well (InvertedResidual, src/nn/layer_factory.py:276-321: autograd then has nothing to accumulate). */
 int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N);
 /* 1: nasseg_conv_pw_bwd_bn loads z for this geometry; 0: it rebuilds z = W x from the input tile it stages anyway (the
  * narrow kernel with its weight in LDS: same operand mapping and accumulation order as the forward kernels, the same
@@ -229,7 +231,8 @@ int nasseg_conv_pw_bwd_bn(const float* x, const float* g, const float* z, const 
                           float* ws, const float* in_scale, const float* in_shift, int in_act, int dx_act,
                           const float* bn_scale, const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                           const float* bn_sums, int bn_train, int bn_act, int B, int H, int W, int K, int N,
-                          const float* in_mean, const float* in_invstd, float* dx_stats, void* stream);
+                          const float* in_mean, const float* in_invstd, float* dx_stats, const float* dx_res,
+                          void* stream);
 int nasseg_conv_wgrad(const float* x, int ldx, const float* dy, int lddy, float* dw, float* ws,
                       const float* in_scale, const float* in_shift, int in_act, int B, int Hs,
                       int Ws, int K, int Ho, int Wo, int N, int kh, int kw, int stride, int pad,
@@ -432,7 +435,7 @@ int nasseg_bf16_conv_pw_bwd_bn(const nasseg_bf16_t* x, const nasseg_bf16_t* g, c
                                int in_act, int dx_act, const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                const float* bn_invstd, const float* bn_sums, int bn_train, int bn_act, int B, int H,
                                int W, int K, int N, const float* in_mean, const float* in_invstd, float* dx_stats,
-                               void* stream);
+                               const nasseg_bf16_t* dx_res, void* stream);
 int nasseg_bf16_sepconv_fwd(const nasseg_bf16_t* x, const float* wdw, const float* wpw, nasseg_bf16_t* zdw,
                             nasseg_bf16_t* y, const float* in_scale, const float* in_shift, int in_act,
                             const float* out_scale, const float* out_shift, int out_act, int B, int H, int W, int C,

@@ -70,6 +70,7 @@ struct PwArgs {
   const float* in_mean;
   const float* in_invstd;
   float* dx_stats;
+  const act_t* dx_res;  // != NULL: a map of dx's shape added to dx (after the mask): the gradient of a skip that x also feeds
   int K, N, KP, NP;  // channels, rounded up to multiples of 16
   int M, pix_per_slab;
 };
@@ -337,6 +338,16 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
       f32x4 acc1[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) acc1[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // (the skip's gradient for this wave's dx tile: in flight during the MFMAs below)
+      float4 rres[KT];
+      if (a.dx_res) {
+        const int pr = t0 + wave * 16 + j;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+          const int k = kt * 16 + kg * 4;
+          rres[kt] = lda4(a.dx_res + ((pr < p_end && k < K) ? (int64_t)pr * K + k : 0));
+        }
+      }
       const float* brow = dzt + (wave * 16 + j) * LSN;
       for (int ns = 0; ns < (a.NP >> 4); ++ns) {
         const int n = ns * 16 + kg * 4;
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256) void conv_pw_bwd_kernel(PwArgs a) {
         if (a.dx_act)
           o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LSK + k]), a.dx_act));
         const bool ok = p < p_end && k < K;
-        if (ok) sta4(a.dx + (int64_t)p * K + k, o);
+        if (ok) sta4(a.dx + (int64_t)p * K + k, a.dx_res ? add4(o, rres[kt]) : o);
         if (DXS) {
           // (the raw input, kept in LDS next to the activated tile: xhat cannot be taken from the activated
           //  value when the BatchNorm's weight is zero, and a global re-load here would queue up behind the
@@ -613,6 +624,14 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_wide_kernel(PwArgs a) {
             f32x4 acc1[NQ];
 #pragma unroll
             for (int q = 0; q < NQ; ++q) acc1[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float4 rres[NQ];  // (the skip's gradient for this chunk of the wave's dx tile: in flight during the MFMAs)
+            if (a.dx_res) {
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) {
+                const int k = kc + q * 16 + kg * 4;
+                rres[q] = lda4(a.dx_res + ((p < p_end && k < K) ? (int64_t)p * K + k : 0));
+              }
+            }
 #pragma unroll 1
             for (int ns = 0; ns < NS; ++ns) {
               const int n = ns * 16 + kg * 4;
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_bwd_wide_kernel(PwArgs a) {
               float4 o = make_float4(acc1[q][0], acc1[q][1], acc1[q][2], acc1[q][3]);
               if (a.dx_act)
                 o = mul4(o, act_mask_of(*reinterpret_cast<const float4*>(&xt[(wave * 16 + j) * LS + kl]), a.dx_act));
-              if (pok && kc + kl < K) sta4(prow + q * 16, o);
+              if (pok && kc + kl < K) sta4(prow + q * 16, a.dx_res ? add4(o, rres[q]) : o);
             }
           }
           // weight gradient rows of this wave: all 64 pixels of the tile, 4 per MFMA
@@ -794,14 +813,18 @@ int64_t nasseg_conv_pw_bwd_rz_min_pixels(int64_t v) {
 // normalisation, in_mean / in_invstd its statistics, dx_act = in_act): per slab the sums {sum dx, sum dx*xhat}
 // of THAT BatchNorm's backward are written to dx_stats[slab][2][K] (nasseg_conv_pw_bwd_slabs rows; add them with
 // nasseg_rows_sum, the buffer needs 64 more rows) - what a nasseg_bn_bwd_reduce pass over dx and x would return.
+// dx_res != NULL (K % 4 == 0, no dx_stats): a [P][K] map added to dx after the mask - the gradient of a skip
+// connection that x feeds as well (InvertedResidual, src/nn/layer_factory.py:276-321), so that no separate
+// accumulation of the two gradients of x is needed.
 int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, const float* wb, act_t* dx,
                               float* dw, float* ws, const float* in_scale, const float* in_shift,
                               int in_act, int dx_act, const float* bn_scale, const float* bn_shift,
                               const float* bn_mean, const float* bn_invstd, const float* bn_sums,
                               int bn_train, int bn_act, int B, int H, int W, int K, int N, const float* in_mean,
-                              const float* in_invstd, float* dx_stats, void* stream) {
+                              const float* in_invstd, float* dx_stats, const act_t* dx_res, void* stream) {
   NASSEG_REQUIRE(x && g && z && wb && dx && ws && bn_scale, "conv_pw_bwd_bn: null tensor");
   NASSEG_REQUIRE(!dx_stats || (in_mean && in_invstd), "conv_pw_bwd_bn: dx_stats needs in_mean / in_invstd");
+  NASSEG_REQUIRE(!dx_res || (!dx_stats && K % 4 == 0), "conv_pw_bwd_bn: dx_res needs K %% 4 == 0 and no dx_stats");
   NASSEG_REQUIRE((!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
                  "conv_pw_bwd_bn: missing BatchNorm tensors");
   NASSEG_REQUIRE(B > 0 && H > 0 && W > 0, "conv_pw_bwd_bn: bad geometry");
@@ -817,7 +840,7 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
   NASSEG_REQUIRE(!dx_act || dx_act == in_act,
                  "conv_pw_bwd_bn: dx can only be masked with the derivative of the input activation");
   a.dx_act = dx_act;
-  a.in_mean = in_mean; a.in_invstd = in_invstd; a.dx_stats = dx_stats;
+  a.in_mean = in_mean; a.in_invstd = in_invstd; a.dx_stats = dx_stats; a.dx_res = dx_res;
   a.K = K; a.N = N; a.KP = (K + 15) & ~15; a.NP = (N + 15) & ~15;
   a.M = (int)M; a.pix_per_slab = p.pix_per_slab;
   const bool pro = in_scale || in_shift || in_act;

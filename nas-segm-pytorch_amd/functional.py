@@ -124,7 +124,6 @@ class deferred_wgrad(object):
     side_ok = False  # first stages may go to a second stream (WGRAD_STREAM; never while a hipGraph is captured)
     side_used = {}   # device -> that stream, once a launch went there
     side_keep = []   # what those launches read and write: alive until the streams have joined
-    side_done = []   # addresses of the gradients whose second stage already ran on that stream
 
     def __init__(self, enabled=True, params=None, second_stream=True):
         """params: the parameters being trained; when given, the exit verifies that every
@@ -166,7 +165,6 @@ class deferred_wgrad(object):
         groups, deferred_wgrad.grouped = deferred_wgrad.grouped, {}
         sides, deferred_wgrad.side_used = deferred_wgrad.side_used, {}
         keep, deferred_wgrad.side_keep = deferred_wgrad.side_keep, []
-        done, deferred_wgrad.side_done = deferred_wgrad.side_done, []
         if exc_type is None:
             for (entry, dtype), calls in groups.items():
                 self._launch_group(entry, dtype, calls, current_stream())
@@ -179,9 +177,9 @@ class deferred_wgrad(object):
         if exc_type is None:
             if todo:
                 self._finalize(todo, current_stream())
-            if self.params is not None and (todo or done):
+            if self.params is not None and todo:
                 adopted = set(p.grad.data_ptr() for p in self.params if p.grad is not None)
-                if any(addr not in adopted for _, addr, _ in todo) or any(addr not in adopted for addr in done):
+                if any(addr not in adopted for _, addr, _ in todo):
                     raise NassegError("deferred_wgrad: autograd copied a weight gradient before it was "
                                       "finalised (gradients not cleared, or a weight used twice?)")
         return False
@@ -196,18 +194,17 @@ _GROUP_WGRAD_BYTES = 48 << 20
 # kernels - or, the grouped small layers, behind the whole backward - although many of them have too few workgroups
 # to fill 256 CUs; on a stream of their own (which first waits for what the chain has launched so far) the GPU runs
 # them beside the chain, and the chain's stream waits for that stream once, at the exit.  Bits of NASSEG_WGRAD_STREAM:
-# 1 = the launches of large layers, 2 = the grouped small layers, _SIDE_GROUP at a time as they come, 4 = second stages
-# too (_SIDE_FINALIZE layers at a time, behind their first stages).  Measured on one
+# 1 = the launches of large layers, 2 = the grouped small layers, _SIDE_GROUP at a time as they come.  Measured on one
 # box (profiles/r05_ab_wgrad_stream_same_box.txt): either bit alone is level, both together +0.5 % on the headline
 # step and +1.2 - 1.5 % on WACV arch1.  0: everything on the chain's stream (A/B).  Never while a hipGraph is being
 # captured (one second stream inside a capture made the replay slower, two crash this runtime: DESIGN_HISTORY.md),
 # and only where the caller asks for it (deferred_wgrad(second_stream=...): a step that is launch-bound on the host
-# gains nothing from more launches - CVPR 321x321 from the host 750.5 / 745.8).  Same kernels on the same data:
-# bit-identical.
-WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "7"))
+# gains nothing from more launches - CVPR 321x321 from the host 750.5 / 745.8).  The second stages stay on the chain's
+# stream, after the join: sixteen at a time on the second stream as backward goes measured level (281.1 / 281.4).
+# Same kernels on the same data: bit-identical.
+WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "3"))
 _SIDE_STREAMS = {}
 _SIDE_GROUP = int(os.environ.get("NASSEG_WGRAD_SIDE_GROUP", "8"))
-_SIDE_FINALIZE = 16  # (bit 4: second stages too, whenever this many layers wait for theirs)
 
 
 def _wgrad_stream(t, keep):
@@ -224,14 +221,6 @@ def _wgrad_stream(t, keep):
         deferred_wgrad.side_used[t.device] = side
     side.wait_stream(torch.cuda.current_stream(t.device))
     deferred_wgrad.side_keep.append(keep)
-    if WGRAD_STREAM & 4 and len(deferred_wgrad.pending) >= _SIDE_FINALIZE:
-        # every first stage queued for finalisation so far was launched before this point - on the chain's stream,
-        # which the second one has just been made to wait for, or earlier on the second one: their second stages
-        # can run there now instead of on the chain's stream behind the whole backward
-        todo, deferred_wgrad.pending = deferred_wgrad.pending, []
-        deferred_wgrad._finalize(todo, side.cuda_stream)
-        deferred_wgrad.side_keep.append(todo)
-        deferred_wgrad.side_done.extend(addr for _, addr, _ in todo)
     return side.cuda_stream
 
 
@@ -1254,6 +1243,7 @@ class _ConvChain(torch.autograd.Function):
                     dx_act = pact if ((i == 0 and in_act0 and psc is None and psh is None) or behind_bn) else ACT_NONE
                     # ... and, K <= 64, comes with the per-slab sums of that BatchNorm's backward (dx_stats)
                     part = pmu_ = pis_ = None
+                    skip_g = dres if (fuse_res and i == 0 and K % 4 == 0) else None  # (x is also the block's skip)
                     if behind_bn and K <= 64:
                         stp = sv[7 * (i - 1) + 4]
                         pmu_, pis_ = stp[0:K], stp[K:2 * K]
@@ -1261,7 +1251,9 @@ class _ConvChain(torch.autograd.Function):
                     lib.call(_k("nasseg_conv_pw_bwd_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(wb), ptr(g_in),
                              _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, dx_act,
                              ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), bact_,
-                             Bc, H, W, K, N, ptr(pmu_), ptr(pis_), ptr(part), s)
+                             Bc, H, W, K, N, ptr(pmu_), ptr(pis_), ptr(part), ptr(skip_g), s)
+                    if skip_g is not None:
+                        dres = None  # (it is inside dx)
                     grads[6 * i] = dwt
                     g = g_in
                     masked_in0 = bool(dx_act) and i == 0

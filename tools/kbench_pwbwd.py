@@ -55,7 +55,7 @@ for B, H, W, K, N in CASES:
 
     def one():
         lib.call("nasseg_conv_pw_bwd_bn", ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws2), None, None, 0,
-                 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N, None, None, None, s)
+                 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N, None, None, None, None, s)
 
     t2, t1 = timeit(two), (timeit(one) if nsl else float("nan"))
     mb = 4e-6 * B * H * W * (2 * K + 2 * N)
