@@ -195,7 +195,7 @@ _GROUP_WGRAD_BYTES = 48 << 20
 # to fill 256 CUs; on a stream of their own (which first waits for what the chain has launched so far) the GPU runs
 # them beside the chain, and the chain's stream waits for that stream once, at the exit.  Bits of NASSEG_WGRAD_STREAM:
 # 1 = the launches of large layers, 2 = the grouped small layers, _SIDE_GROUP at a time as they come.  Measured on one
-# box (profiles/r05_ab_wgrad_stream_same_box.txt): either bit alone is level, both together +0.5 % on the headline
+# box (profiles/r05_ab_second_half_same_box.txt): either bit alone is level, both together +0.5 % on the headline
 # step and +1.2 - 1.5 % on WACV arch1.  0: everything on the chain's stream (A/B).  Never while a hipGraph is being
 # captured (one second stream inside a capture made the replay slower, two crash this runtime: DESIGN_HISTORY.md),
 # and only where the caller asks for it (deferred_wgrad(second_stream=...): a step that is launch-bound on the host
