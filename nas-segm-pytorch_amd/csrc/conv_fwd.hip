@@ -58,6 +58,10 @@ enum { KM_VEC = 0, KM_SCALAR = 1, KM_FLAT = 2 };
 #ifndef NASSEG_PW_MIN_PIXELS
 #define NASSEG_PW_MIN_PIXELS -2
 #endif
+// 0: 17 ... 21 output channels of the LDS-tiled 3x3 kernel as two MFMA tiles (rounds 1-4; A/B, tools/gpu.sh flags)
+#ifndef NASSEG_LDS3X3_VALU_TAIL
+#define NASSEG_LDS3X3_VALU_TAIL 1
+#endif
 
 // 4 floats along the reduction axis starting at k (clamped, always in range); the caller
 // masks what lies beyond K
@@ -718,8 +722,15 @@ constexpr int kLdsMaxIt = ((kLdsTH + 2 * kLdsMaxDil) * (kLdsTW + 2 * kLdsMaxDil)
 
 // STATS == 1: per-workgroup sums of y and y^2 per output channel (the BatchNorm that follows a conv3x3 / conv3x3_dil3
 // op of the CVPR cells, layer_factory.py:56-75) to stats[tile][2][N], tile = (b * tiles_y + ty) * tiles_x + tx.
-template <int NT, bool VECN, bool VECK, int STATS = 0>
+// NV > 0 (the class heads: 19 = 16 + 3, 21 = 16 + 5 output channels): the NV channels behind the NT full tiles are
+// not given a second, mostly empty MFMA tile (13 of 16 rows idle: 41 % of the kernel's MFMAs for N = 19) but are
+// accumulated on the vector ALU from the operand registers the MFMAs read anyway - lane (pixel j, k-group kg) holds
+// x[pixel][4 k] of every step, multiplies it with the NV weight rows' same 4 k (one address per k-group: a broadcast
+// load) and keeps NV partial sums per subtile, which the four k-groups add up once at the end.  The FMAs issue in
+// the shadow of the MFMAs.
+template <int NT, bool VECN, bool VECK, int STATS = 0, int NV = 0>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
+  static_assert(NV == 0 || (STATS == 0 && !VECN), "the vector-ALU channels come without statistics, stored one by one");
   extern __shared__ float tile[];
   __shared__ float sred3[STATS ? 4 : 1][2][STATS ? NT * 16 : 1];
   const int lane = threadIdx.x & 63;
@@ -751,6 +762,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float pv[4][NV ? NV : 1];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int c = 0; c < (NV ? NV : 1); ++c) pv[mt][c] = 0.f;
 
   const act_t* xb = a.x + (int64_t)b * H * W * a.ldx;
   for (int kc0 = 0; kc0 < a.K; kc0 += kLdsKC) {
@@ -822,8 +838,12 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
           }
           av[nt] = keep_if(v, wok[nt] && k < a.K);
         }
+        float4 xv[NV ? NV : 1];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int c = 0; c < NV; ++c)
+          xv[c] = keep_if(load4<VECK>(a.w + ((int64_t)tap * a.N + NT * 16 + c) * a.K, k, a.K), k < a.K);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             acc[mt][nt] = mfma16(av[nt].x, bv[mt].x, acc[mt][nt]);
@@ -831,6 +851,14 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
             acc[mt][nt] = mfma16(av[nt].z, bv[mt].z, acc[mt][nt]);
             acc[mt][nt] = mfma16(av[nt].w, bv[mt].w, acc[mt][nt]);
           }
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            pv[mt][c] = fmaf(bv[mt].x, xv[c].x, pv[mt][c]);
+            pv[mt][c] = fmaf(bv[mt].y, xv[c].y, pv[mt][c]);
+            pv[mt][c] = fmaf(bv[mt].z, xv[c].z, pv[mt][c]);
+            pv[mt][c] = fmaf(bv[mt].w, xv[c].w, pv[mt][c]);
+          }
+        }
       }
       // a short tail of the slice (the class head's backward-data reduces over 19 = 16 + 3 channels per
       // tap): with the vector mapping k = 4*kg + component each of the four MFMAs of a 16-wide step would
@@ -849,8 +877,26 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(as[nt], bs[mt], acc[mt][nt]);
+#pragma unroll
+        for (int c = 0; c < NV; ++c) {
+          const float wv = keep_if(a.w[((int64_t)tap * a.N + NT * 16 + c) * a.K + (kk < a.K ? kk : 0)], kk < a.K);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) pv[mt][c] = fmaf(bs[mt], wv, pv[mt][c]);
+        }
       }
     }
+  }
+  if constexpr (NV > 0) {
+    // the four k-groups' partial sums of the vector-ALU channels: lanes j, j + 16, j + 32, j + 48 -> every lane
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        float v = pv[mt][c];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        pv[mt][c] = v;
+      }
   }
 
   if constexpr (STATS == 1) {
@@ -927,6 +973,24 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
         }
       }
     }
+    if constexpr (NV > 0) {
+      // k-group kg stores channel NT*16 + kg (and + 4 + kg: NV <= 8) of its pixel
+#pragma unroll
+      for (int h = 0; h < (NV + 3) / 4; ++h) {
+        float v = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          if (c / 4 == h) v = (kg == (c & 3)) ? pv[mt][c] : v;
+        const int n = NT * 16 + h * 4 + kg;
+        const bool ok = n < a.N && h * 4 + kg < NV && pok;
+        const int nc = ok ? n : 0;
+        if (a.out_scale) v *= a.out_scale[nc];
+        if (a.out_shift) v += a.out_shift[nc];
+        if (a.out_act) v = act_apply(v, a.out_act);
+        if (a.res) v += lda1(a.res + m * a.ldres + nc);
+        if (ok) sta1(a.y + m * a.ldy + n, v);
+      }
+    }
   }
 }
 
@@ -952,6 +1016,20 @@ int launch_lds3x3(const FwdArgs& a, bool vecn, bool veck, bool stats, hipStream_
   else if (vecn) { if (veck) GO3(true, true, 0); else GO3(true, false, 0); }
   else { if (veck) GO3(false, true, 0); else GO3(false, false, 0); }
 #undef GO3
+  NASSEG_LAUNCH_CHECK("conv3x3_lds_kernel");
+  return NASSEG_OK;
+}
+
+// NT full tiles on the matrix cores + NV channels on the vector ALU (N = 16 * NT + NV, K % 4 == 0, no statistics)
+template <int NT, int NV>
+int launch_lds3x3_nv(const FwdArgs& a, hipStream_t s) {
+  const int dil = a.g.dil;
+  const size_t lds = (size_t)(kLdsTH + 2 * dil) * (kLdsTW + 2 * dil) * kLdsKS * sizeof(float);
+  dim3 grid(cdiv(a.g.Wo, kLdsTW), cdiv(a.g.Ho, kLdsTH), a.g.B);
+  if (lds > (size_t)(64 << 10))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<NT, false, true, 0, NV>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
+  hipLaunchKernelGGL((conv3x3_lds_kernel<NT, false, true, 0, NV>), grid, dim3(256), lds, s, a);
   NASSEG_LAUNCH_CHECK("conv3x3_lds_kernel");
   return NASSEG_OK;
 }
@@ -1187,6 +1265,16 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   if (!g.transposed && lds3x3_geometry(g.B, g.Ho, g.Wo, N, K, g.kh, g.kw, g.stride, g.pad, g.dil) && md.km != KM_FLAT &&
       !md.pro && (md.stats == 0 || (md.stats == 1 && md.vecn))) {
     const bool veck = md.km == KM_VEC;
+    // 17 ... 21 output channels (the class heads' 19 and 21): 16 on the matrix cores, the rest on the vector ALU
+    if (NASSEG_LDS3X3_VALU_TAIL && veck && md.stats == 0 && N > 16 && N <= 21) {
+      switch (N - 16) {
+        case 1: return launch_lds3x3_nv<1, 1>(a, s);
+        case 2: return launch_lds3x3_nv<1, 2>(a, s);
+        case 3: return launch_lds3x3_nv<1, 3>(a, s);
+        case 4: return launch_lds3x3_nv<1, 4>(a, s);
+        default: return launch_lds3x3_nv<1, 5>(a, s);
+      }
+    }
     if (tiles <= 1) return launch_lds3x3<1>(a, md.vecn, veck, md.stats == 1, s);
     if (tiles == 2) return launch_lds3x3<2>(a, md.vecn, veck, md.stats == 1, s);
     if (tiles == 3) return launch_lds3x3<3>(a, md.vecn, veck, md.stats == 1, s);

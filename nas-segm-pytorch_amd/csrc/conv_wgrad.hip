@@ -525,6 +525,10 @@ constexpr int kW3TH = 8, kW3TW = 32, kW3KS = 16, kW3XS = kW3KS;       // tile, k
 constexpr int kW3SP = kW3TH * kW3TW + 2;                              // row stride of dyT[n][pixel]
 constexpr int kW3MaxX = ((kW3TH + 4) * (kW3TW + 4) * (kW3KS / 4) + 255) / 256;  // float4 of the patch per thread (d <= 2)
 constexpr int kW3MaxN = 32;
+// 0: 17 ... 21 rows of n as two MFMA tiles (rounds 3-4; A/B, tools/gpu.sh flags)
+#ifndef NASSEG_W3_VALU_TAIL
+#define NASSEG_W3_VALU_TAIL 1
+#endif
 
 struct W3Args {
   const act_t* x;
@@ -533,8 +537,13 @@ struct W3Args {
   int B, H, W, K, Ho, Wo, N, pad, dil, nslab, tiles_x, tiles_y;
 };
 
-template <int NT>  // 16-row tiles of n: 1 (N <= 16) or 2
+// NV > 0 (N = 16 * NT + NV, the class heads' 19 / 21): the NV rows behind the full tiles are not given a second, mostly
+// empty MFMA tile but are accumulated on the vector ALU from the x operand the MFMAs read anyway: lane (k column li,
+// pixel slot pk) multiplies it with dy[pixel][16 NT + c] (one LDS address per pixel slot: a broadcast read) into 9 x NV
+// partial sums, which the four pixel slots add up once at the end (as conv3x3_lds_kernel does in the forward).
+template <int NT, int NV = 0>  // 16-row tiles of n: 1 (N <= 16 + NV) or 2
 __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
+  constexpr int NVa = NV ? NV : 1;
   extern __shared__ float smem[];
   const int dil = a.dil;
   const int TR = kW3TH + 2 * dil, TC = kW3TW + 2 * dil;
@@ -552,6 +561,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float pvw[9][NVa];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < NVa; ++c) pvw[t][c] = 0.f;
 
   // patch item it of this thread: float4 (tid & 3) of patch pixel (pr, pc) - the same for every tile; what
   // does not depend on the tile is computed once (the staging code is VALU work that the MFMAs of the
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
   //  but the (row, pixel, channel) bookkeeping per element costs more than the scattered loads: 260 / 224 us.)
   const int dr_r = tid >> 5, dr_c = tid & 31;
   // rows of dyT beyond N are read by the MFMAs and never written: zero them once
-  for (int n = N; n < 16 * NT; ++n) dyT[n * kW3SP + tid] = 0.f;
+  for (int n = N; n < 16 * NT + NV; ++n) dyT[n * kW3SP + tid] = 0.f;
   const int tpi = a.tiles_y * a.tiles_x;
   const float inv_tpi = 1.f / (float)tpi, inv_tx = 1.f / (float)a.tiles_x;
   auto fdiv = [](int n, int d, float inv) {  // n / d for 0 <= n < 2^22 (one float multiply and a fix-up)
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
     return q;
   };
   float4 xr[kW3MaxX];
-  float dr[16 * NT];
+  float dr[16 * NT + NV];
   struct TileGeo {
     int b, oy0, ox0;
     bool inner;  // the patch and the dy tile lie inside the image: no clamping, no masks
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
       for (int it = 0; it < kW3MaxX; ++it) xr[it] = lda4(x0 + xg[it]);
       const act_t* dp = a.dy + (((int64_t)g.b * a.Ho + g.oy0 + dr_r) * a.Wo + g.ox0 + dr_c) * N;
 #pragma unroll
-      for (int n = 0; n < 16 * NT; ++n)
+      for (int n = 0; n < 16 * NT + NV; ++n)
         if (n < N) dr[n] = lda1(dp + n);  // (uniform: the 13 surplus loads of N = 19 would each touch 38 lines)
     } else {
 #pragma unroll
@@ -624,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
       ox = ox < a.Wo ? ox : a.Wo - 1;
       const act_t* dp = a.dy + (((int64_t)g.b * a.Ho + oy) * a.Wo + ox) * N;
 #pragma unroll
-      for (int n = 0; n < 16 * NT; ++n)
+      for (int n = 0; n < 16 * NT + NV; ++n)
         if (n < N) dr[n] = lda1(dp + n);
     }
   };
@@ -634,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
       for (int it = 0; it < kW3MaxX; ++it)
         if (tid + 256 * it < xtotal) *reinterpret_cast<float4*>(&xs[xl[it]]) = xr[it];
 #pragma unroll
-      for (int n = 0; n < 16 * NT; ++n)
+      for (int n = 0; n < 16 * NT + NV; ++n)
         if (n < N) dyT[n * kW3SP + tid] = dr[n];
     } else {
       const int iy0 = g.oy0 - a.pad, ix0 = g.ox0 - a.pad;
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
       }
       const bool pok = g.oy0 + dr_r < a.Ho && g.ox0 + dr_c < a.Wo;
 #pragma unroll
-      for (int n = 0; n < 16 * NT; ++n)
+      for (int n = 0; n < 16 * NT + NV; ++n)
         if (n < N) dyT[n * kW3SP + tid] = keep_if(dr[n], pok);
     }
   };
@@ -666,22 +680,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
     // LDS before the MFMAs of step u are issued (explicit ping-pong, scheduling barriers in between: left to
     // itself the compiler reads one tap, waits, issues its two MFMAs, reads the next - nine exposed LDS
     // latencies per step)
-    auto load_ops = [&](int u, float (&av)[NT], float (&bv)[9]) {
+    auto load_ops = [&](int u, float (&av)[NT + NVa], float (&bv)[9]) {
       const int pl = 4 * u + pk;                  // pixel within the wave's two rows
       const int r = 2 * wave + (pl >> 5), c = pl & 31;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) av[nt] = dyT[(nt * 16 + li) * kW3SP + r * kW3TW + c];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) av[NT + v] = dyT[(NT * 16 + v) * kW3SP + r * kW3TW + c];  // (the pixel slot's dy)
       const float* xp = xs + (r * TC + c) * kW3XS + li;
 #pragma unroll
       for (int t = 0; t < 9; ++t) bv[t] = xp[((t / 3) * dil * TC + (t % 3) * dil) * kW3XS];
     };
-    auto mma = [&](const float (&av)[NT], const float (&bv)[9]) {
+    auto mma = [&](const float (&av)[NT + NVa], const float (&bv)[9]) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 9; ++t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma16(av[nt], bv[t], acc[t][nt]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) pvw[t][v] = fmaf(av[NT + v], bv[t], pvw[t][v]);
+      }
     };
-    float a0[NT], b0[9], a1[NT], b1[9];
+    float a0[NT + NVa], b0[9], a1[NT + NVa], b1[9];
     load_ops(0, a0, b0);
 #pragma unroll 1
     for (int u = 0; u < 16; u += 2) {
@@ -695,6 +714,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     gcur = gnext;
+  }
+  if constexpr (NV > 0) {
+    // the four pixel slots' partial sums of the vector-ALU rows: lanes li, li + 16, li + 32, li + 48 -> every lane
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float q = pvw[t][v];
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        pvw[t][v] = q;
+      }
   }
 
   // waves -> workgroup partial, one tap at a time, fixed order (wave 0 + 1 + 2 + 3)
@@ -719,6 +750,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad3x3_lds_kernel(W3Args a) {
                            red[((1 * NT + nt) * 64 + lane) * 4 + rr]) + red[((2 * NT + nt) * 64 + lane) * 4 + rr];
           const int n = nt * 16 + 4 * pk + rr, k = k0 + li;  // D row <-> n, D col <-> k
           if (n < N && k < K) pout[((int64_t)t * N + n) * K + k] = v;
+        }
+    }
+  }
+  if constexpr (NV > 0) {
+    // the vector-ALU rows: [3 waves][9 taps][NV][16 k], all taps at once, same fixed order
+    __syncthreads();
+    if (wave > 0 && pk == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) red[(((wave - 1) * 9 + t) * NV + v) * 16 + li] = pvw[t][v];
+    }
+    __syncthreads();
+    if (wave == 0 && pk == 0) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const float q = ((pvw[t][v] + red[((0 * 9 + t) * NV + v) * 16 + li]) + red[((1 * 9 + t) * NV + v) * 16 + li]) +
+                          red[((2 * 9 + t) * NV + v) * 16 + li];
+          const int n = NT * 16 + v, k = k0 + li;
+          if (n < N && k < K) pout[((int64_t)t * N + n) * K + k] = q;
         }
     }
   }
@@ -859,10 +912,25 @@ int NASSEG_FN(conv_wgrad)(const act_t* x, int ldx, const act_t* dy, int lddy, fl
     w.B = B; w.H = Hs; w.W = Ws; w.K = K; w.Ho = Ho; w.Wo = Wo; w.N = N; w.pad = pad; w.dil = dil;
     w.nslab = p.nslab; w.tiles_x = cdiv(Wo, kW3TW); w.tiles_y = cdiv(Ho, kW3TH);
     const size_t lds = ((size_t)(kW3TH + 4) * (kW3TW + 4) * kW3XS + (size_t)kW3MaxN * kW3SP) * sizeof(float);
+#define W3_NV(V_)                                                                                                   \
+  do {                                                                                                              \
+    (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_lds_kernel<1, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds);                                                                            \
+    hipLaunchKernelGGL((conv_wgrad3x3_lds_kernel<1, V_>), dim3(p.nslab, K / kW3KS), dim3(256), lds, s, w);          \
+  } while (0)
     if (N <= 16) {
       (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_lds_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
       hipLaunchKernelGGL(conv_wgrad3x3_lds_kernel<1>, dim3(p.nslab, K / kW3KS), dim3(256), lds, s, w);
+    } else if (NASSEG_W3_VALU_TAIL && N <= 21) {  // 17 ... 21 rows: 16 on the matrix cores, the rest on the vector ALU
+      switch (N - 16) {
+        case 1: W3_NV(1); break;
+        case 2: W3_NV(2); break;
+        case 3: W3_NV(3); break;
+        case 4: W3_NV(4); break;
+        default: W3_NV(5); break;
+      }
+#undef W3_NV
     } else {
       (void)hipFuncSetAttribute((const void*)conv_wgrad3x3_lds_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
