@@ -729,7 +729,7 @@ constexpr int kLdsMaxIt = ((kLdsTH + 2 * kLdsMaxDil) * (kLdsTW + 2 * kLdsMaxDil)
 // load) and keeps NV partial sums per subtile, which the four k-groups add up once at the end.  The FMAs issue in
 // the shadow of the MFMAs.
 template <int NT, bool VECN, bool VECK, int STATS = 0, int NV = 0>
-__global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   static_assert(NV == 0 || (STATS == 0 && !VECN), "the vector-ALU channels come without statistics, stored one by one");
   extern __shared__ float tile[];
   __shared__ float sred3[STATS ? 4 : 1][2][STATS ? NT * 16 : 1];
@@ -815,56 +815,89 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
     const int rem_last = a.K - kc0 - (nks - 1) * 16;  // channels of the slice's last 16-wide step (>= 16: full)
     const int ntail = rem_last <= 8 ? (rem_last + 3) / 4 : 0;
     const int nvec = ntail ? nks - 1 : nks;
-    for (int tap = 0; tap < 9; ++tap) {
+    // The weights of a 16-wide step are loaded one step AHEAD, into the other of two register sets: they come from
+    // L1 / L2, and with the loads issued right before their MFMAs the two waves of a SIMD spent more time waiting for
+    // them than issuing MFMAs (class head 64 -> 19: 61 us of MFMA issue in a 186 us kernel).  Masks are applied at
+    // use - a select on a loaded value would wait for it at once.  Steps: it = tap * nvec + ks, nvec = 1 or 2.
+    const int nsteps = 9 * nvec;
+    auto step_of = [&](int it, int& tap, int& ks) {
+      tap = nvec == 2 ? (it >> 1) : it;
+      ks = nvec == 2 ? (it & 1) : 0;
+    };
+    auto load_w = [&](int it, float4 (&av)[NT], float4 (&xv)[NV ? NV : 1]) {
+      int tap, ks;
+      step_of(it, tap, ks);
+      const int k = kc0 + ks * 16 + kg * 4;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) av[nt] = load4<VECK>(a.w + ((int64_t)tap * a.N + wn[nt]) * a.K, k, a.K);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) xv[c] = load4<VECK>(a.w + ((int64_t)tap * a.N + NT * 16 + c) * a.K, k, a.K);
+    };
+    auto do_step = [&](int it, const float4 (&avr)[NT], const float4 (&xvr)[NV ? NV : 1]) {
+      int tap, ks;
+      step_of(it, tap, ks);
       const int ty = tap / 3, tx = tap - ty * 3;
       const int tsh = (ty * dil * TC + tx * dil) * kLdsKS;
-      const float* wrow[NT];
+      const int kl = ks * 16 + kg * 4;
+      const int k = kc0 + kl;
+      float4 bv[4], av[NT], xv[NV ? NV : 1];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) wrow[nt] = a.w + ((int64_t)tap * a.N + wn[nt]) * a.K;
-      for (int ks = 0; ks < nvec; ++ks) {
-        const int kl = ks * 16 + kg * 4;
-        const int k = kc0 + kl;
-        float4 bv[4], av[NT];
+      for (int mt = 0; mt < 4; ++mt) bv[mt] = *reinterpret_cast<const float4*>(&tile[toff[mt] + tsh + kl]);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          bv[mt] = *reinterpret_cast<const float4*>(&tile[toff[mt] + tsh + kl]);
+      for (int nt = 0; nt < NT; ++nt) {
+        float4 v = avr[nt];
+        if (!VECK) {
+          v.y = keep_if(v.y, k + 1 < a.K);
+          v.z = keep_if(v.z, k + 2 < a.K);
+          v.w = keep_if(v.w, k + 3 < a.K);
+        }
+        av[nt] = keep_if(v, wok[nt] && k < a.K);
+      }
+#pragma unroll
+      for (int c = 0; c < NV; ++c) xv[c] = keep_if(xvr[c], k < a.K);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          float4 v = load4<VECK>(wrow[nt], k, a.K);
-          if (!VECK) {
-            v.y = keep_if(v.y, k + 1 < a.K);
-            v.z = keep_if(v.z, k + 2 < a.K);
-            v.w = keep_if(v.w, k + 3 < a.K);
-          }
-          av[nt] = keep_if(v, wok[nt] && k < a.K);
+          acc[mt][nt] = mfma16(av[nt].x, bv[mt].x, acc[mt][nt]);
+          acc[mt][nt] = mfma16(av[nt].y, bv[mt].y, acc[mt][nt]);
+          acc[mt][nt] = mfma16(av[nt].z, bv[mt].z, acc[mt][nt]);
+          acc[mt][nt] = mfma16(av[nt].w, bv[mt].w, acc[mt][nt]);
         }
-        float4 xv[NV ? NV : 1];
 #pragma unroll
-        for (int c = 0; c < NV; ++c)
-          xv[c] = keep_if(load4<VECK>(a.w + ((int64_t)tap * a.N + NT * 16 + c) * a.K, k, a.K), k < a.K);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = mfma16(av[nt].x, bv[mt].x, acc[mt][nt]);
-            acc[mt][nt] = mfma16(av[nt].y, bv[mt].y, acc[mt][nt]);
-            acc[mt][nt] = mfma16(av[nt].z, bv[mt].z, acc[mt][nt]);
-            acc[mt][nt] = mfma16(av[nt].w, bv[mt].w, acc[mt][nt]);
-          }
-#pragma unroll
-          for (int c = 0; c < NV; ++c) {
-            pv[mt][c] = fmaf(bv[mt].x, xv[c].x, pv[mt][c]);
-            pv[mt][c] = fmaf(bv[mt].y, xv[c].y, pv[mt][c]);
-            pv[mt][c] = fmaf(bv[mt].z, xv[c].z, pv[mt][c]);
-            pv[mt][c] = fmaf(bv[mt].w, xv[c].w, pv[mt][c]);
-          }
+        for (int c = 0; c < NV; ++c) {
+          pv[mt][c] = fmaf(bv[mt].x, xv[c].x, pv[mt][c]);
+          pv[mt][c] = fmaf(bv[mt].y, xv[c].y, pv[mt][c]);
+          pv[mt][c] = fmaf(bv[mt].z, xv[c].z, pv[mt][c]);
+          pv[mt][c] = fmaf(bv[mt].w, xv[c].w, pv[mt][c]);
         }
       }
-      // a short tail of the slice (the class head's backward-data reduces over 19 = 16 + 3 channels per
-      // tap): with the vector mapping k = 4*kg + component each of the four MFMAs of a 16-wide step would
-      // carry one useful k-slot in four; here lane group kg takes channel 4*step + kg, so ceil(rem / 4)
-      // MFMAs do.  (A loop of its own after the vector steps: as a branch inside them the two paths'
-      // accumulators were copied through 64 v_accvgpr_mov per step.)
+    };
+    if (nsteps) {  // (uniform)
+      float4 avA[NT], avB[NT], xvA[NV ? NV : 1], xvB[NV ? NV : 1];
+      load_w(0, avA, xvA);
+      int it = 0;
+#pragma unroll 1
+      for (; it + 1 < nsteps; it += 2) {
+        load_w(it + 1, avB, xvB);
+        __builtin_amdgcn_sched_barrier(0);
+        do_step(it, avA, xvA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(it + 2 < nsteps ? it + 2 : it + 1, avA, xvA);  // (the last pair re-loads step it + 1: in range, unused)
+        __builtin_amdgcn_sched_barrier(0);
+        do_step(it + 1, avB, xvB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (it < nsteps) do_step(it, avA, xvA);  // (9 steps: the odd one, loaded by the last pair)
+    }
+    // a short tail of the slice (the class head's backward-data reduces over 19 = 16 + 3 channels per
+    // tap): with the vector mapping k = 4*kg + component each of the four MFMAs of a 16-wide step would
+    // carry one useful k-slot in four; here lane group kg takes channel 4*step + kg, so ceil(rem / 4)
+    // MFMAs do.  (Loops of their own after the vector steps: as a branch inside them the two paths'
+    // accumulators were copied through 64 v_accvgpr_mov per step.)
+    for (int tap = 0; tap < (ntail ? 9 : 0); ++tap) {
+      const int ty = tap / 3, tx = tap - ty * 3;
+      const int tsh = (ty * dil * TC + tx * dil) * kLdsKS;
       for (int st = 0; st < ntail; ++st) {
         const int kls = nvec * 16 + st * 4 + kg;
         const int kk = kc0 + kls;
@@ -872,7 +905,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(FwdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) bs[mt] = tile[toff[mt] + tsh + kls];  // (zero beyond K)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) as[nt] = keep_if(wrow[nt][kk < a.K ? kk : 0], wok[nt] && kk < a.K);
+        for (int nt = 0; nt < NT; ++nt)
+          as[nt] = keep_if(a.w[((int64_t)tap * a.N + wn[nt]) * a.K + (kk < a.K ? kk : 0)], wok[nt] && kk < a.K);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -1277,7 +1311,8 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
     }
     if (tiles <= 1) return launch_lds3x3<1>(a, md.vecn, veck, md.stats == 1, s);
     if (tiles == 2) return launch_lds3x3<2>(a, md.vecn, veck, md.stats == 1, s);
-    if (tiles == 3) return launch_lds3x3<3>(a, md.vecn, veck, md.stats == 1, s);
+    // (33 ... 48 channels run on the four-tile form too: with the weights of a step loaded one step ahead the
+    //  three-tile instantiation does not fit two waves per SIMD without spilling, and no layer of the reference has it)
     return launch_lds3x3<4>(a, md.vecn, veck, md.stats == 1, s);
   }
   // (without statistics rows to keep in step with the dispatch is free to look at the taps as well: a workgroup of the
