@@ -450,6 +450,39 @@ def test_clip_and_step_accepts_generators():
     assert abs(float(total) - 0.1) < 1e-4  # (the gradients WERE clipped)
 
 
+def test_skip_gradients_ride_in_the_first_convs_backward(monkeypatch):
+    """InvertedResidual blocks with a skip (src/nn/layer_factory.py:276-321): the block's input receives the gradient
+    through the block and the gradient of the skip.  With functional.FUSE_RES_GRAD the first conv's backward adds the
+    skip's in its epilogue - the residual operand of the plain backward-data call (small maps), or dx_res of the
+    one-kernel pointwise backward (large maps) - and autograd accumulates nothing; without it, one ATen add per skip."""
+    from nas_segm_amd.nn.layer_factory import InvertedResidual
+    from torch import nn
+
+    class Blocks(nn.Module):
+        def __init__(self):
+            super(Blocks, self).__init__()
+            self.a = InvertedResidual(24, 24, 1, 6)
+            self.b = InvertedResidual(24, 24, 1, 6)
+
+        def forward(self, xs):
+            return self.b(self.a(xs[0]))
+
+    for shape, one_kernel in (((2, 24, 20, 24), False), ((4, 24, 256, 512), True)):
+        F, fwd, bwd, xs = _dry_run(monkeypatch, Blocks, [shape])
+        fused = _dry_run.accumulations
+        names = [n for n, _ in bwd]
+        assert ("nasseg_conv_pw_bwd_bn" in names) == one_kernel, names
+        if one_kernel:  # (dx_res: argument 26 of nasseg_conv_pw_bwd_bn, K -> 6K expansions only)
+            with_skip = [a for n, a in bwd if n == "nasseg_conv_pw_bwd_bn" and a[21] == 24 and a[26]]
+        else:           # (the residual operand of nasseg_conv_fwd: argument 11)
+            with_skip = [a for n, a in bwd if n == "nasseg_conv_fwd" and a[11]]
+        assert len(with_skip) == 2 and fused == 0, (shape, len(with_skip), fused)
+        monkeypatch.setattr(F, "FUSE_RES_GRAD", False)
+        F, fwd0, bwd0, xs0 = _dry_run(monkeypatch, Blocks, [shape])
+        monkeypatch.setattr(F, "FUSE_RES_GRAD", True)
+        assert _dry_run.accumulations == 2 and [n for n, _ in bwd0] == names
+
+
 def test_gradient_junctions_replace_autograd_accumulation(monkeypatch):
     """Nodes with several consumers - a cell's input read by five ops, op outputs read by a sum and another op, the
     decoder maps read by several cells / blocks and collect_all (src/nn/micro_decoders.py:95-121,237-251,380-398) -
