@@ -745,6 +745,9 @@ def main():
         def step():
             return graphed.step(image, mask)
 
+        if rank == 0 and getattr(graphed, "layout", None):
+            sys.stderr.write("graph layout: {}\n".format(graphed.layout))
+
     def fence():
         if world > 1:
             dist.barrier()

@@ -249,7 +249,8 @@ int nasseg_bn_stats(const float* x, int64_t ldx, int64_t M, int C, float eps, fl
                     const float* gamma, const float* beta, float* mean, float* invstd,
                     float* scale, float* shift, float* running_mean, float* running_var,
                     int64_t* num_batches_tracked, float* ws, void* stream);
-int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float eps, float momentum,
+/* partial: rows [nblk, nblk + 64) of the buffer are scratch of the two-level reduction (hence not const) */
+int nasseg_bn_finalize(float* partial, int nblk, int64_t M, int C, float eps, float momentum,
                        const float* gamma, const float* beta, float* mean, float* invstd,
                        float* scale, float* shift, float* running_mean, float* running_var,
                        int64_t* num_batches_tracked, void* stream);
@@ -259,8 +260,9 @@ int nasseg_bn_eval_params(int C, float eps, const float* gamma, const float* bet
 int nasseg_bn_bwd_reduce(const float* dy, int64_t lddy, const float* x, int64_t ldx, int64_t M,
                          int C, const float* scale, const float* shift, const float* mean,
                          const float* invstd, int act, float* sums, float* ws, void* stream);
-/* sums[cols] = sum of the rows of partial[nblk][cols] (buffer needs nblk + 64 rows) */
-int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* stream);
+/* sums[cols] = sum of the rows of partial[nblk][cols] (buffer needs nblk + 64 rows: scratch of the two-level
+ * reduction, written - hence not const) */
+int nasseg_rows_sum(float* partial, int nblk, int cols, float* out, void* stream);
 int nasseg_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* sums, int64_t M,
                         int C, int train, int act, float* dx, void* stream);
@@ -415,6 +417,36 @@ int64_t nasseg_optim_chunk(void);
 int nasseg_optim_step(const int64_t* tensors, int n_tensors, const int* chunks, int n_chunks, const double* hyper,
                       int n_hyper, const double* clips, int n_clip, float* dstep, double* partial, float* norms,
                       void* stream);
+
+/* ---- hipGraph scheduling of a captured step (reference src/nn/micro_decoders.py:54-139: the five
+ * ops of a ContextualCell read one input, the two cells of a MergeCell share nothing) ---------------------------------
+ * A step recorded from one stream is a line of nodes.  The host side (engine/graph_dag.py) knows from this header
+ * which pointers every entry point reads (const) and writes (non-const) and with which address ranges it was called;
+ * these host-only calls let it attribute the recorded nodes to calls and replace the line's edges by the real
+ * dependencies (kept in a few lanes), so that independent branches replay side by side.
+ *   nasseg_graph_capture_nodes: nodes recorded so far by the capture `stream` belongs to; -1: not capturing.
+ *   nasseg_graph_node_kinds:    kinds[i] of the i-th recorded node: 0 kernel, 1 memcpy, 2 memset, 3 other.
+ *   nasseg_graph_rewire:        graph = hipGraph_t recorded from ONE stream with n_nodes nodes; its edges are replaced
+ *                               by edges[2*e] -> edges[2*e+1] (indices in recording order, pointing forward).  The
+ *                               caller guarantees they cover every read/write hazard of the recorded launches. */
+int nasseg_graph_capture_nodes(void* stream);
+int nasseg_graph_node_kinds(void* graph, int n_nodes, int* kinds);
+int nasseg_graph_rewire(void* graph, int n_nodes, int n_edges, const int* edges);
+/* Stages and lanes.  A dependency between two branches INSIDE one hipGraph costs this runtime about as much as a small
+ * kernel, and a graph with branches is no longer replayed from pre-built packets; so the host side cuts the recorded
+ * line into STAGES whose LANES share nothing, every (stage, lane) a line graph of its own, and orders them with events:
+ *   nasseg_graph_split:  part[i] = the part of the i-th recorded node (kernel and memset nodes only, else
+ *                        NASSEG_ERR_UNSUPPORTED); execs[p] receives a hipGraphExec_t holding part p's nodes in
+ *                        recording order (0: empty part).  The recorded graph is not modified.
+ *   nasseg_graph_run:    one replay - ops[3*i..] = {kind, a, b}: 0 launch executable graph a on stream b, 1 record
+ *                        event a on stream b, 2 stream b waits for event a; b == 0 means `stream`.  Asynchronous.
+ *   nasseg_lane_*:       the non-blocking streams / timing-free events those ops name (handles as void*). */
+int nasseg_graph_split(void* graph, int n_nodes, const int* part, int n_parts, void** execs);
+int nasseg_graph_exec_destroy(void* exec);
+int nasseg_lane_stream_create(void** stream);
+int nasseg_lane_event_create(void** event);
+int nasseg_lane_destroy(void* stream, void* event);
+int nasseg_graph_run(int n_ops, const int64_t* ops, void* stream);
 
 /* ---- bfloat16 activation storage --------------------------------------------
  * Every entry point above that reads or writes ACTIVATIONS (feature maps and their gradients)

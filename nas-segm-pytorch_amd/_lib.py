@@ -45,6 +45,26 @@ def parse_header(path=HEADER_PATH):
     return protos
 
 
+def pointer_access(path=HEADER_PATH):
+    """{symbol: [(argument index, "r" | "w" | "t")]} for the pointer arguments of every prototype except `stream`:
+    the header's const-ness IS the contract - a `const T*` is only read, a `T*` may be written (engine/graph_dag.py
+    derives the dependencies between the launches of a recorded step from it); "t": a table of pointers."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for _, name, args in _PROTO.findall(text):
+        args = " ".join(args.split())
+        acc = []
+        if args and args != "void":
+            for i, a in enumerate(args.split(",")):
+                a = a.strip()
+                if "*" not in a or a[a.rindex("*") + 1:].strip() == "stream":
+                    continue
+                acc.append((i, "t" if a.count("*") > 1 else ("r" if a.startswith("const ") else "w")))
+        out[name] = acc
+    return out
+
+
 def _address_of(obj):
     """Address behind a ctypes array / pointer / c_void_p (the call shim's slow path; ints and None never get
     here)."""
@@ -120,6 +140,7 @@ class _Library(object):
         self.ffi = None  # "native" | "ctypes" once loaded
         self._memo = {}
         self.profiler = None
+        self.recorder = None  # engine/graph_dag.Recorder while a step is being recorded into a hipGraph
 
     def load(self):
         if self._dll is not None:
@@ -179,7 +200,9 @@ class _Library(object):
             self.load()
             fn = self._fn[name]
         prof = self.profiler
-        if prof is not None and prof.wants(name):
+        if self.recorder is not None:
+            rc = self.recorder.call(name, args, fn)
+        elif prof is not None and prof.wants(name):
             rc = prof.bracket(name, args, fn)
         else:
             rc = fn(*args)
@@ -209,8 +232,13 @@ lib = _Library()
 
 
 def ptr(t):
-    """Device (or host) address of a tensor, None -> NULL."""
-    return None if t is None else t.data_ptr()
+    """Device (or host) address of a tensor, None -> NULL.  (While a step is recorded into a hipGraph the recorder
+    also notes the address range of the tensor's storage: what the next call may read or write behind that address.)"""
+    if t is None:
+        return None
+    if lib.recorder is not None:
+        return lib.recorder.note(t)
+    return t.data_ptr()
 
 
 def current_stream():

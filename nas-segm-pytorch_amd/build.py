@@ -48,7 +48,7 @@ def _headers_of(path, seen=None):
 
 
 # sources whose entry points never touch activations: compiled once (fp32 build only)
-FP32_ONLY_SOURCES = ("capi.cpp", "miou.hip", "optim.hip")
+FP32_ONLY_SOURCES = ("capi.cpp", "graph.cpp", "miou.hip", "optim.hip")
 
 
 def _compile(job):

@@ -391,7 +391,7 @@ int NASSEG_FN(bn_stats)(const act_t* x, int64_t ldx, int64_t M, int C, float eps
 // producer kernel (nasseg_conv_fwd with `stats`) already wrote: same outputs as nasseg_bn_stats.
 // The buffer must have room for 64 more rows ([nblk + 64][2][C]) - scratch of the first level
 // of the two-level reduction used when nblk > 512; `partial` is therefore not const in effect.
-int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float eps, float momentum,
+int nasseg_bn_finalize(float* partial, int nblk, int64_t M, int C, float eps, float momentum,
                        const float* gamma, const float* beta, float* mean, float* invstd,
                        float* scale, float* shift, float* running_mean, float* running_var,
                        int64_t* num_batches_tracked, void* stream) {
@@ -411,7 +411,7 @@ int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float e
     const int G = 64;
     const int rpg = cdiv(nblk, G);
     const int groups = cdiv(nblk, rpg);
-    float* lvl = const_cast<float*>(partial) + (int64_t)nblk * 2 * C;
+    float* lvl = partial + (int64_t)nblk * 2 * C;
     hipLaunchKernelGGL(rows_group_sum_t<NASSEG_RP_SLICES>, dim3(cdiv(2 * C, NASSEG_RP_ELEMS), groups), dim3(256), 0,
                        s, partial, lvl, nblk, (int64_t)2 * C, rpg);
     NASSEG_LAUNCH_CHECK("rows_group_sum");
@@ -429,7 +429,7 @@ int nasseg_bn_finalize(const float* partial, int nblk, int64_t M, int C, float e
 // per-workgroup rows written by nasseg_conv_bwd_data_bn / nasseg_dwconv_bwd_data_bn into the
 // sums[2][C] that nasseg_bn_bwd_reduce produces.  Like nasseg_bn_finalize the buffer needs room
 // for 64 extra rows (first level of the two-level reduction when nblk > 512).
-int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* stream) {
+int nasseg_rows_sum(float* partial, int nblk, int cols, float* out, void* stream) {
   NASSEG_REQUIRE(nblk > 0 && cols > 0 && partial && out, "rows_sum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const float* src = partial;
@@ -443,7 +443,7 @@ int nasseg_rows_sum(const float* partial, int nblk, int cols, float* out, void* 
     const int G = 64;
     const int rpg = cdiv(nblk, G);
     const int groups = cdiv(nblk, rpg);
-    float* lvl = const_cast<float*>(partial) + (int64_t)nblk * cols;
+    float* lvl = partial + (int64_t)nblk * cols;
     hipLaunchKernelGGL(rows_group_sum_t<NASSEG_RP_SLICES>, dim3(cdiv(cols, NASSEG_RP_ELEMS), groups), dim3(256), 0, s,
                        partial, lvl, nblk, (int64_t)cols, rpg);
     NASSEG_LAUNCH_CHECK("rows_group_sum");

@@ -36,6 +36,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
+from . import graph_dag
 from .trainer_common import clip_and_step, inner
 
 logger = logging.getLogger(__name__)
@@ -130,6 +131,7 @@ class _GraphedStep(object):
         # ALSO when the warm-up or the capture raises (HIP out of memory, say): the engine then
         # launches this candidate from the host, and its BatchNorm statistics must not have
         # advanced by the warm-up's momentum updates.
+        self.layout = self.plan = None
         buffers = self._bn_buffers()
         saved = [b.clone() for b in buffers]
         saved_params = saved_state = None
@@ -162,29 +164,69 @@ class _GraphedStep(object):
 
         done = False
         try:
+            # lanes > 1: the recorded line is laid out again with the real dependencies between its launches
+            # (engine/graph_dag.py) - the graph object is kept after the capture; the last warm-up pass is timed
+            # per call (HIP events), which is what the layout's cost model runs on
+            lanes = graph_dag.LANES if hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph") else 1
+            timer = None
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _ in range(max(1, warmup)):
-                    self._fwd_bwd(self.capture_optimisers)
+                for i in range(max(1, warmup)):
+                    if lanes > 1 and i == max(1, warmup) - 1 and F.lib.profiler is None:
+                        timer = F.lib.profiler = F.LaunchProfiler()
+                    try:
+                        self._fwd_bwd(self.capture_optimisers)
+                    finally:
+                        if timer is not None:
+                            F.lib.profiler = None
             torch.cuda.current_stream().wait_stream(side)
+            measured = None
+            if timer is not None:
+                torch.cuda.synchronize()
+                measured = [(name, 1e3 * e0.elapsed_time(e1)) for name, _, e0, e1 in timer.records]
+                timer = None
             restore()
             # No garbage collection while the stream is capturing: a collected cycle may hold device
             # tensors or another candidate's hipGraph, whose destruction inside a capture aborts the
             # process (torch >= 2.9 no longer collects before a capture by itself).  Collect now,
             # hold the collector off for the capture.
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True) if lanes > 1 else torch.cuda.CUDAGraph()
+            self.layout = self.plan = None
             if self._native is not None:
                 self._native.prepare_capture()
             gc.collect()
             gc_was_enabled = gc.isenabled()
             gc.disable()
+            recorder = n_nodes = None
             try:
                 with torch.cuda.graph(self.graph):
-                    self.loss = self._fwd_bwd(self.capture_optimisers)
+                    if lanes > 1:
+                        with graph_dag.Recorder() as recorder:
+                            self.loss = self._fwd_bwd(self.capture_optimisers)
+                            n_nodes = recorder.nodes()
+                    else:
+                        self.loss = self._fwd_bwd(self.capture_optimisers)
             finally:
                 if gc_was_enabled:
                     gc.enable()
+            if self._native is not None:
+                self._native.finish_capture()  # (its tables: uploaded once, here - the graph holds no copy nodes)
+            if recorder is not None:
+                recorder.release()
+                raw = self.graph.raw_cuda_graph()
+                if graph_dag.MODE == "rewire":
+                    # (a failure here is a failed capture: the graph may be left without its order)
+                    self.layout = graph_dag.lay_out(recorder, raw, n_nodes, lanes=lanes, durations=measured)
+                else:
+                    try:
+                        self.plan, self.layout = graph_dag.lay_out_stages(recorder, raw, n_nodes, lanes=lanes,
+                                                                          durations=measured)
+                    except F.NassegError as e:  # (the recorded graph is untouched: replay the line)
+                        logger.warning("graph_dag: %s - replaying the step as recorded", e)
+                        self.plan, self.layout = None, {"mode": "line", "error": str(e)}
+                if self.plan is None:
+                    self.graph.instantiate()
             done = True
         finally:
             if not done:
@@ -223,7 +265,10 @@ class _GraphedStep(object):
                                     "outside the graph (capture_optimisers=False reads param_groups every step)")
             if not native.host_steps_match():
                 native.sync_steps()  # (the optimisers were stepped or reloaded outside this graph)
-        self.graph.replay()
+        if self.plan is not None:
+            self.plan.run()  # (the step as stages of line graphs, engine/graph_dag.py)
+        else:
+            self.graph.replay()
         if native is not None:
             native.bump_host_steps()
         for p, g in self._static_grads:  # (an eager step in between may have re-pointed them)

@@ -230,11 +230,24 @@ class NativeStep(object):
         return self._host_tt[self._cur].numpy()
 
     def _upload_table(self):
+        if torch.cuda.is_current_stream_capturing():
+            # no copy nodes in a recorded step (a graph of kernels only replays from pre-built packets, and the
+            # tables of a recorded step never change: its gradients are static tensors): finish_capture uploads
+            self._upload_pending = True
+            return
         self._dev_t.copy_(self._host_tt[self._cur], non_blocking=True)
-        if not torch.cuda.is_current_stream_capturing():
-            ev = torch.cuda.Event()
-            ev.record()
-            self._tt_events[self._cur] = ev
+        ev = torch.cuda.Event()
+        ev.record()
+        self._tt_events[self._cur] = ev
+
+    def finish_capture(self):
+        """after this object's step was recorded into a hipGraph: the tables the recorded kernels read (tensor
+        addresses, chunk list) go to the device now, once - the graph's owner uses this object for that graph only"""
+        if getattr(self, "_upload_pending", False):
+            self._upload_pending = False
+            self._dev_t.copy_(self._host_tt[self._cur], non_blocking=True)
+            self._dev_c.copy_(self._host_c, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
 
     def _move_gradients(self, key):
         """the same tensors got their gradients at other addresses (the usual host-launched step: backward's
@@ -293,8 +306,8 @@ class NativeStep(object):
             raise _Unsupported()
         self._live_clips = [(mx,) + tuple(by_clip[c]) for c, mx in enumerate(self.clip_norms)]
         self._upload_table()
-        self._dev_c.copy_(self._host_c, non_blocking=True)
         if not torch.cuda.is_current_stream_capturing():
+            self._dev_c.copy_(self._host_c, non_blocking=True)
             self._uploaded = torch.cuda.Event()
             self._uploaded.record()
         self._n_chunks = n_chunks

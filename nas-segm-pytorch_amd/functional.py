@@ -146,6 +146,8 @@ class deferred_wgrad(object):
         flat = [v for c in calls for v in c[1]]
         table = (ctypes.c_int64 * len(flat))(*flat)
         name = entry if dtype == torch.float32 else entry.replace("nasseg_", "nasseg_bf16_", 1)
+        if lib.recorder is not None:  # (a step being recorded: c[0] = (input, dz, prologue scale, shift, partials))
+            lib.recorder.annotate(reads=[t for c in calls for t in c[0][:4]], writes=[c[0][4] for c in calls])
         lib.call(name, len(calls), table, stream)
 
     @staticmethod
@@ -157,6 +159,9 @@ class deferred_wgrad(object):
         dims = (ctypes.c_int * (5 * n))()
         for j, (_, _, d) in enumerate(todo):
             dims[5 * j:5 * j + 5] = d
+        if lib.recorder is not None:  # (dims: rows, taps, N, K, flat - the gradient tensor has taps * N * K floats)
+            lib.recorder.annotate(reads=[ws for ws, _, _ in todo],
+                                  writes=[(addr, 4 * d[1] * d[2] * d[3]) for _, addr, d in todo])
         lib.call("nasseg_wgrad_finalize_many", n, parts, outs, dims, stream)
 
     def __exit__(self, exc_type, exc, tb):
@@ -2358,7 +2363,7 @@ class _LogSoftmaxNLL(torch.autograd.Function):
                  ptr(out), ptr(ws), current_stream())
         ctx.save_for_backward(logits, target, out)
         ctx.cfg = (esz, int(ignore_index))
-        return out[0].clone()
+        return out[0]  # (a view, not a clone: a 4-byte copy node in a recorded step cannot be re-created, graph_dag.py)
 
     @staticmethod
     def backward(ctx, g):
@@ -2390,7 +2395,7 @@ class _BerHu(torch.autograd.Function):
         ws = _ws(p, lib.query("nasseg_ce_workspace"))
         lib.call(_k("nasseg_berhu_fwd", p), ptr(p), ptr(t), p.numel(), ptr(out), ptr(ws), current_stream())
         ctx.save_for_backward(p, t, out)
-        return out[0].clone()
+        return out[0]
 
     @staticmethod
     def backward(ctx, g):
