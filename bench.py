@@ -503,6 +503,65 @@ def roofline_from_profile(records, n_steps=2):
     return rows, groups, launches
 
 
+def secondary_cvpr321(device, rank, steps=30, warmup=5):
+    """BASELINE config 2 beside the headline (north_star: "images/sec on synthetic 321x321 and 2048x1024 batches ...
+    as absolute and fraction-of-roofline"): CVPR arch0, 21 classes, 16x3x321x321, fwd + bwd + clip + optimisers, the
+    whole step recorded once and replayed (engine.graphed: what train_segmenter does by itself at this size), laid out
+    as stages of independent lanes (engine/graph_dag.py).  Timed like the headline: `warmup` untimed steps, `steps`
+    timed ones between device synchronisations.  The roofline figures come from two host-launched steps with HIP
+    events around every entry point (the dominant kernel family's algorithmic bytes / its launch time)."""
+    from nas_segm_amd._lib import LaunchProfiler, lib
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    wl = WORKLOADS["cvpr321"]
+    segmenter, net = build_model(device, "cvpr321")
+    segmenter.train()
+    optim_enc = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+    optim_dec = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+    image, mask = synthetic_batch(wl[3], wl[4], wl[5], rank, device, wl[2])
+    graphed = GraphedSegmenterStep(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
+                                   capture_optimisers=True)
+    for _ in range(warmup):
+        loss = graphed.step(image, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = graphed.step(image, mask)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lay = graphed.layout or {}
+    out = {"workload": "cvpr321: {} - MobileNetV2 encoder + MicroDecoder, {}x3x{}x{}, train_segmenter step".format(
+               wl[6], wl[3], wl[4], wl[5]),
+           "value": wl[3] * steps / elapsed, "unit": "images/sec", "ms_per_step": 1e3 * elapsed / steps,
+           "steps": steps, "warmup": warmup, "dtype": "f32", "loss": float(loss),
+           "launch": "hipGraph(whole step), {}".format(
+               "{} lanes, {} line graphs, {} forks per step".format(lay.get("lanes"), lay.get("parts"), lay.get("forks"))
+               if graphed.plan is not None else "one line"),
+           "line_ms_per_step": lay.get("line_ms"), "roofline": None}
+    lib.profiler = LaunchProfiler()
+    try:
+        for _ in range(2):
+            segmenter_step(segmenter, image, mask, optim_enc, optim_dec, 255, 3.0, 3.0, -1)
+        torch.cuda.synchronize()
+        rows, groups, launches = roofline_from_profile(lib.profiler.records)
+    finally:
+        lib.profiler = None
+    if rows:
+        name, top = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        gbs = top["bytes"] / 1e9 / (top["ms"] / 1e3)
+        total_ms = sum(r["ms"] for r in rows)
+        out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": gbs / HBM_PEAK_GBS, "calls_per_step": len(launches) / 2,
+                           "tiny_launches_per_step": sum(1 for _, _, ms in launches if ms < 0.010) / 2,
+                           "tiny_ms_per_step": sum(ms for _, _, ms in launches if ms < 0.010) / 2,
+                           "share_of_kernel_time": top["ms"] / total_ms,
+                           "algorithmic_bytes_per_step": sum(r["bytes"] for r in rows) / 2,
+                           # the whole step's algorithmic bytes over the replayed step time
+                           "step_algorithmic_gbs": sum(r["bytes"] for r in rows) / 2 / 1e9 / (elapsed / steps)}
+    return out
+
+
 def _free_port():
     import socket
 
@@ -584,6 +643,9 @@ def main():
     ap.add_argument("--fused-optim", type=int, default=0, choices=(0, 1),
                     help="torch.optim fused=True implementations of SGD / Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", type=int, default=-1, choices=(-1, 0, 1),
+                    help="also time BASELINE config 2 (CVPR arch0 16x3x321x321, replayed) after the headline and "
+                         "report it as \"secondary\": 1 = yes, 0 = no, -1 = yes for the default 1-GPU headline run")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     ap.add_argument("--shapes", type=int, default=0,
@@ -895,6 +957,13 @@ def main():
             cpu["config1_321x321_gpu_fwd_images_per_sec"] = 20.0 / (time.perf_counter() - t0)
         segmenter.train()
 
+    secondary = None
+    if rank == 0 and (args.secondary == 1 or (args.secondary == -1 and world == 1 and args.workload == "headline"
+                                              and args.batch == wl[3] and not args.graph and args.dtype == "f32")):
+        # (after everything the headline needs: its timed region, roofline passes and CPU baseline are done)
+        del segmenter, net, optim_enc, optim_dec
+        secondary = secondary_cvpr321(device, rank)
+
     if rank == 0:
         imgs = args.batch * world * args.steps
         out = {
@@ -916,7 +985,7 @@ def main():
                        "loss": loss_value, "reward": reward,
                        "launch": ("host", "hipGraph(fwd+loss+bwd)", "hipGraph(whole step)" if args.workload != "task0"
                                   else "hipGraph(gather+fwd+loss+bwd), chosen by engine.graphed.auto_graph")[args.graph]},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         if cpu:
             out["gpu_over_cpu"] = out["value"] / cpu["value"]

@@ -456,6 +456,10 @@ int nasseg_graph_run(int n_ops, const int64_t* ops, void* stream);
  * parameters, parameter gradients, workspaces and every per-channel vector stay fp32, and the
  * size / workspace queries are shared with the fp32 entry points. */
 typedef uint16_t nasseg_bf16_t;
+/* fp32 -> bf16 (round to nearest even) / bf16 -> fp32 of n values: the (B, C, 1, 1) maps on either side of
+ * GAPConv1x1's fp32 island (layer_factory.py:181-195) in a bf16-storage network */
+int nasseg_to_bf16(const float* x, nasseg_bf16_t* y, int64_t n, void* stream);
+int nasseg_from_bf16(const nasseg_bf16_t* x, float* y, int64_t n, void* stream);
 int nasseg_bf16_dwconv_bwd_bn(const nasseg_bf16_t* xz, const nasseg_bf16_t* g, const nasseg_bf16_t* z, const float* wt,
                               int wt_flipped, nasseg_bf16_t* ge, float* dw, float* ws, const float* in_scale, const float* in_shift,
                               const float* in_mean, const float* in_invstd, int in_act, const float* bn_scale,

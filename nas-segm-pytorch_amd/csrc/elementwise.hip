@@ -334,6 +334,37 @@ int NASSEG_FN(fill)(act_t* y, int64_t n, float v, void* stream) {
   return NASSEG_OK;
 }
 
+#if NASSEG_FP32_ONLY
+// fp32 -> bf16 (round to nearest even) and bf16 -> fp32 of n values: the (B, C, 1, 1) maps on either side of
+// GAPConv1x1's fp32 island in a bf16-storage network (layer_factory.py:181-195; functional._GlobalAvgPool /
+// _Broadcast).  torch's .to() does the same arithmetic - as an ATen kernel that a recorded step cannot place
+// (engine/graph_dag.py treats what it does not know as a barrier).
+__global__ void to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sta1(y + i, x[i]);
+}
+__global__ void from_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = lda1(x + i);
+}
+extern "C" int nasseg_to_bf16(const float* x, uint16_t* y, int64_t n, void* stream) {
+  if (n <= 0) return NASSEG_OK;
+  NASSEG_REQUIRE(x && y, "to_bf16: null pointer");
+  hipLaunchKernelGGL(to_bf16_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     reinterpret_cast<bf16_t*>(y), n);
+  NASSEG_LAUNCH_CHECK("to_bf16");
+  return NASSEG_OK;
+}
+extern "C" int nasseg_from_bf16(const uint16_t* x, float* y, int64_t n, void* stream) {
+  if (n <= 0) return NASSEG_OK;
+  NASSEG_REQUIRE(x && y, "from_bf16: null pointer");
+  hipLaunchKernelGGL(from_bf16_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const bf16_t*>(x), y, n);
+  NASSEG_LAUNCH_CHECK("from_bf16");
+  return NASSEG_OK;
+}
+#endif
+
 int NASSEG_FN(chan_copy)(const act_t* x, int64_t ldx, int xoff, act_t* y, int64_t ldy, int yoff,
                      const act_t* mref, int64_t ldm, int moff, int64_t P, int C, int act, int mact,
                      void* stream) {

@@ -33,7 +33,7 @@ from .._lib import NassegError, current_stream, lib, pointer_access
 logger = logging.getLogger(__name__)
 
 # NASSEG_GRAPH_LANES: lanes a recorded step is laid out in (1 = the line as recorded)
-LANES = int(os.environ.get("NASSEG_GRAPH_LANES", "3"))
+LANES = int(os.environ.get("NASSEG_GRAPH_LANES", "4"))
 # NASSEG_GRAPH_MODE: "stages" (default: stages of independent lanes, every (stage, lane) a line graph, ordered with
 # events) | "rewire" (ONE graph whose edges are the real dependencies laid out in lanes - kept for A/B: on this
 # runtime a graph with branches replays from per-node commands and pays ~10 us per crossing, tools/graph_branches.hip)
@@ -343,6 +343,8 @@ def lay_out(recorder, raw_graph, n_nodes, lanes=None, durations=None):
 # ---------------------------------------------------------------------------------------------------------------
 # stages and lanes: every (stage, lane) a line graph of its own
 # ---------------------------------------------------------------------------------------------------------------
+# NASSEG_GRAPH_TRIALS=0: take the cost model's layout for LANES lanes unmeasured (default: time the candidates)
+TRIALS = os.environ.get("NASSEG_GRAPH_TRIALS", "1") != "0"
 # cost of a stage with more than one lane (event record + waits on both sides), microseconds
 FORK_US = float(os.environ.get("NASSEG_GRAPH_FORK_US", "30"))
 _STAGE_WINDOW = 512  # longest stage the planner looks at, in units
@@ -460,16 +462,82 @@ def verify_stages(units, deps, stage_of, lane):
                                                     stage_of[x], lane[x]))
 
 
-_SIDE_STREAMS = []  # raw handles of this process's lane streams (created once, never destroyed)
+_SIDE_STREAMS = {}  # device index -> raw handles of this process's lane streams (created once, never destroyed)
+_CANDIDATES = 10    # streams tried per device
+
+
+def _overlap_probe(device):
+    """-> overlaps(a, b): do launches on the torch streams a and b run side by side?  HIP maps streams to a few
+    hardware queues (4 by default) and two streams on one queue execute one after the other - which streams share a
+    queue is not exposed, so it is measured: two recorded lines of 150 tiny kernels each, replayed on a and b at the
+    same time, take ~0.7 of the time of the two lines in turn on two queues (measured: 0.345 against 0.49 ms) and all of
+    it on one."""
+    import time
+
+    import torch
+
+    buf = torch.zeros(2, 256, device=device, dtype=torch.float32)
+    graphs = []
+    for k in range(2):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(150):
+                lib.call("nasseg_fill", buf[k].data_ptr(), 256, 1.0, current_stream())
+        graphs.append(g)
+
+    def both(a, b):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            graphs[0].replay()
+        with torch.cuda.stream(b):
+            graphs[1].replay()
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    def overlaps(a, b):
+        both(a, b)
+        pair = min(both(a, b) for _ in range(3))
+        alone = min(both(a, a) for _ in range(3))  # (one stream: the two lines in turn)
+        PROBE_LOG.append(round(pair / alone, 3))
+        return pair < 0.85 * alone
+
+    return overlaps
+
+
+PROBE_LOG = []  # pair / alone of every probe of this process (diagnostics)
 
 
 def side_streams(count):
-    """``count`` non-blocking streams for lanes 1 ... (the step's own stream is lane 0)"""
-    while len(_SIDE_STREAMS) < count:
-        out = (ctypes.c_void_p * 1)()
-        lib.call("nasseg_lane_stream_create", out)
-        _SIDE_STREAMS.append(int(out[0]))
-    return _SIDE_STREAMS[:count]
+    """up to ``count`` non-blocking streams for lanes 1 ... (lane 0 is the stream the step runs on) that run side by
+    side with the current stream and with each other (_overlap_probe) - fewer when the device's hardware queues do
+    not allow more.  Found once per device and process."""
+    import torch
+
+    device = torch.cuda.current_device()
+    have = _SIDE_STREAMS.get(device)
+    if have is None:
+        have = _SIDE_STREAMS[device] = []
+        if os.environ.get("NASSEG_GRAPH_PROBE", "1") == "0":  # (A/B: the first streams created, unprobed)
+            for _ in range(3):
+                out = (ctypes.c_void_p * 1)()
+                lib.call("nasseg_lane_stream_create", out)
+                have.append(int(out[0]))
+        else:
+            overlaps = _overlap_probe(torch.device("cuda", device))
+            main = torch.cuda.current_stream(device)
+            chosen = []
+            for _ in range(_CANDIDATES):
+                if len(chosen) == 3:
+                    break
+                out = (ctypes.c_void_p * 1)()
+                lib.call("nasseg_lane_stream_create", out)
+                cand = torch.cuda.ExternalStream(int(out[0]), device=device)
+                if overlaps(main, cand) and all(overlaps(c, cand) for c in chosen):
+                    chosen.append(cand)
+                    have.append(int(out[0]))
+            logger.info("graph_dag: %d lane streams on queues of their own", len(have))
+    return have[:count]
 
 
 class Plan(object):
@@ -561,33 +629,64 @@ class Plan(object):
             pass
 
 
-def lay_out_stages(recorder, raw_graph, n_nodes, lanes=None, durations=None):
-    """-> (Plan | None, summary): the recorded step as stages of independent lanes (None: one lane is best, or the
-    graph holds nodes that cannot be re-created - the caller replays the line as recorded)"""
+def lay_out_stages(recorder, raw_graph, n_nodes, lanes=None, durations=None, trial=None):
+    """-> (Plan | None, summary): the recorded step as stages of independent lanes (None: the line as recorded is
+    best, or the graph holds nodes that cannot be re-created - the caller replays the line).
+
+    trial(run) -> seconds per replay (the caller's clock around a few replays; it puts back whatever they change):
+    the cost model knows nothing of kernels that fill the GPU by themselves, of the runtime's queues, of what a
+    fork costs today - so the few layouts worth trying (lane counts, two prices for a fork) are built and TIMED on
+    the recorded step itself, the line included, and the fastest one is kept.  Without ``trial`` the model's choice
+    for ``lanes`` is taken unmeasured."""
     units = fill_gaps(recorder.units, n_nodes)
     deps = dependencies(units)
     us = durations_for(units, durations)
-    stages, model_us = plan_stages(units, deps, us, lanes=lanes)
-    stage_of, lane = assign_lanes(units, deps, us, stages, lanes=lanes)
-    verify_stages(units, deps, stage_of, lane)
-    line_us = sum(us)
-    info = {"mode": "stages", "nodes": n_nodes, "units": len(units), "stages": len(stages), "model_us": round(model_us, 1),
-            "line_us": round(line_us, 1), "side_units": sum(1 for v in lane if v),
+    lanes = max(1, int(LANES if lanes is None else lanes))
+    lanes = min(lanes, 1 + len(side_streams(lanes - 1)))
+    info = {"mode": "stages", "probe": list(PROBE_LOG), "nodes": n_nodes, "units": len(units), "line_us": round(sum(us), 1),
+            "barrier_units": sum(1 for x in units if x.barrier),
             "barriers": sorted(set("{}: {}".format(x.name, x.why) for x in units if x.barrier)),
             "measured_durations": durations is not None}
-    _dump(info, units, deps, lane, [], stage_of, us)
-    if not any(lane):
+    if trial is None:
+        candidates = [(lanes, FORK_US)]
+    else:
+        candidates = [(L, f) for L in range(2, lanes + 1) for f in (FORK_US, 4 * FORK_US)]
+    best = None  # (seconds or None, plan, description)
+    tried = []
+    seen = set()
+    for L, fork in candidates:
+        stages, model_us = plan_stages(units, deps, us, lanes=L, fork_us=fork)
+        stage_of, lane = assign_lanes(units, deps, us, stages, lanes=L)
+        verify_stages(units, deps, stage_of, lane)
+        if not any(lane) or (tuple(stage_of), tuple(lane)) in seen:
+            continue
+        seen.add((tuple(stage_of), tuple(lane)))
+        try:
+            plan = Plan(raw_graph, n_nodes, units, stage_of, lane)
+        except NassegError as e:
+            if "neither a kernel nor a memset" not in str(e):
+                raise
+            info["unsupported"] = str(e)
+            break
+        desc = {"lanes": L, "fork_us": fork, "model_us": round(model_us, 1), "parts": plan.n_parts,
+                "launches": plan.n_groups, "forks": plan.n_forks, "side_units": sum(1 for v in lane if v)}
+        seconds = trial(plan.run) if trial is not None else None
+        if seconds is not None:
+            desc["ms"] = round(1e3 * seconds, 3)
+        tried.append(desc)
+        if best is None or (seconds is not None and seconds < best[0]):
+            if best is not None:
+                best[1].close()
+            best = (seconds, plan, desc)
+            _dump(dict(info, **desc), units, deps, lane, [], stage_of, us)
+        else:
+            plan.close()
+    info["tried"] = tried
+    if best is None:
         return None, info
-    try:
-        plan = Plan(raw_graph, n_nodes, units, stage_of, lane)
-    except NassegError as e:
-        if "neither a kernel nor a memset" not in str(e):
-            raise
-        info["unsupported"] = str(e)
-        return None, info
-    info.update(parts=plan.n_parts, launches=plan.n_groups, forks=plan.n_forks)
+    info.update(best[2])
     logger.info("graph_dag: %s", info)
-    return plan, info
+    return best[1], info
 
 
 def durations_for(units, measured):

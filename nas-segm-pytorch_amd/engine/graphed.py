@@ -168,24 +168,30 @@ class _GraphedStep(object):
             # (engine/graph_dag.py) - the graph object is kept after the capture; the last warm-up pass is timed
             # per call (HIP events), which is what the layout's cost model runs on
             lanes = graph_dag.LANES if hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph") else 1
-            timer = None
+            timers = []
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for i in range(max(1, warmup)):
-                    if lanes > 1 and i == max(1, warmup) - 1 and F.lib.profiler is None:
-                        timer = F.lib.profiler = F.LaunchProfiler()
+                    timing = lanes > 1 and F.lib.profiler is None
+                    if timing:
+                        timers.append(F.LaunchProfiler())
+                        F.lib.profiler = timers[-1]
                     try:
                         self._fwd_bwd(self.capture_optimisers)
                     finally:
-                        if timer is not None:
+                        if timing:
                             F.lib.profiler = None
             torch.cuda.current_stream().wait_stream(side)
             measured = None
-            if timer is not None:
+            if timers:
                 torch.cuda.synchronize()
-                measured = [(name, 1e3 * e0.elapsed_time(e1)) for name, _, e0, e1 in timer.records]
-                timer = None
+                passes = [[(name, 1e3 * e0.elapsed_time(e1)) for name, _, e0, e1 in t.records] for t in timers]
+                measured = passes[-1]
+                for other in passes[:-1]:  # (the same calls in the same order: the shorter sample of each)
+                    if [n for n, _ in other] == [n for n, _ in measured]:
+                        measured = [(n, min(a, b)) for (n, a), (_, b) in zip(measured, other)]
+                timers = passes = None
             restore()
             # No garbage collection while the stream is capturing: a collected cycle may hold device
             # tensors or another candidate's hipGraph, whose destruction inside a capture aborts the
@@ -218,15 +224,10 @@ class _GraphedStep(object):
                 if graph_dag.MODE == "rewire":
                     # (a failure here is a failed capture: the graph may be left without its order)
                     self.layout = graph_dag.lay_out(recorder, raw, n_nodes, lanes=lanes, durations=measured)
-                else:
-                    try:
-                        self.plan, self.layout = graph_dag.lay_out_stages(recorder, raw, n_nodes, lanes=lanes,
-                                                                          durations=measured)
-                    except F.NassegError as e:  # (the recorded graph is untouched: replay the line)
-                        logger.warning("graph_dag: %s - replaying the step as recorded", e)
-                        self.plan, self.layout = None, {"mode": "line", "error": str(e)}
-                if self.plan is None:
                     self.graph.instantiate()
+                else:
+                    self.graph.instantiate()
+                    self._lay_out(recorder, raw, n_nodes, lanes, measured, restore)
             done = True
         finally:
             if not done:
@@ -243,6 +244,38 @@ class _GraphedStep(object):
         # capture left in ``param.grad`` are the static tensors every replay refills.
         self._static_grads = [(p, p.grad) for p in self._params if p.grad is not None]
         self._captured_hyper = self._native.hyper_values() if self._native is not None else None
+
+    def _lay_out(self, recorder, raw, n_nodes, lanes, measured, restore):
+        """the recorded step as stages of independent lanes (engine/graph_dag.py): the candidate layouts and the line
+        as recorded are timed on the step itself - what those replays change is put back - and the fastest is kept"""
+        import time
+
+        def trial(run, reps=4):
+            run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / reps
+
+        try:
+            timed = graph_dag.TRIALS
+            plan, layout = graph_dag.lay_out_stages(recorder, raw, n_nodes, lanes=lanes, durations=measured,
+                                                    trial=trial if timed else None)
+            if plan is not None and timed:
+                line = trial(self.graph.replay)
+                layout["line_ms"] = round(1e3 * line, 3)
+                if layout.get("ms") is None or 1e-3 * layout["ms"] >= line:
+                    plan.close()
+                    plan = None
+            self.plan, self.layout = plan, layout
+        except F.NassegError as e:  # (the recorded graph is untouched: replay the line)
+            logger.warning("graph_dag: %s - replaying the step as recorded", e)
+            self.plan, self.layout = None, {"mode": "line", "error": str(e)}
+        finally:
+            torch.cuda.synchronize()
+            restore()
 
     def _sync_gradients(self):
         """the step's gradient collective - RankParallel's, so that the failure protocol (status element,

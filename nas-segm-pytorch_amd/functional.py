@@ -33,6 +33,21 @@ def _k(name, t):
     return _BF16_PREFIX + name[7:]
 
 
+def _to_dtype(t, dtype):
+    """t.to(dtype) between fp32 and bf16 as a nasseg launch (nasseg_to_bf16 / nasseg_from_bf16: the same rounding as
+    torch's; an ATen kernel inside a recorded step would be a barrier for engine/graph_dag.py); anything else:
+    torch's .to()"""
+    if t.dtype == dtype:
+        return t
+    t = t.contiguous()
+    if t.is_cuda and t.numel() and (t.dtype, dtype) in ((torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32)):
+        y = torch.empty_like(t, dtype=dtype)
+        lib.call("nasseg_to_bf16" if dtype == torch.bfloat16 else "nasseg_from_bf16", ptr(t), ptr(y), t.numel(),
+                 current_stream())
+        return y
+    return t.to(dtype)
+
+
 def _cl(x):
     """NHWC-contiguous view/copy of a 4-D NCHW-shaped activation (fp32 or bf16 storage)."""
     require_device(x)
@@ -210,6 +225,9 @@ _GROUP_WGRAD_BYTES = 48 << 20
 WGRAD_STREAM = int(os.environ.get("NASSEG_WGRAD_STREAM", "3"))
 _SIDE_STREAMS = {}
 _SIDE_GROUP = int(os.environ.get("NASSEG_WGRAD_SIDE_GROUP", "8"))
+# (in a step being recorded for lanes: measured slower at 8 and level at 16 - more launches of the grouped kernels -,
+#  profiles/r06_ab_lanes.txt; kept as a switch)
+_RECORD_GROUP = int(os.environ.get("NASSEG_WGRAD_RECORD_GROUP", "1000000"))
 
 
 def _wgrad_stream(t, keep):
@@ -239,6 +257,13 @@ def _group_wgrad(entry, cur, tensors, desc, fin):
     if WGRAD_STREAM & 2 and deferred_wgrad.side_ok and cur.is_cuda and len(calls) >= _SIDE_GROUP:
         del deferred_wgrad.grouped[key]
         deferred_wgrad._launch_group(entry, cur.dtype, calls, _wgrad_stream(cur, calls))
+        deferred_wgrad.pending.extend(c[2] for c in calls)
+    elif lib.recorder is not None and len(calls) >= _RECORD_GROUP:
+        # a step being recorded for replay in lanes (engine/graph_dag.py): _SIDE_GROUP layers at a time as backward
+        # goes, on the recording stream - the layout then runs such a launch beside the NEXT piece of the backward
+        # chain; one launch of all of them behind the chain would be a stage of its own
+        del deferred_wgrad.grouped[key]
+        deferred_wgrad._launch_group(entry, cur.dtype, calls, current_stream())
         deferred_wgrad.pending.extend(c[2] for c in calls)
 
 
@@ -2293,7 +2318,7 @@ class _GlobalAvgPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, C, H, W = ctx.shape
-        dy = dy.contiguous().view(B, C, 1, 1).to(ctx.dtype)
+        dy = _to_dtype(dy.contiguous().view(B, C, 1, 1), ctx.dtype)
         # every pixel receives dy / (H*W): a broadcast with a scale
         scale = _vec(dy, C)
         lib.call("nasseg_fill", ptr(scale), C, 1.0 / (H * W), current_stream())
@@ -2317,7 +2342,7 @@ class _Broadcast(torch.autograd.Function):
         require_device(v)
         B, C = v.shape[0], v.shape[1]
         ctx.vdtype = v.dtype
-        v = v.contiguous().view(B, C, 1, 1).to(dtype)
+        v = _to_dtype(v.contiguous().view(B, C, 1, 1), dtype)
         y = _new(v, B, C, H, W)
         lib.call(_k("nasseg_bilinear_fwd", v), ptr(v), ptr(y), C, 0, B, 1, 1, C, H, W, ACT_NONE,
                  current_stream())
@@ -2329,7 +2354,7 @@ class _Broadcast(torch.autograd.Function):
         B, C, H, W = ctx.shape
         dy = _cl(dy)
         dv = _colred(RED_SUM, dy, C, None, 0, None, 0, B, H * W, C)  # (fp32 sums)
-        return dv.view(B, C, 1, 1).to(ctx.vdtype), None, None, None
+        return _to_dtype(dv.view(B, C, 1, 1), ctx.vdtype), None, None, None
 
 
 def broadcast_to(v, size, dtype=None):

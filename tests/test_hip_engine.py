@@ -396,6 +396,78 @@ def test_graphed_step_equals_eager_step(net_name, capture_opt, plain):
         assert torch.equal(sd0[k], sd1[k]), k
 
 
+@pytest.mark.parametrize("net_name,lanes", [("cvpr_arch0", 2), ("cvpr_arch0", 4), ("wacv_arch0", 3)])
+def test_lanes_replay_equals_the_line(net_name, lanes, monkeypatch):
+    """A recorded step laid out as stages of independent lanes (engine/graph_dag.py: dependencies from the address
+    ranges every entry point was handed, one line graph per (stage, lane), events between stages) leaves exactly
+    what the line as recorded leaves - parameters, running statistics, optimiser state, losses - over changing
+    batches; the layout really has side lanes (the cells of a MergeCell / the blocks of a template decoder share
+    nothing, src/nn/micro_decoders.py:54-139,380-398), and every dependency sits inside a lane or points to an
+    earlier stage (verified at the capture; here the layout taken is the cost model's, untimed, so that it is used
+    whatever this box's clock says)."""
+    from nas_segm_amd.engine import graph_dag
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+
+    rec = load_json("nets_meta.json")[net_name]
+    aux_w = 0.15 if rec["kind"] != "template" else -1
+    g = torch.Generator().manual_seed(12)
+    batches = [(torch.randn(2, 3, 97, 129, generator=g).to(DEV).contiguous(memory_format=torch.channels_last),
+                torch.randint(0, rec["classes"], (2, 97, 129), generator=g).to(DEV)) for _ in range(4)]
+    monkeypatch.setattr(graph_dag, "TRIALS", False)
+
+    def run(n_lanes):
+        monkeypatch.setattr(graph_dag, "LANES", n_lanes)
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+        oe = torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-5)
+        od = torch.optim.Adam(net.decoder.parameters(), lr=3e-3, weight_decay=1e-5)
+        stepper = GraphedSegmenterStep(net, batches[0][0], batches[0][1], oe, od, 255, 3.0, 3.0, aux_w,
+                                       capture_optimisers=True)
+        losses = [float(stepper.step(x, t)) for x, t in batches]
+        state = [v.detach().cpu().clone() for st in od.state.values() for v in st.values() if torch.is_tensor(v)]
+        return losses, _cpu_sd(net), state, stepper
+
+    l1, sd1, st1, line = run(1)
+    assert line.plan is None
+    ln, sdn, stn, laid = run(lanes)
+    assert laid.plan is not None and laid.layout["forks"] >= 1 and laid.layout["side_units"] > 0, laid.layout
+    assert laid.layout["lanes"] <= lanes
+    assert l1 == ln, (l1, ln)
+    for k in sd1:
+        assert torch.equal(sd1[k], sdn[k]), k
+    assert len(st1) == len(stn) and all(torch.equal(a, b) for a, b in zip(st1, stn))
+
+
+def test_timed_layouts_never_lose_to_the_line():
+    """with trials on (the default) the stepper keeps a layout only when its replays measured faster than the line's;
+    either way the step it replays equals the host-launched one"""
+    from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+    from nas_segm_amd.engine.trainer import segmenter_step
+
+    rec = load_json("nets_meta.json")["cvpr_arch0"]
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 3, 97, 129, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    t = torch.randint(0, rec["classes"], (2, 97, 129), generator=g).to(DEV)
+
+    def nets():
+        net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+        return (net, torch.optim.SGD(net.encoder.parameters(), lr=1e-3, momentum=0.9),
+                torch.optim.Adam(net.decoder.parameters(), lr=3e-3))
+
+    net, oe, od = nets()
+    stepper = GraphedSegmenterStep(net, x, t, oe, od, 255, 3.0, 3.0, 0.15, capture_optimisers=True)
+    lay = stepper.layout
+    assert lay and lay["mode"] == "stages" and lay["tried"], lay
+    if stepper.plan is not None:
+        assert lay["ms"] < lay["line_ms"], lay
+    got = [float(stepper.step(x, t)) for _ in range(3)]
+    net2, oe2, od2 = nets()
+    want = [float(segmenter_step(net2, x, t, oe2, od2, 255, 3.0, 3.0, 0.15)) for _ in range(3)]
+    assert got == want
+    sd, sd2 = _cpu_sd(net), _cpu_sd(net2)
+    for k in sd:
+        assert torch.equal(sd[k], sd2[k]), k
+
+
 def test_graphed_step_with_a_custom_loss_equals_eager():
     """GraphedSegmenterStep(loss_fn=F.berhu_loss): the depth-head step (BASELINE config 5) replayed from
     a hipGraph leaves the parameters of the same steps written out eagerly"""

@@ -44,7 +44,7 @@ PY
 }
 bench() {  # name args... -> $OUT/name.json, one line
   local n=$1; shift
-  timeout 400 python bench.py --no-cpu-baseline --pmc 0 "$@" > $OUT/$n.json 2> $OUT/$n.err
+  timeout 400 python bench.py --no-cpu-baseline --pmc 0 --secondary 0 "$@" > $OUT/$n.json 2> $OUT/$n.err
   line "$n" $OUT/$n.json | tee -a $SUM
 }
 
@@ -72,7 +72,7 @@ ab)
   VAR=$1; VALS=$2; shift 2
   for rep in 1 2; do for v in $VALS; do
     n="${VAR}_${v}_$(echo "$*" | tr -c 'a-zA-Z0-9' '_')"
-    env $VAR=$v timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 "$@" > $OUT/$n.json 2> $OUT/$n.err
+    env $VAR=$v timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pmc 0 --secondary 0 "$@" > $OUT/$n.json 2> $OUT/$n.err
     line "$VAR=$v $*" $OUT/$n.json | tee -a $SUM
   done; done ;;
 workloads)
@@ -92,17 +92,17 @@ workloads)
 trace)
   ABS=$PWD/$OUT
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ABS/prof -o run -- \
-     python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --pmc 0 "$@" > $ABS/bench.json 2> $ABS/bench.err)
+     python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --pmc 0 --secondary 0 "$@" > $ABS/bench.json 2> $ABS/bench.err)
   python tools/trace_gaps.py $OUT | tee $OUT/trace.txt | head -60 ;;
 stats)
   ABS=$PWD/$OUT
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ABS/prof -o run -- \
-     python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --pmc 0 "$@" > $ABS/prof.log 2>&1)
+     python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --pmc 0 --secondary 0 "$@" > $ABS/prof.log 2>&1)
   echo "stats exit $?" | tee -a $SUM
   python tools/prof_summary.py $(find $OUT/prof -name "*kernel_stats*" | head -1) | tee $OUT/kernel_families.txt | head -40 ;;
 tree)
   OTHER=$1
-  run() { (cd $1 && shift && python bench.py --no-cpu-baseline --no-roofline --pmc 0 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],3))"); }
+  run() { (cd $1 && shift && python bench.py --no-cpu-baseline --no-roofline --pmc 0 --secondary 0 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value'],1), round(d['ms_per_step'],3))"); }
   for i in 1 2; do for t in . $OTHER; do
     echo "$t headline            $(run $t --steps 12 --warmup 4)" | tee -a $SUM
     echo "$t arch1               $(run $t --workload arch1 --steps 8 --warmup 3)" | tee -a $SUM
