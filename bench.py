@@ -395,7 +395,7 @@ def collect_pmc(passthrough, timeout_s=300):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, c), "-o",
                    "run", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-roofline", "--pmc", "0"] + list(passthrough)
+                   "--no-cpu-baseline", "--no-roofline", "--pmc", "0", "--secondary", "0"] + list(passthrough)
             r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL)
             if r.returncode != 0:
