@@ -152,8 +152,118 @@ def test_train_step_at_size_matches_the_oracle(net_name, batch, monkeypatch):
         if err > tol:
             bad.append((k, err, tol, float(ref.abs().max())))
     assert not bad, "{} of {} gradients off: {}".format(len(bad), len(want_g), bad[:8])
-    print("train step at size ({}, B = {}): logits err {:.2e} (floor {:.2e}), worst relative gradient error {:.2e}".format(
-        net_name, B, err_out, floor_out, worst))
+    # What the floors mean.  A tensor whose tolerance is mostly floor (> 10 % of its own largest entry) is one the
+    # ORACLE cannot pin either: its gradient is zero in exact arithmetic and what both sides compute is rounding
+    # noise - a BatchNorm weight or bias whose effect the next BatchNorm removes (Pool's conv + BatchNorm in front of
+    # ConcatReduce's BatchNorm, src/nn/layer_factory.py:161-178,369-382: shift and positive scale commute with
+    # max pooling and vanish in the normalisation; a BatchNorm weight in front of ReLU -> concatenation ->
+    # BatchNorm; a bias in front of conv -> BatchNorm).  So: only BatchNorm affine parameters may be in that class,
+    # they must be small beside the well-conditioned gradients, and they must stay a small share of all tensors;
+    # everything else is compared WITHOUT help from the floor in the distribution printed below.
+    modules = dict(net.named_modules())
+    rel, floored = {}, []
+    for k, p in net.named_parameters():
+        ref = want_g[k]
+        mx = float(ref.abs().max())
+        floor = float((pert_g[k] - ref).abs().max())
+        if 4.0 * floor + 1e-7 > 0.1 * mx:
+            floored.append(k)
+        else:
+            rel[k] = float((p.grad.cpu() - ref).abs().max()) / mx
+    not_bn = [k for k in floored
+              if not isinstance(modules[k.rsplit(".", 1)[0]], torch.nn.modules.batchnorm._BatchNorm)]
+    # (measured, B = 2 / 4, both nets: 31 - 39 of 250 / 328 tensors; all but one to three of them BatchNorm affine
+    #  parameters; the others are conv weights of a block between two normalisations whose gradient the oracle
+    #  itself moves by > 2.5 % under a 1e-6 change of the image)
+    assert len(not_bn) <= 0.02 * len(want_g) + 1, "floor-dominated tolerances outside BatchNorm affine parameters: " \
+        "{}".format([(k, float(want_g[k].abs().max())) for k in not_bn])
+    assert len(floored) <= 0.17 * len(want_g), (len(floored), len(want_g))
+    typical = sorted(float(want_g[k].abs().max()) for k in rel)[len(rel) // 2]
+    bn_floored = [k for k in floored if k not in not_bn]
+    loud = [(k, float(want_g[k].abs().max())) for k in bn_floored if float(want_g[k].abs().max()) > typical]
+    assert not loud, "BatchNorm parameters with a floor-dominated tolerance and a large gradient (typical {:.2e}): " \
+        "{}".format(typical, loud)
+    errs = sorted(rel.values())
+    median, p95 = errs[len(errs) // 2], errs[int(0.95 * (len(errs) - 1))]
+    # (measured: median 3.0e-3 - 3.7e-3, p95 6.5e-3 - 8.0e-3 of the tensor's largest entry - train-mode BatchNorm over
+    #  2 - 8 M pixels; the frozen-BatchNorm test below shows the fp32 CPU oracle is that far from float64 itself)
+    assert median <= 6e-3 and p95 <= 1.5e-2, (median, p95)
+    print("train step at size ({}, B = {}): logits err {:.2e} (floor {:.2e}); gradient error / max over the {} "
+          "well-conditioned tensors: median {:.2e}, p95 {:.2e}, worst {:.2e}; {} floor-dominated tensors ({} not "
+          "BatchNorm affine; largest {:.1e}, typical gradient {:.1e}) compared against the oracle's own noise".format(
+              net_name, B, err_out, floor_out, len(errs), median, p95, errs[-1], len(floored), len(not_bn),
+              max([float(want_g[k].abs().max()) for k in floored] or [0.0]), typical))
+
+
+@pytest.mark.parametrize("net_name", ["wacv_arch0", "wacv_arch1"])
+def test_frozen_batchnorm_train_step_at_size_matches_the_oracle_without_floors(net_name):
+    """The large-map backward kernels pinned where the problem is well conditioned: a train step at 1x3x1024x2048
+    with every BatchNorm on its running statistics (the engine's freeze_bn mode, src/engine/trainer.py:124-127,
+    219-222 - no batch statistics, hence no gradient that a later normalisation cancels) against the CPU oracle,
+    against the oracle with NO sensitivity floor from perturbed inputs.  The running statistics are the batch's own
+    (one forward with momentum 1), so the activations are normalised as in training.
+    The oracle runs in FLOAT64, and in fp32 beside it: measured, the kernels sit at median 8e-4 / p95 3.9e-3 / worst
+    1.0e-2 of a tensor's largest entry from the float64 gradients - and the fp32 CPU oracle at 7.6e-4 / 3.8e-3 /
+    1.03e-2: forward rounding through ReLU / max-pool decisions at 2 M pixels, the same for any fp32 implementation.
+    A flat "2e-3 of the largest entry" is therefore not a bound fp32 can meet; what is asserted is that a tensor is
+    within 2e-3 of its largest entry OR no further from float64 than twice the fp32 CPU oracle is, and that the
+    distribution over tensors matches the CPU's (median and 95th percentile within 25 %)."""
+    from _util import oracle_forward
+    from nas_segm_amd.engine.trainer import _freeze_bn
+    from oracle import engine as oeng
+
+    if min(_host_memory_gib(), _cgroup_headroom_gib()) < 40.0:
+        pytest.skip("the CPU oracle needs ~40 GiB of host memory at this size")
+    rec = load_json("nets_meta.json")[net_name]
+    net = build_product_net(rec["kind"], rec["genotype"], rec["classes"], rec["dec_kwargs"], 0).to(DEV).train()
+    gen = torch.Generator().manual_seed(23)
+    B, H, W = 1, 1024, 2048
+    x = torch.randn(B, 3, H, W, generator=gen)
+    target = _labels(gen, B, H, W, 19)
+    xd, td = _cl(x), target.to(DEV)
+    bns = [m for m in net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    for m in bns:
+        m.momentum = 1.0
+    with torch.no_grad():
+        net(xd)  # running statistics := this batch's
+    for m in bns:
+        m.momentum = 0.1
+    sd0 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    pkeys = {k for k, _ in net.named_parameters()}
+    g = _frozen_bn_gradients(net, xd, lambda out: _train_loss(out, td).backward())
+    for k, v in net.state_dict().items():  # frozen: the buffers did not move
+        if "running" in k:
+            assert torch.equal(v.cpu(), sd0[k]), k
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+
+    def oracle_grads(dtype):
+        sd = {k: (v.to(dtype).requires_grad_(True) if k in pkeys else
+                  (v.to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd0.items()}
+        out = oracle_forward(sd, x.to(dtype), rec, training=False)
+        oeng.train_loss(out, target).backward()
+        return {k: sd[k].grad.double() for k in pkeys}
+
+    want = oracle_grads(torch.float64)
+    cpu32 = oracle_grads(torch.float32)
+    bad, rel, rel32 = [], [], []
+    for k in sorted(pkeys):
+        ref = want[k]
+        mx = float(ref.abs().max())
+        err = float((g[k].cpu().double() - ref).abs().max())
+        err32 = float((cpu32[k] - ref).abs().max())
+        rel.append(err / (mx + 1e-300))
+        rel32.append(err32 / (mx + 1e-300))
+        if err > 2e-3 * mx + 2.0 * err32 + 1e-12:
+            bad.append((k, err, err32, mx))
+    rel.sort()
+    rel32.sort()
+    print("frozen-BatchNorm train step at 1x3x1024x2048 ({}), {} tensors, gradient error / max against the float64 "
+          "oracle: kernels median {:.2e}, p95 {:.2e}, worst {:.2e}; the fp32 CPU oracle itself median {:.2e}, p95 "
+          "{:.2e}, worst {:.2e}".format(net_name, len(rel), rel[len(rel) // 2], rel[int(0.95 * (len(rel) - 1))], rel[-1],
+                                        rel32[len(rel32) // 2], rel32[int(0.95 * (len(rel32) - 1))], rel32[-1]))
+    assert not bad, "{} of {} gradients off: {}".format(len(bad), len(rel), bad[:8])
+    assert rel[len(rel) // 2] <= 1.25 * rel32[len(rel32) // 2] + 1e-5, (rel[len(rel) // 2], rel32[len(rel32) // 2])
+    assert rel[int(0.95 * (len(rel) - 1))] <= 1.25 * rel32[int(0.95 * (len(rel32) - 1))] + 1e-5
 
 
 @pytest.mark.parametrize("net_name", ["wacv_arch0", "wacv_arch1"])
@@ -199,6 +309,13 @@ def test_baseline_batch_replay_equals_host_launches(net_name):
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k
     assert len(mo0) == len(mo1) and all(torch.equal(a, b) for a, b in zip(mo0, mo1))
+
+
+def _train_loss(out, target):
+    """the loss of engine.trainer.segmenter_step (src/engine/trainer.py:236-241): labels resized to the logits"""
+    from nas_segm_amd import functional as F
+
+    return F.log_softmax_nll(out, F.nearest_label_resize(target, out.shape[2:]), 255)
 
 
 def _frozen_bn_gradients(net, x, backward):
