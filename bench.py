@@ -838,6 +838,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_value = float(loss.item())
+    peak_gib = torch.cuda.max_memory_allocated(device) / 2.0 ** 30  # (warm-up + timed steps; before the roofline passes)
     reward = None
     if args.workload == "search713":
         # the candidate's reward on one batch: fused upsample -> argmax -> confusion matrix on the GPU,
@@ -983,6 +984,7 @@ def main():
                                        args.workload, wl[6], args.batch, args.height, args.width),
                        "global_batch": args.batch * world, "parallelism": "dp{}".format(world),
                        "loss": loss_value, "reward": reward,
+                       "max_memory_allocated_gib": round(peak_gib, 2),
                        "launch": ("host", "hipGraph(fwd+loss+bwd)", "hipGraph(whole step)" if args.workload != "task0"
                                   else "hipGraph(gather+fwd+loss+bwd), chosen by engine.graphed.auto_graph")[args.graph]},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,

@@ -138,7 +138,6 @@ class deferred_wgrad(object):
     #                (nasseg_conv_wgrad_many / nasseg_dwconv_wgrad_many)
     side_ok = False  # first stages may go to a second stream (WGRAD_STREAM; never while a hipGraph is captured)
     side_used = {}   # device -> that stream, once a launch went there
-    side_keep = []   # what those launches read and write: alive until the streams have joined
 
     def __init__(self, enabled=True, params=None, second_stream=True):
         """params: the parameters being trained; when given, the exit verifies that every
@@ -184,16 +183,13 @@ class deferred_wgrad(object):
         todo, deferred_wgrad.pending = deferred_wgrad.pending, []
         groups, deferred_wgrad.grouped = deferred_wgrad.grouped, {}
         sides, deferred_wgrad.side_used = deferred_wgrad.side_used, {}
-        keep, deferred_wgrad.side_keep = deferred_wgrad.side_keep, []
         if exc_type is None:
             for (entry, dtype), calls in groups.items():
                 self._launch_group(entry, dtype, calls, current_stream())
                 todo.extend(c[2] for c in calls)
-        # the second stream's launches read tensors of this one and fill the partial sums finalised below: join
-        # (also after an exception: what they read is released when this returns)
+        # the second stream's launches fill the partial sums finalised below: join (also after an exception)
         for dev, side in sides.items():
             torch.cuda.current_stream(dev).wait_stream(side)
-        del keep
         if exc_type is None:
             if todo:
                 self._finalize(todo, current_stream())
@@ -232,7 +228,8 @@ _RECORD_GROUP = int(os.environ.get("NASSEG_WGRAD_RECORD_GROUP", "1000000"))
 
 def _wgrad_stream(t, keep):
     """the stream a first-stage weight-gradient launch over ``t`` goes to, after it has been made to wait for the
-    current one: the second stream (``keep`` then stays referenced until the exit of deferred_wgrad), else the current"""
+    current one: the second stream (``keep`` - the tensors the launch touches, or the queued calls of a grouped launch -
+    is then recorded on it for the allocator), else the current"""
     if not (deferred_wgrad.side_ok and t.is_cuda and (WGRAD_STREAM & 1 or isinstance(keep, list))):
         return current_stream()
     side = deferred_wgrad.side_used.get(t.device)
@@ -243,7 +240,13 @@ def _wgrad_stream(t, keep):
             LaunchProfiler.streams[side.cuda_stream] = side
         deferred_wgrad.side_used[t.device] = side
     side.wait_stream(torch.cuda.current_stream(t.device))
-    deferred_wgrad.side_keep.append(keep)
+    # What the launch reads and writes must not be handed out again before the second stream is through with it -
+    # and must not stay allocated until the end of backward either (round 5 kept references until the exit: peak
+    # memory of a large step grew towards activations + every dz).  record_stream tells the caching allocator
+    # exactly that: the block is reusable once the second stream has passed the point where it was freed.
+    for item in (keep if isinstance(keep, tuple) else [x for c in keep for x in c[0]]):
+        if item is not None:
+            item.record_stream(side)
     return side.cuda_stream
 
 

@@ -885,7 +885,9 @@ def test_weight_gradients_on_the_second_stream_are_bit_identical(mode, monkeypat
     """inside deferred_wgrad the first stages may run on a second stream (functional.WGRAD_STREAM: 1 = the launches of
     large layers, 2 = the grouped small ones, eight at a time as backward meets them) that waits for the chain's stream
     before each launch and is waited for once at the exit: same gradients bit for bit as with everything on one
-    stream - on poisoned memory, with the memory the launches read released and overwritten right after the exit"""
+    stream - on poisoned memory, with the memory the launches read released and overwritten right after the exit (what
+    the second stream touches is recorded on it for the caching allocator, Tensor.record_stream: nothing is kept alive
+    until the exit, and peak memory with the second stream equals peak memory without - profiles/r06_wgrad_stream_memory.txt)"""
     f = F()
     torch.manual_seed(5)
     # 20 small layers (two groups of eight flushed during backward + a rest at the exit), alternating dense /
@@ -918,7 +920,7 @@ def test_weight_gradients_on_the_second_stream_are_bit_identical(mode, monkeypat
         del x, yb, loss
         poison = torch.full((96 << 20,), float("nan"), device=DEV)  # (recycles what the second stream was reading)
         del poison
-        assert not f.deferred_wgrad.side_used and not f.deferred_wgrad.side_keep
+        assert not f.deferred_wgrad.side_used
         return [t.grad.clone() for t in leaves], used
 
     g0, used0 = run(0)
