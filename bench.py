@@ -93,12 +93,21 @@ def algorithmic_bytes(name, a):
         from nas_segm_amd import functional as NF
 
         # (z = W x is rebuilt from the input tile where the kernel can: not an operand it needs, not charged)
-        nz = 2 if NF.lib.query("nasseg_conv_pw_bwd_reads_z", B, H, W, K, N) else 1
+        # (... and always where z == NULL: the expansion behind nasseg_irdw_fwd was never stored)
+        nz = 2 if (a[2] and NF.lib.query("nasseg_conv_pw_bwd_reads_z", B, H, W, K, N)) else 1
         skip = 1 if a[26] else 0  # (dx_res: the skip's gradient, read once)
         return 4 * (B * H * W * ((2 + skip) * K + nz * N) + 2 * N * K)
     if name == "nasseg_dwconv_bwd_bn":  # xz, g, z read, ge written
         B, H, W, C, Ho, Wo = a[20], a[21], a[22], a[23], a[24], a[25]
         return 4 * (2 * B * C * H * W + 2 * B * C * Ho * Wo + 18 * C)
+    if name == "nasseg_irdw_fwd":  # x read, the depthwise output written: the expanded map exists in registers only
+        B, H, W, K, C, Ho, Wo = a[10], a[11], a[12], a[13], a[14], a[15], a[16]
+        return 4 * (B * H * W * K + B * Ho * Wo * C + C * K + 9 * C)
+    if name == "nasseg_irdw_bwd":  # x, g, z2 read, ge written
+        B, H, W, K, C, Ho, Wo = a[24], a[25], a[26], a[27], a[28], a[29], a[30]
+        return 4 * (B * H * W * (K + C) + 2 * B * Ho * Wo * C + C * K + 18 * C)
+    if name == "nasseg_irdw_stats":  # one pass over the block's input
+        return 4 * a[5] * a[6] * a[7] * a[8]
     if name == "nasseg_conv_wgrad_bn":  # x, g, z read, dz written (BatchNorm backward applied on load)
         B, H, W, K, N = a[20], a[21], a[22], a[23], a[24]
         return 4 * (B * H * W * (K + 3 * N) + N * K)
@@ -465,7 +474,9 @@ def kernel_family(name, a):
            "nasseg_dwconv": "dw_fwd_strip", "nasseg_dwconv_bwd_data_bn": "dw_fwd_strip",
            "nasseg_dwconv_wgrad": "dw_wgrad_strip", "nasseg_dwconv_wgrad_bn": "dw_wgrad_strip",
            "nasseg_bn_bwd_apply": "bn_bwd_apply_kernel", "nasseg_affine_act": "affine_act_kernel",
-           "nasseg_bn_stats": "colred_kernel", "nasseg_bn_bwd_reduce": "colred_kernel"}
+           "nasseg_bn_stats": "colred_kernel", "nasseg_bn_bwd_reduce": "colred_kernel",
+           "nasseg_irdw_fwd": "irdw_fwd_kernel", "nasseg_irdw_bwd": "irdw_bwd_kernel",
+           "nasseg_irdw_stats": "ir_moments_kernel"}
     return fam.get(base, base)
 
 

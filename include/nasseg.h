@@ -94,6 +94,35 @@ int nasseg_sepconv_fwd(const float* x, const float* wdw, const float* wpw, float
                        int W, int C, int Ho, int Wo, int N, int K, int stride, int pad, int dil,
                        float* stats, void* stream);
 
+/* ---- InvertedResidual with its expansion never stored (layer_factory.py:125-158) ---------------------------
+ * The 1x1 expansion K -> C = 6 K + BatchNorm + ReLU6 in front of the 3x3 depthwise conv is six times wider than the
+ * block's input; its raw output z1 = W1 x is K / 4 MFMA steps per 16 x 16 tile.  Statistics of z1: a nasseg_conv_fwd
+ * call with y == NULL (nothing stored).  nasseg_irdw_fwd: z2 = dwconv3x3(act1(bn1_scale * (W1 pro(x)) + bn1_shift)),
+ * pad 1, stride 1 | 2, with statistics rows of z2; nasseg_irdw_bwd: nasseg_dwconv_bwd_bn with z1 rebuilt from x.
+ * w1: (C, K, 1, 1) as PyTorch stores it; wdw: packed [9][C] (nasseg_dw_pack_weight; wdw_flipped != 0: its rotated
+ * packing); pro(x) = in_act(in_scale * x + in_shift) (null: none).  Rows (workgroups) of statistics [r][2][C] and of
+ * weight-gradient partials [r][9][C]: nasseg_irdw_rows(.., backward); 0 = geometry not served (K % 4 == 0, K <= 32,
+ * C % 16 == 0, C <= 192: MobileNetV2's 16 -> 96, 24 -> 144, 32 -> 192). */
+int64_t nasseg_irdw_rows(int B, int H, int W, int K, int C, int stride, int backward);
+/* Training-mode BatchNorm statistics of z1 = W1 pro(x) WITHOUT computing z1: z1 is linear in pro(x), so its first and
+ * second moments per output channel follow from the K-vector and K x K matrix of moments of pro(x) (one pass over the
+ * block's input).  Writes what nasseg_bn_finalize writes for the stored map (to the rounding of the sums).
+ * ws: nasseg_irdw_stats_workspace(K) floats. */
+int64_t nasseg_irdw_stats_workspace(int K);
+int nasseg_irdw_stats(const float* x, const float* w1, const float* in_scale, const float* in_shift, int in_act, int B,
+                      int H, int W, int K, int C, float eps, float momentum, const float* gamma, const float* beta,
+                      float* mean, float* invstd, float* scale, float* shift, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float* ws, void* stream);
+int nasseg_irdw_fwd(const float* x, const float* w1, const float* wdw, float* z2, const float* in_scale,
+                    const float* in_shift, int in_act, const float* bn1_scale, const float* bn1_shift, int act1,
+                    int B, int H, int W, int K, int C, int Ho, int Wo, int stride, float* stats, void* stream);
+int nasseg_irdw_bwd(const float* x, const float* w1, const float* g, const float* z2, const float* wdw,
+                    int wdw_flipped, float* ge, float* dw, float* ws, const float* in_scale, const float* in_shift,
+                    int in_act, const float* bn1_scale, const float* bn1_shift, const float* bn1_mean,
+                    const float* bn1_invstd, int act1, const float* bn2_scale, const float* bn2_shift,
+                    const float* bn2_mean, const float* bn2_invstd, const float* bn2_sums, int bn2_train, int bn2_act,
+                    int B, int H, int W, int K, int C, int Ho, int Wo, int stride, float* stats, void* stream);
+
 /* ---- dense convolution on the fp32 matrix cores ----------------------------
  * replaces conv1x1 / conv3x3 / conv_bn / conv_bn_relu (layer_factory.py:7-24,
  * 94-122), every pointwise stage (:125-382) and the classifier heads
@@ -108,6 +137,8 @@ int nasseg_conv_pack_weight(const float* w, float* wp, int N, int K, int kh, int
 int nasseg_pack_weights(int count, const float* const* w, float* const* wp, const int* dims,
                         void* stream);
 int nasseg_conv_fwd_pack_mode(int K, int kh, int kw);
+/* y == NULL with stats != NULL: only the statistics rows are produced, nothing is stored - for a pointwise conv the
+ * N-split persistent kernel serves (nasseg_conv_pointwise_kernel == 2), else an error. */
 int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
                     const float* in_scale, const float* in_shift, int in_act,
                     const float* out_scale, const float* out_shift, int out_act, const float* res,
@@ -222,7 +253,9 @@ int nasseg_dwconv_wgrad_bn(const float* x, const float* g, const float* z, float
 int64_t nasseg_conv_pw_bwd_slabs(int B, int H, int W, int K, int N);
 /* 1: nasseg_conv_pw_bwd_bn loads z for this geometry; 0: it rebuilds z = W x from the input tile it stages anyway (the
  * narrow kernel with its weight in LDS: same operand mapping and accumulation order as the forward kernels, the same
- * bits) and z is not read.  Either way z must BE the conv's raw output.  For measurement tools and tests. */
+ * bits) and z is not read.  A z that is passed must BE the conv's raw output; z == NULL says it was never stored
+ * (nasseg_irdw_fwd) and forces the rebuild - an error where no kernel can (K > 32, N > 144).  For measurement tools
+ * and tests. */
 int64_t nasseg_conv_pw_bwd_reads_z(int B, int H, int W, int K, int N);
 /* pixels from which nasseg_conv_pw_bwd_bn rebuilds z (where it can: K <= 32, N <= 96): 2^18 initially; 0: every
  * supported geometry, a huge value: none.  v < 0 only queries.  Returns the previous setting. */
@@ -460,6 +493,22 @@ typedef uint16_t nasseg_bf16_t;
  * GAPConv1x1's fp32 island (layer_factory.py:181-195) in a bf16-storage network */
 int nasseg_to_bf16(const float* x, nasseg_bf16_t* y, int64_t n, void* stream);
 int nasseg_from_bf16(const nasseg_bf16_t* x, float* y, int64_t n, void* stream);
+int nasseg_bf16_irdw_stats(const nasseg_bf16_t* x, const float* w1, const float* in_scale, const float* in_shift,
+                           int in_act, int B, int H, int W, int K, int C, float eps, float momentum, const float* gamma,
+                           const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float* ws,
+                           void* stream);
+int nasseg_bf16_irdw_fwd(const nasseg_bf16_t* x, const float* w1, const float* wdw, nasseg_bf16_t* z2,
+                         const float* in_scale, const float* in_shift, int in_act, const float* bn1_scale,
+                         const float* bn1_shift, int act1, int B, int H, int W, int K, int C, int Ho, int Wo, int stride,
+                         float* stats, void* stream);
+int nasseg_bf16_irdw_bwd(const nasseg_bf16_t* x, const float* w1, const nasseg_bf16_t* g, const nasseg_bf16_t* z2,
+                         const float* wdw, int wdw_flipped, nasseg_bf16_t* ge, float* dw, float* ws,
+                         const float* in_scale, const float* in_shift, int in_act, const float* bn1_scale,
+                         const float* bn1_shift, const float* bn1_mean, const float* bn1_invstd, int act1,
+                         const float* bn2_scale, const float* bn2_shift, const float* bn2_mean,
+                         const float* bn2_invstd, const float* bn2_sums, int bn2_train, int bn2_act, int B, int H, int W,
+                         int K, int C, int Ho, int Wo, int stride, float* stats, void* stream);
 int nasseg_bf16_dwconv_bwd_bn(const nasseg_bf16_t* xz, const nasseg_bf16_t* g, const nasseg_bf16_t* z, const float* wt,
                               int wt_flipped, nasseg_bf16_t* ge, float* dw, float* ws, const float* in_scale, const float* in_shift,
                               const float* in_mean, const float* in_invstd, int in_act, const float* bn_scale,

@@ -1275,6 +1275,8 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
   if (!g.transposed && fwd_pack_mode(K, g.kh, g.kw) == 2) md.km = KM_FLAT;
   NASSEG_REQUIRE(!md.pro || (md.km == KM_VEC && !md.gather && md.vecn),
                  "conv_fwd: the input prologue needs a pointwise conv with K %% 4 == 0, N %% 4 == 0");
+  NASSEG_REQUIRE(a.y || (md.stats == 1 && !md.gather && md.km != KM_FLAT),
+                 "conv_fwd: y == NULL needs statistics rows and a pointwise conv");
   const int tiles = cdiv(N, 16);
   if (!md.gather && md.km != KM_FLAT) {
     // the N-split persistent kernel (conv_pwn.hip) where its plan says so
@@ -1285,6 +1287,7 @@ int conv_dispatch(FwdArgs& a, int stats_mode, hipStream_t s) {
                      "conv_fwd: the pointwise statistics path needs channel strides that are multiples of 4");
       if (aligned) return NASSEG_INTERNAL(pwn_launch)(a, pn, md.stats, s);
     }
+    NASSEG_REQUIRE(a.y, "conv_fwd: y == NULL (statistics only) is served by the N-split pointwise kernel alone");
     const PwFwdPlan pw = pw_fwd_plan((int64_t)g.B * g.Ho * g.Wo, N, K, stats_mode >= 2 ? 2 : 1);
     if (pw.ok) {
       const bool aligned = md.km == KM_VEC && md.vecn;

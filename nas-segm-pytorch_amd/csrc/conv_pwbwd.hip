@@ -822,15 +822,21 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
                               const float* bn_mean, const float* bn_invstd, const float* bn_sums,
                               int bn_train, int bn_act, int B, int H, int W, int K, int N, const float* in_mean,
                               const float* in_invstd, float* dx_stats, const act_t* dx_res, void* stream) {
-  NASSEG_REQUIRE(x && g && z && wb && dx && ws && bn_scale, "conv_pw_bwd_bn: null tensor");
+  NASSEG_REQUIRE(x && g && wb && dx && ws && bn_scale, "conv_pw_bwd_bn: null tensor");
   NASSEG_REQUIRE(!dx_stats || (in_mean && in_invstd), "conv_pw_bwd_bn: dx_stats needs in_mean / in_invstd");
   NASSEG_REQUIRE(!dx_res || (!dx_stats && K % 4 == 0), "conv_pw_bwd_bn: dx_res needs K %% 4 == 0 and no dx_stats");
   NASSEG_REQUIRE((!bn_train || (bn_mean && bn_invstd && bn_sums)) && (!bn_act || bn_shift),
                  "conv_pw_bwd_bn: missing BatchNorm tensors");
   NASSEG_REQUIRE(B > 0 && H > 0 && W > 0, "conv_pw_bwd_bn: bad geometry");
   const int64_t M = (int64_t)B * H * W;
-  const PwPlan p = pw_plan(M, N, K);
+  PwPlan p = pw_plan(M, N, K);
   NASSEG_REQUIRE(p.ok, "conv_pw_bwd_bn: no fused kernel for K=%d N=%d", K, N);
+  if (!z) {
+    // the conv's output was never stored (nasseg_irdw_fwd): the kernel must rebuild it, whatever the plan prefers
+    NASSEG_REQUIRE(!p.wide && p.kt <= 2 && p.nt <= 9 && pw_weight_in_lds(p.nt, p.kt),
+                   "conv_pw_bwd_bn: z == NULL, but K=%d N=%d has no kernel that rebuilds z", K, N);
+    p.rz = 1;
+  }
   PwArgs a = {};
   a.x = x; a.g = g; a.z = z; a.dx = dx; a.partial = ws; a.wb = wb;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
@@ -874,6 +880,7 @@ int NASSEG_FN(conv_pw_bwd_bn)(const act_t* x, const act_t* g, const act_t* z, co
   }
 #define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_ && p.rz) pw_launch<NT_, KT_, true>(a, p.nslab, pro, s); else
   PW_CASE(2, 1) PW_CASE(3, 1) PW_CASE(4, 1) PW_CASE(6, 1) PW_CASE(2, 2) PW_CASE(3, 2) PW_CASE(4, 2) PW_CASE(6, 2)
+  PW_CASE(9, 2)  // (24 -> 144: slower than loading z by itself, faster than storing z for it - only when z == NULL)
 #undef PW_CASE
 #define PW_CASE(NT_, KT_) if (p.nt == NT_ && p.kt == KT_) pw_launch<NT_, KT_>(a, p.nslab, pro, s); else
   PW_CASE(2, 1) PW_CASE(3, 1) PW_CASE(4, 1) PW_CASE(6, 1) PW_CASE(9, 1) PW_CASE(12, 1)

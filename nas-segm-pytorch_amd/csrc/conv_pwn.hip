@@ -316,8 +316,9 @@ __global__ __launch_bounds__(256, 2) void conv_pwn_kernel(FwdArgs a) {
           const float4 d0 = sel4(lo, fin[0], got);  // pixel (j & 7)
           const float4 d1 = sel4(lo, got, fin[1]);  // pixel (j & 7) + 8
           const int m0 = m_base + mt * 16 + (j & 7);
-          if (nsok && m0 < Mtot) sta4(a.y + (int64_t)m0 * a.ldy + ns, d0);
-          if (nsok && m0 + 8 < Mtot) sta4(a.y + (int64_t)(m0 + 8) * a.ldy + ns, d1);
+          // (a.y == null: the statistics-only pass in front of nasseg_irdw_fwd - nothing is stored)
+          if (a.y && nsok && m0 < Mtot) sta4(a.y + (int64_t)m0 * a.ldy + ns, d0);
+          if (a.y && nsok && m0 + 8 < Mtot) sta4(a.y + (int64_t)(m0 + 8) * a.ldy + ns, d1);
         }
       }
     }

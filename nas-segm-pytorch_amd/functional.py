@@ -868,6 +868,49 @@ def _sepconv_ok(x, w_dw, w_pw, op_dw, op_pw, needs_grad):
     return lib.query("nasseg_sepconv_blocks", B, C, Ho, Wo, N, k, stride, dil) > 0
 
 
+# InvertedResidual's expansion never stored (csrc/irdw.hip; reference src/nn/layer_factory.py:125-158): a pointwise
+# conv K -> N = 6 K + BatchNorm + activation in front of a 3x3 depthwise conv + BatchNorm, in a training step.  The
+# expansion's statistics come from the moments of its INPUT (nasseg_irdw_stats), the depthwise forward and the
+# one-kernel depthwise backward rebuild the expanded map on the matrix cores (nasseg_irdw_fwd / _bwd), the pointwise
+# backward rebuilds it as it already did (nasseg_conv_pw_bwd_bn with z == NULL): the map - six times the block's input,
+# 805 MB for 16 -> 96 at 4x512x1024 - is neither written nor read.  Where it pays (tools/kbench_irdw.py, MI355X, us for
+# expansion + depthwise forward / depthwise backward): 16 -> 96 stride 2 at 4x512x1024 426 -> 230 / 404 -> 470,
+# 24 -> 144 stride 1 at 4x256x512 257 -> 184 / 332 -> 318; not 24 -> 144 stride 2 (190 -> 135 / 164 -> 213, and its
+# pointwise backward loses 9 us to the rebuild) nor 32 -> 192 (no kernel of the pointwise backward rebuilds twelve
+# channel tiles).  NASSEG_IRDW=0 switches it off (A/B); maps below NASSEG_IRDW_MIN_PIXELS keep the stored form (the
+# extra launches of the statistics cost more than the bytes).
+IRDW = os.environ.get("NASSEG_IRDW", "1") != "0"
+_IRDW_MIN_PIXELS = int(os.environ.get("NASSEG_IRDW_MIN_PIXELS", 1 << 18))
+
+
+def _irdw_ok(ops, i, weights, cur, pend, needs_in_grad, need_w, training):
+    """op i is such an expansion, op i + 1 its depthwise conv, and every kernel involved serves the geometry"""
+    if not IRDW or i + 1 >= len(ops):
+        return False
+    kind, stride, pad, dil, has_bn, act = ops[i][:6]
+    kind2, stride2, pad2, dil2, has_bn2 = ops[i + 1][:5]
+    w, w2 = weights[i], weights[i + 1]
+    if not (kind == "dense" and kind2 == "dw" and has_bn and has_bn2 and training and ops[i + 1][6]):
+        return False
+    N, K, kh, kw = w.shape
+    if not (kh == 1 and kw == 1 and stride == 1 and pad == 0 and w2.shape[-1] == 3 and pad2 == 1 and dil2 == 1
+            and stride2 in (1, 2) and w2.shape[0] == N):
+        return False
+    if not (needs_in_grad and need_w):  # (the one-kernel backwards need both gradients)
+        return False
+    B, _, H, W = cur.shape
+    if B * H * W < _IRDW_MIN_PIXELS or not (N > K and K % 4 == 0):
+        return False
+    if not ((stride2 == 1 and N <= 144) or (stride2 == 2 and K <= 16)):
+        return False
+    if pend is not None and pend[0] is None and pend[1] is None and not pend[2]:
+        return False
+    return (lib.query("nasseg_irdw_rows", B, H, W, K, N, stride2, 0) > 0
+            and lib.query("nasseg_irdw_rows", B, H, W, K, N, stride2, 1) > 0
+            and lib.query("nasseg_conv_pw_bwd_slabs", B, H, W, K, N) > 0
+            and lib.query("nasseg_dwconv_bwd_bn_rows", B, N, H, W, 3, stride2, 1, 1) > 0)
+
+
 class _ConvChain(torch.autograd.Function):
     """A run of convolutions (dense on the MFMA path or depthwise), each optionally followed
     by BatchNorm (+ReLU/ReLU6), as ONE autograd node in which a normalised activation that
@@ -930,11 +973,49 @@ class _ConvChain(torch.autograd.Function):
                     items.append((weights[i], 1 if fused else _dense_dgrad_form(weights[i], stride, pad, dil)))
         packed = _pack_many(x, items)
         fused_dw = None  # (z_dw, ...) of a depthwise conv already computed together with the next op
+        skip_op = False
         for i, (kind, stride, pad, dil, has_bn, act, training, momentum, eps) in enumerate(ops):
+            if skip_op:  # (the depthwise half of an InvertedResidual expansion: done with op i - 1 below)
+                skip_op = False
+                continue
             w, gamma, beta, rm, rv, nbt = tensors[6 * i:6 * i + 6]
             w = weights[i]
             B, K, H, W = cur.shape
             last = i == n_ops - 1
+            if (needs_grad and fused_dw is None and i + 1 < n_ops
+                    and _irdw_ok(ops, i, weights, cur, pend, i > 0 or ctx.needs_input_grad[1],
+                                 ctx.needs_input_grad[3 + 6 * i] and ctx.needs_input_grad[3 + 6 * (i + 1)], training)):
+                # ---- expansion + depthwise with the expanded map never stored (csrc/irdw.hip) ----
+                N = w.shape[0]
+                psc, psh, pact = pend if pend is not None else (None, None, ACT_NONE)
+                st1 = _vec(cur, 4 * N)
+                mean1, invstd1, scale1, shift1 = st1[0:N], st1[N:2 * N], st1[2 * N:3 * N], st1[3 * N:]
+                wsm = _ws(cur, lib.query("nasseg_irdw_stats_workspace", K))
+                lib.call(_k("nasseg_irdw_stats", cur), ptr(cur), ptr(w), ptr(psc), ptr(psh), pact, B, H, W, K, N,
+                         float(eps), float(momentum), ptr(gamma), ptr(beta), ptr(mean1), ptr(invstd1), ptr(scale1),
+                         ptr(shift1), ptr(rm), ptr(rv), ptr(nbt), ptr(wsm), s)
+                saved.extend([cur, psc, psh, None, st1, w, packed[bwd_slot[i]] if bwd_slot[i] is not None else None])
+                meta.append((pact,))
+                _, stride2, pad2, dil2, _, act2, _, momentum2, eps2 = ops[i + 1]
+                w2, gamma2, beta2, rm2, rv2, nbt2 = tensors[6 * (i + 1):6 * (i + 1) + 6]
+                w2 = weights[i + 1]
+                Ho, Wo = conv_out_size(H, 3, stride2, 1, 1), conv_out_size(W, 3, stride2, 1, 1)
+                z2 = _new(cur, B, N, Ho, Wo)
+                st2 = _vec(cur, 4 * N)
+                rows2 = lib.query("nasseg_irdw_rows", B, H, W, K, N, stride2, 0)
+                part2 = _ws(cur, (rows2 + 64) * 2 * N)
+                lib.call(_k("nasseg_irdw_fwd", cur), ptr(cur), ptr(w), ptr(packed[i + 1]), ptr(z2), ptr(psc), ptr(psh),
+                         pact, ptr(scale1), ptr(shift1), act, B, H, W, K, N, Ho, Wo, stride2, ptr(part2), s)
+                lib.call("nasseg_bn_finalize", ptr(part2), rows2, B * Ho * Wo, N, float(eps2), float(momentum2),
+                         ptr(gamma2), ptr(beta2), ptr(st2[0:N]), ptr(st2[N:2 * N]), ptr(st2[2 * N:3 * N]),
+                         ptr(st2[3 * N:]), ptr(rm2), ptr(rv2), ptr(nbt2), s)
+                # (input None: the depthwise conv's input does not exist - backward rebuilds it from op i's)
+                saved.extend([None, scale1, shift1, z2, st2, w2,
+                              packed[bwd_slot[i + 1]] if bwd_slot[i + 1] is not None else None])
+                meta.append((act,))
+                cur, pend = z2, (st2[2 * N:3 * N], st2[3 * N:], act2)
+                skip_op = True
+                continue
             if (kind == "dw" and not has_bn and not last and FUSE_SEPCONV and ops[i + 1][0] == "dense"
                     and not (i + 2 == n_ops and res is not None and not needs_grad)
                     and _sepconv_ok(cur, w, weights[i + 1], ops[i], ops[i + 1], needs_grad)):
@@ -1149,22 +1230,35 @@ class _ConvChain(torch.autograd.Function):
             kind, stride, pad, dil, has_bn, act, training, momentum, eps = ops[i]
             cur, psc, psh, z, stats, w, wb = sv[7 * i:7 * i + 7]
             (pact,) = meta[i]
-            B, N, Ho, Wo = z.shape
+            # InvertedResidual's expansion that was never stored (forward: _irdw_ok): the depthwise op has no input
+            # tensor, the expansion no output tensor - their one-kernel backwards rebuild it
+            ir_dw = cur is None
+            ir_pw = z is None
+            if ir_pw:
+                B, N, Ho, Wo = cur.shape[0], w.shape[0], cur.shape[2], cur.shape[3]
+            else:
+                B, N, Ho, Wo = z.shape
             M = B * Ho * Wo
             need_dw = ctx.needs_input_grad[3 + 6 * i]
             need_dx = i > 0 or ctx.needs_input_grad[1]
             fused_bn = None  # BatchNorm backward applied by the weight-gradient kernel on load
             if has_bn:
                 mean, invstd, scale, shift = stats[0:N], stats[N:2 * N], stats[2 * N:3 * N], stats[3 * N:]
-                sums = _vec(z, 2 * N)
+                sums = _vec(g, 2 * N)
                 act_left = ACT_NONE if (pre is not None or g_masked) else act  # (the mask still to be applied to g)
                 pw_bact = act_left
                 go_on = need_dw or need_dx
-                pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops) if go_on else 0
-                dw_rows = _dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops) if go_on else 0
+                if ir_pw:
+                    pw_nsl, dw_rows = lib.query("nasseg_conv_pw_bwd_slabs", B, Ho, Wo, cur.shape[1], N), 0
+                elif ir_dw:
+                    pw_nsl, dw_rows = 0, 1
+                else:
+                    pw_nsl = _pw_bwd_slabs(kind, cur, z, w, stride, pad, need_dw, need_dx, i, ops) if go_on else 0
+                    dw_rows = (_dw_bwd_rows(kind, cur, z, w, stride, pad, dil, need_dw, need_dx, i, ops)
+                               if go_on else 0)
                 # the stem (small-K k x k conv, no gradient for the image): BatchNorm backward on load in the
                 # weight-gradient kernel, dz never written (nasseg_conv_wgrad_bn_flat)
-                flat_bn = go_on and _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z)
+                flat_bn = go_on and not (ir_pw or ir_dw) and _flat_bn_ok(kind, need_dw, need_dx, psc, psh, pact, w, N, z)
                 on_load = go_on and (pw_nsl > 0 or dw_rows > 0 or flat_bn)  # (a kernel below applies the BatchNorm backward)
                 wgrad_bn = go_on and not on_load and need_dw and _wgrad_bn_ok(kind, cur, z, w, stride, pad, dil)
                 plain_apply = go_on and not on_load and not wgrad_bn  # (dz by a bn_bwd_apply pass)
@@ -1202,6 +1296,26 @@ class _ConvChain(torch.autograd.Function):
                 if not (need_dw or need_dx):
                     g = None
                     break
+            if ir_dw:
+                # ---- the depthwise conv behind a rebuilt expansion: nasseg_dwconv_bwd_bn with z1 = W1 x from op i - 1 ----
+                x_in, xpsc, xpsh, _, st1, w1, _ = sv[7 * (i - 1):7 * (i - 1) + 7]
+                (xpact,) = meta[i - 1]
+                Bc, K1, H, W = x_in.shape
+                K = N
+                rows = lib.query("nasseg_irdw_rows", Bc, H, W, K1, K, stride, 1)
+                dwt = torch.empty_like(w)
+                ws = _ws(g, rows * 9 * K)
+                part = _ws(g, (rows + 64) * 2 * K)
+                g_in = _new(g, Bc, K, H, W)
+                lib.call(_k("nasseg_irdw_bwd", x_in), ptr(x_in), ptr(w1), ptr(g), ptr(z), ptr(wb), int(stride == 1),
+                         ptr(g_in), _finish_wgrad(ws, dwt, 9, K, 1, 0), ptr(ws), ptr(xpsc), ptr(xpsh), xpact,
+                         ptr(st1[2 * K:3 * K]), ptr(st1[3 * K:]), ptr(st1[0:K]), ptr(st1[K:2 * K]), ops[i - 1][5],
+                         ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), pw_bact,
+                         Bc, H, W, K1, K, Ho, Wo, stride, ptr(part), s)
+                grads[6 * i] = dwt
+                g, pre = g_in, (part, rows)
+                g_masked = False
+                continue
             Bc, K, H, W = cur.shape
             pre = None
             g_masked = False

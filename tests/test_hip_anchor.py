@@ -131,14 +131,29 @@ EXPECT = {  # entry points the case is there for (fp32 names)
 }
 
 
+# ... with InvertedResidual's expansion never stored (functional._irdw_ok, csrc/irdw.hip): statistics from the moments of
+# the block's input, the expanded map rebuilt inside the depthwise forward / backward kernels and the pointwise backward
+EXPECT_IRDW = {
+    "ir_16_24_s2": ("nasseg_irdw_stats", "nasseg_irdw_fwd", "nasseg_irdw_bwd", "nasseg_conv_pw_bwd_bn"),
+    "ir_24_24": ("nasseg_irdw_stats", "nasseg_irdw_fwd", "nasseg_irdw_bwd", "nasseg_conv_pw_bwd_bn"),
+    "stem_stage1_2": ("nasseg_conv_wgrad_bn_flat", "nasseg_irdw_stats", "nasseg_irdw_fwd", "nasseg_irdw_bwd",
+                      "nasseg_conv_pw_bwd_bn"),
+}
+
+
 @pytest.mark.parametrize("batch", [1, 3])
+@pytest.mark.parametrize("irdw", [False, True], ids=["stored", "rebuilt"])
 @pytest.mark.parametrize("kind", sorted(EXPECT))
-def test_fused_chain_kernels_against_torch_cpu_autograd(kind, batch, monkeypatch):
+def test_fused_chain_kernels_against_torch_cpu_autograd(kind, irdw, batch, monkeypatch):
     """batch 3: several images per slab of the one-kernel backwards, tiles of the persistent pointwise kernel that
-    straddle image boundaries"""
+    straddle image boundaries; rebuilt: the expansions of the InvertedResidual cases are never stored"""
     if batch > 1 and kind in ("stem", "stem_stage1_2"):
         pytest.skip("the 128 x 256 image cases stay at one image (the float64 reference of three takes a minute)")
+    if irdw and kind not in EXPECT_IRDW:
+        pytest.skip("no InvertedResidual expansion that is served in this case")
     Fm = lower_thresholds(monkeypatch)
+    monkeypatch.setattr(Fm, "IRDW", irdw)
+    monkeypatch.setattr(Fm, "_IRDW_MIN_PIXELS", 0)
     mods, cin, (H, W), residual, relu_in = build(kind)
     randomise(mods, 5)
     ref = copy.deepcopy(mods).train()
@@ -178,8 +193,10 @@ def test_fused_chain_kernels_against_torch_cpu_autograd(kind, batch, monkeypatch
     yg = mods(xg) if is_pool else mods(xg, residual=xg if residual else None, relu_in=relu_in)
     yg.backward(dev(cot))
     monkeypatch.setattr(Fm.lib, "call", orig)
-    for name in EXPECT[kind]:
+    for name in (EXPECT_IRDW if irdw else EXPECT)[kind]:
         assert name in seen, "{}: {} did not run ({})".format(kind, name, sorted(set(seen)))
+    if irdw and kind != "stem_stage1_2":
+        assert "nasseg_dwconv_bwd_bn" not in seen and "nasseg_dwconv" not in seen
 
     def rel(a, b):
         return float((a.detach().cpu().double() - b.detach().double()).abs().max()) / (float(b.abs().max()) + 1e-30)
