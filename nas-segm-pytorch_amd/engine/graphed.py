@@ -76,6 +76,9 @@ class _GraphedStep(object):
     ``_forward_loss()`` (device tensors of ``self`` in, device scalar out), the modules whose
     parameters train (``self._trained``) and the clip / optimiser groups (``self.groups``)."""
 
+    plan = None    # engine/graph_dag.Plan when the recorded step replays as stages of lanes (else: the line, self.graph)
+    layout = None  # its summary
+
     def _init_common(self, segmenter, capture_optimisers, optimisers, warmup):
         self.segmenter = segmenter
         self.model = inner(segmenter)

@@ -55,7 +55,7 @@ env)
    free -g | head -2; cat /sys/fs/cgroup/memory.max 2>/dev/null) >> $OUT/env.log
   cat $OUT/env.log | tee -a $SUM ;;
 tests)
-  for f in tests/test_hip_kernels.py tests/test_hip_anchor.py tests/test_hip_golden.py tests/test_hip_engine.py \
+  for f in tests/test_hip_kernels.py tests/test_hip_irdw.py tests/test_hip_anchor.py tests/test_hip_golden.py tests/test_hip_engine.py \
            tests/test_hip_bf16.py tests/test_hip_fullsize.py tests/test_hip_optim.py; do
     n=$(basename $f .py)
     timeout 1200 python -m pytest $f -m gpu -q --tb=short --timeout 900 -p no:cacheprovider ${1:+-k "$1"} > $OUT/$n.log 2>&1
