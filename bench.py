@@ -404,7 +404,8 @@ def collect_pmc(passthrough, timeout_s=300):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, c), "-o",
                    "run", "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-roofline", "--pmc", "0", "--secondary", "0"] + list(passthrough)
+                   "--no-cpu-baseline", "--no-roofline", "--pmc", "0", "--secondary", "0", "--graph", "0"]
+            cmd += list(passthrough)  # (host-launched: the same kernels as a replay, and no capture-time trial replays)
             r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL)
             if r.returncode != 0:
@@ -645,9 +646,12 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: all ranks share GPU 0 (with --backend gloo on a 1-GPU box)")
-    ap.add_argument("--graph", type=int, default=0, choices=(0, 1, 2),
-                    help="0 = launch every kernel from the host; 1 = replay forward+loss+backward from a "
-                         "hipGraph (all-reduce, clip, optimisers outside); 2 = whole step in the graph (1 GPU)")
+    ap.add_argument("--graph", type=int, default=-1, choices=(-1, 0, 1, 2),
+                    help="-1 (default) = what the engine does by itself (engine.graphed.auto_graph: train_segmenter "
+                         "replays forward+loss+backward of steps up to AUTO_GRAPH_MAX_PIXELS image pixels per rank, "
+                         "laid out in lanes - mode 1 - and launches larger ones from the host - mode 0); 0 = launch "
+                         "every kernel from the host; 1 = replay forward+loss+backward from a hipGraph (all-reduce, "
+                         "clip, optimisers outside); 2 = whole step in the graph (1 GPU)")
     ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
                     help="storage type of activations and their gradients (arithmetic, statistics, "
                          "parameters and parameter gradients are fp32 either way); the BASELINE metric is f32")
@@ -799,6 +803,11 @@ def main():
         def eager_step():  # noqa: F811
             return task0_eager(rng.permutation(n_cache)[:args.batch])
 
+    graph_layout = None
+    graph_auto = args.graph < 0
+    if graph_auto and args.workload != "task0":
+        from nas_segm_amd.engine.graphed import auto_graph
+        args.graph = 1 if auto_graph(segmenter, args.batch * args.height * args.width) else 0
     step = eager_step
     if args.workload == "task0":
         args.graph = 2 if getattr(task0_step, "__self__", None) is not None else 0
@@ -818,6 +827,7 @@ def main():
         def step():
             return graphed.step(image, mask)
 
+        graph_layout = getattr(graphed, "layout", None) if getattr(graphed, "plan", None) is not None else None
         if rank == 0 and getattr(graphed, "layout", None):
             sys.stderr.write("graph layout: {}\n".format(graphed.layout))
 
@@ -888,7 +898,7 @@ def main():
             pmc_source = None
             if args.pmc == 1 or (args.pmc == -1 and os.environ.get("NASSEG_BENCH_PMC", "1") != "0"
                                  and world == 1 and args.workload == "headline" and args.batch == wl[3]
-                                 and not args.graph):
+                                 and (graph_auto or not args.graph)):
                 passthrough = ["--workload", args.workload, "--dtype", args.dtype, "--batch", str(args.batch),
                                "--height", str(args.height), "--width", str(args.width)]
                 torch.cuda.synchronize()
@@ -971,7 +981,8 @@ def main():
 
     secondary = None
     if rank == 0 and (args.secondary == 1 or (args.secondary == -1 and world == 1 and args.workload == "headline"
-                                              and args.batch == wl[3] and not args.graph and args.dtype == "f32")):
+                                              and args.batch == wl[3] and (graph_auto or not args.graph)
+                                              and args.dtype == "f32")):
         # (after everything the headline needs: its timed region, roofline passes and CPU baseline are done)
         del segmenter, net, optim_enc, optim_dec
         secondary = secondary_cvpr321(device, rank)
@@ -997,7 +1008,11 @@ def main():
                        "loss": loss_value, "reward": reward,
                        "max_memory_allocated_gib": round(peak_gib, 2),
                        "launch": ("host", "hipGraph(fwd+loss+bwd)", "hipGraph(whole step)" if args.workload != "task0"
-                                  else "hipGraph(gather+fwd+loss+bwd), chosen by engine.graphed.auto_graph")[args.graph]},
+                                  else "hipGraph(gather+fwd+loss+bwd), chosen by engine.graphed.auto_graph")[args.graph]
+                       + (", chosen by engine.graphed.auto_graph" if graph_auto and args.workload != "task0" else "")
+                       + (", {} lanes, {} line graphs, {} forks per step (line {} ms)".format(
+                           graph_layout.get("lanes"), graph_layout.get("parts"), graph_layout.get("forks"),
+                           graph_layout.get("line_ms")) if graph_layout and graph_layout.get("parts") else "")},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         if cpu:

@@ -42,7 +42,11 @@ from .trainer_common import clip_and_step, inner
 logger = logging.getLogger(__name__)
 
 # NASSEG_GRAPH: "auto" (default) | "0" (always launch from the host) | "1" (always replay)
-AUTO_GRAPH_MAX_PIXELS = 6 << 20
+# (round 6: 32 M pixels.  Until round 5 a replay of the 4x1024x2048 step ran level with host launches - the step is
+#  GPU-bound - and the limit stood at 6 M; laid out in lanes (engine/graph_dag.py) the replay is 8 % ahead: 279.5 ->
+#  302.4 images/s on the headline step, 204.5 -> 222.3 on WACV arch1, profiles/r06_graph_modes.txt.  The price is the
+#  graph's memory pool, which holds the SUM of the step's temporaries: 14.2 GiB instead of 6.2 at that size.)
+AUTO_GRAPH_MAX_PIXELS = 32 << 20
 
 
 def auto_graph(segmenter, n_pixels):
