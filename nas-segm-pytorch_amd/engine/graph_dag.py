@@ -345,35 +345,59 @@ def lay_out(recorder, raw_graph, n_nodes, lanes=None, durations=None):
 # ---------------------------------------------------------------------------------------------------------------
 # NASSEG_GRAPH_TRIALS=0: take the cost model's layout for LANES lanes unmeasured (default: time the candidates)
 TRIALS = os.environ.get("NASSEG_GRAPH_TRIALS", "1") != "0"
+# the order stages are cut in when layouts are not timed: "asap" | "recorded" (asap_order)
+ORDER = os.environ.get("NASSEG_GRAPH_ORDER", "asap")
 # cost of a stage with more than one lane (event record + waits on both sides), microseconds
 FORK_US = float(os.environ.get("NASSEG_GRAPH_FORK_US", "30"))
 _STAGE_WINDOW = 512  # longest stage the planner looks at, in units
 
 
-def plan_stages(units, deps, us, lanes=None, fork_us=None):
-    """Cut the recorded units into stages of connected components.
+def asap_order(units, deps, us):
+    """the units sorted by the time they could start at the earliest (unlimited lanes, no cost for crossing them) -
+    a topological order like the recording order, but one in which work that CAN overlap sits side by side: autograd
+    runs the backward of the most expensive cell first and the encoder's backward last, although the deep half of the
+    encoder's backward only waits for the small cells - in recording order no contiguous stage holds both."""
+    start = [0.0] * len(units)
+    end = [0.0] * len(units)
+    for u in range(len(units)):
+        t = 0.0
+        for d in deps[u]:
+            if end[d] > t:
+                t = end[d]
+        start[u] = t
+        end[u] = t + us[u]
+    return sorted(range(len(units)), key=lambda u: (start[u], u))
 
-    A stage is a range [i, j) of the recording order; inside it, units tied by a dependency form a component, and
-    components share nothing - they may run side by side, a component per lane at a time, with no synchronisation
-    until the stage ends.  Its cost: the sum of its units when it is one component, else max(largest component, sum /
-    lanes) + fork_us.  Dynamic programme over the cut points (best[j] = min over i of best[i] + cost(i, j)); a barrier
-    is a stage of its own.  Cutting right behind a small shared producer (the 1x1 adapt conv four cells read) is what
-    makes its consumers independent components of the NEXT stage - the programme finds that by itself.
-    Returns [(i, j)] covering range(len(units))."""
+
+def plan_stages(units, deps, us, lanes=None, fork_us=None, order=None):
+    """Cut the units into stages of connected components.
+
+    A stage is a range [i, j) of ``order`` (a topological order of the units: the recording order, or asap_order);
+    inside it, units tied by a dependency form a component, and components share nothing - they may run side by
+    side, a component per lane at a time, with no synchronisation until the stage ends.  Its cost: the sum of its
+    units when it is one component, else max(largest component, sum / lanes) + fork_us.  Dynamic programme over the
+    cut points (best[j] = min over i of best[i] + cost(i, j)); a barrier is a stage of its own.  Cutting right
+    behind a small shared producer (the 1x1 adapt conv four cells read) is what makes its consumers independent
+    components of the NEXT stage - the programme finds that by itself.
+    Returns ([(i, j)] covering range(len(units)) as POSITIONS in ``order``, modelled microseconds)."""
     L = max(1, int(LANES if lanes is None else lanes))
     fork = FORK_US if fork_us is None else float(fork_us)
     n = len(units)
+    order = list(range(n)) if order is None else order
+    pos_of = [0] * n
+    for k, u in enumerate(order):
+        pos_of[u] = k
     inf = float("inf")
     best = [inf] * (n + 1)
     cut = [0] * (n + 1)
     best[0] = 0.0
-    dep_lists = [sorted(d) for d in deps]
+    dep_pos = [sorted(pos_of[d] for d in deps[order[k]]) for k in range(n)]
     for i in range(n):
         if best[i] == inf:
             continue
         base = best[i]
-        if units[i].barrier:
-            c = base + us[i]
+        if units[order[i]].barrier:
+            c = base + us[order[i]]
             if c < best[i + 1]:
                 best[i + 1], cut[i + 1] = c, i
             continue
@@ -383,14 +407,14 @@ def plan_stages(units, deps, us, lanes=None, fork_us=None):
         biggest = 0.0
         comps = 0
         for j in range(i, min(n, i + _STAGE_WINDOW)):
-            if units[j].barrier:
+            if units[order[j]].barrier:
                 break
             parent[j] = j
-            w = us[j]
+            w = us[order[j]]
             root = j
             weight[j] = w
             comps += 1
-            for d in dep_lists[j]:
+            for d in dep_pos[j]:
                 if d < i:
                     continue
                 r = d
@@ -416,13 +440,17 @@ def plan_stages(units, deps, us, lanes=None, fork_us=None):
     return out, best[n]
 
 
-def assign_lanes(units, deps, us, stages, lanes=None):
+def assign_lanes(units, deps, us, stages, lanes=None, order=None):
     """lane[u] inside its stage: components, longest first, each to the lane with the least work so far (the longest
-    lands in lane 0, the stream the step runs on); stage_of[u]."""
+    lands in lane 0, the stream the step runs on); stage_of[u].  Both indexed by unit."""
     L = max(1, int(LANES if lanes is None else lanes))
-    lane = [0] * len(units)
-    stage_of = [0] * len(units)
+    n = len(units)
+    order = list(range(n)) if order is None else order
+    lane = [0] * n
+    stage_of = [0] * n
     for s, (i, j) in enumerate(stages):
+        members = order[i:j]
+        local = dict((u, k) for k, u in enumerate(members))
         parent = list(range(j - i))
 
         def find(x):
@@ -431,23 +459,23 @@ def assign_lanes(units, deps, us, stages, lanes=None):
                 x = parent[x]
             return x
 
-        for u in range(i, j):
+        for u in members:
             stage_of[u] = s
             for d in deps[u]:
-                if d >= i:
-                    a, b = find(u - i), find(d - i)
+                if d in local:
+                    a, b = find(local[u]), find(local[d])
                     if a != b:
                         parent[a] = b
         comps = {}
-        for u in range(i, j):
-            comps.setdefault(find(u - i), []).append(u)
+        for u in members:
+            comps.setdefault(find(local[u]), []).append(u)
         if len(comps) == 1 or L == 1:
             continue
         load = [0.0] * L
-        for members in sorted(comps.values(), key=lambda m: (-sum(us[u] for u in m), m[0])):
+        for group in sorted(comps.values(), key=lambda m: (-sum(us[u] for u in m), min(m))):
             l = min(range(L), key=lambda k: (load[k], k))
-            load[l] += sum(us[u] for u in members)
-            for u in members:
+            load[l] += sum(us[u] for u in group)
+            for u in group:
                 lane[u] = l
     return stage_of, lane
 
@@ -456,6 +484,7 @@ def verify_stages(units, deps, stage_of, lane):
     """every dependency stays inside a lane of its stage or points to an earlier stage"""
     for u, d in enumerate(deps):
         for x in d:
+            # (inside a (stage, lane) line the nodes run in recording order: x < u holds for every dependency)
             if not (stage_of[x] < stage_of[u] or (stage_of[x] == stage_of[u] and lane[x] == lane[u] and x < u)):
                 raise NassegError("graph_dag: {} (unit {}, stage {} lane {}) is not ordered after {} (unit {}, stage {} "
                                   "lane {})".format(units[u].name, u, stage_of[u], lane[u], units[x].name, x,
@@ -647,16 +676,17 @@ def lay_out_stages(recorder, raw_graph, n_nodes, lanes=None, durations=None, tri
             "barrier_units": sum(1 for x in units if x.barrier),
             "barriers": sorted(set("{}: {}".format(x.name, x.why) for x in units if x.barrier)),
             "measured_durations": durations is not None}
+    orders = {"recorded": None, "asap": asap_order(units, deps, us)}
     if trial is None:
-        candidates = [(lanes, FORK_US)]
+        candidates = [(lanes, FORK_US, ORDER)]
     else:
-        candidates = [(L, f) for L in range(2, lanes + 1) for f in (FORK_US, 4 * FORK_US)]
+        candidates = [(L, f, o) for o in ("asap", "recorded") for L in range(2, lanes + 1) for f in (FORK_US, 4 * FORK_US)]
     best = None  # (seconds or None, plan, description)
     tried = []
     seen = set()
-    for L, fork in candidates:
-        stages, model_us = plan_stages(units, deps, us, lanes=L, fork_us=fork)
-        stage_of, lane = assign_lanes(units, deps, us, stages, lanes=L)
+    for L, fork, oname in candidates:
+        stages, model_us = plan_stages(units, deps, us, lanes=L, fork_us=fork, order=orders[oname])
+        stage_of, lane = assign_lanes(units, deps, us, stages, lanes=L, order=orders[oname])
         verify_stages(units, deps, stage_of, lane)
         if not any(lane) or (tuple(stage_of), tuple(lane)) in seen:
             continue
@@ -668,7 +698,7 @@ def lay_out_stages(recorder, raw_graph, n_nodes, lanes=None, durations=None, tri
                 raise
             info["unsupported"] = str(e)
             break
-        desc = {"lanes": L, "fork_us": fork, "model_us": round(model_us, 1), "parts": plan.n_parts,
+        desc = {"lanes": L, "fork_us": fork, "order": oname, "model_us": round(model_us, 1), "parts": plan.n_parts,
                 "launches": plan.n_groups, "forks": plan.n_forks, "side_units": sum(1 for v in lane if v)}
         seconds = trial(plan.run) if trial is not None else None
         if seconds is not None:

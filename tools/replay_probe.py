@@ -53,6 +53,18 @@ def main():
     timed("replay", once)
     timed("twice", lambda: (once(), once()), per=2)
     timed("full", lambda: g.step(image, mask))
+    # one replay alone on an idle GPU, by events on the step's stream: what a step costs the GPU without a neighbour
+    ts = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        once()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    print("one replay alone (events): median {:.3f} ms, min {:.3f} ms".format(ts[len(ts) // 2], ts[0]))
 
 
 if __name__ == "__main__":
