@@ -10,7 +10,7 @@ P=profiles
 cp $G/bench.json $P/${R}_bench_headline.json
 grep -v "amdgpu.ids" $G/bench.err > $P/${R}_bench_headline_breakdown.txt || true
 cp $G/env.log $P/${R}_env.txt
-for n in graph1 graph2 headline_bf16 arch1_g0 arch1_g2 cvpr321_g0 cvpr321_g2 search713_g0 search713_g2 depth480_g0 \
+for n in graph0 graph1 graph2 headline_bf16 arch1_g0 arch1_g2 cvpr321_g0 cvpr321_g2 search713_g0 search713_g2 depth480_g0 \
          depth480_bf16 depth480_bf16_g2 task0_auto task0_g0 teacher; do
   [ -f $G/bench_$n.json ] && cp $G/bench_$n.json $P/${R}_bench_$n.json
 done

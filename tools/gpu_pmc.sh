@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o run -- \
-     python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_$c.log 2>&1)
+     python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --graph 0 --secondary 0 > $OUT/pmc_$c.log 2>&1)
   echo "$c exit $?"
   find $OUT/pmc_$c -name "*.csv" | head
 done

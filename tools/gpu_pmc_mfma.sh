@@ -11,7 +11,7 @@ mkdir -p $OUT
 ARGS="${*:---steps 2 --warmup 1}"
 (cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE \
    --kernel-trace --output-format csv -d $OUT/pmc_mfma -o run -- \
-   python $OLDPWD/bench.py $ARGS --no-cpu-baseline --no-roofline > $OUT/pmc_mfma.log 2>&1)
+   python $OLDPWD/bench.py $ARGS --no-cpu-baseline --no-roofline --graph 0 --secondary 0 > $OUT/pmc_mfma.log 2>&1)
 echo "pmc_mfma exit $?"
 python - <<'PY'
 import collections, csv, glob, re
