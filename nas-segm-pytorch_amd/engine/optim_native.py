@@ -121,7 +121,7 @@ class NativeStep(object):
         self._slot = dict((id(e[0]), i) for i, e in enumerate(self.entries))
         self._optims = []  # (weak references, one per optimiser)
         for e in self.entries:
-            if not any(e[1] is o for o in self._optims):
+            if not any(e[1]() is o() for o in self._optims):  # (referents, not weakref objects)
                 self._optims.append(e[1])
         n = len(self.entries)
         max_chunks = sum((e[0].numel() + self.chunk - 1) // self.chunk for e in self.entries)

@@ -1395,7 +1395,10 @@ class _ConvChain(torch.autograd.Function):
                         stp = sv[7 * (i - 1) + 4]
                         pmu_, pis_ = stp[0:K], stp[K:2 * K]
                         part = _ws(cur, (nsl + 64) * 2 * K)
-                    lib.call(_k("nasseg_conv_pw_bwd_bn", cur), ptr(cur), ptr(g), ptr(z), ptr(wb), ptr(g_in),
+                    # (z only where the kernel loads it: where it rebuilds z = W x the argument is NULL - an explicit
+                    #  contract instead of a pointer the kernel ignores, and NULL is also what says "never stored")
+                    z_arg = z if (z is not None and lib.query("nasseg_conv_pw_bwd_reads_z", Bc, H, W, K, N)) else None
+                    lib.call(_k("nasseg_conv_pw_bwd_bn", cur), ptr(cur), ptr(g), ptr(z_arg), ptr(wb), ptr(g_in),
                              _finish_wgrad(ws, dwt, 1, N, K, 0), ptr(ws), ptr(psc), ptr(psh), pact, dx_act,
                              ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), int(training), bact_,
                              Bc, H, W, K, N, ptr(pmu_), ptr(pis_), ptr(part), ptr(skip_g), s)

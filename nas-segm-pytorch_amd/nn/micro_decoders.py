@@ -67,7 +67,18 @@ class _Handles(object):
             got = F.fan_out(node, len(flags) - n_fin, n_fin)
             raw, fin = got[:len(flags) - n_fin], got[len(flags) - n_fin:]
             queue = self.out[idx] = [fin.pop(0) if f else raw.pop(0) for f in flags]
+        if not queue:
+            # (more consumers than were counted: the extra one would read a node whose alias already went to
+            #  somebody else, and its gradient would never reach the junction)
+            raise F.NassegError("node {} has more consumers than the decoder counted ({})".format(idx, len(flags)))
         return queue.pop(0)
+
+    def check_all_taken(self):
+        """every handle that was made has a consumer: an alias nobody reads leaves its share out of the junction's
+        sum without a word (a collect index listed twice, say).  Called at the end of a decoder's forward."""
+        left = dict((idx, len(q)) for idx, q in self.out.items() if q)
+        if left:
+            raise F.NassegError("decoder nodes fanned out to consumers that never came: {}".format(left))
 
 
 def _hw(t):
@@ -230,6 +241,7 @@ class ContextualCell(nn.Module):
         for i in self._collect_inds:
             node = handles.take(i)
             out = node if out is None else F.add(out, node)
+        handles.check_all_taken()
         return F.materialize(out)
 
     def prettify(self):
@@ -320,6 +332,7 @@ class MicroDecoder(nn.Module):
             aux_outs.append(head(handles.take(len(x) + block)))
         # F.relu(collect_all(...)) of the reference: the ReLU is applied as pre_clf loads
         picked = {i: handles.take(i) for i in self.collect_inds}
+        handles.check_all_taken()
         out = collect_all(picked, self.collect_inds)
         return self.conv_clf(self.pre_clf(out, relu_in=True)), aux_outs
 
@@ -442,5 +455,6 @@ class TemplateDecoder(nn.Module):
                 values[out_id] = ops[rep * 3 + 2](a, b)
         # F.relu(collect_all(...)) of the reference: the ReLU is applied as pre_clf loads
         picked = {i: handles.take(i) for i in self._collect_inds}
+        handles.check_all_taken()
         out = collect_all(picked, self._collect_inds)
         return self.conv_clf(self.pre_clf(out, relu_in=True))

@@ -521,3 +521,26 @@ def test_gradient_junctions_replace_autograd_accumulation(monkeypatch):
             assert reduces(with_j[1]) < reduces(without[1])
             # every launch the old graph made that the new one does not is a reduction; what the new one adds are junctions
             assert len(with_j[1]) - n_j <= len(without[1])
+
+
+def test_fanned_out_nodes_are_consumed_exactly_once():
+    """functional.fan_out hands every consumer of a decoder node its own alias so that their gradients meet in one
+    junction launch; an alias nobody reads would leave its share out of that sum silently, and a consumer the decoder
+    did not count would read an alias that belongs to somebody else: both are loud now."""
+    import torch
+
+    from nas_segm_amd import functional as F
+    from nas_segm_amd.nn.micro_decoders import _Handles
+
+    t = torch.zeros(1, 4, 2, 2)
+    h = _Handles([t], [[False, False, False]])
+    assert h.take(0) is t and h.take(0) is t
+    with pytest.raises(F.NassegError):
+        h.check_all_taken()          # the third consumer never came
+    assert h.take(0) is t
+    h.check_all_taken()
+    with pytest.raises(F.NassegError):
+        h.take(0)                    # a fourth was never counted
+    single = _Handles([t], [[False]])
+    assert single.take(0) is t       # (a node with one consumer is not fanned out)
+    single.check_all_taken()
