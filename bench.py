@@ -814,8 +814,15 @@ def main():
 
         def step():  # noqa: F811
             return task0_step(rng.permutation(n_cache)[:args.batch])
+
+        stepper0 = getattr(task0_step, "__self__", None)
+        if stepper0 is not None and getattr(stepper0, "plan", None) is not None:
+            graph_layout = stepper0.layout
+            if rank == 0:
+                sys.stderr.write("graph layout: {}\n".format(stepper0.layout))
     elif args.graph:
         from nas_segm_amd.engine.graphed import GraphedSegmenterStep
+        t_capture = time.perf_counter()
         if args.workload == "depth480":
             graphed = GraphedSegmenterStep(segmenter, image, depth, optim_enc, optim_dec, 255, 3.0, 3.0, -1,
                                            capture_optimisers=args.graph == 2, loss_fn=NF.berhu_loss)
@@ -829,7 +836,8 @@ def main():
 
         graph_layout = getattr(graphed, "layout", None) if getattr(graphed, "plan", None) is not None else None
         if rank == 0 and getattr(graphed, "layout", None):
-            sys.stderr.write("graph layout: {}\n".format(graphed.layout))
+            sys.stderr.write("graph layout ({:.2f} s to warm up, record, lay out and time the layouts): {}\n".format(
+                time.perf_counter() - t_capture, graphed.layout))
 
     def fence():
         if world > 1:

@@ -2,8 +2,8 @@
 
   python tools/dag_report.py gpurun_out/.../dag.json [--sync US] [--lanes "1 2 3 4 8 64"]
 
-Prints the model's span for several lane counts (sync 0 and the configured cost), the critical path (unlimited lanes,
-sync 0), the barriers, and - for the units on the critical path - which address range made each dependency (so that a
+Prints the stage planner's model for several lane counts in both orders, the one-graph scheduler's span, the critical
+path (unlimited lanes, sync 0), the barriers, and - for the units on the critical path - which address range made each dependency (so that a
 false dependency, e.g. two writers of disjoint parts of one storage, shows up by name).
 """
 import json
@@ -25,11 +25,21 @@ def main():
     deps = G.dependencies(units)
     n = units[-1].last
     print("units", len(units), "nodes", n, "line", round(sum(u.us for u in units)), "us (model)")
-    for L in lanes:
+    us_list = [u["us"] for u in d["units"]]  # (the durations the layout was made with: measured where available)
+    for oname, order in (("recorded", None), ("asap", G.asap_order(units, deps, us_list))):
+        for L in lanes:
+            if L > 8:
+                continue
+            stages, model = G.plan_stages(units, deps, us_list, lanes=L, order=order)
+            stage_of, lane = G.assign_lanes(units, deps, us_list, stages, lanes=L, order=order)
+            G.verify_stages(units, deps, stage_of, lane)
+            multi = sum(1 for s_ in range(len(stages)) if len(set(lane[u] for u in range(len(units)) if stage_of[u] == s_)) > 1)
+            print("stages, {:8s} order, {} lanes: model {:8.0f} us of {:8.0f}; {} stages ({} with side lanes), {} units in side "
+                  "lanes".format(oname, L, model, sum(us_list), len(stages), multi, sum(1 for v in lane if v)))
+    for L in lanes:  # (the one-graph form, NASSEG_GRAPH_MODE=rewire)
         for s in (0.0, sync):
             lane, edges, us = G.schedule(units, deps, lanes=L, sync_us=s)
-            cross = sum(1 for a, b in edges if b != a + 1 or True) 
-            print("lanes {:3d} sync {:4.1f}: span {:8.0f} us, per lane {}".format(L, s, us, [lane.count(l) for l in range(max(lane) + 1)]))
+            print("rewire: lanes {:3d} sync {:4.1f}: span {:8.0f} us, per lane {}".format(L, s, us, [lane.count(l) for l in range(max(lane) + 1)]))
     # critical path
     fin = [0.0] * len(units)
     prev = [-1] * len(units)
