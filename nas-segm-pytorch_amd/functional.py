@@ -875,12 +875,15 @@ def _sepconv_ok(x, w_dw, w_pw, op_dw, op_pw, needs_grad):
 # backward rebuilds it as it already did (nasseg_conv_pw_bwd_bn with z == NULL): the map - six times the block's input,
 # 805 MB for 16 -> 96 at 4x512x1024 - is neither written nor read.  Where it pays (tools/kbench_irdw.py, MI355X, us for
 # expansion + depthwise forward / depthwise backward): 16 -> 96 stride 2 at 4x512x1024 426 -> 230 / 404 -> 470,
-# 24 -> 144 stride 1 at 4x256x512 257 -> 184 / 332 -> 318; not 24 -> 144 stride 2 (190 -> 135 / 164 -> 213, and its
-# pointwise backward loses 9 us to the rebuild) nor 32 -> 192 (no kernel of the pointwise backward rebuilds twelve
-# channel tiles).  NASSEG_IRDW=0 switches it off (A/B); maps below NASSEG_IRDW_MIN_PIXELS keep the stored form (the
+# 24 -> 144 stride 1 at 4x256x512 257 -> 184 / 332 -> 318, 24 -> 144 stride 2 190 -> 135 / 164 -> 213 (level in time,
+# taken for the bytes); not 32 -> 192 (no kernel of the pointwise backward rebuilds twelve channel tiles).  NASSEG_IRDW=0 switches it off (A/B); maps below NASSEG_IRDW_MIN_PIXELS keep the stored form (the
 # extra launches of the statistics cost more than the bytes).
 IRDW = os.environ.get("NASSEG_IRDW", "1") != "0"
 _IRDW_MIN_PIXELS = int(os.environ.get("NASSEG_IRDW_MIN_PIXELS", 1 << 18))
+# (stride 2 with K = 24: by the kernels alone the rebuilt backward loses what the forward wins - 190 -> 135 / 164 -> 213 us -
+#  but replayed in lanes the step is level or ahead, 306.7 -> 308.5 images/s over three runs each, with 0.9 GB less HBM
+#  traffic and 0.3 GiB less memory: profiles/r06_ab_irdw_s2_k24.txt)
+_IRDW_S2_MAX_K = int(os.environ.get("NASSEG_IRDW_S2_MAX_K", 24))
 
 
 def _irdw_ok(ops, i, weights, cur, pend, needs_in_grad, need_w, training):
@@ -901,7 +904,7 @@ def _irdw_ok(ops, i, weights, cur, pend, needs_in_grad, need_w, training):
     B, _, H, W = cur.shape
     if B * H * W < _IRDW_MIN_PIXELS or not (N > K and K % 4 == 0):
         return False
-    if not ((stride2 == 1 and N <= 144) or (stride2 == 2 and K <= 16)):
+    if not ((stride2 == 1 and N <= 144) or (stride2 == 2 and K <= _IRDW_S2_MAX_K)):
         return False
     if pend is not None and pend[0] is None and pend[1] is None and not pend[2]:
         return False
