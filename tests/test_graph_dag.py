@@ -158,3 +158,75 @@ def test_header_const_is_the_read_write_contract():
         proto = re.search(r"\b" + name + r"\s*\(([^)]*)\)", text).group(1)
         n_ptr = sum(1 for a in proto.split(",") if "*" in a and a[a.rindex("*") + 1:].strip() != "stream")
         assert n_ptr == len(args), name
+
+
+class _FakeTensor(object):
+    """what Recorder.note needs of a tensor: an address inside a storage"""
+
+    class _Storage(object):
+        def __init__(self, lo, n):
+            self._lo, self._n = lo, n
+
+        def data_ptr(self):
+            return self._lo
+
+        def nbytes(self):
+            return self._n
+
+    def __init__(self, lo, n, offset=0):
+        self._st, self._addr = self._Storage(lo, n), lo + offset
+
+    def data_ptr(self):
+        return self._addr
+
+    def untyped_storage(self):
+        return self._st
+
+
+def test_recorder_classifies_what_a_call_was_handed(monkeypatch):
+    """What the Recorder makes of a call (no GPU: the node counter is faked): pointers that `ptr()` handed out for
+    THIS call become read (const in include/nasseg.h) or written ranges - the whole storage behind a view -; an
+    address from an earlier call, a pointer table nobody annotated or an entry point the header does not know make
+    the call a barrier; an annotation replaces the header's view; a call that recorded no node leaves no unit."""
+    rec = G.Recorder()
+    count = [0]
+    monkeypatch.setattr(rec, "_nodes", lambda: count[0])
+
+    def launch(n_nodes):
+        def fn(*args):
+            count[0] += n_nodes
+            return 0
+        return fn
+
+    x, y, sc = _FakeTensor(1000, 400), _FakeTensor(5000, 800, offset=64), _FakeTensor(9000, 64)
+    # nasseg_affine_act(const x, const scale, const shift, const res, y, n, C, act, stream)
+    args = (rec.note(x), rec.note(sc), None, None, rec.note(y), 100, 4, 0, 0)
+    rec.call("nasseg_affine_act", args, launch(1))
+    u = rec.units[-1]
+    assert not u.barrier and (u.first, u.last) == (0, 1)
+    assert sorted(u.reads) == [(1000, 1400), (9000, 9064)] and u.writes == [(5000, 5800)]  # (the view's whole storage)
+    # the same addresses again WITHOUT ptr(): what they point to may have been freed and handed out again since
+    rec.call("nasseg_affine_act", args, launch(1))
+    assert rec.units[-1].barrier and "ptr() did not hand out" in rec.units[-1].why
+    # a pointer table (nasseg_pack_weights: const float* const* w) is a barrier ...
+    rec.call("nasseg_pack_weights", (2, object(), object(), object(), 0), launch(2))
+    assert rec.units[-1].barrier and (rec.units[-1].first, rec.units[-1].last) == (2, 4)
+    # ... unless the caller says what the launches behind it touch
+    rec.annotate(reads=[x], writes=[y, (7000, 16)])
+    rec.call("nasseg_pack_weights", (2, object(), object(), object(), 0), launch(1))
+    u = rec.units[-1]
+    assert not u.barrier and u.reads == [(1000, 1400)] and u.writes == [(5000, 5800), (7000, 7016)]
+    assert rec.annotation is None
+    # an entry point the header does not declare: a barrier
+    rec.call("nasseg_not_in_the_header", (rec.note(x),), launch(1))
+    assert rec.units[-1].barrier
+    # a call that recorded nothing (a query, an empty launch) leaves no unit - and consumes the noted addresses
+    n_units = len(rec.units)
+    rec.call("nasseg_affine_act", (rec.note(x), None, None, None, rec.note(y), 0, 4, 0, 0), launch(0))
+    assert len(rec.units) == n_units and rec.fresh == {}
+    # a failing call reports its status and records nothing
+    assert rec.call("nasseg_affine_act", args, lambda *a: -1) == -1 and len(rec.units) == n_units
+    # every noted storage stays referenced until the capture ends (no block is handed out twice while recording)
+    assert len(rec.keep) >= 5
+    rec.release()
+    assert rec.keep == []
