@@ -37,6 +37,7 @@ struct FwdArgs {
   int b_act;
   int K, N;
   ConvGeom g;
+  int th, tw;  // conv3x3_lds_kernel: the workgroup's output tile, rows x columns (lds3x3_tile)
 };
 
 

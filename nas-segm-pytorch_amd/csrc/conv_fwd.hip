@@ -30,6 +30,8 @@
 #include "conv_args.h"
 
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 
 // Which pointwise calls take the persistent kernel (conv_pw_kernel).  Default (-2): where it measured
 // faster (pw_fwd_plan).  v >= 0: every call it supports over at least v output pixels (0: all of them - what
@@ -707,8 +709,9 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 // ---------------------------------------------------------------------------
 // 3x3 stride-1 convolution (dilation 1 ... 3) with the input tile staged in LDS.
 // The gather kernel above re-reads X once per tap through L1/L2 (9x the tensor), which
-// is what bounds the 64->19 class head and its backward-data; here a workgroup owns an
-// 8 x 32 patch of output pixels, stages the (8+2d) x (32+2d) input patch of a 32-channel
+// is what bounds the 64->19 class head and its backward-data; here a workgroup owns a
+// th x tw patch of output pixels (at most 256: 8 x 32 unless lds3x3_tile finds a shape that
+// leaves fewer workgroups per CU), stages the (th+2d) x (tw+2d) input patch of a 32-channel
 // slice in LDS once (zero-filled outside the image and beyond K) and serves all nine taps
 // from there: ds_read_b128 per lane, pixel stride padded to 36 floats so that the 16 pixel
 // lanes of a k-group hit distinct banks.  MFMA operand mapping, weight layout (mode 0,
@@ -719,6 +722,43 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 constexpr int kLdsTH = 8, kLdsTW = 32, kLdsKC = 32, kLdsKS = kLdsKC + 4;
 constexpr int kLdsMaxDil = 3;
 constexpr int kLdsMaxIt = ((kLdsTH + 2 * kLdsMaxDil) * (kLdsTW + 2 * kLdsMaxDil) * (kLdsKC / 4) + 255) / 256;  // float4 of the patch per thread
+constexpr int kLdsMaxPatch = kLdsMaxIt * 256 / (kLdsKC / 4);  // pixels of the largest patch a workgroup stages (544)
+
+// The output tile of a workgroup.  A workgroup issues the MFMAs of 256 pixel slots whatever it fills them with and two
+// workgroups share a CU's matrix cores, so what a launch costs is the number of workgroups the fullest CU gets: 8 x 32
+// tiles cut a 16 x 81 x 81 map (the CVPR cells at 321 x 321) into 528 workgroups - 16 more than the 512 that run at
+// once, a second round for 3 % of the work (148 us where one round is ~75) - while 9 x 27 tiles make 432.  Picked:
+// fewest workgroups per CU, then fewest patch pixels staged in all; 8 x 32 wherever it ties.  The pixel slot f of a
+// tile is row f / tw, column f % tw (f < th * tw).
+struct Lds3Tile {
+  int th, tw;
+};
+inline Lds3Tile lds3x3_tile(int B, int Ho, int Wo, int dil) {
+  Lds3Tile best = {kLdsTH, kLdsTW};
+#ifdef NASSEG_TUNE  // (tools/kbench_conv3x3.py: any tile by hand)
+  if (const char* e = getenv("NASSEG_LDS3_TILE")) {
+    int h = 0, w = 0;
+    if (sscanf(e, "%d,%d", &h, &w) == 2 && h > 0 && w > 0 && h * w <= 256 && (h + 2 * dil) * (w + 2 * dil) <= kLdsMaxPatch)
+      return Lds3Tile{h, w};
+  }
+#endif
+  auto cost = [&](int th, int tw, int64_t& per_cu, int64_t& staged) {
+    const int64_t wgs = (int64_t)B * cdiv(Ho, th) * cdiv(Wo, tw);
+    per_cu = (wgs + 255) / 256;
+    staged = wgs * (th + 2 * dil) * (tw + 2 * dil);
+  };
+  int64_t bc, bs;
+  cost(best.th, best.tw, bc, bs);
+  for (int tw = 16; tw <= 128 && tw <= Wo; ++tw) {
+    const int th = 256 / tw < Ho ? 256 / tw : Ho;
+    if ((th + 2 * dil) * (tw + 2 * dil) > kLdsMaxPatch) continue;
+    int64_t c, s;
+    cost(th, tw, c, s);
+    // (a candidate has to win by a whole workgroup per CU, or by 10 % of the staged pixels)
+    if (c < bc || (c == bc && s * 10 < bs * 9)) best = Lds3Tile{th, tw}, bc = c, bs = s;
+  }
+  return best;
+}
 
 // STATS == 1: per-workgroup sums of y and y^2 per output channel (the BatchNorm that follows a conv3x3 / conv3x3_dil3
 // op of the CVPR cells, layer_factory.py:56-75) to stats[tile][2][N], tile = (b * tiles_y + ty) * tiles_x + tx.
@@ -738,9 +778,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   const int j = lane & 15;
   const int kg = lane >> 4;
   const int dil = a.g.dil;
-  const int TR = kLdsTH + 2 * dil, TC = kLdsTW + 2 * dil;
+  const int TR = a.th + 2 * dil, TC = a.tw + 2 * dil;
   const int b = blockIdx.z;
-  const int oy0 = blockIdx.y * kLdsTH, ox0 = blockIdx.x * kLdsTW;
+  const int oy0 = blockIdx.y * a.th, ox0 = blockIdx.x * a.tw;
   const int iy0 = oy0 - a.g.pad, ix0 = ox0 - a.g.pad;
   const int H = a.g.Hs, W = a.g.Ws;
 
@@ -752,10 +792,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
     wok[nt] = n < a.N;
     wn[nt] = wok[nt] ? n : a.N - 1;
   }
-  // this lane's pixel in each of the wave's four 16-pixel subtiles: rows 2w, 2w+1; two halves
-  int toff[4];
+  // this lane's pixel in each of the wave's four 16-pixel subtiles: slot f = 64 w + 16 mt + j of the tile, row f / tw,
+  // column f % tw (8 x 32: rows 2w, 2w+1; two halves); slots past the tile compute its pixel 0 and store nothing
+  int toff[4], prow[4], pcol[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) toff[mt] = ((2 * wave + (mt >> 1)) * TC + (mt & 1) * 16 + j) * kLdsKS;
+  for (int mt = 0; mt < 4; ++mt) {
+    const int f = (4 * wave + mt) * 16 + j;
+    const bool in_tile = f < a.th * a.tw;
+    const int r = in_tile ? f / a.tw : 0;
+    const int c = in_tile ? f - r * a.tw : 0;
+    prow[mt] = in_tile ? oy0 + r : a.g.Ho;  // (a row beyond the map: masked like one)
+    pcol[mt] = ox0 + c;
+    toff[mt] = (r * TC + c) * kLdsKS;
+  }
 
   f32x4 acc[4][NT];
 #pragma unroll
@@ -940,7 +989,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
       float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + (mt & 1) * 16 + j;
+        const int oy = prow[mt], ox = pcol[mt];
         const bool pok = oy < a.g.Ho && ox < a.g.Wo;
         const f32x4 c = acc[mt][nt];
 #pragma unroll
@@ -976,7 +1025,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   // epilogue: lane holds pixel j of each subtile, channels nt*16 + 4*kg + {0..3}
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + (mt & 1) * 16 + j;
+    const int oy = prow[mt], ox = pcol[mt];
     const bool pok = oy < a.g.Ho && ox < a.g.Wo;
     const int64_t m = ((int64_t)b * a.g.Ho + (oy < a.g.Ho ? oy : a.g.Ho - 1)) * a.g.Wo +
                       (ox < a.g.Wo ? ox : a.g.Wo - 1);
@@ -1029,10 +1078,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
 }
 
 template <int NT>
-int launch_lds3x3(const FwdArgs& a, bool vecn, bool veck, bool stats, hipStream_t s) {
+int launch_lds3x3(const FwdArgs& a0, bool vecn, bool veck, bool stats, hipStream_t s) {
+  FwdArgs a = a0;
   const int dil = a.g.dil;
-  const size_t lds = (size_t)(kLdsTH + 2 * dil) * (kLdsTW + 2 * dil) * kLdsKS * sizeof(float);
-  dim3 grid(cdiv(a.g.Wo, kLdsTW), cdiv(a.g.Ho, kLdsTH), a.g.B);
+  const Lds3Tile t = lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, dil);
+  a.th = t.th;
+  a.tw = t.tw;
+  const size_t lds = (size_t)(t.th + 2 * dil) * (t.tw + 2 * dil) * kLdsKS * sizeof(float);
+  dim3 grid(cdiv(a.g.Wo, t.tw), cdiv(a.g.Ho, t.th), a.g.B);
   if (lds > (size_t)(64 << 10)) {  // (dilation 3: 76.6 KB)
     static std::atomic<int> raised{0};
     if (!raised.load()) {
@@ -1056,10 +1109,14 @@ int launch_lds3x3(const FwdArgs& a, bool vecn, bool veck, bool stats, hipStream_
 
 // NT full tiles on the matrix cores + NV channels on the vector ALU (N = 16 * NT + NV, K % 4 == 0, no statistics)
 template <int NT, int NV>
-int launch_lds3x3_nv(const FwdArgs& a, hipStream_t s) {
+int launch_lds3x3_nv(const FwdArgs& a0, hipStream_t s) {
+  FwdArgs a = a0;
   const int dil = a.g.dil;
-  const size_t lds = (size_t)(kLdsTH + 2 * dil) * (kLdsTW + 2 * dil) * kLdsKS * sizeof(float);
-  dim3 grid(cdiv(a.g.Wo, kLdsTW), cdiv(a.g.Ho, kLdsTH), a.g.B);
+  const Lds3Tile t = lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, dil);
+  a.th = t.th;
+  a.tw = t.tw;
+  const size_t lds = (size_t)(t.th + 2 * dil) * (t.tw + 2 * dil) * kLdsKS * sizeof(float);
+  dim3 grid(cdiv(a.g.Wo, t.tw), cdiv(a.g.Ho, t.th), a.g.B);
   if (lds > (size_t)(64 << 10))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<NT, false, true, 0, NV>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
@@ -1435,7 +1492,10 @@ int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int po
 int64_t nasseg_conv_fwd_stats_rows(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil) {
   const int pointwise = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? 1 : 0;
   if (!pointwise && (N & 3) == 0 && lds3x3_geometry(B, Ho, Wo, N, K, kh, kw, stride, pad, dil))
-    return (int64_t)cdiv(Wo, kLdsTW) * cdiv(Ho, kLdsTH) * B;
+  {
+    const Lds3Tile t = lds3x3_tile(B, Ho, Wo, dil);
+    return (int64_t)cdiv(Wo, t.tw) * cdiv(Ho, t.th) * B;
+  }
   return nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N, K, pointwise);
 }
 #endif  // NASSEG_FP32_ONLY

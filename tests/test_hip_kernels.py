@@ -1966,6 +1966,9 @@ def test_gradient_junction_against_float64(shape, n, pending, dtype):
     # CVPR cells at 81 x 81, ragged tiles, one to four channel tiles, dilation 2 and 3, K not a multiple of 32
     (2, 64, 20, 70, 64, 1, 1), (1, 32, 17, 45, 48, 3, 3), (2, 16, 12, 40, 32, 2, 2), (2, 64, 9, 33, 24, 3, 3),
     (1, 48, 81, 81, 64, 3, 3), (1, 24, 8, 32, 16, 1, 1),
+    # the cells' own batch: 8 x 32 tiles would make 528 workgroups (more than the 512 that run at once), the tile picked
+    # makes 432 / 480 of them (lds3x3_tile, conv_fwd.hip); a map whose 8 x 32 tiling is already the best
+    (16, 64, 81, 81, 64, 1, 1), (16, 64, 81, 81, 64, 3, 3), (2, 32, 64, 128, 32, 1, 1),
 ])
 def test_3x3_forward_statistics_from_the_lds_tiled_kernel(case):
     f = F()
@@ -1977,7 +1980,14 @@ def test_3x3_forward_statistics_from_the_lds_tiled_kernel(case):
     s = f.current_stream()
     f.lib.call("nasseg_conv_pack_weight", f.ptr(w), f.ptr(wp), N, K, 3, 3, 0, s)
     rows = f.lib.query("nasseg_conv_fwd_stats_rows", B, Ho, Wo, N, K, 3, 3, 1, pad, dil)
-    assert rows == B * ((Ho + 7) // 8) * ((Wo + 31) // 32)  # (the tile count: this geometry takes the LDS kernel)
+    # (the tile count: this geometry takes the LDS kernel - 8 x 32 tiles, or a shape of at most 256 pixels that needs fewer
+    #  workgroups per CU or stages fewer pixels)
+    rows_8x32 = B * ((Ho + 7) // 8) * ((Wo + 31) // 32)
+    assert (B * Ho * Wo + 255) // 256 <= rows and (rows + 255) // 256 <= (rows_8x32 + 255) // 256
+    if (B, H, W) == (16, 81, 81):
+        assert rows == {1: 432, 3: 480}[dil] and rows_8x32 == 528
+    if (B, H, W) == (2, 64, 128):
+        assert rows == rows_8x32
     part = torch.full(((rows + 64) * 2 * N,), float("nan"), device=DEV)
     y = dev(torch.empty(B, N, Ho, Wo))
     f.lib.call("nasseg_conv_fwd", f.ptr(x), K, f.ptr(wp), f.ptr(y), N, None, None, 0, None, None, 0, None, 0, B, H, W,

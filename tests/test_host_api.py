@@ -36,6 +36,12 @@ def test_workspace_queries_are_pure_host_calls():
     assert lib.query("nasseg_colred_workspace", 1, 1 << 20, 64) >= 2 * 64
     assert lib.query("nasseg_conv_wgrad_workspace", 4, 256, 512, 64, 224, 1, 1) >= 64 * 224
     assert lib.query("nasseg_dwconv_wgrad_workspace", 4, 24, 256, 512, 5) >= 25 * 24
+    # the output tile of the LDS-tiled 3x3 kernel (one statistics row per workgroup): 8 x 32 where that is as good as any
+    # (the headline's 4 x 128 x 256 maps), fewer workgroups per CU where another shape of <= 256 pixels gives them (the
+    # CVPR cells' 16 x 81 x 81 maps: 528 -> 432 with dilation 1, 480 with dilation 3)
+    assert lib.query("nasseg_conv_fwd_stats_rows", 4, 128, 256, 48, 48, 3, 3, 1, 1, 1) == 4 * 16 * 8
+    assert lib.query("nasseg_conv_fwd_stats_rows", 16, 81, 81, 64, 64, 3, 3, 1, 1, 1) == 432
+    assert lib.query("nasseg_conv_fwd_stats_rows", 16, 81, 81, 64, 64, 3, 3, 1, 3, 3) == 480
 
 
 def test_error_convention_is_runtime_error():
