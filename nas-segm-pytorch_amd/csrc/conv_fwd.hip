@@ -768,7 +768,10 @@ inline Lds3Tile lds3x3_tile(int B, int Ho, int Wo, int dil) {
 // x[pixel][4 k] of every step, multiplies it with the NV weight rows' same 4 k (one address per k-group: a broadcast
 // load) and keeps NV partial sums per subtile, which the four k-groups add up once at the end.  The FMAs issue in
 // the shadow of the MFMAs.
-template <int NT, bool VECN, bool VECK, int STATS = 0, int NV = 0>
+// FLEX: the tile is a.th x a.tw (lds3x3_tile) instead of 8 x 32 - instantiated for the four-tile form and the two class
+// heads only: with the tile a run-time value the four subtiles of a wave no longer sit at constant LDS offsets from
+// each other, which costs the calls that stay on 8 x 32 tiles 3-6 % (64 -> 19 at 4 x 256 x 512: 176 -> 182 us).
+template <int NT, bool VECN, bool VECK, int STATS = 0, int NV = 0, bool FLEX = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   static_assert(NV == 0 || (STATS == 0 && !VECN), "the vector-ALU channels come without statistics, stored one by one");
   extern __shared__ float tile[];
@@ -778,9 +781,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   const int j = lane & 15;
   const int kg = lane >> 4;
   const int dil = a.g.dil;
-  const int TR = a.th + 2 * dil, TC = a.tw + 2 * dil;
+  const int th = FLEX ? a.th : kLdsTH, tw = FLEX ? a.tw : kLdsTW;
+  const int TR = th + 2 * dil, TC = tw + 2 * dil;
   const int b = blockIdx.z;
-  const int oy0 = blockIdx.y * a.th, ox0 = blockIdx.x * a.tw;
+  const int oy0 = blockIdx.y * th, ox0 = blockIdx.x * tw;
   const int iy0 = oy0 - a.g.pad, ix0 = ox0 - a.g.pad;
   const int H = a.g.Hs, W = a.g.Ws;
 
@@ -794,16 +798,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   }
   // this lane's pixel in each of the wave's four 16-pixel subtiles: slot f = 64 w + 16 mt + j of the tile, row f / tw,
   // column f % tw (8 x 32: rows 2w, 2w+1; two halves); slots past the tile compute its pixel 0 and store nothing
-  int toff[4], prow[4], pcol[4];
+  // (the output coordinates are worked out again where they are needed, after the main loop: eight registers held
+  //  across it were what made the two-tile instantiations spill)
+  auto slot_pixel = [&](int mt, int& oy, int& ox) {
+    if (!FLEX) {
+      oy = oy0 + 2 * wave + (mt >> 1);
+      ox = ox0 + (mt & 1) * 16 + j;
+      return ((2 * wave + (mt >> 1)) * TC + (mt & 1) * 16 + j) * kLdsKS;
+    }
+    const int f = (4 * wave + mt) * 16 + j;
+    const bool in_tile = f < th * tw;
+    const int r = in_tile ? f / tw : 0;
+    const int c = in_tile ? f - r * tw : 0;
+    oy = in_tile ? oy0 + r : a.g.Ho;  // (a row beyond the map: masked like one)
+    ox = ox0 + c;
+    return (r * TC + c) * kLdsKS;
+  };
+  int toff[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int f = (4 * wave + mt) * 16 + j;
-    const bool in_tile = f < a.th * a.tw;
-    const int r = in_tile ? f / a.tw : 0;
-    const int c = in_tile ? f - r * a.tw : 0;
-    prow[mt] = in_tile ? oy0 + r : a.g.Ho;  // (a row beyond the map: masked like one)
-    pcol[mt] = ox0 + c;
-    toff[mt] = (r * TC + c) * kLdsKS;
+    int oy, ox;
+    toff[mt] = slot_pixel(mt, oy, ox);
   }
 
   f32x4 acc[4][NT];
@@ -989,7 +1004,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
       float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const int oy = prow[mt], ox = pcol[mt];
+        int oy, ox;
+        slot_pixel(mt, oy, ox);
         const bool pok = oy < a.g.Ho && ox < a.g.Wo;
         const f32x4 c = acc[mt][nt];
 #pragma unroll
@@ -1025,7 +1041,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   // epilogue: lane holds pixel j of each subtile, channels nt*16 + 4*kg + {0..3}
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
-    const int oy = prow[mt], ox = pcol[mt];
+    int oy, ox;
+    slot_pixel(mt, oy, ox);
     const bool pok = oy < a.g.Ho && ox < a.g.Wo;
     const int64_t m = ((int64_t)b * a.g.Ho + (oy < a.g.Ho ? oy : a.g.Ho - 1)) * a.g.Wo +
                       (ox < a.g.Wo ? ox : a.g.Wo - 1);
@@ -1077,20 +1094,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   }
 }
 
-template <int NT>
-int launch_lds3x3(const FwdArgs& a0, bool vecn, bool veck, bool stats, hipStream_t s) {
-  FwdArgs a = a0;
+// FX: the tile is the planner's (lds3x3_tile) and not 8 x 32
+template <int NT, bool FX>
+int launch_lds3x3_t(const FwdArgs& a, bool vecn, bool veck, bool stats, hipStream_t s) {
   const int dil = a.g.dil;
-  const Lds3Tile t = lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, dil);
-  a.th = t.th;
-  a.tw = t.tw;
-  const size_t lds = (size_t)(t.th + 2 * dil) * (t.tw + 2 * dil) * kLdsKS * sizeof(float);
-  dim3 grid(cdiv(a.g.Wo, t.tw), cdiv(a.g.Ho, t.th), a.g.B);
+  const size_t lds = (size_t)(a.th + 2 * dil) * (a.tw + 2 * dil) * kLdsKS * sizeof(float);
+  dim3 grid(cdiv(a.g.Wo, a.tw), cdiv(a.g.Ho, a.th), a.g.B);
   if (lds > (size_t)(64 << 10)) {  // (dilation 3: 76.6 KB)
     static std::atomic<int> raised{0};
     if (!raised.load()) {
 #define ATTR3(V_, K_, S_)                                                                                    \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<NT, V_, K_, S_>),              \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<NT, V_, K_, S_, 0, FX>),       \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10)
       ATTR3(true, true, 0); ATTR3(true, false, 0); ATTR3(false, true, 0); ATTR3(false, false, 0);
       ATTR3(true, true, 1); ATTR3(true, false, 1);
@@ -1098,7 +1112,7 @@ int launch_lds3x3(const FwdArgs& a0, bool vecn, bool veck, bool stats, hipStream
       raised.store(1);
     }
   }
-#define GO3(V_, K_, S_) hipLaunchKernelGGL((conv3x3_lds_kernel<NT, V_, K_, S_>), grid, dim3(256), lds, s, a)
+#define GO3(V_, K_, S_) hipLaunchKernelGGL((conv3x3_lds_kernel<NT, V_, K_, S_, 0, FX>), grid, dim3(256), lds, s, a)
   if (stats) { if (veck) GO3(true, true, 1); else GO3(true, false, 1); }  // (statistics need N % 4 == 0)
   else if (vecn) { if (veck) GO3(true, true, 0); else GO3(true, false, 0); }
   else { if (veck) GO3(false, true, 0); else GO3(false, false, 0); }
@@ -1107,22 +1121,45 @@ int launch_lds3x3(const FwdArgs& a0, bool vecn, bool veck, bool stats, hipStream
   return NASSEG_OK;
 }
 
+inline bool lds3x3_is_default(const Lds3Tile& t) { return t.th == kLdsTH && t.tw == kLdsTW; }
+
+template <int NT>
+int launch_lds3x3(const FwdArgs& a0, bool vecn, bool veck, bool stats, hipStream_t s) {
+  FwdArgs a = a0;
+  // (the four-tile form picks its tile: nasseg_conv_fwd_stats_rows counts the rows under the same condition)
+  const Lds3Tile t = NT == 4 ? lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, a.g.dil) : Lds3Tile{kLdsTH, kLdsTW};
+  a.th = t.th;
+  a.tw = t.tw;
+  if constexpr (NT == 4) {
+    if (!lds3x3_is_default(t)) return launch_lds3x3_t<NT, true>(a, vecn, veck, stats, s);
+  }
+  return launch_lds3x3_t<NT, false>(a, vecn, veck, stats, s);
+}
+
 // NT full tiles on the matrix cores + NV channels on the vector ALU (N = 16 * NT + NV, K % 4 == 0, no statistics)
+template <int NT, int NV, bool FX>
+int launch_lds3x3_nv_t(const FwdArgs& a, hipStream_t s) {
+  const int dil = a.g.dil;
+  const size_t lds = (size_t)(a.th + 2 * dil) * (a.tw + 2 * dil) * kLdsKS * sizeof(float);
+  dim3 grid(cdiv(a.g.Wo, a.tw), cdiv(a.g.Ho, a.th), a.g.B);
+  if (lds > (size_t)(64 << 10))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<NT, false, true, 0, NV, FX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
+  hipLaunchKernelGGL((conv3x3_lds_kernel<NT, false, true, 0, NV, FX>), grid, dim3(256), lds, s, a);
+  NASSEG_LAUNCH_CHECK("conv3x3_lds_kernel");
+  return NASSEG_OK;
+}
 template <int NT, int NV>
 int launch_lds3x3_nv(const FwdArgs& a0, hipStream_t s) {
   FwdArgs a = a0;
-  const int dil = a.g.dil;
-  const Lds3Tile t = lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, dil);
+  constexpr bool kPick = NV == 3 || NV == 5;  // (19 and 21 classes)
+  const Lds3Tile t = kPick ? lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, a.g.dil) : Lds3Tile{kLdsTH, kLdsTW};
   a.th = t.th;
   a.tw = t.tw;
-  const size_t lds = (size_t)(t.th + 2 * dil) * (t.tw + 2 * dil) * kLdsKS * sizeof(float);
-  dim3 grid(cdiv(a.g.Wo, t.tw), cdiv(a.g.Ho, t.th), a.g.B);
-  if (lds > (size_t)(64 << 10))
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lds_kernel<NT, false, true, 0, NV>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 << 10);
-  hipLaunchKernelGGL((conv3x3_lds_kernel<NT, false, true, 0, NV>), grid, dim3(256), lds, s, a);
-  NASSEG_LAUNCH_CHECK("conv3x3_lds_kernel");
-  return NASSEG_OK;
+  if constexpr (kPick) {
+    if (!lds3x3_is_default(t)) return launch_lds3x3_nv_t<NT, NV, true>(a, s);
+  }
+  return launch_lds3x3_nv_t<NT, NV, false>(a, s);
 }
 
 // Several weight tensors re-packed by ONE launch (a chain of convolutions packs the
@@ -1493,7 +1530,8 @@ int64_t nasseg_conv_fwd_stats_rows(int B, int Ho, int Wo, int N, int K, int kh, 
   const int pointwise = (kh == 1 && kw == 1 && stride == 1 && pad == 0) ? 1 : 0;
   if (!pointwise && (N & 3) == 0 && lds3x3_geometry(B, Ho, Wo, N, K, kh, kw, stride, pad, dil))
   {
-    const Lds3Tile t = lds3x3_tile(B, Ho, Wo, dil);
+    // (the four-tile form picks its tile; one and two channel tiles stay on 8 x 32: launch_lds3x3)
+    const Lds3Tile t = cdiv(N, 16) > 2 ? lds3x3_tile(B, Ho, Wo, dil) : Lds3Tile{kLdsTH, kLdsTW};
     return (int64_t)cdiv(Wo, t.tw) * cdiv(Ho, t.th) * B;
   }
   return nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N, K, pointwise);

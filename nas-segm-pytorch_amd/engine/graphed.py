@@ -64,6 +64,10 @@ def auto_graph(segmenter, n_pixels):
     return n_pixels <= AUTO_GRAPH_MAX_PIXELS
 
 
+class StaleCapture(F.NassegError):
+    """a recorded step no longer matches its optimisers (``_GraphedStep.stale``): record a new one"""
+
+
 def _capturable(optim):
     """An optimiser step may be baked into a graph only if none of its scalars live on
     the host: plain SGD qualifies, Adam only with ``capturable=True`` (its bias
@@ -293,16 +297,25 @@ class _GraphedStep(object):
             raise F.NassegError("graphed step: the data-parallel segmenter it was captured for is gone")
         owner.sync_gradients()
 
+    def stale(self):
+        """True when a replay would step with other hyper-parameters than the optimisers hold NOW: lr, weight decay,
+        betas, eps and the clip norms are recorded BY VALUE (kernel arguments of nasseg_optim_step), so a schedule that
+        edits param_group["lr"] needs a new capture.  The owner of a cached stepper asks before it replays and builds
+        a new one (engine/trainer._cached_stepper); ``_replay`` itself refuses with StaleCapture."""
+        return (self.capture_optimisers and self._native is not None
+                and self._native.hyper_values() != self._captured_hyper)
+
     def _replay(self):
         native = self._native if self.capture_optimisers else None
         if native is not None:
             # lr, weight decay, betas, eps and the clip norms were recorded BY VALUE (kernel arguments of
             # nasseg_optim_step): a schedule that edits param_group["lr"] must not be ignored silently
-            if native.hyper_values() != self._captured_hyper:
-                raise F.NassegError("graphed step: an optimiser's hyper-parameters changed after its step was "
-                                    "captured (capture_optimisers=True bakes lr / weight decay / betas / eps / "
-                                    "max_norm into the graph) - build a new stepper, or keep the optimisers "
-                                    "outside the graph (capture_optimisers=False reads param_groups every step)")
+            if self.stale():
+                raise StaleCapture("graphed step: an optimiser's hyper-parameters changed after its step was "
+                                   "captured (capture_optimisers=True bakes lr / weight decay / betas / eps / "
+                                   "max_norm into the graph) - build a new stepper (engine/trainer.py's cache does: it "
+                                   "asks stale() first), or keep the optimisers outside the graph "
+                                   "(capture_optimisers=False reads param_groups every step)")
             if not native.host_steps_match():
                 native.sync_steps()  # (the optimisers were stepped or reloaded outside this graph)
         if self.plan is not None:

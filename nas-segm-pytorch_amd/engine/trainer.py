@@ -195,7 +195,12 @@ def _cached_stepper(owner, slot, base_key, shape_key, build):
         setattr(owner, slot, ent)
     steppers = ent[1]
     if shape_key in steppers:
-        return steppers[shape_key]
+        stepper = steppers[shape_key]
+        if stepper is None or not stepper.stale():
+            return stepper
+        # (optimisers inside the graph and a schedule moved lr / weight decay / a clip norm: those are recorded by
+        #  value - record the step again instead of failing in the middle of an epoch)
+        del steppers[shape_key]
     if len(steppers) >= _STEPPERS_PER_CANDIDATE:
         return None
     try:

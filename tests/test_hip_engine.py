@@ -466,6 +466,18 @@ def test_timed_layouts_never_lose_to_the_line():
     sd, sd2 = _cpu_sd(net), _cpu_sd(net2)
     for k in sd:
         assert torch.equal(sd[k], sd2[k]), k
+    # the optimisers are inside the graph, their hyper-parameters recorded by value: a schedule that moves lr makes the
+    # capture stale - the stepper says so (the trainer's cache asks and records a new step) and refuses to replay
+    from nas_segm_amd.engine.graphed import StaleCapture
+
+    assert not stepper.stale()
+    od.param_groups[0]["lr"] = 1e-3
+    assert stepper.stale()
+    with pytest.raises(StaleCapture):
+        stepper.step(x, t)
+    od.param_groups[0]["lr"] = 3e-3
+    assert not stepper.stale()
+    assert float(stepper.step(x, t)) == float(segmenter_step(net2, x, t, oe2, od2, 255, 3.0, 3.0, 0.15))
 
 
 def test_graphed_step_with_a_custom_loss_equals_eager():

@@ -550,3 +550,40 @@ def test_fanned_out_nodes_are_consumed_exactly_once():
     single = _Handles([t], [[False]])
     assert single.take(0) is t       # (a node with one consumer is not fanned out)
     single.check_all_taken()
+
+
+def test_a_stale_stepper_is_recorded_again_by_the_cache():
+    """engine/trainer._cached_stepper: a cached stepper whose capture no longer matches its optimisers (stale(): the
+    hyper-parameters a capture with optimisers inside bakes in by value) is dropped and built again; a shape whose
+    capture failed once stays on the host path"""
+    from nas_segm_amd.engine.trainer import _cached_stepper
+
+    class Stepper(object):
+        def __init__(self):
+            self.is_stale = False
+
+        def stale(self):
+            return self.is_stale
+
+    class Owner(object):
+        pass
+
+    owner, built = Owner(), []
+
+    def build():
+        built.append(Stepper())
+        return built[-1]
+
+    a = _cached_stepper(owner, "_slot", ("base",), ("shape",), build)
+    assert _cached_stepper(owner, "_slot", ("base",), ("shape",), build) is a and len(built) == 1
+    a.is_stale = True
+    b = _cached_stepper(owner, "_slot", ("base",), ("shape",), build)
+    assert b is not a and len(built) == 2
+    assert _cached_stepper(owner, "_slot", ("base",), ("shape",), build) is b
+
+    def failing():
+        raise RuntimeError("out of memory")
+
+    assert _cached_stepper(owner, "_slot", ("base",), ("other",), failing) is None
+    assert _cached_stepper(owner, "_slot", ("base",), ("other",), build) is None and len(built) == 2
+
