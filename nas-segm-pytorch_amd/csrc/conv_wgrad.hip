@@ -817,6 +817,17 @@ inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps, int lds3x3 = 0) {
   if (s > cap_bytes) s = cap_bytes;
   if (s > Mtot / kMinPix) s = Mtot / kMinPix;
   if (s < 1) s = 1;
+  // The 4 x 4 form holds 49 KB of LDS: three workgroups per CU, 768 at once, and its workgroups live for the whole
+  // launch - 1024 (64 x 128 at 4 x 256 x 512) or 990 (the CVPR cells' 3 x 3 64 -> 64 at 16 x 81 x 81) of them are a
+  // full round and a third of one.  Whole rounds only: longer slabs instead of a partly filled last round (the
+  // workgroups of a CU share its issue slots and its bandwidth - the same work in rounds that are all full is never
+  // slower and, where latency bounds the kernel, faster: tools/kbench_wgrad.py, 128 -> 64 at 4 x 256 x 512 234 ->
+  // 176 us, 3 x 3 64 -> 64 at 16 x 81 x 81 154 -> 127 us).
+  if (p.vn == 4 && p.vk == 4) {
+    constexpr int64_t kAtOnce = 256 * 3;
+    const int64_t wgs = s * per, full = wgs / kAtOnce;
+    if (full >= 1 && full <= 3 && full * kAtOnce / per >= 1) s = full * kAtOnce / per;
+  }
   // the LDS-tiled 3x3 kernel: (slabs x K / 16) workgroups, two resident per CU, several tiles each
   if (lds3x3 && Mtot >= (int64_t)64 * kW3TH * kW3TW) {
     s = 512 / (K / kW3KS);

@@ -15,7 +15,7 @@ SHAPES = [  # B, K, H, W, N, k
     (4, 64, 32, 64, 64, 1), (4, 128, 32, 64, 64, 1), (4, 32, 128, 256, 32, 1), (4, 32, 128, 256, 64, 1),
     (4, 128, 128, 256, 64, 1), (4, 64, 256, 512, 32, 1), (4, 24, 256, 512, 144, 1), (4, 144, 256, 512, 24, 1),
     (4, 128, 256, 512, 64, 1), (4, 224, 256, 512, 64, 1), (4, 16, 512, 1024, 96, 1), (4, 64, 256, 512, 19, 3),
-    (4, 64, 256, 512, 20, 3),
+    (4, 64, 256, 512, 20, 3), (16, 64, 81, 81, 64, 3), (16, 64, 81, 81, 64, 1), (8, 48, 179, 179, 48, 3),
 ]
 
 
