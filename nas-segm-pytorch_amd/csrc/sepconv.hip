@@ -51,7 +51,13 @@ struct SepArgs {
 // WLDS: depthwise weights in LDS; PRO: input prologue; NT: 16-channel output tiles (N <= 16*NT);
 // MT: 16-pixel subtiles per wave (P * Wt <= 64 * MT pixels).  Whether the statistics rows are
 // emitted (a.stats) and the depthwise output is stored (a.zdw) are run-time: neither sits in a loop.
-template <int K, int E, bool WLDS, bool PRO, int NT, int MT>
+// X: output columns per thread in the depthwise phase.  With one column a thread loads K input columns per input
+// row for one output column - 10 loads per output float4 for a 5 x 5 - and every load carries the input prologue
+// (BatchNorm + ReLU of the stage in front: fma + clamp + border mask, ~12 vector instructions) against the 100 FMAs of
+// the output itself: half of what the phase issues.  X = 2 (stride 1, dilation 1): two adjacent columns share K - 1
+// of their K input columns - 6 loads per output float4; the tile is twice as wide so that all lanes still work.  The
+// sums run in the same order (rows, then taps, ascending) per output: the same bits.
+template <int K, int E, bool WLDS, bool PRO, int NT, int MT, int X = 1>
 __global__ __launch_bounds__(256) void sepconv_fwd_kernel(SepArgs a) {
   // dynamic LDS: the depthwise output tile zt[P * Wt][LS] (rows of LS = KP + 4 floats:
   // ds_read_b128 by the 16 lanes of a k-group conflict-free) and, with WLDS, the depthwise
@@ -84,7 +90,90 @@ __global__ __launch_bounds__(256) void sepconv_fwd_kernel(SepArgs a) {
   const int ox0 = blockIdx.x * a.Wt;
 
   // ---- phase 1: depthwise strip -> LDS (and, optionally, HBM) -----------------------------
-  if (tid < a.Wt * C4) {
+  if constexpr (X == 2) {
+    if (tid < (a.Wt >> 1) * C4) {
+      const int xp = tid / C4;
+      const int c4 = tid - xp * C4;
+      const int xl = xp * 2;
+      const int ox = ox0 + xl;
+      constexpr int KX = K + 1;
+      float4 w[WLDS ? 1 : K * K];
+      if (!WLDS) {
+#pragma unroll
+        for (int t = 0; t < K * K; ++t) w[t] = lda4(a.wdw + (size_t)t * C + c4 * 4);
+      }
+      Prologue pro;
+      if (PRO) pro = make_prologue(a.in_scale, a.in_shift, a.in_act, c4);
+      int xoff[KX];
+      bool xok[KX];
+#pragma unroll
+      for (int t = 0; t < KX; ++t) {  // (stride 1, dilation 1: input column ox - pad + t)
+        const int ix = ox - a.pad + t;
+        xok[t] = (ix >= 0) && (ix < W);
+        xoff[t] = (ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;
+      }
+      float4 acc[P][2];
+#pragma unroll
+      for (int j = 0; j < P; ++j) acc[j][0] = acc[j][1] = f4zero();
+      const act_t* xb = a.x + (size_t)b * H * W * C + c4 * 4;
+      const int iy0 = oy0 - a.pad;
+      constexpr int Q = (P - 1) * E + K;
+      auto load_row = [&](int q, float4* v) {
+        const int iy = iy0 + q;
+        const bool yok = (iy >= 0) && (iy < H);
+        const act_t* xr = xb + (size_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
+#pragma unroll
+        for (int t = 0; t < KX; ++t) {
+          float4 u = lda4(xr + xoff[t]);
+          if (PRO) u = apply_prologue(u, pro);
+          v[t] = keep4(u, yok && xok[t]);
+        }
+      };
+      float4 vcur[KX], vnext[KX];
+      load_row(0, vcur);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if (q + 1 < Q) load_row(q + 1, vnext);
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          const int ty = q - j * E;
+          if (ty >= 0 && ty < K) {
+#pragma unroll
+            for (int tx = 0; tx < K; ++tx) {
+              const float4 wv = WLDS ? lw[(ty * K + tx) * C4 + c4] : w[WLDS ? 0 : ty * K + tx];
+              acc[j][0] = fma4(wv, vcur[tx], acc[j][0]);
+              acc[j][1] = fma4(wv, vcur[tx + 1], acc[j][1]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+          pin(acc[j][0]);
+          pin(acc[j][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < KX; ++t) vcur[t] = vnext[t];
+      }
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int oy = oy0 + j * a.g;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bool ok = ox + c < Wo && oy < Ho;
+          float4 o = acc[j][c];
+#ifdef NASSEG_BF16
+          o = make_float4(bf16_to_f32(f32_to_bf16(o.x)), bf16_to_f32(f32_to_bf16(o.y)),
+                          bf16_to_f32(f32_to_bf16(o.z)), bf16_to_f32(f32_to_bf16(o.w)));
+#endif
+          if (WRZ) {
+            if (ok) sta4(a.zdw + (((size_t)b * Ho + oy) * Wo + ox + c) * C + c4 * 4, o);
+          }
+          *reinterpret_cast<float4*>(&zt[(j * a.Wt + xl + c) * LS + c4 * 4]) = keep4(o, ok);
+        }
+      }
+    }
+  } else if (tid < a.Wt * C4) {
     const int xl = tid / C4;
     const int c4 = tid - xl * C4;
     const int ox = ox0 + xl;
@@ -271,8 +360,12 @@ __global__ __launch_bounds__(256) void sepconv_fwd_kernel(SepArgs a) {
   }
 }
 
+// 1: two output columns per thread where the geometry allows (stride 1, dilation 1); 0: one everywhere (A/B)
+#ifndef NASSEG_SEP_X2
+#define NASSEG_SEP_X2 1
+#endif
 struct SepPlan {
-  int ok, Wt, KP, g, e, nchunk, gx, gy;
+  int ok, Wt, KP, g, e, nchunk, gx, gy, x;
 };
 inline SepPlan sep_plan(int B, int C, int Ho, int Wo, int N, int K, int stride, int dil) {
   SepPlan p = {};
@@ -286,9 +379,20 @@ inline SepPlan sep_plan(int B, int C, int Ho, int Wo, int N, int K, int stride, 
   // columns per tile: a multiple of 16 where the channel count allows it, so that the P * Wt / 16
   // pixel subtiles divide evenly among the four waves (24 / 48 channels: 192 of the 256 lanes work
   // in the depthwise phase - measured better than 240 lanes and 3,3,2,2 subtiles), else of 4
-  int wt = 256 / C4;
+  // two columns per thread (X = 2) where the wider tiles still make 384 workgroups: tools/kbench_sepconv.py, 5 x 5
+  // 32 -> 32 at 4 x 128 x 256 21.8 -> 18.2 us, 64 -> 64 45.6 -> 37.9, 48 -> 48 at 8 x 179 x 179 70.1 -> 60.9, 3 x 3
+  // 32 -> 32 at 4 x 256 x 512 42.2 -> 39.1; but 64 -> 64 at 4 x 32 x 64 (64 workgroups instead of 128) 10.1 -> 12.1
+  p.x = 1;
+  if (NASSEG_SEP_X2 && stride == 1 && dil == 1 && C4 >= 8) {
+    int w2 = 512 / C4;
+    w2 = w2 >= 16 ? (w2 & ~15) : (w2 & ~3);
+    const int need2 = (Wo + 3) & ~3;
+    if (w2 > need2) w2 = need2;
+    if (w2 >= 4 && (int64_t)B * cdiv(Ho, kSepP * sc.g) * sc.g * cdiv(Wo, w2) >= 384) p.x = 2;
+  }
+  int wt = 256 * p.x / C4;
   wt = wt >= 16 ? (wt & ~15) : (wt & ~3);
-  if (wt > 48) wt = 48;
+  if (wt > 48 * p.x) wt = 48 * p.x;
   if (wt < 4) return p;
   // narrow maps: do not spread a tile far beyond the row
   const int need = (Wo + 3) & ~3;
@@ -303,22 +407,31 @@ inline SepPlan sep_plan(int B, int C, int Ho, int Wo, int N, int K, int stride, 
 }
 
 template <int K, int E, bool WLDS, bool PRO, int NT>
-int sep_launch2(const SepArgs& a, dim3 grid, size_t lds, int mt, hipStream_t s) {
-#define GO_SEP(MT_) hipLaunchKernelGGL((sepconv_fwd_kernel<K, E, WLDS, PRO, NT, MT_>), grid, dim3(256), lds, s, a)
-  if (mt <= 1) GO_SEP(1);
-  else if (mt == 2) GO_SEP(2);
-  else GO_SEP(3);
+int sep_launch2(const SepArgs& a, dim3 grid, size_t lds, int mt, int x, hipStream_t s) {
+#define GO_SEP(MT_, X_) hipLaunchKernelGGL((sepconv_fwd_kernel<K, E, WLDS, PRO, NT, MT_, X_>), grid, dim3(256), lds, s, a)
+  if constexpr (E == 1) {
+    if (x == 2) {  // (tiles twice as wide: C >= 32 channels, at most 64 columns = four subtiles per wave, < 64 KB of LDS)
+      if (mt <= 1) GO_SEP(1, 2);
+      else if (mt == 2) GO_SEP(2, 2);
+      else if (mt == 3) GO_SEP(3, 2);
+      else GO_SEP(4, 2);
+      return NASSEG_OK;
+    }
+  }
+  if (mt <= 1) GO_SEP(1, 1);
+  else if (mt == 2) GO_SEP(2, 1);
+  else GO_SEP(3, 1);
 #undef GO_SEP
   return NASSEG_OK;
 }
 template <int K, int E, bool WLDS>
-int sep_launch1(const SepArgs& a, dim3 grid, size_t lds, bool pro, int nt, int mt, hipStream_t s) {
+int sep_launch1(const SepArgs& a, dim3 grid, size_t lds, bool pro, int nt, int mt, int x, hipStream_t s) {
 #define GO_NT(PR_)                                                       \
   do {                                                                   \
-    if (nt <= 1) return sep_launch2<K, E, WLDS, PR_, 1>(a, grid, lds, mt, s); \
-    if (nt == 2) return sep_launch2<K, E, WLDS, PR_, 2>(a, grid, lds, mt, s); \
-    if (nt == 3) return sep_launch2<K, E, WLDS, PR_, 3>(a, grid, lds, mt, s); \
-    return sep_launch2<K, E, WLDS, PR_, 4>(a, grid, lds, mt, s);              \
+    if (nt <= 1) return sep_launch2<K, E, WLDS, PR_, 1>(a, grid, lds, mt, x, s); \
+    if (nt == 2) return sep_launch2<K, E, WLDS, PR_, 2>(a, grid, lds, mt, x, s); \
+    if (nt == 3) return sep_launch2<K, E, WLDS, PR_, 3>(a, grid, lds, mt, x, s); \
+    return sep_launch2<K, E, WLDS, PR_, 4>(a, grid, lds, mt, x, s);              \
   } while (0)
   if (pro) GO_NT(true);
   GO_NT(false);
@@ -374,10 +487,10 @@ int NASSEG_FN(sepconv_fwd)(const act_t* x, const float* wdw, const float* wpw, a
   const bool pro = in_scale || in_shift || in_act;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (K == 3 && p.e == 1) rc = sep_launch1<3, 1, false>(a, grid, lds, pro, nt, mt, s);
-  else if (K == 3) rc = sep_launch1<3, 2, false>(a, grid, lds, pro, nt, mt, s);
-  else if (p.e == 1) rc = sep_launch1<5, 1, true>(a, grid, lds, pro, nt, mt, s);
-  else rc = sep_launch1<5, 2, true>(a, grid, lds, pro, nt, mt, s);
+  if (K == 3 && p.e == 1) rc = sep_launch1<3, 1, false>(a, grid, lds, pro, nt, mt, p.x, s);
+  else if (K == 3) rc = sep_launch1<3, 2, false>(a, grid, lds, pro, nt, mt, p.x, s);
+  else if (p.e == 1) rc = sep_launch1<5, 1, true>(a, grid, lds, pro, nt, mt, p.x, s);
+  else rc = sep_launch1<5, 2, true>(a, grid, lds, pro, nt, mt, p.x, s);
   if (rc) return rc;
   NASSEG_LAUNCH_CHECK("sepconv_fwd_kernel");
   return NASSEG_OK;
