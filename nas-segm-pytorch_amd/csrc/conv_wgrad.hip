@@ -17,6 +17,14 @@
 
 namespace {
 
+// 1: the 4 x 4 form parks its waves' accumulators one wave at a time and is held to 128 registers - four workgroups
+// per CU instead of three; 0: as rounds 1-5 (A/B: tools/gpu.sh flags)
+#ifndef NASSEG_WGRAD_STAGED
+#define NASSEG_WGRAD_STAGED 1
+#endif
+constexpr int wg_min_waves(int vn, int vk) { return (NASSEG_WGRAD_STAGED && vn * vk == 16) ? 4 : 1; }
+constexpr int kWgAtOnce44 = 256 * (NASSEG_WGRAD_STAGED ? 4 : 3);  // workgroups of the 4 x 4 form resident at once
+
 struct WgArgs {
   const act_t* x;  // activations: fp32 or bf16 storage (common.h)   // forward input  [B][Hs][Ws][ldx], K channels
   int ldx;
@@ -94,7 +102,10 @@ __device__ __forceinline__ void load_vec(const float* p, int i0, int len, float*
 template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO, bool BN = false>
 __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const int by, const int bz) {
   constexpr int NACC = VN * VK * 4;
-  __shared__ float red[3][NACC][65];  // waves 1..3 park their accumulators here
+  // waves 1..3 park their accumulators here - the 4 x 4 form one wave at a time (a third of the LDS: 16.6 instead of
+  // 49.9 KB, which alone held the kernel at three workgroups per CU for the whole of its main loop)
+  constexpr bool kStaged = NASSEG_WGRAD_STAGED && NACC == 64;
+  __shared__ float red[kStaged ? 1 : 3][NACC][65];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 15;  // row/col index inside a 16-wide MFMA tile
@@ -236,15 +247,39 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const 
         for (int cb = 0; cb < VK; ++cb) acc[ca][cb] = mfma16(dv[u][ca], xv[u][cb], acc[ca][cb]);
   }
   // cross-wave reduction through LDS (fixed order -> deterministic)
-  if (wave > 0) {
+  if constexpr (kStaged) {
+    // wave 0 adds waves 1, 2, 3 in turn: ((w0 + w1) + w2) + w3, the order of the one-pass form below
+    for (int w = 1; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-    for (int ca = 0; ca < VN; ++ca)
+        for (int ca = 0; ca < VN; ++ca)
 #pragma unroll
-      for (int cb = 0; cb < VK; ++cb)
+          for (int cb = 0; cb < VK; ++cb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave - 1][(ca * VK + cb) * 4 + r][lane] = acc[ca][cb][r];
+            for (int r = 0; r < 4; ++r) red[0][(ca * VK + cb) * 4 + r][lane] = acc[ca][cb][r];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int ca = 0; ca < VN; ++ca)
+#pragma unroll
+          for (int cb = 0; cb < VK; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ca][cb][r] += red[0][(ca * VK + cb) * 4 + r][lane];
+      }
+      __syncthreads();
+    }
+  } else {
+    if (wave > 0) {
+#pragma unroll
+      for (int ca = 0; ca < VN; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < VK; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wave - 1][(ca * VK + cb) * 4 + r][lane] = acc[ca][cb][r];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (wave == 0) {
     float* pout = a.partial + (((int64_t)bx * (FLAT ? 1 : ntaps) + tap) * a.N) * Kq;
 #pragma unroll
@@ -254,7 +289,9 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int e = (ca * VK + cb) * 4 + r;
-          const float v = acc[ca][cb][r] + red[0][e][lane] + red[1][e][lane] + red[2][e][lane];
+          const float v = kStaged ? acc[ca][cb][r]
+                                  : acc[ca][cb][r] + red[0][e][lane] + red[kStaged ? 0 : 1][e][lane] +
+                                        red[kStaged ? 0 : 2][e][lane];
           // D row i = 4*pk + r  <-> n ; D col = li <-> k
           const int n = nchunk * 16 * VN + VN * (4 * pk + r) + ca;
           const int k = kchunk * 16 * VK + VK * li + cb;
@@ -264,10 +301,11 @@ __device__ __forceinline__ void wgrad_tile(const WgArgs& a, const int bx, const 
 }
 
 template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+__global__ __launch_bounds__(256, wg_min_waves(VN, VK)) void conv_wgrad_kernel(WgArgs a) {
   wgrad_tile<VN, VK, ALN, ALK, GATHER, FLAT, PRO>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 // pointwise conv followed by a BatchNorm: the BatchNorm's backward is applied to dy on load
+// (its 4 x 4 form stays at three waves per SIMD: sixteen more registers of BatchNorm constants would spill under 128)
 template <int VN, int VK, bool PRO>
 __global__ __launch_bounds__(256) void conv_wgrad_bn_kernel(WgArgs a) {
   wgrad_tile<VN, VK, true, true, false, false, PRO, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -292,7 +330,7 @@ struct WgGroup {
   WgArgs a[kWgGroup];
 };
 template <int VN, int VK, bool ALN, bool ALK, bool GATHER, bool FLAT, bool PRO>
-__global__ __launch_bounds__(256) void conv_wgrad_group_kernel(WgGroup g) {
+__global__ __launch_bounds__(256, wg_min_waves(VN, VK)) void conv_wgrad_group_kernel(WgGroup g) {
   int d = 0;
   while (d + 1 < g.n && (int)blockIdx.x >= g.start[d + 1]) ++d;
   const int local = blockIdx.x - g.start[d];
@@ -824,7 +862,7 @@ inline WgPlan wgrad_plan(int64_t Mtot, int N, int K, int taps, int lds3x3 = 0) {
   // slower and, where latency bounds the kernel, faster: tools/kbench_wgrad.py, 128 -> 64 at 4 x 256 x 512 234 ->
   // 176 us, 3 x 3 64 -> 64 at 16 x 81 x 81 154 -> 127 us).
   if (p.vn == 4 && p.vk == 4) {
-    constexpr int64_t kAtOnce = 256 * 3;
+    constexpr int64_t kAtOnce = kWgAtOnce44;
     const int64_t wgs = s * per, full = wgs / kAtOnce;
     if (full >= 1 && full <= 3 && full * kAtOnce / per >= 1) s = full * kAtOnce / per;
   }

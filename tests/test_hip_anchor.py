@@ -234,6 +234,55 @@ def test_fused_chain_kernels_against_torch_cpu_autograd(kind, irdw, batch, monke
             assert_close(gb[k], cb[k], 1e-6, 2e-5, "{}: buffer {}".format(kind, k))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("kind", ["sep3x3_r2", "ir_16_24_s2", "stem_stage1_2"])
+def test_the_rebuilt_conv_output_trains_like_the_stored_one(kind, dtype, monkeypatch):
+    """nasseg_conv_pw_bwd_bn with z == NULL rebuilds z = W x from the input tile it stages (conv_pwbwd.hip, RZ); with z
+    given it loads what the forward stored.  A chain trained through a fused SepConv / merged encoder forward and either
+    backward ends in the same bits - output, input gradient, every parameter gradient - in fp32 and with bfloat16
+    storage (where the rebuilt value is rounded like the stored one)"""
+    Fm = lower_thresholds(monkeypatch)
+    monkeypatch.setattr(Fm, "IRDW", False)
+    mods, cin, (H, W), residual, relu_in = build(kind)
+    randomise(mods, 5)
+    mods = mods.to(DEV).train()
+    state = copy.deepcopy(mods.state_dict())
+    x0 = dev(rnd(2 if kind != "stem_stage1_2" else 1, cin, H, W, seed=2)).to(dtype)
+    cot = None
+    got = {}
+    for mode, min_pixels in (("rebuilt", 0), ("stored", 1 << 40)):
+        Fm.lib.query("nasseg_conv_pw_bwd_rz_min_pixels", min_pixels)
+        Fm.lib._memo.clear()
+        mods.load_state_dict(state)
+        for q in mods.parameters():
+            q.grad = None
+        seen = []
+        orig = Fm.lib.call
+
+        def rec(fn, *a):
+            if fn.endswith("conv_pw_bwd_bn"):
+                seen.append(a[2] is None)  # (the z argument)
+            return orig(fn, *a)
+
+        monkeypatch.setattr(Fm.lib, "call", rec)
+        xg = x0.clone().requires_grad_(cin > 3)
+        yg = mods(xg, residual=xg if residual else None, relu_in=relu_in)
+        if cot is None:
+            cot = dev(rnd(*yg.shape, seed=3)).to(dtype)
+        yg.backward(cot)
+        monkeypatch.setattr(Fm.lib, "call", orig)
+        assert seen and (any(seen) if mode == "rebuilt" else not any(seen)), (mode, seen)
+        got[mode] = (yg.detach().clone(), xg.grad.clone() if cin > 3 else None,
+                     dict((k, q.grad.clone()) for k, q in mods.named_parameters()))
+    ya, xa, pa = got["rebuilt"]
+    yb, xb, pb = got["stored"]
+    assert torch.equal(ya, yb)
+    if xa is not None:
+        assert torch.equal(xa, xb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+
+
 @pytest.mark.parametrize("cfg", [(24, 24, 6, 33, 40), (64, 64, 6, 16, 20), (32, 32, 6, 20, 28)])
 def test_residual_gradient_in_the_backward_data_epilogue(cfg, monkeypatch):
     """InvertedResidual on a small map (src/nn/layer_factory.py:276-321): the block's input is also its skip, and the
