@@ -48,8 +48,11 @@ extern "C" int nasseg_conv_pwn_mode(int v);
 namespace {
 
 constexpr int kTP = 64;     // pixels per tile
-constexpr int kRing = 4;    // k-blocks in flight per workgroup
-constexpr int kSlots = 8;   // LDS ring: two groups of kRing
+#ifndef NASSEG_PWN_RING
+#define NASSEG_PWN_RING 4
+#endif
+constexpr int kRing = NASSEG_PWN_RING;  // k-blocks in flight per workgroup
+constexpr int kSlots = 2 * kRing;       // LDS ring: two groups of kRing
 constexpr int kRow = 66;    // float4 slots per chunk row of a k-block in LDS: [4][kRow]
 constexpr int kSlotF = 4 * kRow * 4;  // floats per LDS slot
 
