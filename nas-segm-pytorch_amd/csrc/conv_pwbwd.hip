@@ -20,6 +20,7 @@
 // combined through LDS in a fixed order, slabs by the deterministic second stage of
 // conv_wgrad.hip (nasseg_wgrad_finalize_many) - no float atomics.
 #include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -736,6 +737,12 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
   int64_t s = lds > (40 << 10) ? 512 : 1024;
   const int64_t cap = (int64_t)((p.wide ? 64 : 16) << 20) / ((int64_t)N * K * 4);
   while (s > 1 && (s > cap || s > M / (4 * kPwTile))) s >>= 1;
+#ifdef NASSEG_TUNE  // (tools/kbench_pwbwd.py: any slab count by hand)
+  if (const char* e = getenv("NASSEG_PW_SLABS")) {
+    const int64_t v = atoll(e);
+    if (v > 0 && v <= cap) s = v;
+  }
+#endif
   int64_t ppb = cdiv64(M, s);
   ppb = (ppb + kPwTile - 1) / kPwTile * kPwTile;
   p.pix_per_slab = (int)ppb;

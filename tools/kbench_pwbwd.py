@@ -57,6 +57,17 @@ for B, H, W, K, N in CASES:
         lib.call("nasseg_conv_pw_bwd_bn", ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws2), None, None, 0,
                  0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N, None, None, None, None, s)
 
+    def one_dxs():  # (the conv sits behind a BatchNorm of the chain: the first half of ITS backward in the epilogue)
+        lib.call("nasseg_conv_pw_bwd_bn", ptr(x), ptr(g), ptr(z), ptr(wb), ptr(dx), None, ptr(ws2), ptr(psc), ptr(psh), 2,
+                 0, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(sums), 1, 1, B, H, W, K, N, ptr(imean), ptr(iis),
+                 ptr(dxs), None, s)
+
+    if os.environ.get("KBENCH_DXS") and nsl and K <= 64:
+        psc, psh, imean, iis = v(K), v(K), v(K), v(K)
+        dxs = torch.empty((nsl + 64) * 2 * K, device=DEV)
+        print("{}: one kernel with the sums of the BatchNorm in front {:7.1f} us, slabs {}".format(
+            (B, H, W, K, N), timeit(one_dxs), nsl))
+        continue
     t2, t1 = timeit(two), (timeit(one) if nsl else float("nan"))
     mb = 4e-6 * B * H * W * (2 * K + 2 * N)
     print("{}: two kernels {:7.1f} us, one kernel {:7.1f} us ({:5.0f} GB/s of x+g+z+dx), slabs {}".format(
