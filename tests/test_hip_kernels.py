@@ -958,7 +958,15 @@ SEP_CASES = [
     (3, 8, 16, 9, 5, 3, 1, 2, 2),     # DilConv geometry, a map narrower than a tile
     (1, 128, 32, 8, 9, 3, 1, 1, 1),   # 32 channel groups: 8 columns per tile
     (2, 4, 4, 70, 64, 3, 1, 1, 1),    # 4 channels: tile width capped at 48 columns
+    # stride 1, dilation 1 and at least 384 workgroups of twice-as-wide tiles: TWO output columns per thread in the
+    # depthwise phase (sep_plan: X = 2) - 64 / 32 / 32 columns per tile, ragged last tiles, an odd width (the second
+    # column of the last pair lies outside the map), rows that do not fill the last strip
+    (4, 32, 32, 96, 260, 5, 1, 2, 1),
+    (4, 64, 48, 70, 189, 3, 1, 1, 1),
+    (4, 48, 64, 65, 190, 5, 1, 2, 1),
 ]
+SEP_WIDE_TILES = {(4, 32, 32, 96, 260, 5, 1, 2, 1): 64, (4, 64, 48, 70, 189, 3, 1, 1, 1): 32,
+                  (4, 48, 64, 65, 190, 5, 1, 2, 1): 32}
 
 
 @pytest.mark.parametrize("case", SEP_CASES, ids=lambda c: "B{}C{}N{}_{}x{}_k{}s{}p{}d{}".format(*c))
@@ -975,6 +983,8 @@ def test_sepconv_stage_equals_the_two_kernel_chain_bit_for_bit(case, dtype, pro)
     Ho, Wo = Fm.conv_out_size(H, k, stride, pad, dil), Fm.conv_out_size(W, k, stride, pad, dil)
     nblk = lib.query("nasseg_sepconv_blocks", B, C, Ho, Wo, N, k, stride, dil)
     assert nblk > 0
+    if case in SEP_WIDE_TILES:  # (one statistics row per workgroup: the wide tiles are what runs)
+        assert nblk == B * ((Ho + 3) // 4) * ((Wo + SEP_WIDE_TILES[case] - 1) // SEP_WIDE_TILES[case])
     x = dev(rnd(B, C, H, W, seed=1)).to(dtype)
     wdw = dev(rnd(C, 1, k, k, seed=2) * 0.3)
     wpw = dev(rnd(N, C, 1, 1, seed=3) * 0.2).contiguous()
