@@ -711,7 +711,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
 // The gather kernel above re-reads X once per tap through L1/L2 (9x the tensor), which
 // is what bounds the 64->19 class head and its backward-data; here a workgroup owns a
 // th x tw patch of output pixels (at most 256: 8 x 32 unless lds3x3_tile finds a shape that
-// leaves fewer workgroups per CU), stages the (th+2d) x (tw+2d) input patch of a 32-channel
+// costs the fullest CU less), stages the (th+2d) x (tw+2d) input patch of a 32-channel
 // slice in LDS once (zero-filled outside the image and beyond K) and serves all nine taps
 // from there: ds_read_b128 per lane, pixel stride padded to 36 floats so that the 16 pixel
 // lanes of a k-group hit distinct banks.  MFMA operand mapping, weight layout (mode 0,
@@ -724,16 +724,22 @@ constexpr int kLdsMaxDil = 3;
 constexpr int kLdsMaxIt = ((kLdsTH + 2 * kLdsMaxDil) * (kLdsTW + 2 * kLdsMaxDil) * (kLdsKC / 4) + 255) / 256;  // float4 of the patch per thread
 constexpr int kLdsMaxPatch = kLdsMaxIt * 256 / (kLdsKC / 4);  // pixels of the largest patch a workgroup stages (544)
 
-// The output tile of a workgroup.  A workgroup issues the MFMAs of 256 pixel slots whatever it fills them with and two
-// workgroups share a CU's matrix cores, so what a launch costs is the number of workgroups the fullest CU gets: 8 x 32
-// tiles cut a 16 x 81 x 81 map (the CVPR cells at 321 x 321) into 528 workgroups - 16 more than the 512 that run at
-// once, a second round for 3 % of the work (148 us where one round is ~75) - while 9 x 27 tiles make 432.  Picked:
-// fewest workgroups per CU, then fewest patch pixels staged in all; 8 x 32 wherever it ties.  The pixel slot f of a
-// tile is row f / tw, column f % tw (f < th * tw).
+// The output tile of a workgroup: th x tw pixels, at most 256.  The pixel slot f of a tile is row f / tw, column f % tw
+// (f < th * tw); subtile s (16 slots) belongs to wave s % 4, which multiplies its subtiles in rounds - a tile of 64
+// pixels is ONE round of every wave, 256 pixels four.  512 workgroups run at once, two per CU; what a launch costs is
+// (tools/tile_sweep.py on MI355X, 64 -> 64, microseconds): ~5 to launch, and per wave of up to 512 workgroups ~14
+// (two slices staged and waited for, prologue, epilogue) + 8 per round where a CU holds one workgroup, 2 x 10.5 per round
+// where it holds two.  Two things follow.
+//   * Whole waves: 8 x 32 tiles cut a 16 x 81 x 81 map (the CVPR cells at 321 x 321) into 528 workgroups - 16 more than
+//     run at once, a second wave for 3 % of the work - while 9 x 27 tiles make 432: 139 -> 107 us.
+//   * Small maps want small tiles: 8 x 30 x 40 (the depth head's cells) in 8 x 32 tiles are 64 workgroups of four rounds
+//     on 64 of the 256 CUs - 50 us for 0.7 GFLOP; in 64-pixel tiles 160-240 workgroups of one round - 27 us; 8 x 60 x 80
+//     in 4 x 40 tiles (240 workgroups of three rounds) 54 -> 47, 16 x 41 x 41 in 6 x 21 tiles 53 -> 38.
+// 8 x 32 stays wherever nothing beats it by 10 %.
 struct Lds3Tile {
   int th, tw;
 };
-inline Lds3Tile lds3x3_tile(int B, int Ho, int Wo, int dil) {
+inline Lds3Tile lds3x3_tile(int B, int Ho, int Wo, int dil, int nt) {
   Lds3Tile best = {kLdsTH, kLdsTW};
 #ifdef NASSEG_TUNE  // (tools/kbench_conv3x3.py: any tile by hand)
   if (const char* e = getenv("NASSEG_LDS3_TILE")) {
@@ -742,20 +748,23 @@ inline Lds3Tile lds3x3_tile(int B, int Ho, int Wo, int dil) {
       return Lds3Tile{h, w};
   }
 #endif
-  auto cost = [&](int th, int tw, int64_t& per_cu, int64_t& staged) {
+  auto cost = [&](int th, int tw) {
     const int64_t wgs = (int64_t)B * cdiv(Ho, th) * cdiv(Wo, tw);
-    per_cu = (wgs + 255) / 256;
-    staged = wgs * (th + 2 * dil) * (tw + 2 * dil);
+    const int rounds = (th * tw + 63) / 64;
+    const double kf = 0.25 * nt;  // (channel tiles of MFMAs per round, relative to 64 outputs)
+    const double alone = 14.0 + 8.0 * rounds * kf, shared = 14.0 + 2 * 10.5 * rounds * kf;
+    const int64_t full = wgs / 512, rem = wgs % 512;
+    return 5.0 + full * shared + (rem > 256 ? shared : (rem > 0 ? alone : 0.0)) +
+           0.01 * (th + 2 * dil) * (tw + 2 * dil);  // (+ the patch: what decides between equals)
   };
-  int64_t bc, bs;
-  cost(best.th, best.tw, bc, bs);
-  for (int tw = 16; tw <= 128 && tw <= Wo; ++tw) {
-    const int th = 256 / tw < Ho ? 256 / tw : Ho;
-    if ((th + 2 * dil) * (tw + 2 * dil) > kLdsMaxPatch) continue;
-    int64_t c, s;
-    cost(th, tw, c, s);
-    // (a candidate has to win by a whole workgroup per CU, or by 10 % of the staged pixels)
-    if (c < bc || (c == bc && s * 10 < bs * 9)) best = Lds3Tile{th, tw}, bc = c, bs = s;
+  double bc = 0.9 * cost(best.th, best.tw);
+  for (int tw = 8; tw <= 128 && tw <= Wo; ++tw) {
+    for (int px = 64; px <= 256; px += 64) {
+      const int th = px / tw < Ho ? px / tw : Ho;
+      if (th < 1 || (th + 2 * dil) * (tw + 2 * dil) > kLdsMaxPatch) continue;
+      const double c = cost(th, tw);
+      if (c < bc) best = Lds3Tile{th, tw}, bc = c;
+    }
   }
   return best;
 }
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
       ox = ox0 + (mt & 1) * 16 + j;
       return ((2 * wave + (mt >> 1)) * TC + (mt & 1) * 16 + j) * kLdsKS;
     }
-    const int f = (4 * wave + mt) * 16 + j;
+    const int f = (4 * mt + wave) * 16 + j;  // (subtile 4 mt + wave: round mt of this wave)
     const bool in_tile = f < th * tw;
     const int r = in_tile ? f / tw : 0;
     const int c = in_tile ? f - r * tw : 0;
@@ -819,6 +828,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
   for (int mt = 0; mt < 4; ++mt) {
     int oy, ox;
     toff[mt] = slot_pixel(mt, oy, ox);
+  }
+  // rounds this wave multiplies (wave-uniform): its subtiles 4 mt + wave that begin inside the tile
+  int nmt = 4;
+  if (FLEX) {
+    const int rem = th * tw - 16 * wave;
+    nmt = rem <= 0 ? 0 : (rem + 63) / 64;
+    nmt = nmt > 4 ? 4 : nmt;
   }
 
   f32x4 acc[4][NT];
@@ -906,7 +922,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
       const int k = kc0 + kl;
       float4 bv[4], av[NT], xv[NV ? NV : 1];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) bv[mt] = *reinterpret_cast<const float4*>(&tile[toff[mt] + tsh + kl]);
+      for (int mt = 0; mt < 4; ++mt)
+        if (!FLEX || mt < nmt) bv[mt] = *reinterpret_cast<const float4*>(&tile[toff[mt] + tsh + kl]);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         float4 v = avr[nt];
@@ -921,6 +938,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
       for (int c = 0; c < NV; ++c) xv[c] = keep_if(xvr[c], k < a.K);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
+        if (FLEX && mt >= nmt) continue;  // (wave-uniform: a round of subtiles beyond the tile)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           acc[mt][nt] = mfma16(av[nt].x, bv[mt].x, acc[mt][nt]);
@@ -967,14 +985,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_lds_kernel(FwdArgs a) {
         const int kk = kc0 + kls;
         float bs[4], as[NT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) bs[mt] = tile[toff[mt] + tsh + kls];  // (zero beyond K)
+        for (int mt = 0; mt < 4; ++mt) bs[mt] = (!FLEX || mt < nmt) ? tile[toff[mt] + tsh + kls] : 0.f;  // (zero beyond K)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           as[nt] = keep_if(a.w[((int64_t)tap * a.N + wn[nt]) * a.K + (kk < a.K ? kk : 0)], wok[nt] && kk < a.K);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt) {
+          if (FLEX && mt >= nmt) continue;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(as[nt], bs[mt], acc[mt][nt]);
+        }
 #pragma unroll
         for (int c = 0; c < NV; ++c) {
           const float wv = keep_if(a.w[((int64_t)tap * a.N + NT * 16 + c) * a.K + (kk < a.K ? kk : 0)], kk < a.K);
@@ -1127,7 +1147,7 @@ template <int NT>
 int launch_lds3x3(const FwdArgs& a0, bool vecn, bool veck, bool stats, hipStream_t s) {
   FwdArgs a = a0;
   // (the four-tile form picks its tile: nasseg_conv_fwd_stats_rows counts the rows under the same condition)
-  const Lds3Tile t = NT == 4 ? lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, a.g.dil) : Lds3Tile{kLdsTH, kLdsTW};
+  const Lds3Tile t = NT == 4 ? lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, a.g.dil, 4) : Lds3Tile{kLdsTH, kLdsTW};
   a.th = t.th;
   a.tw = t.tw;
   if constexpr (NT == 4) {
@@ -1153,7 +1173,7 @@ template <int NT, int NV>
 int launch_lds3x3_nv(const FwdArgs& a0, hipStream_t s) {
   FwdArgs a = a0;
   constexpr bool kPick = NV == 3 || NV == 5;  // (19 and 21 classes)
-  const Lds3Tile t = kPick ? lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, a.g.dil) : Lds3Tile{kLdsTH, kLdsTW};
+  const Lds3Tile t = kPick ? lds3x3_tile(a.g.B, a.g.Ho, a.g.Wo, a.g.dil, 1) : Lds3Tile{kLdsTH, kLdsTW};
   a.th = t.th;
   a.tw = t.tw;
   if constexpr (kPick) {
@@ -1531,7 +1551,7 @@ int64_t nasseg_conv_fwd_stats_rows(int B, int Ho, int Wo, int N, int K, int kh, 
   if (!pointwise && (N & 3) == 0 && lds3x3_geometry(B, Ho, Wo, N, K, kh, kw, stride, pad, dil))
   {
     // (the four-tile form picks its tile; one and two channel tiles stay on 8 x 32: launch_lds3x3)
-    const Lds3Tile t = cdiv(N, 16) > 2 ? lds3x3_tile(B, Ho, Wo, dil) : Lds3Tile{kLdsTH, kLdsTW};
+    const Lds3Tile t = cdiv(N, 16) > 2 ? lds3x3_tile(B, Ho, Wo, dil, 4) : Lds3Tile{kLdsTH, kLdsTW};
     return (int64_t)cdiv(Wo, t.tw) * cdiv(Ho, t.th) * B;
   }
   return nasseg_conv_fwd_stats_blocks(B, Ho, Wo, N, K, pointwise);
