@@ -737,6 +737,15 @@ inline PwPlan pw_plan(int64_t M, int N, int K) {
   int64_t s = lds > (40 << 10) ? 512 : 1024;
   const int64_t cap = (int64_t)((p.wide ? 64 : 16) << 20) / ((int64_t)N * K * 4);
   while (s > 1 && (s > cap || s > M / (4 * kPwTile))) s >>= 1;
+  // Small maps (fewer than 256 slabs of four tiles): one workgroup per CU and as many CUs as there are tiles rather than
+  // long slabs on a few of them - tools/kbench_pwbwd.py, us: 32 -> 192 at 8 x 60 x 80 120 slabs 65, 200 slabs 45 (300: 65
+  // again - two workgroups on some CUs); at 16 x 41 x 41 61 slabs 83, 211 slabs 34; 64 -> 64 at 8 x 60 x 80 120 slabs
+  // 33, 200 slabs 24.5.
+  if (!p.wide && s < 256 && M / kPwTile > s) {
+    s = M / kPwTile < 256 ? M / kPwTile : 256;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+  }
 #ifdef NASSEG_TUNE  // (tools/kbench_pwbwd.py: any slab count by hand)
   if (const char* e = getenv("NASSEG_PW_SLABS")) {
     const int64_t v = atoll(e);

@@ -16,6 +16,8 @@ CASES = [(4, 512, 1024, 16, 96), (4, 256, 512, 24, 144), (4, 128, 256, 32, 192),
          (16, 11, 11, 320, 64)]
 
 
+if os.environ.get("KBENCH_CASES"):  # "B,H,W,K,N;..."
+    CASES = [tuple(int(v) for v in c.split(",")) for c in os.environ["KBENCH_CASES"].split(";")]
 if os.environ.get("KBENCH_WIDE"):
     CASES = [c for c in CASES if c[3] > 64] + [(4, 256, 512, 128, 64), (8, 179, 179, 192, 48)]
 
