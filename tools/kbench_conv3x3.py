@@ -29,7 +29,8 @@ def timeit(fn, reps=30):
 for B, K, H, W, N, pad, dil in [(16, 64, 81, 81, 64, 1, 1), (16, 64, 81, 81, 64, 3, 3), (16, 64, 81, 81, 21, 1, 1),
                                 (16, 64, 41, 41, 64, 1, 1), (16, 64, 21, 21, 64, 1, 1), (16, 64, 11, 11, 64, 3, 3),
                                 (4, 64, 256, 512, 19, 1, 1), (4, 32, 128, 256, 32, 1, 1), (8, 48, 120, 160, 48, 1, 1),
-                                (8, 64, 179, 179, 64, 3, 3)]:
+                                (8, 64, 179, 179, 64, 3, 3), (8, 64, 30, 40, 64, 1, 1), (8, 64, 60, 80, 64, 1, 1),
+                                (8, 64, 60, 80, 64, 3, 3), (8, 48, 90, 90, 48, 1, 1)]:
     x = torch.randn(B, H, W, K, device=DEV)
     w = torch.randn(N, K, 3, 3, device=DEV) * 0.05
     wp = torch.empty(9 * N * K, device=DEV)
