@@ -45,6 +45,17 @@ def test_workspace_queries_are_pure_host_calls():
     assert lib.query("nasseg_conv_fwd_stats_rows", 16, 81, 81, 64, 64, 3, 3, 1, 1, 1) <= 512
     assert lib.query("nasseg_conv_fwd_stats_rows", 16, 81, 81, 64, 64, 3, 3, 1, 3, 3) <= 512
     assert 64 < lib.query("nasseg_conv_fwd_stats_rows", 8, 30, 40, 64, 64, 3, 3, 1, 1, 1) <= 256
+    # slabs of the one-kernel pointwise backward: 1024 / 512 on large maps (four / two workgroups per CU), one slab per
+    # tile and CU on small ones (32 -> 192 at 8 x 60 x 80 ran 120 slabs of five tiles on 120 of the 256 CUs)
+    assert lib.query("nasseg_conv_pw_bwd_slabs", 4, 512, 1024, 16, 96) == 1024
+    assert lib.query("nasseg_conv_pw_bwd_slabs", 4, 256, 512, 24, 144) == 512
+    assert lib.query("nasseg_conv_pw_bwd_slabs", 8, 60, 80, 32, 192) == 200
+    assert lib.query("nasseg_conv_pw_bwd_slabs", 16, 41, 41, 64, 64) == 211
+    # the generic weight gradient's 4 x 4 form (N, K > 32): whole waves of the 1024 workgroups that run at once - slabs x
+    # k-chunks x taps: 64 x 128 at 4 x 256 x 512 was 512 x 2 + a third of a wave more, the cells' 3 x 3 64 -> 64 at
+    # 16 x 81 x 81 is 110 x 9 = 990
+    assert lib.query("nasseg_conv_wgrad_workspace", 4, 256, 512, 64, 128, 1, 1) // (64 * 128) == 512
+    assert lib.query("nasseg_conv_wgrad_workspace", 16, 81, 81, 64, 64, 3, 3) // (9 * 64 * 64) == 110
 
 
 def test_error_convention_is_runtime_error():
