@@ -60,7 +60,9 @@ def both(fn, acts, params=()):
 
 @pytest.mark.parametrize("case", [(2, 24, 13, 17, 64, 1, 1, 0, 1), (2, 64, 20, 70, 19, 3, 1, 1, 1),
                                   (2, 3, 33, 37, 32, 3, 2, 1, 1), (1, 144, 16, 16, 24, 1, 1, 0, 1),
-                                  (2, 16, 12, 40, 32, 3, 1, 0, 1), (1, 19, 17, 45, 64, 3, 1, 1, 1)])
+                                  (2, 16, 12, 40, 32, 3, 1, 0, 1), (1, 19, 17, 45, 64, 3, 1, 1, 1),
+                                  # the depth head's cells: the LDS-tiled 3x3 kernel in small tiles, dilation 1 and 3
+                                  (8, 64, 30, 40, 64, 3, 1, 1, 1), (4, 64, 60, 80, 64, 3, 1, 3, 3)])
 def test_dense_conv_bf16(case):
     B, K, H, W, N, k, s, p, d = case
     w = (rnd(N, K, k, k, seed=2) / (K * k * k) ** 0.5).to(DEV)
