@@ -151,8 +151,10 @@ int nasseg_conv_fwd(const float* x, int ldx, const float* wp, float* y, int ldy,
 int64_t nasseg_conv_fwd_stats_blocks(int B, int Ho, int Wo, int N, int K, int pointwise);
 /* ... of a FORWARD call with any kernel size: nasseg_conv_fwd_stats_blocks for 1x1 and strided forms, the tile count of
  * the LDS-tiled kernel for the stride-1 3x3 forms it takes (dilation 1 ... 3, N <= 64, maps of at least 8 x 32 pixels:
- * conv3x3 / conv3x3_dil3 of the CVPR cells, layer_factory.py:56-75).  A forward call that passes `stats` for a 3x3
- * geometry must size them with THIS query. */
+ * conv3x3 / conv3x3_dil3 of the CVPR cells, layer_factory.py:56-75).  The tile is picked per map (tiles of 64 to 256
+ * pixels: whole waves of the 512 workgroups that run at once, small tiles on small maps), so the count is NOT
+ * B * ceil(Ho / 8) * ceil(Wo / 32) in general.  A forward call that passes `stats` for a 3x3 geometry must size them
+ * with THIS query. */
 int64_t nasseg_conv_fwd_stats_rows(int B, int Ho, int Wo, int N, int K, int kh, int kw, int stride, int pad, int dil);
 /* tuning / testing knob: which pointwise calls take the persistent kernel.  -2 (initial): where it measured
  * faster; v >= 0: every call it supports over at least v output pixels (0 = all, a huge value = none);
