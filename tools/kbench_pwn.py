@@ -21,7 +21,11 @@ FWD = [(16, 96, 512, 1024, 0), (24, 144, 256, 512, 0), (32, 192, 128, 256, 0), (
        (24, 96, 256, 512, 0), (32, 16, 512, 1024, 1), (64, 128, 128, 256, 0), (64, 64, 32, 64, 0)]
 BWD = [(64, 128, 256, 512), (32, 64, 256, 512), (24, 144, 256, 512), (16, 32, 512, 1024), (32, 192, 128, 256),
        (24, 96, 256, 512), (64, 128, 128, 256), (16, 96, 512, 1024), (64, 224, 256, 512), (32, 64, 128, 256)]
-B = 4
+B = int(os.environ.get("KBENCH_B", "4"))
+if os.environ.get("KBENCH_FWD"):  # "K,N,H,W,pro;..."
+    FWD = [tuple(int(v) for v in c.split(",")) for c in os.environ["KBENCH_FWD"].split(";")]
+if os.environ.get("KBENCH_BWD"):  # "K,N,H,W;..."
+    BWD = [tuple(int(v) for v in c.split(",")) for c in os.environ["KBENCH_BWD"].split(";")]
 
 
 def cl(c, h, w, dtype):
